@@ -1,0 +1,90 @@
+/* liboatrans_hip.so - C ABI of the MI355X (gfx950) kernels behind the OA-Transformer training
+ * hot path.  The reference (FingerRec/OA-Transformer) is 100 % Python on ATen and has NO
+ * native/FFI interface; each entry point below therefore cites the
+ * reference *Python* lines whose ATen work it replaces.  A maintainer of the reference binds
+ * these with ctypes - there are no torch types in any signature.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error; oat_last_error() gives the message
+ *     (thread-local).  Nothing is allocated, freed or synchronised inside the library: all
+ *     buffers, including workspaces, are caller-owned device memory; every launch is ordered
+ *     on the `stream` argument (a hipStream_t passed as void*).
+ *   - bf16 tensors are passed as `void*` (raw uint16 storage), fp32 as `float*`.
+ *   - token-row layout used engine-wide: patch (b,f,n) -> row (b*T+f)*N+n ; CLS(b) -> row
+ *     B*T*N+b  (M = B*T*N + B rows).  ld* arguments are row pitches in ELEMENTS.
+ *   - head_dim is fixed at 64 (ViT-B/16 and DistilBERT-base).
+ */
+#ifndef OATRANS_HIP_H
+#define OATRANS_HIP_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* oat_last_error(void);
+int oat_abi_version(void);
+
+/* ---- GEMM -------------------------------------------------------------------------------
+ * C[M,N] = A[M,K] * B[N,K]^T (+epilogue), bf16 in, fp32 accumulate.  K % 64 == 0.
+ * Replaces nn.Linear forward / dgrad: video_transformer.py:102 (qkv), :133 (proj), :46-50
+ * (fc1/GELU/fc2), oa_model.py:68-74 (txt_proj/vid_proj), and Conv2d patch-embed :69-75.
+ * epi: 0 out(bf16)=acc+bias | 1 out(f32)=acc+bias+resid[row % resid_mod] |
+ *      2 out(bf16)=h=acc+bias, out2(bf16)=gelu(h) | 3 out(bf16)=acc*gelu'(aux) |
+ *      4 like 1 plus bf16 copy in out2.   bias/resid/out2/aux may be NULL where unused. */
+int oat_gemm_nt(const void* A, const void* B, int M, int N, int K, int lda, int ldb, int epi,
+                void* out, int ldc, void* out2, int ld2, const float* bias, const float* resid,
+                int ldr, int resid_mod, const void* aux, int ldaux, void* stream);
+
+/* out[N1,N2] (fp32, (+)=) sum_m P[m,N1]^T Q[m,N2]  - weight gradients of every nn.Linear.
+ * Rows [M, round_up(M,64)) of P must be readable and ZERO, of Q readable and finite. */
+size_t oat_gemm_tn_workspace_bytes(int M, int N1, int N2);
+int oat_gemm_tn(const void* P, const void* Q, int M, int N1, int N2, int ldp, int ldq, float* out,
+                int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- LayerNorm (video_transformer.py:164,167,174,346; DistilBERT LayerNorms) ------------- */
+int oat_layernorm_fwd(const float* x, int ldx, const float* gamma, const float* beta, void* y_bf16,
+                      int ldy, float* y_f32, int ldy32, float* mean, float* rstd, int M, int D,
+                      float eps, void* stream);
+int oat_ln_bwd_blocks(int M);   /* partial workspace = blocks * 2 * D floats */
+int oat_layernorm_bwd(const void* dy, int dy_is_bf16, int lddy, const float* x, int ldx,
+                      const float* mean, const float* rstd, const float* gamma, const float* dres,
+                      int lddres, float* dx, int lddx, void* dx_bf16, int lddx16, float* dgamma,
+                      float* dbeta, int accumulate, float* part, int M, int D, void* stream);
+
+/* ---- reductions (bias / positional-table gradients) ------------------------------------- */
+int oat_colsum_rows(int M);     /* partial workspace = rows * N floats */
+int oat_colsum(const void* A, int is_bf16, int lda, int M, int N, float* out, int accumulate,
+               float* part, void* stream);
+int oat_periodic_rowsum(const float* in, int ld, int R, int P, int D, float* out, int accumulate, void* stream);
+int oat_grouped_rowsum(const float* in, int ld, int G, int R, int D, float* out, int accumulate, void* stream);
+
+/* ---- patch embedding inputs (video_transformer.py:71-76, 313-324) ----------------------- */
+int oat_im2col(const void* video, int is_bf16, void* A_bf16, int BT, int C, int R, int ps, int lda, void* stream);
+int oat_pos_table(const float* pos, const float* temporal, const float* cls_token, float* table,
+                  float* cls0, int T, int N, int D, void* stream);
+int oat_broadcast_rows(const float* src, float* dst, int ld, int R, int D, void* stream);
+int oat_cast_bf16(const float* src, void* dst_bf16, void* dstT_bf16, int R, int C, void* stream);
+
+/* ---- divided space-time attention (video_transformer.py:99-135, :28-32) ------------------
+ * qkv: bf16 [M, 3*D] (q | k | v, heads contiguous); out: bf16 [M, D]; lse: fp32 [M, H].
+ * The CLS-query kernel must run before either backward (it writes lse/out of the CLS rows). */
+int oat_attn_space_fwd(const void* qkv, int ldqkv, void* out, int ldo, float* lse, int B, int T, int N,
+                       int H, int D, float scale, void* stream);
+int oat_attn_time_fwd(const void* qkv, int ldqkv, void* out, int ldo, float* lse, int B, int T, int N,
+                      int H, int D, float scale, void* stream);
+int oat_attn_cls_fwd(const void* qkv, int ldqkv, void* out, int ldo, float* lse, int B, int T, int N,
+                     int H, int D, float scale, void* stream);
+/* cls_side: fp32 [B,H,3,64], zero on entry; finish with oat_attn_cls_finalize. */
+int oat_attn_space_bwd(const void* qkv, int ldqkv, const void* out, int ldo, const float* lse,
+                       const void* dout, int lddo, void* dqkv, int lddqkv, float* cls_side, int B, int T,
+                       int N, int H, int D, float scale, void* stream);
+int oat_attn_time_bwd(const void* qkv, int ldqkv, const void* out, int ldo, const float* lse,
+                      const void* dout, int lddo, void* dqkv, int lddqkv, float* cls_side, int B, int T,
+                      int N, int H, int D, float scale, void* stream);
+int oat_attn_cls_finalize(const float* cls_side, void* dqkv, int lddqkv, int B, int T, int N, int H, int D,
+                          void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,206 @@
+"""ctypes binding of liboatrans_hip.so (include/oatrans_hip.h).
+
+The library is the product path: if it is missing or a symbol is absent this
+module raises - there is no CPU / eager fallback (a silent fallback would void
+every parity claim).  ``import torch`` must happen before the library is loaded
+so that it binds to the HIP runtime torch already mapped (same soname).
+"""
+import ctypes
+import os
+import re
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PKG_ROOT = os.path.dirname(os.path.dirname(_HERE))            # oa-transformer_amd/
+LIB_PATH = os.path.join(_PKG_ROOT, "liboatrans_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_PKG_ROOT), "include", "oatrans_hip.h")
+
+_lib = None
+
+
+class OatError(RuntimeError):
+    pass
+
+
+def declared_symbols():
+    """Every function name include/oatrans_hip.h declares (used by the CPU-side ABI test)."""
+    with open(HEADER_PATH) as fh:
+        text = re.sub(r"/\*.*?\*/", "", fh.read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(oat_[a-z0-9_]+)\s*\(", text)))
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OatError(f"{LIB_PATH} not built - run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(hipcc --offload-arch=gfx950); there is no fallback path")
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.oat_last_error.restype = ctypes.c_char_p
+        _lib.oat_gemm_tn_workspace_bytes.restype = ctypes.c_size_t
+        for name in declared_symbols():
+            if not hasattr(_lib, name):
+                raise OatError(f"liboatrans_hip.so lacks symbol {name}")
+    return _lib
+
+
+def _ptr(t):
+    if t is None:
+        return ctypes.c_void_p(0)
+    if isinstance(t, torch.Tensor):
+        return ctypes.c_void_p(t.data_ptr())
+    raise TypeError(type(t))
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise OatError(f"{what} failed ({rc}): {lib().oat_last_error().decode()}")
+
+
+def _f(x):
+    return ctypes.c_float(float(x))
+
+
+EPI_BF16, EPI_F32, EPI_GELU_DUAL, EPI_DGELU, EPI_F32_BF16 = 0, 1, 2, 3, 4
+
+
+def gemm_nt(A, B, M, N, K, epi, out, out2=None, bias=None, resid=None, resid_mod=0, aux=None,
+            lda=None, ldb=None, ldc=None, ld2=None, ldr=None, ldaux=None):
+    """out[M,N] = A[M,K] @ B[N,K]^T (+epilogue).  Tensors may hold more rows than M."""
+    rc = lib().oat_gemm_nt(_ptr(A), _ptr(B), M, N, K, lda or A.stride(0), ldb or B.stride(0), epi,
+                           _ptr(out), ldc or out.stride(0), _ptr(out2),
+                           (ld2 or (out2.stride(0) if out2 is not None else 0)), _ptr(bias), _ptr(resid),
+                           (ldr or (resid.stride(0) if resid is not None else 0)), resid_mod, _ptr(aux),
+                           (ldaux or (aux.stride(0) if aux is not None else 0)), _stream())
+    _check(rc, "oat_gemm_nt")
+
+
+_tn_ws = {}
+
+
+def tn_workspace(device, N1, N2):
+    need = lib().oat_gemm_tn_workspace_bytes(0, N1, N2)
+    ws = _tn_ws.get(device)
+    if ws is None or ws.numel() * 4 < need:
+        ws = torch.empty(need // 4, dtype=torch.float32, device=device)
+        _tn_ws[device] = ws
+    return ws
+
+
+def gemm_tn(P, Q, M, N1, N2, out, accumulate=False, ldp=None, ldq=None):
+    """out[N1,N2] (+)= P[:M,:N1]^T @ Q[:M,:N2]  (weight gradient)."""
+    ws = tn_workspace(out.device, N1, N2)
+    rc = lib().oat_gemm_tn(_ptr(P), _ptr(Q), M, N1, N2, ldp or P.stride(0), ldq or Q.stride(0), _ptr(out),
+                           int(accumulate), _ptr(ws), ctypes.c_size_t(ws.numel() * 4), _stream())
+    _check(rc, "oat_gemm_tn")
+
+
+def layernorm_fwd(x, gamma, beta, M, D, eps, y=None, y32=None, mean=None, rstd=None):
+    rc = lib().oat_layernorm_fwd(_ptr(x), x.stride(0), _ptr(gamma), _ptr(beta), _ptr(y),
+                                 y.stride(0) if y is not None else 0, _ptr(y32),
+                                 y32.stride(0) if y32 is not None else 0, _ptr(mean), _ptr(rstd), M, D, _f(eps),
+                                 _stream())
+    _check(rc, "oat_layernorm_fwd")
+
+
+_part_ws = {}
+
+
+def _partials(device, n):
+    ws = _part_ws.get(device)
+    if ws is None or ws.numel() < n:
+        ws = torch.empty(n, dtype=torch.float32, device=device)
+        _part_ws[device] = ws
+    return ws
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, M, D, dx=None, dx16=None, dres=None, dgamma=None, dbeta=None,
+                  accumulate=False):
+    part = None
+    if dgamma is not None or dbeta is not None:
+        part = _partials(x.device, lib().oat_ln_bwd_blocks(M) * 2 * D)
+    rc = lib().oat_layernorm_bwd(_ptr(dy), int(dy.dtype == torch.bfloat16), dy.stride(0), _ptr(x), x.stride(0),
+                                 _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(dres),
+                                 dres.stride(0) if dres is not None else 0, _ptr(dx),
+                                 dx.stride(0) if dx is not None else 0, _ptr(dx16),
+                                 dx16.stride(0) if dx16 is not None else 0, _ptr(dgamma), _ptr(dbeta),
+                                 int(accumulate), _ptr(part), M, D, _stream())
+    _check(rc, "oat_layernorm_bwd")
+
+
+def colsum(A, M, N, out, accumulate=False):
+    part = _partials(A.device, lib().oat_colsum_rows(M) * N)
+    rc = lib().oat_colsum(_ptr(A), int(A.dtype == torch.bfloat16), A.stride(0), M, N, _ptr(out), int(accumulate),
+                          _ptr(part), _stream())
+    _check(rc, "oat_colsum")
+
+
+def periodic_rowsum(x, R, P, D, out, accumulate=False):
+    _check(lib().oat_periodic_rowsum(_ptr(x), x.stride(0), R, P, D, _ptr(out), int(accumulate), _stream()),
+           "oat_periodic_rowsum")
+
+
+def grouped_rowsum(x, G, R, D, out, accumulate=False, ld=None):
+    _check(lib().oat_grouped_rowsum(_ptr(x), ld or x.stride(0), G, R, D, _ptr(out), int(accumulate), _stream()),
+           "oat_grouped_rowsum")
+
+
+def im2col(video, A, BT, C, R, ps):
+    _check(lib().oat_im2col(_ptr(video), int(video.dtype == torch.bfloat16), _ptr(A), BT, C, R, ps, A.stride(0),
+                            _stream()), "oat_im2col")
+
+
+def pos_table(pos, temporal, cls_token, table, cls0, T, N, D):
+    _check(lib().oat_pos_table(_ptr(pos), _ptr(temporal), _ptr(cls_token), _ptr(table), _ptr(cls0), T, N, D,
+                               _stream()), "oat_pos_table")
+
+
+def broadcast_rows(src, dst, R, D):
+    _check(lib().oat_broadcast_rows(_ptr(src), _ptr(dst), dst.stride(0), R, D, _stream()), "oat_broadcast_rows")
+
+
+def cast_bf16(src, dst=None, dstT=None):
+    R, C = src.shape
+    _check(lib().oat_cast_bf16(_ptr(src), _ptr(dst), _ptr(dstT), R, C, _stream()), "oat_cast_bf16")
+
+
+def _attn_fwd(fn, name, qkv, out, lse, B, T, N, H, D, scale):
+    _check(fn(_ptr(qkv), qkv.stride(0), _ptr(out), out.stride(0), _ptr(lse), B, T, N, H, D, _f(scale), _stream()),
+           name)
+
+
+def attn_space_fwd(qkv, out, lse, B, T, N, H, D, scale):
+    _attn_fwd(lib().oat_attn_space_fwd, "oat_attn_space_fwd", qkv, out, lse, B, T, N, H, D, scale)
+
+
+def attn_time_fwd(qkv, out, lse, B, T, N, H, D, scale):
+    _attn_fwd(lib().oat_attn_time_fwd, "oat_attn_time_fwd", qkv, out, lse, B, T, N, H, D, scale)
+
+
+def attn_cls_fwd(qkv, out, lse, B, T, N, H, D, scale):
+    _attn_fwd(lib().oat_attn_cls_fwd, "oat_attn_cls_fwd", qkv, out, lse, B, T, N, H, D, scale)
+
+
+def _attn_bwd(fn, name, qkv, out, lse, dout, dqkv, cls_side, B, T, N, H, D, scale):
+    _check(fn(_ptr(qkv), qkv.stride(0), _ptr(out), out.stride(0), _ptr(lse), _ptr(dout), dout.stride(0),
+              _ptr(dqkv), dqkv.stride(0), _ptr(cls_side), B, T, N, H, D, _f(scale), _stream()), name)
+
+
+def attn_space_bwd(qkv, out, lse, dout, dqkv, cls_side, B, T, N, H, D, scale):
+    _attn_bwd(lib().oat_attn_space_bwd, "oat_attn_space_bwd", qkv, out, lse, dout, dqkv, cls_side, B, T, N, H, D,
+              scale)
+
+
+def attn_time_bwd(qkv, out, lse, dout, dqkv, cls_side, B, T, N, H, D, scale):
+    _attn_bwd(lib().oat_attn_time_bwd, "oat_attn_time_bwd", qkv, out, lse, dout, dqkv, cls_side, B, T, N, H, D,
+              scale)
+
+
+def attn_cls_finalize(cls_side, dqkv, B, T, N, H, D):
+    _check(lib().oat_attn_cls_finalize(_ptr(cls_side), _ptr(dqkv), dqkv.stride(0), B, T, N, H, D, _stream()),
+           "oat_attn_cls_finalize")

@@ -1,0 +1,389 @@
+// Divided SPACE attention of the SpaceTimeTransformer, fused (never materialises the
+// [B*H*T, N, N+1] score tensor the reference writes: video_transformer.py:99-135 with the
+// '(b f) n d' pattern :275-276, attn() :28-32).
+//
+// One workgroup = one (sample b, frame f, head h).  Keys/values = the frame's N patches + the
+// sample's CLS token (key index N); padding keys up to NKP = 16*NKT are masked.
+//   forward : S^T = K Q^T by MFMA (lane owns ONE query column -> softmax row reductions are
+//             in-lane + 2 shuffles), P stays in registers as the B operand of O^T = V^T P^T,
+//             V^T fragments come from the row-major LDS tile through ds_read_b64_tr_b16.
+//   backward: flash-style with saved LSE and delta = rowsum(dO * O); phase A (lane = query)
+//             produces dQ, phase B (lane = key) produces dK, dV.  The CLS *query* rides along
+//             as query index N with its global LSE, so patch-key gradients are complete in one
+//             pass; gradients of the shared CLS row are fp32 atomics into a side buffer.
+// Token row layout (engine-wide): patch (b,f,n) -> row (b*T+f)*N+n ; CLS(b) -> row B*T*N+b.
+#include "common.h"
+
+namespace oat {
+
+// chunk swizzle for [rows][64 bf16] LDS tiles: conflict-free for ds_read_b128 row fragments
+// (16 consecutive rows) AND for transpose reads (8 consecutive rows x 32 B).
+OAT_DEV int sw8(int row) { const int rp = (row >> 1) & 7; return ((rp & 3) << 1) | (rp >> 2); }
+OAT_DEV int tile_off(int row, int lc) { return row * 128 + ((lc ^ sw8(row)) << 4); }
+
+// row fragment (A/B operand with k = head dim): 16 rows starting at r0, k-step ks (32 dims)
+OAT_DEV bf16x8 row_frag(const char* tile, int r0, int ks, int lane) {
+  const int row = r0 + (lane & 15);
+  return *reinterpret_cast<const bf16x8*>(tile + tile_off(row, ks * 4 + (lane >> 4)));
+}
+// transposed fragment: A operand [i = dim dt*16 + (lane&15)][k-slot (g,e)] = tile[row(g,e)][dim]
+// rows of slot (g,e): e < 4 -> r0 + g*4 + e ; e >= 4 -> r0 + 16 + g*4 + (e-4)
+OAT_DEV bf16x8 tr_frag(const char* tile, int r0, int dt, int lane) {
+  const int s = lane & 15, g = lane >> 4;
+  bf16x8 out;
+  s16x4* o = reinterpret_cast<s16x4*>(&out);
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int row = r0 + half * 16 + g * 4 + (s >> 2);
+    const int lc = dt * 2 + ((s & 3) >> 1);
+    o[half] = lds_tr16(tile + tile_off(row, lc) + ((s & 1) << 3));
+  }
+  return out;
+}
+
+struct SpaceArgs {
+  const bf16* qkv; int ldqkv;
+  bf16* out; int ldo;              // fwd: attention output ; bwd: saved attention output (read)
+  float* lse;                      // [M, H]
+  const bf16* dout; int lddo;      // bwd
+  bf16* dqkv; int lddqkv;          // bwd
+  float* cls_side;                 // bwd: [B, H, 3, 64] fp32 (dq, dk, dv of the CLS row)
+  int B, T, N, H, D;
+  float scale;
+};
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+// stage a [NKP][64] tile from token rows: j < N -> patch row, j == N -> CLS row, else zeros
+template <int NKT>
+OAT_DEV void load_tile(char* tile, const bf16* src, int ld, int col, size_t base_row, size_t cls_row, int N) {
+  constexpr int NKP = NKT * 16;
+  for (int idx = threadIdx.x; idx < NKP * 8; idx += 256) {
+    const int j = idx >> 3, c = idx & 7;
+    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (j <= N) {
+      const size_t r = j < N ? base_row + j : cls_row;
+      v = *reinterpret_cast<const bf16x8*>(src + r * ld + col + c * 8);
+    }
+    *reinterpret_cast<bf16x8*>(tile + tile_off(j, c)) = v;
+  }
+}
+
+template <int NKT>
+__global__ __launch_bounds__(256) void attn_space_fwd_kernel(SpaceArgs a) {
+  constexpr int NKP = NKT * 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Kt = smem;
+  char* Vt = smem + NKP * 128;
+  const int h = blockIdx.x % a.H;
+  const int bf = blockIdx.x / a.H;            // b * T + f
+  const int b = bf / a.T;
+  const int N = a.N;
+  const size_t base_row = (size_t)bf * N;
+  const size_t cls_row = (size_t)a.B * a.T * N + b;
+  load_tile<NKT>(Kt, a.qkv, a.ldqkv, a.D + h * 64, base_row, cls_row, N);
+  load_tile<NKT>(Vt, a.qkv, a.ldqkv, 2 * a.D + h * 64, base_row, cls_row, N);
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4;
+  const float c2 = a.scale * LOG2E;
+  const int nqt = (N + 15) / 16;
+  for (int qt = wave; qt < nqt; qt += 4) {
+    const int qi = qt * 16 + (lane & 15);
+    const size_t qrow = base_row + min(qi, N - 1);
+    bf16x8 qf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      qf[ks] = *reinterpret_cast<const bf16x8*>(a.qkv + qrow * a.ldqkv + h * 64 + ks * 32 + g * 8);
+    f32x4 st[NKT];
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      f32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Kt, kt * 16, ks, lane), qf[ks], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kt * 16 + g * 4 + r;
+        acc[r] = key <= N ? acc[r] * c2 : -INFINITY;
+        m = fmaxf(m, acc[r]);
+      }
+      st[kt] = acc;
+    }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { st[kt][r] = exp2f(st[kt][r] - m); l += st[kt][r]; }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    f32x4 ot[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) ot[dt] = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int u = 0; u < NKT / 2; ++u) {
+      const bf16x8 pb = {f2bf(st[2 * u][0]), f2bf(st[2 * u][1]), f2bf(st[2 * u][2]), f2bf(st[2 * u][3]),
+                         f2bf(st[2 * u + 1][0]), f2bf(st[2 * u + 1][1]), f2bf(st[2 * u + 1][2]), f2bf(st[2 * u + 1][3])};
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Vt, u * 32, dt, lane), pb, ot[dt], 0, 0, 0);
+    }
+    if (qi < N) {
+      const float inv = 1.0f / l;
+      bf16* orow = a.out + (base_row + qi) * a.ldo + h * 64 + g * 4;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const bf16x4 o = {f2bf(ot[dt][0] * inv), f2bf(ot[dt][1] * inv), f2bf(ot[dt][2] * inv), f2bf(ot[dt][3] * inv)};
+        *reinterpret_cast<bf16x4*>(orow + dt * 16) = o;
+      }
+      if (g == 0) a.lse[(base_row + qi) * a.H + h] = (m + log2f(l)) * LN2;
+    }
+  }
+}
+
+template <int NKT>
+__global__ __launch_bounds__(256) void attn_space_bwd_kernel(SpaceArgs a) {
+  constexpr int NKP = NKT * 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Qt = smem;
+  char* Kt = smem + NKP * 128;
+  char* Vt = smem + 2 * NKP * 128;
+  char* Dt = smem + 3 * NKP * 128;                       // dO tile
+  float* lse_s = reinterpret_cast<float*>(smem + 4 * NKP * 128);
+  float* del_s = lse_s + NKP;
+  const int h = blockIdx.x % a.H;
+  const int bf = blockIdx.x / a.H;
+  const int b = bf / a.T, f = bf % a.T;
+  const int N = a.N;
+  const size_t base_row = (size_t)bf * N;
+  const size_t cls_row = (size_t)a.B * a.T * N + b;
+  load_tile<NKT>(Qt, a.qkv, a.ldqkv, h * 64, base_row, cls_row, N);
+  load_tile<NKT>(Kt, a.qkv, a.ldqkv, a.D + h * 64, base_row, cls_row, N);
+  load_tile<NKT>(Vt, a.qkv, a.ldqkv, 2 * a.D + h * 64, base_row, cls_row, N);
+  // dO tile + delta = rowsum(dO * O) + lse (log2 units); 8 lanes per row
+  for (int idx = threadIdx.x; idx < NKP * 8; idx += 256) {
+    const int j = idx >> 3, c = idx & 7;
+    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    float d = 0.f;
+    size_t r = 0;
+    if (j <= N) {
+      r = j < N ? base_row + j : cls_row;
+      v = *reinterpret_cast<const bf16x8*>(a.dout + r * a.lddo + h * 64 + c * 8);
+      const bf16x8 o = *reinterpret_cast<const bf16x8*>(a.out + r * a.ldo + h * 64 + c * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) d += bf2f(v[e]) * bf2f(o[e]);
+    }
+    *reinterpret_cast<bf16x8*>(Dt + tile_off(j, c)) = v;
+    d += __shfl_xor(d, 1, 64);
+    d += __shfl_xor(d, 2, 64);
+    d += __shfl_xor(d, 4, 64);
+    if (c == 0) {
+      del_s[j] = d;
+      lse_s[j] = j <= N ? a.lse[r * a.H + h] * LOG2E : 0.f;
+    }
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4;
+  const float c2 = a.scale * LOG2E;
+  float* side = a.cls_side + ((size_t)b * a.H + h) * 3 * 64;
+
+  // ------------------------------------------------ phase A: lane = query column, produces dQ
+  for (int qt = wave; qt < NKT; qt += 4) {
+    if (qt * 16 > N) break;
+    const int qi = qt * 16 + (lane & 15);
+    const float lq = lse_s[qi], dq_ = del_s[qi];
+    bf16x8 qf[2], df[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) { qf[ks] = row_frag(Qt, qt * 16, ks, lane); df[ks] = row_frag(Dt, qt * 16, ks, lane); }
+    f32x4 ds[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      f32x4 s = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Kt, kt * 16, ks, lane), qf[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Vt, kt * 16, ks, lane), df[ks], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kt * 16 + g * 4 + r;
+        bool ok = key <= N && qi <= N;
+        if (qi == N && key == N && f != 0) ok = false;      // CLS->CLS pair is counted once (frame 0)
+        const float p = ok ? exp2f(s[r] * c2 - lq) : 0.f;
+        ds[kt][r] = p * (dp[r] - dq_);
+      }
+    }
+    f32x4 dq[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int u = 0; u < NKT / 2; ++u) {
+      const bf16x8 sb = {f2bf(ds[2 * u][0]), f2bf(ds[2 * u][1]), f2bf(ds[2 * u][2]), f2bf(ds[2 * u][3]),
+                         f2bf(ds[2 * u + 1][0]), f2bf(ds[2 * u + 1][1]), f2bf(ds[2 * u + 1][2]), f2bf(ds[2 * u + 1][3])};
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Kt, u * 32, dt, lane), sb, dq[dt], 0, 0, 0);
+    }
+    if (qi < N) {
+      bf16* drow = a.dqkv + (base_row + qi) * a.lddqkv + h * 64 + g * 4;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const bf16x4 o = {f2bf(dq[dt][0] * a.scale), f2bf(dq[dt][1] * a.scale), f2bf(dq[dt][2] * a.scale),
+                          f2bf(dq[dt][3] * a.scale)};
+        *reinterpret_cast<bf16x4*>(drow + dt * 16) = o;
+      }
+    } else if (qi == N) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(side + dt * 16 + g * 4 + r, dq[dt][r] * a.scale);
+    }
+  }
+
+  // ------------------------------------------------ phase B: lane = key column, produces dK, dV
+  for (int kt = wave; kt < NKT; kt += 4) {
+    if (kt * 16 > N) break;
+    const int key = kt * 16 + (lane & 15);
+    bf16x8 kf[2], vf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) { kf[ks] = row_frag(Kt, kt * 16, ks, lane); vf[ks] = row_frag(Vt, kt * 16, ks, lane); }
+    f32x4 dk[4], dv[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0, 0, 0, 0}; dv[dt] = f32x4{0, 0, 0, 0}; }
+#pragma unroll 1
+    for (int u = 0; u < NKT / 2; ++u) {
+      if (u * 32 > N) break;
+      float pv[8], sv[8];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int q0 = u * 32 + half * 16;
+        f32x4 s = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Qt, q0, ks, lane), kf[ks], s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Dt, q0, ks, lane), vf[ks], dp, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int qi = q0 + g * 4 + r;
+          bool ok = key <= N && qi <= N;
+          if (qi == N && key == N && f != 0) ok = false;
+          const float p = ok ? exp2f(s[r] * c2 - lse_s[qi]) : 0.f;
+          pv[half * 4 + r] = p;
+          sv[half * 4 + r] = p * (dp[r] - del_s[qi]);
+        }
+      }
+      const bf16x8 pb = {f2bf(pv[0]), f2bf(pv[1]), f2bf(pv[2]), f2bf(pv[3]), f2bf(pv[4]), f2bf(pv[5]), f2bf(pv[6]), f2bf(pv[7])};
+      const bf16x8 sb = {f2bf(sv[0]), f2bf(sv[1]), f2bf(sv[2]), f2bf(sv[3]), f2bf(sv[4]), f2bf(sv[5]), f2bf(sv[6]), f2bf(sv[7])};
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Dt, u * 32, dt, lane), pb, dv[dt], 0, 0, 0);
+        dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Qt, u * 32, dt, lane), sb, dk[dt], 0, 0, 0);
+      }
+    }
+    if (key < N) {
+      bf16* drow = a.dqkv + (base_row + key) * a.lddqkv + h * 64 + g * 4;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const bf16x4 ok_ = {f2bf(dk[dt][0] * a.scale), f2bf(dk[dt][1] * a.scale), f2bf(dk[dt][2] * a.scale),
+                            f2bf(dk[dt][3] * a.scale)};
+        const bf16x4 ov = {f2bf(dv[dt][0]), f2bf(dv[dt][1]), f2bf(dv[dt][2]), f2bf(dv[dt][3])};
+        *reinterpret_cast<bf16x4*>(drow + a.D + dt * 16) = ok_;
+        *reinterpret_cast<bf16x4*>(drow + 2 * a.D + dt * 16) = ov;
+      }
+    } else if (key == N) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          atomicAdd(side + 64 + dt * 16 + g * 4 + r, dk[dt][r] * a.scale);
+          atomicAdd(side + 128 + dt * 16 + g * 4 + r, dv[dt][r]);
+        }
+    }
+  }
+}
+
+// dqkv[cls row(b)][which*D + h*64 + d] = bf16(side[b][h][which][d])
+__global__ void attn_cls_finalize_kernel(const float* side, bf16* dqkv, int lddqkv, int B, int H, int D, size_t cls_row0) {
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int t = threadIdx.x;                       // 192 threads: which = t / 64, d = t % 64
+  if (t >= 192) return;
+  const float v = side[((size_t)b * H + h) * 192 + t];
+  dqkv[(cls_row0 + b) * lddqkv + (t >> 6) * D + h * 64 + (t & 63)] = f2bf(v);
+}
+
+template <int NKT>
+static int launch_fwd(const SpaceArgs& a, hipStream_t s) {
+  const int lds = 2 * NKT * 16 * 128;
+  static bool set = false;
+  if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_space_fwd_kernel<NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
+  hipLaunchKernelGGL(attn_space_fwd_kernel<NKT>, dim3(a.B * a.T * a.H), dim3(256), lds, s, a);
+  return check_launch("attn_space_fwd");
+}
+template <int NKT>
+static int launch_bwd(const SpaceArgs& a, hipStream_t s) {
+  const int lds = 4 * NKT * 16 * 128 + 2 * NKT * 16 * 4;
+  static bool set = false;
+  if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_space_bwd_kernel<NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
+  hipLaunchKernelGGL(attn_space_bwd_kernel<NKT>, dim3(a.B * a.T * a.H), dim3(256), lds, s, a);
+  return check_launch("attn_space_bwd");
+}
+
+static int pick_nkt(int N) {
+  const int need = (N + 1 + 31) / 32 * 2;     // even number of 16-key tiles
+  const int opts[] = {2, 4, 8, 14};
+  for (int o : opts) if (o >= need) return o;
+  return -1;
+}
+
+}  // namespace oat
+
+using namespace oat;
+
+extern "C" int oat_attn_space_fwd(const void* qkv, int ldqkv, void* out, int ldo, float* lse, int B, int T, int N,
+                                  int H, int D, float scale, void* stream) {
+  if (D != H * 64) { set_error("attn_space: head_dim must be 64"); return -3; }
+  const int nkt = pick_nkt(N);
+  if (nkt < 0) { set_error("attn_space: patches per frame > 223 not supported by this build"); return -3; }
+  SpaceArgs a{(const bf16*)qkv, ldqkv, (bf16*)out, ldo, lse, nullptr, 0, nullptr, 0, nullptr, B, T, N, H, D, scale};
+  hipStream_t s = (hipStream_t)stream;
+  switch (nkt) {
+    case 2: return launch_fwd<2>(a, s);
+    case 4: return launch_fwd<4>(a, s);
+    case 8: return launch_fwd<8>(a, s);
+    default: return launch_fwd<14>(a, s);
+  }
+}
+
+// cls_side: fp32 [B, H, 3, 64], must be ZERO on entry (caller memsets); it receives the CLS row's
+// dq/dk/dv partial sums.  Call oat_attn_cls_finalize afterwards to write them into dqkv.
+extern "C" int oat_attn_space_bwd(const void* qkv, int ldqkv, const void* out, int ldo, const float* lse,
+                                  const void* dout, int lddo, void* dqkv, int lddqkv, float* cls_side, int B, int T,
+                                  int N, int H, int D, float scale, void* stream) {
+  if (D != H * 64) { set_error("attn_space: head_dim must be 64"); return -3; }
+  const int nkt = pick_nkt(N);
+  if (nkt < 0) { set_error("attn_space: patches per frame > 223 not supported by this build"); return -3; }
+  SpaceArgs a{(const bf16*)qkv, ldqkv, (bf16*)out, ldo, (float*)lse, (const bf16*)dout, lddo, (bf16*)dqkv, lddqkv,
+              cls_side, B, T, N, H, D, scale};
+  hipStream_t s = (hipStream_t)stream;
+  switch (nkt) {
+    case 2: return launch_bwd<2>(a, s);
+    case 4: return launch_bwd<4>(a, s);
+    case 8: return launch_bwd<8>(a, s);
+    default: return launch_bwd<14>(a, s);
+  }
+}
+
+extern "C" int oat_attn_cls_finalize(const float* cls_side, void* dqkv, int lddqkv, int B, int T, int N, int H, int D,
+                                     void* stream) {
+  hipLaunchKernelGGL(attn_cls_finalize_kernel, dim3(B * H), dim3(192), 0, (hipStream_t)stream, cls_side, (bf16*)dqkv,
+                     lddqkv, B, H, D, (size_t)B * T * N);
+  return check_launch("attn_cls_finalize");
+}

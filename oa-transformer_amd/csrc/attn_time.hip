@@ -1,0 +1,284 @@
+// Divided TIME attention + the CLS-query attention of the SpaceTimeTransformer.
+//   reference: video_transformer.py:99-135 with the '(b n) f d' pattern (:277-278) and the
+//   cls_out = attn(cls_q, k, v) line (:110).
+//
+// Time attention is B*H*N tiny problems (T queries x (T+1) keys x 64 dims): HBM/latency bound,
+// MFMA would idle.  Eight lanes own one problem; lane p holds the 8-dim slice [8p, 8p+8) of every
+// q/k/v row of the problem (16-byte loads: 8 lanes cover one 128-byte line), scores are
+// 8-lane butterfly reductions, everything else is in-lane fp32.  The reference's gather
+// copies 'b (f n) d -> (b n) f d' (3 full passes over QKV) disappear into index math.
+//
+// CLS-query attention (1 query x all 1+T*N keys per (b,h)) is its own kernel and writes the
+// global LSE that both backward kernels use to treat the CLS query as "one more query".
+#include "common.h"
+
+namespace oat {
+
+constexpr float T_LOG2E = 1.4426950408889634f;
+constexpr float T_LN2 = 0.6931471805599453f;
+
+OAT_DEV float dot8(const bf16x8 a, const bf16x8 b) {
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s += bf2f(a[e]) * bf2f(b[e]);
+  return s;
+}
+OAT_DEV float red8(float v) {
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 4, 64);
+  return v;
+}
+
+struct TimeArgs {
+  const bf16* qkv; int ldqkv;
+  bf16* out; int ldo;
+  float* lse;
+  const bf16* dout; int lddo;
+  bf16* dqkv; int lddqkv;
+  float* cls_side;
+  int B, T, N, H, D;
+  float scale;
+};
+
+// grid: B*H*ceil(N/8) waves (4 per block); wave -> (b, h, n0), 8-lane group gq -> n = n0 + gq
+template <int TT>
+__global__ __launch_bounds__(256) void attn_time_fwd_kernel(TimeArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int ng = (a.N + 7) / 8;
+  if (wid >= a.B * a.H * ng) return;
+  const int bh = wid / ng, b = bh / a.H, h = bh % a.H;
+  const int n = (wid % ng) * 8 + (lane >> 3);
+  const int pl = lane & 7;
+  const bool valid = n < a.N;
+  const int nn = valid ? n : a.N - 1;
+  const size_t cls_row = (size_t)a.B * a.T * a.N + b;
+  const int col = h * 64 + pl * 8;
+  bf16x8 k[TT + 1], v[TT + 1];
+#pragma unroll
+  for (int j = 0; j <= TT; ++j) {
+    const size_t r = j < TT ? ((size_t)b * TT + j) * a.N + nn : cls_row;
+    k[j] = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + a.D + col);
+    v[j] = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + 2 * a.D + col);
+  }
+  const float c2 = a.scale * T_LOG2E;
+#pragma unroll
+  for (int f = 0; f < TT; ++f) {
+    const size_t r = ((size_t)b * TT + f) * a.N + nn;
+    const bf16x8 q = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + col);
+    float s[TT + 1], m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j <= TT; ++j) { s[j] = red8(dot8(q, k[j])) * c2; m = fmaxf(m, s[j]); }
+    float l = 0.f, o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j <= TT; ++j) {
+      const float p = exp2f(s[j] - m);
+      l += p;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] += p * bf2f(v[j][e]);
+    }
+    if (valid) {
+      const float inv = 1.0f / l;
+      const bf16x8 ob = {f2bf(o[0] * inv), f2bf(o[1] * inv), f2bf(o[2] * inv), f2bf(o[3] * inv),
+                         f2bf(o[4] * inv), f2bf(o[5] * inv), f2bf(o[6] * inv), f2bf(o[7] * inv)};
+      *reinterpret_cast<bf16x8*>(a.out + r * a.ldo + col) = ob;
+      if (pl == 0) a.lse[r * a.H + h] = (m + log2f(l)) * T_LN2;
+    }
+  }
+}
+
+// backward: queries i = 0..T (i = T is the CLS query, global LSE), keys j = 0..T (j = T = CLS key).
+// Two passes keep the live register set small (<= 9 packed rows + one accumulator set):
+//   pass A (query-major): dQ_i, and the per-query scalars (delta_i, lse_i)
+//   pass B (key-major)  : dK_j, dV_j   (scores are recomputed; loads hit L1/L2)
+template <int TT>
+__global__ __launch_bounds__(256) void attn_time_bwd_kernel(TimeArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int ng = (a.N + 7) / 8;
+  if (wid >= a.B * a.H * ng) return;
+  const int bh = wid / ng, b = bh / a.H, h = bh % a.H;
+  const int n = (wid % ng) * 8 + (lane >> 3);
+  const int pl = lane & 7;
+  const bool valid = n < a.N;
+  const int nn = valid ? n : a.N - 1;
+  const size_t cls_row = (size_t)a.B * a.T * a.N + b;
+  const int col = h * 64 + pl * 8;
+  const size_t row0 = (size_t)b * TT * a.N + nn;     // row of frame j = row0 + j * N
+  const float c2 = a.scale * T_LOG2E;
+  float* side = a.cls_side + ((size_t)b * a.H + h) * 192;
+  float delta[TT + 1], lse2[TT + 1];
+  {
+    bf16x8 k[TT + 1], v[TT + 1];
+#pragma unroll
+    for (int j = 0; j <= TT; ++j) {
+      const size_t r = j < TT ? row0 + (size_t)j * a.N : cls_row;
+      k[j] = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + a.D + col);
+      v[j] = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + 2 * a.D + col);
+    }
+#pragma unroll
+    for (int i = 0; i <= TT; ++i) {
+      const size_t r = i < TT ? row0 + (size_t)i * a.N : cls_row;
+      const bf16x8 q = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + col);
+      const bf16x8 go = *reinterpret_cast<const bf16x8*>(a.dout + r * a.lddo + col);
+      const bf16x8 oo = *reinterpret_cast<const bf16x8*>(a.out + r * a.ldo + col);
+      lse2[i] = a.lse[r * a.H + h] * T_LOG2E;
+      delta[i] = red8(dot8(go, oo));
+      float dq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int j = 0; j <= TT; ++j) {
+        float p = exp2f(red8(dot8(q, k[j])) * c2 - lse2[i]);
+        if (i == TT && j == TT && n != 0) p = 0.f;        // CLS->CLS pair is counted once (n == 0)
+        const float ds = p * (red8(dot8(go, v[j])) - delta[i]) * a.scale;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dq[e] += ds * bf2f(k[j][e]);
+      }
+      if (i < TT) {
+        if (valid) {
+          const bf16x8 ob = {f2bf(dq[0]), f2bf(dq[1]), f2bf(dq[2]), f2bf(dq[3]), f2bf(dq[4]), f2bf(dq[5]), f2bf(dq[6]), f2bf(dq[7])};
+          *reinterpret_cast<bf16x8*>(a.dqkv + r * a.lddqkv + col) = ob;
+        }
+      } else {
+        // CLS query: reduce the 8 problems of this wave (same b,h), then one atomic per slot
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float t = valid ? dq[e] : 0.f;
+          t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
+          if (lane < 8) atomicAdd(side + pl * 8 + e, t);
+        }
+      }
+    }
+  }
+  {
+    bf16x8 q[TT + 1], go[TT + 1];
+#pragma unroll
+    for (int i = 0; i <= TT; ++i) {
+      const size_t r = i < TT ? row0 + (size_t)i * a.N : cls_row;
+      q[i] = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + col);
+      go[i] = *reinterpret_cast<const bf16x8*>(a.dout + r * a.lddo + col);
+    }
+#pragma unroll
+    for (int j = 0; j <= TT; ++j) {
+      const size_t r = j < TT ? row0 + (size_t)j * a.N : cls_row;
+      const bf16x8 kk = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + a.D + col);
+      const bf16x8 vv = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + 2 * a.D + col);
+      float dk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int i = 0; i <= TT; ++i) {
+        float p = exp2f(red8(dot8(q[i], kk)) * c2 - lse2[i]);
+        if (i == TT && j == TT && n != 0) p = 0.f;
+        const float ds = p * (red8(dot8(go[i], vv)) - delta[i]) * a.scale;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { dk[e] += ds * bf2f(q[i][e]); dv[e] += p * bf2f(go[i][e]); }
+      }
+      if (j < TT) {
+        if (valid) {
+          const bf16x8 kb = {f2bf(dk[0]), f2bf(dk[1]), f2bf(dk[2]), f2bf(dk[3]), f2bf(dk[4]), f2bf(dk[5]), f2bf(dk[6]), f2bf(dk[7])};
+          const bf16x8 vb = {f2bf(dv[0]), f2bf(dv[1]), f2bf(dv[2]), f2bf(dv[3]), f2bf(dv[4]), f2bf(dv[5]), f2bf(dv[6]), f2bf(dv[7])};
+          *reinterpret_cast<bf16x8*>(a.dqkv + r * a.lddqkv + a.D + col) = kb;
+          *reinterpret_cast<bf16x8*>(a.dqkv + r * a.lddqkv + 2 * a.D + col) = vb;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float tk = valid ? dk[e] : 0.f, tv = valid ? dv[e] : 0.f;
+          tk += __shfl_xor(tk, 8, 64); tk += __shfl_xor(tk, 16, 64); tk += __shfl_xor(tk, 32, 64);
+          tv += __shfl_xor(tv, 8, 64); tv += __shfl_xor(tv, 16, 64); tv += __shfl_xor(tv, 32, 64);
+          if (lane < 8) { atomicAdd(side + 64 + pl * 8 + e, tk); atomicAdd(side + 128 + pl * 8 + e, tv); }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- CLS query over all keys
+// one workgroup per (b,h): 32 groups of 8 lanes stride over the 1 + T*N keys with an online
+// softmax each, then merge through LDS.  Writes out[cls row] and lse[cls row].
+__global__ __launch_bounds__(256) void attn_cls_fwd_kernel(TimeArgs a) {
+  __shared__ float sm[32], sl[32], so[32][64];
+  const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+  const int grp = threadIdx.x >> 3, pl = threadIdx.x & 7;
+  const int S1 = a.T * a.N;                       // patch keys; key S1 = CLS
+  const size_t cls_row = (size_t)a.B * S1 + b;
+  const size_t row0 = (size_t)b * S1;
+  const int col = h * 64 + pl * 8;
+  const bf16x8 q = *reinterpret_cast<const bf16x8*>(a.qkv + cls_row * a.ldqkv + col);
+  const float c2 = a.scale * T_LOG2E;
+  float m = -INFINITY, l = 0.f, o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int j = grp; j <= S1; j += 32) {
+    const size_t r = j < S1 ? row0 + j : cls_row;
+    const bf16x8 kk = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + a.D + col);
+    const bf16x8 vv = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + 2 * a.D + col);
+    const float s = red8(dot8(q, kk)) * c2;
+    const float mn = fmaxf(m, s);
+    const float alpha = exp2f(m - mn), p = exp2f(s - mn);
+    l = l * alpha + p;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = o[e] * alpha + p * bf2f(vv[e]);
+    m = mn;
+  }
+  if (pl == 0) { sm[grp] = m; sl[grp] = l; }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) so[grp][pl * 8 + e] = o[e];
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float mm = -INFINITY;
+    for (int gq = 0; gq < 32; ++gq) mm = fmaxf(mm, sm[gq]);
+    float ll = 0.f, acc = 0.f;
+    for (int gq = 0; gq < 32; ++gq) {
+      const float w = exp2f(sm[gq] - mm);          // groups that saw no key have m = -inf -> w = 0
+      ll += sl[gq] * w;
+      acc += so[gq][threadIdx.x] * w;
+    }
+    a.out[cls_row * a.ldo + h * 64 + threadIdx.x] = f2bf(acc / ll);
+    if (threadIdx.x == 0) a.lse[cls_row * a.H + h] = (mm + log2f(ll)) * T_LN2;
+  }
+}
+
+}  // namespace oat
+
+using namespace oat;
+
+#define OAT_TIME_DISPATCH(KERNEL)                                                                     \
+  switch (T) {                                                                                        \
+    case 1: hipLaunchKernelGGL(KERNEL<1>, dim3(blocks), dim3(256), 0, s, a); break;                   \
+    case 2: hipLaunchKernelGGL(KERNEL<2>, dim3(blocks), dim3(256), 0, s, a); break;                   \
+    case 3: hipLaunchKernelGGL(KERNEL<3>, dim3(blocks), dim3(256), 0, s, a); break;                   \
+    case 4: hipLaunchKernelGGL(KERNEL<4>, dim3(blocks), dim3(256), 0, s, a); break;                   \
+    case 8: hipLaunchKernelGGL(KERNEL<8>, dim3(blocks), dim3(256), 0, s, a); break;                   \
+    case 16: hipLaunchKernelGGL(KERNEL<16>, dim3(blocks), dim3(256), 0, s, a); break;                 \
+    default: set_error("attn_time: supported frame counts are 1,2,3,4,8,16"); return -3;              \
+  }
+
+extern "C" int oat_attn_time_fwd(const void* qkv, int ldqkv, void* out, int ldo, float* lse, int B, int T, int N,
+                                 int H, int D, float scale, void* stream) {
+  if (D != H * 64) { set_error("attn_time: head_dim must be 64"); return -3; }
+  TimeArgs a{(const bf16*)qkv, ldqkv, (bf16*)out, ldo, lse, nullptr, 0, nullptr, 0, nullptr, B, T, N, H, D, scale};
+  hipStream_t s = (hipStream_t)stream;
+  const int waves = B * H * ((N + 7) / 8);
+  const int blocks = (waves + 3) / 4;
+  OAT_TIME_DISPATCH(attn_time_fwd_kernel)
+  return check_launch("attn_time_fwd");
+}
+
+extern "C" int oat_attn_time_bwd(const void* qkv, int ldqkv, const void* out, int ldo, const float* lse,
+                                 const void* dout, int lddo, void* dqkv, int lddqkv, float* cls_side, int B, int T,
+                                 int N, int H, int D, float scale, void* stream) {
+  if (D != H * 64) { set_error("attn_time: head_dim must be 64"); return -3; }
+  TimeArgs a{(const bf16*)qkv, ldqkv, (bf16*)out, ldo, (float*)lse, (const bf16*)dout, lddo, (bf16*)dqkv, lddqkv,
+             cls_side, B, T, N, H, D, scale};
+  hipStream_t s = (hipStream_t)stream;
+  const int waves = B * H * ((N + 7) / 8);
+  const int blocks = (waves + 3) / 4;
+  OAT_TIME_DISPATCH(attn_time_bwd_kernel)
+  return check_launch("attn_time_bwd");
+}
+
+extern "C" int oat_attn_cls_fwd(const void* qkv, int ldqkv, void* out, int ldo, float* lse, int B, int T, int N, int H,
+                                int D, float scale, void* stream) {
+  if (D != H * 64) { set_error("attn_cls: head_dim must be 64"); return -3; }
+  TimeArgs a{(const bf16*)qkv, ldqkv, (bf16*)out, ldo, lse, nullptr, 0, nullptr, 0, nullptr, B, T, N, H, D, scale};
+  hipLaunchKernelGGL(attn_cls_fwd_kernel, dim3(B * H), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("attn_cls_fwd");
+}

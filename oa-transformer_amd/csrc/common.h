@@ -1,0 +1,69 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of liboatrans_hip.so.
+// Wave = 64 lanes; MFMA 16x16x32 bf16 fragments:
+//   A operand: lane l holds A[row = l & 15][k = (l >> 4) * 8 .. +8]   (8 contiguous bf16 = 16 B)
+//   B operand: lane l holds B[k = (l >> 4) * 8 .. +8][col = l & 15]
+//   C/D      : lane l holds D[row = (l >> 4) * 4 + r][col = l & 15], r = 0..3
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+#define OAT_DEV __device__ __forceinline__
+
+namespace oat {
+
+void set_error(const char* msg);     // defined in capi.hip; thread-local message
+int check_launch(const char* what);  // hipGetLastError -> error code
+
+OAT_DEV float bf2f(bf16 v) { return static_cast<float>(v); }
+OAT_DEV bf16 f2bf(float v) { return static_cast<bf16>(v); }
+
+OAT_DEV float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+OAT_DEV float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below bf16 resolution).
+OAT_DEV float erf_as(float x) {
+  const float ax = fabsf(x);
+  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+  float p = 1.061405429f;
+  p = p * t - 1.453152027f;
+  p = p * t + 1.421413741f;
+  p = p * t - 0.284496736f;
+  p = p * t + 0.254829592f;
+  const float y = 1.0f - p * t * __expf(-ax * ax);
+  return copysignf(y, x);
+}
+// exact-erf GELU (reference: nn.GELU default, video_transformer.py:37)
+OAT_DEV float gelu_f(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118f)); }
+OAT_DEV float dgelu_f(float x) {
+  const float cdf = 0.5f * (1.0f + erf_as(x * 0.70710678118f));
+  return cdf + x * 0.3989422804f * __expf(-0.5f * x * x);
+}
+
+// 16-byte async global -> LDS copy: lane i's 16 B land at lds_base + 16 * i.
+OAT_DEV void glds16(const void* gptr, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// LDS transpose read: within each 16-lane group, lane s fetches 4 contiguous bf16 at its own
+// address; output lane i, element j = fetched[lane 4*j + (i >> 2)][i & 3].
+OAT_DEV s16x4 lds_tr16(const void* lds_ptr) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)lds_ptr);
+}
+
+}  // namespace oat

@@ -1,0 +1,367 @@
+// HBM-bound row kernels: LayerNorm fwd/bwd, column reductions, im2col, positional tables.
+// One wave (64 lanes) owns one token row; lanes read float4 (16 B) so a wave instruction
+// moves 1 KiB contiguous.  All statistics and reductions are fp32.
+//
+// Reference ops replaced (all /root/reference/OATrans/model/video_transformer.py):
+//   norm1/norm2/norm3/norm   :164,167,174,346  (nn.LayerNorm eps=1e-6, :228)
+//   VideoPatchEmbed conv     :69-75            (im2col feeding the patch GEMM)
+//   cls/pos/temporal tables  :313-324
+#include "common.h"
+
+namespace oat {
+
+constexpr int LN_MAXV = 4;   // up to 4 float4 per lane -> D <= 1024
+
+// ------------------------------------------------------------------ LayerNorm forward
+// y = (x - mean) * rstd * gamma + beta ; writes bf16 y (GEMM operand) and optionally fp32 y32.
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int ldx,
+                                                     const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, bf16* y, int ldy,
+                                                     float* y32, int ldy32, float* mean, float* rstd,
+                                                     int M, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    const float* xr = x + (size_t)row * ldx;
+    f32x4 v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < D) {
+        v[i] = *reinterpret_cast<const f32x4*>(xr + c);
+        s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+      }
+    }
+    const float mu = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < D) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mu; q += d * d; }
+      }
+    }
+    const float rs = rsqrtf(wave_sum(q) / D + eps);
+    if (lane == 0 && mean) { mean[row] = mu; rstd[row] = rs; }
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < D) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mu) * rs * g[e] + b[e];
+        if (y) {
+          bf16x4 ob = {f2bf(o[0]), f2bf(o[1]), f2bf(o[2]), f2bf(o[3])};
+          *reinterpret_cast<bf16x4*>(y + (size_t)row * ldy + c) = ob;
+        }
+        if (y32) *reinterpret_cast<f32x4*>(y32 + (size_t)row * ldy32 + c) = o;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ LayerNorm backward
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
+// out fp32 dx (+ optional fp32 addend `dres`), optional bf16 copy; per-block partial
+// (dgamma, dbeta) sums go to part[blockIdx][2][D] and are finished by reduce_partials.
+template <bool DY_BF16>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* dy_, int lddy, const float* __restrict__ x,
+                                                     int ldx, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma, const float* dres,
+                                                     int lddres, float* dx, int lddx, bf16* dx16, int lddx16,
+                                                     float* part, int M, int D) {
+  __shared__ float red[4][2][LN_MAXV * 256];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  f32x4 ag[LN_MAXV], ab[LN_MAXV];
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) { ag[i] = f32x4{0, 0, 0, 0}; ab[i] = f32x4{0, 0, 0, 0}; }
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    const float mu = mean[row], rs = rstd[row];
+    f32x4 xh[LN_MAXV], g[LN_MAXV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < D) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)row * ldx + c);
+        f32x4 dyv;
+        if constexpr (DY_BF16) {
+          const bf16x4 t = *reinterpret_cast<const bf16x4*>((const bf16*)dy_ + (size_t)row * lddy + c);
+          dyv = f32x4{bf2f(t[0]), bf2f(t[1]), bf2f(t[2]), bf2f(t[3])};
+        } else {
+          dyv = *reinterpret_cast<const f32x4*>((const float*)dy_ + (size_t)row * lddy + c);
+        }
+        const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          xh[i][e] = (xv[e] - mu) * rs;
+          g[i][e] = dyv[e] * gm[e];
+          s1 += g[i][e];
+          s2 += g[i][e] * xh[i][e];
+          ag[i][e] += dyv[e] * xh[i][e];
+          ab[i][e] += dyv[e];
+        }
+      }
+    }
+    const float c1 = wave_sum(s1) / D, c2 = wave_sum(s2) / D;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < D) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = rs * (g[i][e] - c1 - xh[i][e] * c2);
+        if (dres) o += *reinterpret_cast<const f32x4*>(dres + (size_t)row * lddres + c);
+        if (dx) *reinterpret_cast<f32x4*>(dx + (size_t)row * lddx + c) = o;
+        if (dx16) {
+          bf16x4 ob = {f2bf(o[0]), f2bf(o[1]), f2bf(o[2]), f2bf(o[3])};
+          *reinterpret_cast<bf16x4*>(dx16 + (size_t)row * lddx16 + c) = ob;
+        }
+      }
+    }
+  }
+  if (!part) return;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[wave][0][c + e] = ag[i][e]; red[wave][1][c + e] = ab[i][e]; }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += 256) {
+    part[((size_t)blockIdx.x * 2 + 0) * D + c] = red[0][0][c] + red[1][0][c] + red[2][0][c] + red[3][0][c];
+    part[((size_t)blockIdx.x * 2 + 1) * D + c] = red[0][1][c] + red[1][1][c] + red[2][1][c] + red[3][1][c];
+  }
+}
+
+// out[c] (+)= sum_p part[p * stride + c]
+__global__ void reduce_partials_kernel(const float* part, int P, size_t stride, float* out, int n, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  float s = 0.f;
+  for (int p = 0; p < P; ++p) s += part[(size_t)p * stride + c];
+  out[c] = accumulate ? out[c] + s : s;
+}
+
+// ------------------------------------------------------------------ column sums (bias grads)
+// part[blockIdx.y][c] = sum over this block's rows of A[r][c]; block = 32 column-groups x 8 rows
+template <bool IN_BF16>
+__global__ __launch_bounds__(256) void colsum_kernel(const void* A_, int lda, int M, int N, float* part) {
+  __shared__ float red[8][256];
+  const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = (blockIdx.x * 32 + cg) * 8;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (c < N) {
+    for (int r = blockIdx.y * 8 + rl; r < M; r += gridDim.y * 8) {
+      if constexpr (IN_BF16) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>((const bf16*)A_ + (size_t)r * lda + c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += bf2f(v[e]);
+      } else {
+        const float* p = (const float*)A_ + (size_t)r * lda + c;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(p), v1 = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc[e] += v0[e]; acc[4 + e] += v1[e]; }
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[rl][cg * 8 + e] = acc[e];
+  __syncthreads();
+  const int cc = blockIdx.x * 256 + threadIdx.x;
+  if (cc < N) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) s += red[r][threadIdx.x];
+    part[(size_t)blockIdx.y * N + cc] = s;
+  }
+}
+
+// ------------------------------------------------------------------ periodic row sum
+// out[p][:] = sum_r in[(r * P + p)][:]   (fp32, row length D; used for pos/temporal grads)
+__global__ void periodic_rowsum_kernel(const float* in, int ld, int R, int P, int D, float* out, int accumulate) {
+  const int p = blockIdx.x;
+  for (int c = threadIdx.x * 4; c < D; c += blockDim.x * 4) {
+    f32x4 s = {0, 0, 0, 0};
+    for (int r = 0; r < R; ++r) s += *reinterpret_cast<const f32x4*>(in + (size_t)(r * P + p) * ld + c);
+    f32x4* o = reinterpret_cast<f32x4*>(out + (size_t)p * D + c);
+    *o = accumulate ? *o + s : s;
+  }
+}
+// out[g][:] = sum_r in[(g * R + r)][:]
+__global__ void grouped_rowsum_kernel(const float* in, int ld, int G, int R, int D, float* out, int accumulate) {
+  const int g = blockIdx.x;
+  for (int c = threadIdx.x * 4; c < D; c += blockDim.x * 4) {
+    f32x4 s = {0, 0, 0, 0};
+    for (int r = 0; r < R; ++r) s += *reinterpret_cast<const f32x4*>(in + (size_t)(g * R + r) * ld + c);
+    f32x4* o = reinterpret_cast<f32x4*>(out + (size_t)g * D + c);
+    *o = accumulate ? *o + s : s;
+  }
+}
+
+// ------------------------------------------------------------------ patch gather (im2col)
+// video [BT, C, R, R] (fp32 or bf16) -> A [BT * g * g, C * ps * ps] bf16, k = (c, i, j)
+template <bool IN_BF16>
+__global__ void im2col_kernel(const void* video, bf16* A, int BT, int C, int R, int ps, int lda) {
+  const int g = R / ps;
+  const int Kp = C * ps * ps;
+  const int k8n = Kp / 8;
+  const size_t total = (size_t)BT * g * g * k8n;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+    const int k = (int)(t % k8n) * 8;
+    const size_t row = t / k8n;
+    const int gx = (int)(row % g), gy = (int)((row / g) % g);
+    const size_t bt = row / ((size_t)g * g);
+    const int c = k / (ps * ps), i = (k / ps) % ps, j = k % ps;
+    const size_t src = ((bt * C + c) * R + (size_t)gy * ps + i) * R + (size_t)gx * ps + j;
+    bf16x8 o;
+    if constexpr (IN_BF16) {
+      o = *reinterpret_cast<const bf16x8*>((const bf16*)video + src);
+    } else {
+      const float* p = (const float*)video + src;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+      o = bf16x8{f2bf(a[0]), f2bf(a[1]), f2bf(a[2]), f2bf(a[3]), f2bf(b[0]), f2bf(b[1]), f2bf(b[2]), f2bf(b[3])};
+    }
+    *reinterpret_cast<bf16x8*>(A + row * lda + k) = o;
+  }
+}
+
+// table[f * N + n][:] = pos[1 + n][:] + temporal[f][:] ; cls0[:] = cls_token[:] + pos[0][:]
+__global__ void pos_table_kernel(const float* pos, const float* temporal, const float* cls_token, float* table,
+                                 float* cls0, int T, int N, int D) {
+  const int r = blockIdx.x;
+  for (int c = threadIdx.x; c < D; c += blockDim.x) {
+    if (r < T * N) table[(size_t)r * D + c] = pos[(size_t)(1 + r % N) * D + c] + temporal[(size_t)(r / N) * D + c];
+    else cls0[c] = cls_token[c] + pos[c];
+  }
+}
+// dst[r][:] = src[:]  for r in [0, R)
+__global__ void broadcast_rows_kernel(const float* src, float* dst, int ld, int R, int D) {
+  const int r = blockIdx.x;
+  for (int c = threadIdx.x; c < D; c += blockDim.x) dst[(size_t)r * ld + c] = src[c];
+}
+
+// fp32 -> bf16 cast with optional transposed copy: dst[r][c] = src[r][c]; dstT[c][r] = src[r][c]
+__global__ void cast_bf16_kernel(const float* src, bf16* dst, bf16* dstT, int R, int C) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    float v = 0.f;
+    if (r < R && c < C) { v = src[(size_t)r * C + c]; if (dst) dst[(size_t)r * C + c] = f2bf(v); }
+    tile[i][tx] = v;
+  }
+  if (!dstT) return;
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + tx;
+    if (r < R && c < C) dstT[(size_t)c * R + r] = f2bf(tile[tx][i]);
+  }
+}
+
+}  // namespace oat
+
+using namespace oat;
+
+extern "C" int oat_layernorm_fwd(const float* x, int ldx, const float* gamma, const float* beta, void* y,
+                                 int ldy, float* y32, int ldy32, float* mean, float* rstd, int M, int D,
+                                 float eps, void* stream) {
+  if (M <= 0) return 0;
+  if (D % 4 || D > LN_MAXV * 256 || ldx % 4 || (y && ldy % 4)) { set_error("layernorm_fwd: D%4==0, D<=1024 required"); return -3; }
+  int blocks = (M + 3) / 4; if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta,
+                     (bf16*)y, ldy, y32, ldy32, mean, rstd, M, D, eps);
+  return check_launch("layernorm_fwd");
+}
+
+extern "C" int oat_ln_bwd_blocks(int M) { int b = (M + 3) / 4; return b > 512 ? 512 : b; }
+
+// part: fp32 workspace of oat_ln_bwd_blocks(M) * 2 * D floats (or NULL to skip dgamma/dbeta)
+extern "C" int oat_layernorm_bwd(const void* dy, int dy_is_bf16, int lddy, const float* x, int ldx,
+                                 const float* mean, const float* rstd, const float* gamma, const float* dres,
+                                 int lddres, float* dx, int lddx, void* dx16, int lddx16, float* dgamma,
+                                 float* dbeta, int accumulate, float* part, int M, int D, void* stream) {
+  if (M <= 0) return 0;
+  if (D % 4 || D > LN_MAXV * 256) { set_error("layernorm_bwd: D%4==0, D<=1024 required"); return -3; }
+  if ((dgamma || dbeta) && !part) { set_error("layernorm_bwd: dgamma/dbeta need the partial workspace"); return -4; }
+  const int blocks = oat_ln_bwd_blocks(M);
+  hipStream_t s = (hipStream_t)stream;
+  if (dy_is_bf16)
+    hipLaunchKernelGGL(ln_bwd_kernel<true>, dim3(blocks), dim3(256), 0, s, dy, lddy, x, ldx, mean, rstd, gamma, dres,
+                       lddres, dx, lddx, (bf16*)dx16, lddx16, part, M, D);
+  else
+    hipLaunchKernelGGL(ln_bwd_kernel<false>, dim3(blocks), dim3(256), 0, s, dy, lddy, x, ldx, mean, rstd, gamma, dres,
+                       lddres, dx, lddx, (bf16*)dx16, lddx16, part, M, D);
+  int rc = check_launch("layernorm_bwd");
+  if (rc || !part) return rc;
+  if (dgamma) hipLaunchKernelGGL(reduce_partials_kernel, dim3((D + 255) / 256), dim3(256), 0, s, part, blocks,
+                                 (size_t)2 * D, dgamma, D, accumulate);
+  if (dbeta) hipLaunchKernelGGL(reduce_partials_kernel, dim3((D + 255) / 256), dim3(256), 0, s, part + D, blocks,
+                                (size_t)2 * D, dbeta, D, accumulate);
+  return check_launch("layernorm_bwd_finish");
+}
+
+extern "C" int oat_colsum_rows(int M) { int r = (M + 7) / 8; return r > 256 ? 256 : (r < 1 ? 1 : r); }
+
+// out[N] (+)= column sums of A[M,N]; part = workspace of oat_colsum_rows(M) * N floats
+extern "C" int oat_colsum(const void* A, int is_bf16, int lda, int M, int N, float* out, int accumulate,
+                          float* part, void* stream) {
+  if (M <= 0 || N <= 0) return 0;
+  if (N % 8 || lda % 8) { set_error("colsum: N%8, lda%8 required"); return -3; }
+  const int rows = oat_colsum_rows(M);
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((N + 255) / 256, rows);
+  if (is_bf16) hipLaunchKernelGGL(colsum_kernel<true>, grid, dim3(256), 0, s, A, lda, M, N, part);
+  else hipLaunchKernelGGL(colsum_kernel<false>, grid, dim3(256), 0, s, A, lda, M, N, part);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 255) / 256), dim3(256), 0, s, part, rows, (size_t)N, out, N,
+                     accumulate);
+  return check_launch("colsum");
+}
+
+extern "C" int oat_periodic_rowsum(const float* in, int ld, int R, int P, int D, float* out, int accumulate, void* stream) {
+  if (D % 4 || ld % 4) { set_error("periodic_rowsum: D%4 required"); return -3; }
+  if (P <= 0) return 0;
+  hipLaunchKernelGGL(periodic_rowsum_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, in, ld, R, P, D, out, accumulate);
+  return check_launch("periodic_rowsum");
+}
+extern "C" int oat_grouped_rowsum(const float* in, int ld, int G, int R, int D, float* out, int accumulate, void* stream) {
+  if (D % 4 || ld % 4) { set_error("grouped_rowsum: D%4 required"); return -3; }
+  if (G <= 0) return 0;
+  hipLaunchKernelGGL(grouped_rowsum_kernel, dim3(G), dim3(256), 0, (hipStream_t)stream, in, ld, G, R, D, out, accumulate);
+  return check_launch("grouped_rowsum");
+}
+
+extern "C" int oat_im2col(const void* video, int is_bf16, void* A, int BT, int C, int R, int ps, int lda, void* stream) {
+  if (ps % 8 || R % ps || lda % 8) { set_error("im2col: patch size must be a multiple of 8 and divide R"); return -3; }
+  const size_t total = (size_t)BT * (R / ps) * (R / ps) * (C * ps * ps / 8);
+  int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
+  hipStream_t s = (hipStream_t)stream;
+  if (is_bf16) hipLaunchKernelGGL(im2col_kernel<true>, dim3(blocks), dim3(256), 0, s, video, (bf16*)A, BT, C, R, ps, lda);
+  else hipLaunchKernelGGL(im2col_kernel<false>, dim3(blocks), dim3(256), 0, s, video, (bf16*)A, BT, C, R, ps, lda);
+  return check_launch("im2col");
+}
+
+extern "C" int oat_pos_table(const float* pos, const float* temporal, const float* cls_token, float* table,
+                             float* cls0, int T, int N, int D, void* stream) {
+  hipLaunchKernelGGL(pos_table_kernel, dim3(T * N + 1), dim3(256), 0, (hipStream_t)stream, pos, temporal, cls_token,
+                     table, cls0, T, N, D);
+  return check_launch("pos_table");
+}
+extern "C" int oat_broadcast_rows(const float* src, float* dst, int ld, int R, int D, void* stream) {
+  if (R <= 0) return 0;
+  hipLaunchKernelGGL(broadcast_rows_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, src, dst, ld, R, D);
+  return check_launch("broadcast_rows");
+}
+extern "C" int oat_cast_bf16(const float* src, void* dst, void* dstT, int R, int C, void* stream) {
+  if (R <= 0 || C <= 0) return 0;
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, (hipStream_t)stream, src,
+                     (bf16*)dst, (bf16*)dstT, R, C);
+  return check_launch("cast_bf16");
+}

@@ -1,0 +1,277 @@
+"""Per-kernel parity on a real MI355X: every C-ABI entry point of liboatrans_hip.so against
+fp32 torch math on the same (bf16-rounded) inputs.  Tolerances are written next to each check:
+outputs that the kernel stores as bf16 are compared at bf16 resolution (2^-8 relative)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _hip():
+    from OATrans.ops import hip
+    hip.lib()
+    return hip
+
+
+def rnd(*shape, scale=1.0, dtype=torch.float32, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(DEV).to(dtype)
+
+
+def close(a, b, atol, rtol, what=""):
+    a, b = a.float(), b.float()
+    err = (a - b).abs()
+    bound = atol + rtol * b.abs()
+    bad = err > bound
+    assert not bad.any(), f"{what}: max err {err.max().item():.4g}, {bad.sum().item()} / {bad.numel()} beyond tol"
+
+
+# ----------------------------------------------------------------------------- GEMM NT
+@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (1000, 768, 768), (130, 64, 64), (4, 128, 3072), (2049, 2304, 768)])
+def test_gemm_nt_bias_bf16(M, N, K):
+    hip = _hip()
+    A = rnd(M, K, dtype=torch.bfloat16, seed=1)
+    B = rnd(N, K, scale=K ** -0.5, dtype=torch.bfloat16, seed=2)
+    bias = rnd(N, seed=3)
+    out = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    hip.gemm_nt(A, B, M, N, K, hip.EPI_BF16, out, bias=bias)
+    ref = A.float() @ B.float().t() + bias
+    close(out, ref, atol=2e-2, rtol=1e-2, what="gemm_nt bf16")
+
+
+def test_gemm_nt_asymmetric_identity():
+    """A = I with an ASYMMETRIC B catches row/col swaps of the MFMA C layout."""
+    hip = _hip()
+    M = N = K = 128
+    A = torch.eye(M, K, device=DEV).to(torch.bfloat16)
+    B = (torch.arange(N, device=DEV)[:, None] * 2 + torch.arange(K, device=DEV)[None, :] * 0.25).to(torch.bfloat16)
+    out = torch.zeros(M, N, dtype=torch.float32, device=DEV)
+    hip.gemm_nt(A, B, M, N, K, hip.EPI_F32, out)
+    assert torch.equal(out, B.float().t().contiguous())
+
+
+def test_gemm_nt_f32_resid_mod_and_copy():
+    hip = _hip()
+    M, N, K, P = 700, 384, 192, 100
+    A = rnd(M, K, dtype=torch.bfloat16, seed=4)
+    B = rnd(N, K, scale=K ** -0.5, dtype=torch.bfloat16, seed=5)
+    bias = rnd(N, seed=6)
+    table = rnd(P, N, seed=7)
+    out = torch.zeros(M, N, device=DEV)
+    out2 = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    hip.gemm_nt(A, B, M, N, K, hip.EPI_F32_BF16, out, out2=out2, bias=bias, resid=table, resid_mod=P)
+    ref = A.float() @ B.float().t() + bias + table[torch.arange(M, device=DEV) % P]
+    close(out, ref, atol=2e-4, rtol=1e-4, what="f32 epilogue")
+    close(out2, ref, atol=2e-2, rtol=1e-2, what="bf16 copy")
+    # in-place residual (out aliases resid)
+    x = rnd(M, N, seed=8)
+    x0 = x.clone()
+    hip.gemm_nt(A, B, M, N, K, hip.EPI_F32, x, bias=bias, resid=x)
+    close(x, A.float() @ B.float().t() + bias + x0, atol=2e-4, rtol=1e-4, what="in-place residual")
+
+
+def test_gemm_nt_gelu_and_dgelu():
+    hip = _hip()
+    M, N, K = 515, 512, 128
+    A = rnd(M, K, dtype=torch.bfloat16, seed=9)
+    B = rnd(N, K, scale=K ** -0.5, dtype=torch.bfloat16, seed=10)
+    bias = rnd(N, seed=11)
+    h = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    g = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    hip.gemm_nt(A, B, M, N, K, hip.EPI_GELU_DUAL, h, out2=g, bias=bias)
+    href = A.float() @ B.float().t() + bias
+    close(h, href, atol=2e-2, rtol=1e-2, what="pre-activation")
+    close(g, torch.nn.functional.gelu(h.float()), atol=1e-2, rtol=1e-2, what="gelu(h)")
+    # dgelu epilogue: out = (A2 @ B2^T) * gelu'(h)
+    K2 = 256
+    A2 = rnd(M, K2, dtype=torch.bfloat16, seed=12)
+    B2 = rnd(N, K2, scale=K2 ** -0.5, dtype=torch.bfloat16, seed=13)
+    out = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    hip.gemm_nt(A2, B2, M, N, K2, hip.EPI_DGELU, out, aux=h)
+    hf = h.float().requires_grad_(True)
+    torch.nn.functional.gelu(hf).backward(A2.float() @ B2.float().t())
+    close(out, hf.grad, atol=2e-2, rtol=1.5e-2, what="dgelu")
+
+
+# ----------------------------------------------------------------------------- GEMM TN
+@pytest.mark.parametrize("M,N1,N2", [(1000, 256, 384), (64, 128, 128), (5000, 768, 768), (777, 64, 2304), (333, 3072, 128)])
+def test_gemm_tn(M, N1, N2):
+    hip = _hip()
+    Mp = (M + 255) // 256 * 256
+    P = torch.zeros(Mp, N1, dtype=torch.bfloat16, device=DEV)
+    Q = torch.zeros(Mp, N2, dtype=torch.bfloat16, device=DEV)
+    P[:M] = rnd(M, N1, dtype=torch.bfloat16, seed=14)
+    Q[:M] = rnd(M, N2, dtype=torch.bfloat16, seed=15)
+    out = torch.full((N1, N2), 7.0, device=DEV)
+    hip.gemm_tn(P, Q, M, N1, N2, out)
+    ref = P[:M].float().t() @ Q[:M].float()
+    close(out, ref, atol=2e-3 * math.sqrt(M), rtol=2e-3, what="gemm_tn")
+    hip.gemm_tn(P, Q, M, N1, N2, out, accumulate=True)
+    close(out, 2 * ref, atol=4e-3 * math.sqrt(M), rtol=2e-3, what="gemm_tn accumulate")
+
+
+def test_gemm_tn_asymmetric():
+    hip = _hip()
+    M, N1, N2 = 64, 128, 128
+    P = torch.zeros(256, N1, dtype=torch.bfloat16, device=DEV)
+    Q = torch.zeros(256, N2, dtype=torch.bfloat16, device=DEV)
+    P[:M, :M] = torch.eye(M, device=DEV).to(torch.bfloat16)           # P^T Q = Q rows in the first 64 rows
+    Q[:M] = (torch.arange(M, device=DEV)[:, None] * 2 + torch.arange(N2, device=DEV)[None, :] * 0.25).to(torch.bfloat16)
+    out = torch.zeros(N1, N2, device=DEV)
+    hip.gemm_tn(P, Q, M, N1, N2, out)
+    ref = P[:M].float().t() @ Q[:M].float()
+    assert torch.equal(out, ref)
+
+
+# ----------------------------------------------------------------------------- LayerNorm / reductions
+@pytest.mark.parametrize("M,D", [(1000, 768), (37, 128), (5, 1024)])
+def test_layernorm_fwd_bwd(M, D):
+    hip = _hip()
+    x = rnd(M, D, scale=2.0, seed=16) + 0.5
+    gamma = rnd(D, seed=17) * 0.1 + 1.0
+    beta = rnd(D, seed=18) * 0.1
+    y = torch.zeros(M, D, dtype=torch.bfloat16, device=DEV)
+    y32 = torch.zeros(M, D, device=DEV)
+    mean = torch.zeros(M, device=DEV)
+    rstd = torch.zeros(M, device=DEV)
+    hip.layernorm_fwd(x, gamma, beta, M, D, 1e-6, y=y, y32=y32, mean=mean, rstd=rstd)
+    xr = x.clone().requires_grad_(True)
+    gr = gamma.clone().requires_grad_(True)
+    br = beta.clone().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-6)
+    close(y32, ref, atol=2e-5, rtol=1e-5, what="ln fwd f32")
+    close(y, ref, atol=1e-2, rtol=1e-2, what="ln fwd bf16")
+    for dy_dtype in (torch.bfloat16, torch.float32):
+        dy = rnd(M, D, seed=19).to(dy_dtype)
+        dres = rnd(M, D, seed=20)
+        dx = torch.zeros(M, D, device=DEV)
+        dx16 = torch.zeros(M, D, dtype=torch.bfloat16, device=DEV)
+        dg = torch.zeros(D, device=DEV)
+        db = torch.zeros(D, device=DEV)
+        hip.layernorm_bwd(dy, x, mean, rstd, gamma, M, D, dx=dx, dx16=dx16, dres=dres, dgamma=dg, dbeta=db)
+        for t in (xr, gr, br):
+            t.grad = None
+        ref.backward(dy.float(), retain_graph=True)
+        close(dx, xr.grad + dres, atol=1e-4, rtol=1e-4, what="ln dx")
+        close(dx16, xr.grad + dres, atol=2e-2, rtol=1e-2, what="ln dx bf16")
+        close(dg, gr.grad, atol=2e-3, rtol=1e-3, what="ln dgamma")
+        close(db, br.grad, atol=2e-3, rtol=1e-3, what="ln dbeta")
+
+
+def test_reductions_and_misc():
+    hip = _hip()
+    M, N = 1003, 2304
+    A = rnd(M, N, dtype=torch.bfloat16, seed=21)
+    out = torch.zeros(N, device=DEV)
+    hip.colsum(A, M, N, out)
+    close(out, A.float().sum(0), atol=5e-3, rtol=1e-4, what="colsum bf16")
+    Af = rnd(M, 768, seed=22)
+    out = torch.ones(768, device=DEV)
+    hip.colsum(Af, M, 768, out, accumulate=True)
+    close(out, Af.sum(0) + 1, atol=5e-3, rtol=1e-4, what="colsum f32 accumulate")
+    R, P, D = 5, 27, 128
+    x = rnd(R * P, D, seed=23)
+    o = torch.zeros(P, D, device=DEV)
+    hip.periodic_rowsum(x, R, P, D, o)
+    close(o, x.view(R, P, D).sum(0), atol=1e-5, rtol=1e-5, what="periodic")
+    o2 = torch.zeros(R, D, device=DEV)
+    hip.grouped_rowsum(x, R, P, D, o2)
+    close(o2, x.view(R, P, D).sum(1), atol=1e-4, rtol=1e-5, what="grouped")
+    # cast + transpose
+    W = rnd(300, 130, seed=24)
+    w16 = torch.zeros(300, 130, dtype=torch.bfloat16, device=DEV)
+    wT = torch.zeros(130, 300, dtype=torch.bfloat16, device=DEV)
+    hip.cast_bf16(W, w16, wT)
+    assert torch.equal(w16, W.to(torch.bfloat16))
+    assert torch.equal(wT, W.to(torch.bfloat16).t().contiguous())
+
+
+@pytest.mark.parametrize("in_dtype", [torch.float32, torch.bfloat16])
+def test_im2col_and_pos_table(in_dtype):
+    hip = _hip()
+    BT, C, R, ps = 5, 3, 48, 16
+    g = R // ps
+    video = rnd(BT, C, R, R, seed=25).to(in_dtype)
+    A = torch.zeros(BT * g * g, C * ps * ps, dtype=torch.bfloat16, device=DEV)
+    hip.im2col(video, A, BT, C, R, ps)
+    ref = video.reshape(BT, C, g, ps, g, ps).permute(0, 2, 4, 1, 3, 5).reshape(BT * g * g, -1).to(torch.bfloat16)
+    assert torch.equal(A, ref)
+    T, N, D = 3, 9, 128
+    pos, tem, cls = rnd(N + 1, D, seed=26), rnd(T, D, seed=27), rnd(D, seed=28)
+    table = torch.zeros(T * N, D, device=DEV)
+    cls0 = torch.zeros(D, device=DEV)
+    hip.pos_table(pos, tem, cls, table, cls0, T, N, D)
+    assert torch.equal(table.view(T, N, D), pos[1:][None] + tem[:, None])
+    assert torch.equal(cls0, cls + pos[0])
+    dst = torch.zeros(4, D, device=DEV)
+    hip.broadcast_rows(cls0, dst, 4, D)
+    assert torch.equal(dst, cls0.expand(4, D))
+
+
+# ----------------------------------------------------------------------------- attention
+def rows_to_ref(x, B, T, N):
+    """engine rows (patch-major, CLS tail) -> reference token order [B, 1+T*N, C]"""
+    C = x.shape[1]
+    return torch.cat([x[B * T * N:B * T * N + B].view(B, 1, C), x[:B * T * N].view(B, T * N, C)], dim=1)
+
+
+def ref_to_rows(y, B, T, N):
+    return torch.cat([y[:, 1:].reshape(B * T * N, -1), y[:, 0]], dim=0)
+
+
+def ref_attention(qkv_ref, mode, B, T, N, H):
+    """fp32 restatement of VarAttention's attention part on [B,S,3D] (see oracle.divided_attention)."""
+    S = 1 + T * N
+    D = qkv_ref.shape[-1] // 3
+    d = D // H
+    qkv = qkv_ref.reshape(B, S, 3, H, d).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0] * d ** -0.5, qkv[1], qkv[2]
+    sm = lambda q_, k_, v_: torch.softmax(q_ @ k_.transpose(-1, -2), -1) @ v_
+    cls_out = sm(q[:, :, :1], k, v)
+    qp, kp, vp = (t[:, :, 1:].reshape(B, H, T, N, d) for t in (q, k, v))
+    ck, cv = k[:, :, :1].unsqueeze(2), v[:, :, :1].unsqueeze(2)
+    if mode == "space":
+        out = sm(qp, torch.cat([ck.expand(B, H, T, 1, d), kp], 3), torch.cat([cv.expand(B, H, T, 1, d), vp], 3))
+    else:
+        qt, kt, vt = (t.transpose(2, 3) for t in (qp, kp, vp))
+        out = sm(qt, torch.cat([ck.expand(B, H, N, 1, d), kt], 3), torch.cat([cv.expand(B, H, N, 1, d), vt], 3)).transpose(2, 3)
+    out = torch.cat([cls_out, out.reshape(B, H, T * N, d)], 2)
+    return out.permute(0, 2, 1, 3).reshape(B, S, D)
+
+
+@pytest.mark.parametrize("mode", ["space", "time"])
+@pytest.mark.parametrize("B,T,N,H", [(2, 3, 9, 2), (2, 2, 9, 2), (1, 1, 4, 1), (2, 8, 196, 12), (1, 4, 196, 12)])
+def test_attention_fwd_bwd(mode, B, T, N, H):
+    hip = _hip()
+    D = H * 64
+    M = B * T * N + B
+    Mp = (M + 255) // 256 * 256
+    qkv = torch.zeros(Mp, 3 * D, dtype=torch.bfloat16, device=DEV)
+    qkv[:M] = rnd(M, 3 * D, scale=1.5, dtype=torch.bfloat16, seed=30)
+    out = torch.zeros(Mp, D, dtype=torch.bfloat16, device=DEV)
+    lse = torch.zeros(Mp, H, device=DEV)
+    scale = 64 ** -0.5
+    fwd = hip.attn_space_fwd if mode == "space" else hip.attn_time_fwd
+    bwd = hip.attn_space_bwd if mode == "space" else hip.attn_time_bwd
+    fwd(qkv, out, lse, B, T, N, H, D, scale)
+    hip.attn_cls_fwd(qkv, out, lse, B, T, N, H, D, scale)
+    qr = rows_to_ref(qkv[:M].float(), B, T, N).requires_grad_(True)
+    ref = ref_attention(qr, mode, B, T, N, H)
+    close(out[:M], ref_to_rows(ref, B, T, N), atol=2e-2, rtol=2e-2, what=f"{mode} attention fwd")
+    assert torch.count_nonzero(out[M:]) == 0
+    # backward
+    dout = torch.zeros(Mp, D, dtype=torch.bfloat16, device=DEV)
+    dout[:M] = rnd(M, D, dtype=torch.bfloat16, seed=31)
+    dqkv = torch.zeros(Mp, 3 * D, dtype=torch.bfloat16, device=DEV)
+    side = torch.zeros(B, H, 3, 64, device=DEV)
+    bwd(qkv, out, lse, dout, dqkv, side, B, T, N, H, D, scale)
+    hip.attn_cls_finalize(side, dqkv, B, T, N, H, D)
+    ref.backward(rows_to_ref(dout[:M].float(), B, T, N))
+    gref = ref_to_rows(qr.grad, B, T, N)
+    gs = gref.abs().max().item()
+    close(dqkv[:M], gref, atol=2e-2 * gs, rtol=3e-2, what=f"{mode} attention bwd")
+    assert torch.count_nonzero(dqkv[M:]) == 0
