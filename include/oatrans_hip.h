@@ -36,7 +36,7 @@ int oat_gemm_nt(const void* A, const void* B, int M, int N, int K, int lda, int 
                 int ldr, int resid_mod, const void* aux, int ldaux, void* stream);
 
 /* out[N1,N2] (fp32, (+)=) sum_m P[m,N1]^T Q[m,N2]  - weight gradients of every nn.Linear.
- * Rows [M, round_up(M,64)) of P must be readable and ZERO, of Q readable and finite. */
+ * Rows [M, round_up(M,64)) of P and Q must be readable (contents ignored). */
 size_t oat_gemm_tn_workspace_bytes(int M, int N1, int N2);
 int oat_gemm_tn(const void* P, const void* Q, int M, int N1, int N2, int ldp, int ldq, float* out,
                 int accumulate, void* workspace, size_t workspace_bytes, void* stream);
@@ -48,8 +48,9 @@ int oat_layernorm_fwd(const float* x, int ldx, const float* gamma, const float* 
 int oat_ln_bwd_blocks(int M);   /* partial workspace = blocks * 2 * D floats */
 int oat_layernorm_bwd(const void* dy, int dy_is_bf16, int lddy, const float* x, int ldx,
                       const float* mean, const float* rstd, const float* gamma, const float* dres,
-                      int lddres, float* dx, int lddx, void* dx_bf16, int lddx16, float* dgamma,
-                      float* dbeta, int accumulate, float* part, int M, int D, void* stream);
+                      int lddres, float* dx, int lddx, void* dx_bf16, int lddx16, int dx16_excl_res,
+                      float* dgamma, float* dbeta, int accumulate, float* part, int M, int D, void* stream);
+/* dx = LNbwd(dy) + dres ; dx_bf16 = bf16(dx) or, with dx16_excl_res, bf16(LNbwd(dy)) only. */
 
 /* ---- reductions (bias / positional-table gradients) ------------------------------------- */
 int oat_colsum_rows(int M);     /* partial workspace = rows * N floats */

@@ -1,0 +1,192 @@
+"""SpaceTimeTransformer - host-side mirror of the reference class, executed by HIP kernels.
+
+Same constructor signature, parameter names and return convention as
+/root/reference/OATrans/model/video_transformer.py:179-357 so that reference checkpoints load
+(`blocks.{i}.{norm1,norm2,norm3,attn.qkv,attn.proj,timeattn.qkv,timeattn.proj,mlp.fc1,mlp.fc2}`,
+`cls_token`, `pos_embed`, `temporal_embed`, `patch_embed.proj`, `norm`).  The nn.Module tree
+below only *holds parameters*; forward/backward are the launch schedules of
+OATrans.engine.video.VideoEngine.  There is no eager fallback: without liboatrans_hip.so or
+off-GPU the forward raises.
+"""
+from functools import partial
+
+import torch
+from torch import nn
+
+from ..engine.video import VideoEngine
+from ..ops import hip
+
+
+def _trunc_normal_(t, std):
+    return nn.init.trunc_normal_(t, std=std, a=-2.0, b=2.0)
+
+
+class _Mlp(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.fc2 = nn.Linear(hidden, dim)
+
+
+class _VarAttention(nn.Module):
+    """Parameter holder for VarAttention (reference :79-97), incl. the 'zeros' time init that sets
+    qkv to 0 and proj.weight to ONE (:89-95)."""
+
+    def __init__(self, dim, qkv_bias, initialize):
+        super().__init__()
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+        if initialize == "zeros":
+            self.qkv.weight.data.fill_(0)
+            self.qkv.bias.data.fill_(0)
+            self.proj.weight.data.fill_(1)
+            self.proj.bias.data.fill_(0)
+
+
+class _Block(nn.Module):
+    def __init__(self, dim, mlp_ratio, qkv_bias, norm_layer, time_init):
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.attn = _VarAttention(dim, qkv_bias, "random")
+        self.timeattn = _VarAttention(dim, qkv_bias, time_init)
+        self.norm2 = norm_layer(dim)
+        self.mlp = _Mlp(dim, int(dim * mlp_ratio))
+        self.norm3 = norm_layer(dim)
+
+
+class _PatchEmbed(nn.Module):
+    def __init__(self, img_size, patch_size, in_chans, embed_dim, num_frames):
+        super().__init__()
+        self.img_size = (img_size, img_size) if isinstance(img_size, int) else tuple(img_size)
+        self.patch_size = (patch_size, patch_size) if isinstance(patch_size, int) else tuple(patch_size)
+        self.num_frames = num_frames
+        self.embed_dim = embed_dim
+        self.num_patches = (self.img_size[1] // self.patch_size[1]) * (self.img_size[0] // self.patch_size[0]) * num_frames
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=self.patch_size, stride=self.patch_size)
+
+
+class _EncoderFn(torch.autograd.Function):
+    """Bridges the explicit schedules into autograd.  Parameter gradients are written by the
+    kernels straight into persistent `.grad` buffers (overwrite semantics, one call per step),
+    so the function returns None for them."""
+
+    @staticmethod
+    def forward(ctx, module, video, need_patches, *params):
+        eng = module._engine
+        pd = module._param_data()
+        cls, patches, plan = eng.forward(video, pd, need_patches)
+        ctx.module, ctx.plan = module, plan
+        ctx.set_materialize_grads(False)
+        cls_out = cls.clone()
+        if need_patches:
+            B = video.shape[0]
+            return cls_out, patches.view(B, -1, patches.shape[-1])
+        return cls_out, None
+
+    @staticmethod
+    def backward(ctx, d_cls, d_patches):
+        module, plan = ctx.module, ctx.plan
+        D = module.embed_dim
+        if d_cls is None:
+            d_cls = torch.zeros(plan.B, D, device=plan.G.device)
+        if d_patches is not None:
+            d_patches = d_patches.reshape(-1, D).float()
+        module._engine.backward(plan, module._param_data(), module._grad_views(), d_cls.float(), d_patches)
+        return (None, None, None) + (None,) * module._n_params
+
+
+class SpaceTimeTransformer(nn.Module):
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=1000, embed_dim=768, depth=12,
+                 num_heads=12, mlp_ratio=4., qkv_bias=True, qk_scale=None, representation_size=None,
+                 drop_rate=0., attn_drop_rate=0., drop_path_rate=0., hybrid_backbone=None, norm_layer=None,
+                 num_frames=8, time_init='rand', attention_style='frozen-in-time'):
+        super().__init__()
+        if hybrid_backbone is not None:
+            raise NotImplementedError('hybrid backbone not implemented')
+        if attention_style != 'frozen-in-time':
+            raise NotImplementedError(attention_style)                       # reference :171-172
+        if drop_rate or attn_drop_rate or drop_path_rate:
+            raise NotImplementedError("dropout / stochastic depth are 0 in every shipped config")
+        if qk_scale is not None or not qkv_bias:
+            raise NotImplementedError("qk_scale / qkv_bias=False are unused by the shipped configs")
+        self.num_classes = num_classes
+        self.num_features = self.embed_dim = embed_dim
+        self.num_frames = num_frames
+        self.num_heads = num_heads
+        norm_layer = norm_layer or partial(nn.LayerNorm, eps=1e-6)
+        self.patch_embed = _PatchEmbed(img_size, patch_size, in_chans, embed_dim, num_frames)
+        self.patches_per_frame = self.patch_embed.num_patches // num_frames
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, self.patches_per_frame + 1, embed_dim))
+        self.temporal_embed = nn.Parameter(torch.zeros(1, num_frames, embed_dim))
+        self.blocks = nn.ModuleList([_Block(embed_dim, mlp_ratio, qkv_bias, norm_layer, time_init)
+                                     for _ in range(depth)])
+        self.norm = norm_layer(embed_dim)
+        if representation_size:
+            raise NotImplementedError("representation_size is unused on the hot path")
+        self.pre_logits = nn.Identity()
+        self.head = nn.Linear(self.num_features, num_classes) if num_classes > 0 else nn.Identity()
+        _trunc_normal_(self.pos_embed, .02)
+        _trunc_normal_(self.cls_token, .02)
+        if num_frames == 1:
+            self.apply(self._init_weights)
+        self.need_patch_tokens = True
+        self._engine = VideoEngine(depth, embed_dim, num_heads, mlp_ratio, self.patch_embed.patch_size[0], in_chans,
+                                   num_frames)
+        self._names = None
+        self._gradbuf = None
+
+    def _init_weights(self, m):
+        if isinstance(m, nn.Linear):
+            _trunc_normal_(m.weight, .02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return {'pos_embed', 'cls_token'}
+
+    # ------------------------------------------------------------------ engine plumbing
+    def _engine_params(self):
+        """(name, Parameter) pairs the encoder uses (the classifier head is not on the path)."""
+        if self._names is None:
+            self._names = [n for n, _ in self.named_parameters() if not n.startswith("head.")]
+            self._n_params = len(self._names)
+        d = dict(self.named_parameters())
+        return [(n, d[n]) for n in self._names]
+
+    def _param_data(self):
+        return {n: p.data for n, p in self._engine_params()}
+
+    def _grad_views(self):
+        """Persistent flat fp32 gradient buffer; each Parameter's .grad is a view of it."""
+        pairs = self._engine_params()
+        dev = pairs[0][1].device
+        total = sum(p.numel() for _, p in pairs)
+        if self._gradbuf is None or self._gradbuf.device != dev or self._gradbuf.numel() != total:
+            self._gradbuf = torch.zeros(total, dtype=torch.float32, device=dev)
+        views, off = {}, 0
+        for n, p in pairs:
+            v = self._gradbuf[off:off + p.numel()].view_as(p)
+            off += p.numel()
+            if p.requires_grad and (p.grad is None or p.grad.data_ptr() != v.data_ptr()):
+                p.grad = v
+            views[n] = v
+        return views
+
+    def forward_features(self, x, aug=False):
+        if not x.is_cuda:
+            raise hip.OatError("SpaceTimeTransformer runs on MI355X only (no CPU path); use the oracle for CPU")
+        hip.lib()
+        params = [p for _, p in self._engine_params()]
+        cls, patches = _EncoderFn.apply(self, x, bool(self.need_patch_tokens), *params)
+        return cls, patches
+
+    def forward(self, x, aug=False):
+        x = self.forward_features(x, aug=aug)
+        if isinstance(self.head, nn.Identity):
+            return x                      # oa_model.py:50 sets head = Identity -> tuple passes through
+        return self.head(x[0])

@@ -120,7 +120,7 @@ def _partials(device, n):
 
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, M, D, dx=None, dx16=None, dres=None, dgamma=None, dbeta=None,
-                  accumulate=False):
+                  accumulate=False, dx16_excl_res=False):
     part = None
     if dgamma is not None or dbeta is not None:
         part = _partials(x.device, lib().oat_ln_bwd_blocks(M) * 2 * D)
@@ -128,7 +128,8 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, M, D, dx=None, dx16=None, dres=None,
                                  _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(dres),
                                  dres.stride(0) if dres is not None else 0, _ptr(dx),
                                  dx.stride(0) if dx is not None else 0, _ptr(dx16),
-                                 dx16.stride(0) if dx16 is not None else 0, _ptr(dgamma), _ptr(dbeta),
+                                 dx16.stride(0) if dx16 is not None else 0, int(dx16_excl_res), _ptr(dgamma),
+                                 _ptr(dbeta),
                                  int(accumulate), _ptr(part), M, D, _stream())
     _check(rc, "oat_layernorm_bwd")
 

@@ -9,8 +9,8 @@
 // v1: 128x128 output tile, 64 rows of m per stage, 4 waves (2x2) x (4x4 MFMA 16x16x32),
 // global_load_lds staging (double-buffered 64 KB), split over m across grid.y with fp32
 // slabs + a deterministic reduce kernel (no atomics).
-// Contract: rows [M, round_up(M,64)) of P and Q must be readable; P's must be zero and Q's
-// finite (engine buffers are zero-initialised and kernels never write rows >= M).
+// Contract: rows [M, round_up(M,64)) of P and Q must be READABLE (inside the allocation); their
+// contents are ignored (the ragged tail of the last chunk is zeroed in LDS).
 #include "common.h"
 
 namespace oat {
@@ -79,8 +79,18 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs g) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (ch + 1 < ch1) stage((ch + 1 - ch0) & 1, ch + 1);
-    const char* sp = smem + ((ch - ch0) & 1) * TSTAGE;
-    const char* sq = sp + TK * 256;
+    char* sp = smem + ((ch - ch0) & 1) * TSTAGE;
+    char* sq = sp + TK * 256;
+    if (ch == nchunks_total - 1 && g.M - ch * TK < TK) {
+      // ragged tail: rows >= M of the last chunk must not contribute (they are readable, not zero)
+      const int valid = g.M - ch * TK;
+      for (int idx = tid; idx < (TK - valid) * 16; idx += 256) {
+        const int off = (valid + (idx >> 4)) * 256 + ((idx & 15) << 4);
+        *reinterpret_cast<f32x4*>(sp + off) = f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(sq + off) = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      __syncthreads();
+    }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 pf[4], qf[4];

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* dy_, int lddy, 
                                                      const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* dres,
                                                      int lddres, float* dx, int lddx, bf16* dx16, int lddx16,
-                                                     float* part, int M, int D) {
+                                                     int dx16_excl_res, float* part, int M, int D) {
   __shared__ float red[4][2][LN_MAXV * 256];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -117,10 +117,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* dy_, int lddy, 
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = rs * (g[i][e] - c1 - xh[i][e] * c2);
+        const f32x4 o_nores = o;
         if (dres) o += *reinterpret_cast<const f32x4*>(dres + (size_t)row * lddres + c);
         if (dx) *reinterpret_cast<f32x4*>(dx + (size_t)row * lddx + c) = o;
         if (dx16) {
-          bf16x4 ob = {f2bf(o[0]), f2bf(o[1]), f2bf(o[2]), f2bf(o[3])};
+          const f32x4 w = dx16_excl_res ? o_nores : o;
+          bf16x4 ob = {f2bf(w[0]), f2bf(w[1]), f2bf(w[2]), f2bf(w[3])};
           *reinterpret_cast<bf16x4*>(dx16 + (size_t)row * lddx16 + c) = ob;
         }
       }
@@ -286,8 +288,9 @@ extern "C" int oat_ln_bwd_blocks(int M) { int b = (M + 3) / 4; return b > 512 ? 
 // part: fp32 workspace of oat_ln_bwd_blocks(M) * 2 * D floats (or NULL to skip dgamma/dbeta)
 extern "C" int oat_layernorm_bwd(const void* dy, int dy_is_bf16, int lddy, const float* x, int ldx,
                                  const float* mean, const float* rstd, const float* gamma, const float* dres,
-                                 int lddres, float* dx, int lddx, void* dx16, int lddx16, float* dgamma,
-                                 float* dbeta, int accumulate, float* part, int M, int D, void* stream) {
+                                 int lddres, float* dx, int lddx, void* dx16, int lddx16, int dx16_excl_res,
+                                 float* dgamma, float* dbeta, int accumulate, float* part, int M, int D,
+                                 void* stream) {
   if (M <= 0) return 0;
   if (D % 4 || D > LN_MAXV * 256) { set_error("layernorm_bwd: D%4==0, D<=1024 required"); return -3; }
   if ((dgamma || dbeta) && !part) { set_error("layernorm_bwd: dgamma/dbeta need the partial workspace"); return -4; }
@@ -295,10 +298,10 @@ extern "C" int oat_layernorm_bwd(const void* dy, int dy_is_bf16, int lddy, const
   hipStream_t s = (hipStream_t)stream;
   if (dy_is_bf16)
     hipLaunchKernelGGL(ln_bwd_kernel<true>, dim3(blocks), dim3(256), 0, s, dy, lddy, x, ldx, mean, rstd, gamma, dres,
-                       lddres, dx, lddx, (bf16*)dx16, lddx16, part, M, D);
+                       lddres, dx, lddx, (bf16*)dx16, lddx16, dx16_excl_res, part, M, D);
   else
     hipLaunchKernelGGL(ln_bwd_kernel<false>, dim3(blocks), dim3(256), 0, s, dy, lddy, x, ldx, mean, rstd, gamma, dres,
-                       lddres, dx, lddx, (bf16*)dx16, lddx16, part, M, D);
+                       lddres, dx, lddx, (bf16*)dx16, lddx16, dx16_excl_res, part, M, D);
   int rc = check_launch("layernorm_bwd");
   if (rc || !part) return rc;
   if (dgamma) hipLaunchKernelGGL(reduce_partials_kernel, dim3((D + 255) / 256), dim3(256), 0, s, part, blocks,
