@@ -35,6 +35,9 @@ int oat_gemm_nt(const void* A, const void* B, int M, int N, int K, int lda, int 
                 void* out, int ldc, void* out2, int ld2, const float* bias, const float* resid,
                 int ldr, int resid_mod, const void* aux, int ldaux, void* stream);
 
+/* tuning hook: 0 = auto tile choice, 1 = force 128x128 (4 waves), 2 = force 256x256 (8 waves) */
+void oat_gemm_set_variant(int v);
+
 /* out[N1,N2] (fp32, (+)=) sum_m P[m,N1]^T Q[m,N2]  - weight gradients of every nn.Linear.
  * Rows [M, round_up(M,64)) of P and Q must be readable (contents ignored). */
 size_t oat_gemm_tn_workspace_bytes(int M, int N1, int N2);

@@ -80,6 +80,10 @@ def gemm_nt(A, B, M, N, K, epi, out, out2=None, bias=None, resid=None, resid_mod
     _check(rc, "oat_gemm_nt")
 
 
+def gemm_set_variant(v):
+    lib().oat_gemm_set_variant(int(v))
+
+
 _tn_ws = {}
 
 

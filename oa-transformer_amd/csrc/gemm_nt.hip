@@ -34,21 +34,26 @@ struct GemmArgs {
   const float* bias;
   const float* resid; int ldr; int resid_mod;
   const bf16* aux; int ldaux;
+  int dbg;
 };
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int STAGE_BYTES = (BM + BN) * BK * 2;   // 32 KB
+constexpr int BK = 64;
 
 // physical byte offset of logical 16B-chunk `lc` (0..7) of row r in a [rows][64 bf16] tile
 OAT_DEV int swz(int r, int lc) { return r * 128 + ((lc ^ ((r >> 1) & 7)) << 4); }
 
-template <int EPI>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
+// WM x WN waves, each owning TM x TN MFMA tiles of 16x16:  <2,2,4,4> = 128x128 / 4 waves,
+// <2,4,8,4> = 256x256 / 8 waves (one workgroup per CU, 128 KB LDS).
+template <int EPI, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
+  constexpr int BM = WM * TM * 16, BN = WN * TN * 16, NW = WM * WN;
+  constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
+  constexpr int GA = BM / 8 / NW, GB = BN / 8 / NW;       // glds instructions per wave per tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
 
   // XCD-aware tile order: consecutive ids on one XCD share the A row-panel (M-major walk of N).
   const int ntn = (g.N + BN - 1) / BN;
@@ -62,33 +67,35 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
   const int tm = bid / ntn, tn = bid % ntn;
   const int m0 = tm * BM, n0 = tn * BN;
 
-  // ---- staging addresses: wave w stages rows [w*32, w*32+32) of A and of B, 4 glds each
+  // ---- staging addresses: wave w stages GA (GB) slabs of 8 rows of A (B), one glds each
   const int srow = lane >> 3;                   // row within an 8-row slab
-  const bf16* a_src[4];
-  const bf16* b_src[4];
+  const bf16* a_src[GA];
+  const bf16* b_src[GB];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = wave * 32 + i * 8 + srow;
+  for (int i = 0; i < GA; ++i) {
+    const int r = (wave * GA + i) * 8 + srow;
     const int lc = (lane & 7) ^ ((r >> 1) & 7);            // inverse swizzle on the source side
-    const int ra = min(m0 + r, g.M - 1);                   // clamp: ragged M/N read a valid row
-    const int rb = min(n0 + r, g.N - 1);
-    a_src[i] = g.A + (size_t)ra * g.lda + lc * 8;
-    b_src[i] = g.B + (size_t)rb * g.ldb + lc * 8;
+    a_src[i] = g.A + (size_t)min(m0 + r, g.M - 1) * g.lda + lc * 8;   // clamp: ragged M reads a valid row
+  }
+#pragma unroll
+  for (int i = 0; i < GB; ++i) {
+    const int r = (wave * GB + i) * 8 + srow;
+    const int lc = (lane & 7) ^ ((r >> 1) & 7);
+    b_src[i] = g.B + (size_t)min(n0 + r, g.N - 1) * g.ldb + lc * 8;
   }
   auto stage = [&](int buf, int k0) {
     char* base = smem + buf * STAGE_BYTES;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      glds16(a_src[i] + k0, base + (wave * 32 + i * 8) * 128);
-      glds16(b_src[i] + k0, base + BM * 128 + (wave * 32 + i * 8) * 128);
-    }
+    for (int i = 0; i < GA; ++i) glds16(a_src[i] + k0, base + (wave * GA + i) * 8 * 128);
+#pragma unroll
+    for (int i = 0; i < GB; ++i) glds16(b_src[i] + k0, base + BM * 128 + (wave * GB + i) * 8 * 128);
   };
 
-  f32x4 acc[4][4];
+  f32x4 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = g.K / BK;
   stage(0, 0);
@@ -101,81 +108,140 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
     const char* sb = sa + BM * 128;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 af[4], bfr[4];
+      bf16x8 af[TM], bfr[TN];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int ra = wm * 64 + i * 16 + frow;
-        af[i] = *reinterpret_cast<const bf16x8*>(sa + swz(ra, kk * 4 + fk));
-        const int rb = wn * 64 + i * 16 + frow;
-        bfr[i] = *reinterpret_cast<const bf16x8*>(sb + swz(rb, kk * 4 + fk));
-      }
+      for (int j = 0; j < TN; ++j)
+        bfr[j] = *reinterpret_cast<const bf16x8*>(sb + swz(wn * TN * 16 + j * 16 + frow, kk * 4 + fk));
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < TM; ++i)
+        af[i] = *reinterpret_cast<const bf16x8*>(sa + swz(wm * TM * 16 + i * 16 + frow, kk * 4 + fk));
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
     }
   }
 
-  // ---- epilogue: lane owns C[row = .. + (lane & 15)][col = .. + (lane >> 4) * 4 + 0..3]
+  if (g.dbg & 1) {   // tuning experiment: keep the accumulators live but skip the epilogue
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = m0 + wm * 64 + i * 16 + frow;
-    if (row >= g.M) continue;
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int col = n0 + wn * 64 + j * 16 + fk * 4;
-      if (col >= g.N) continue;            // N is a multiple of 4 (checked on the host)
-      f32x4 v = acc[i][j];
-      if (g.bias) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(g.bias + col);
-        v += b;
+      for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(acc[i][j]));
+    return;
+  }
+  // ---- epilogue.  Each lane owns C[row = .. + (lane & 15)][col = .. + (lane >> 4) * 4 + 0..3]
+  // (4 columns = 8..16 B): storing that directly gives 32-64 B fragments per row and an
+  // issue-bound store tail (measured: 40 % of a K=768 GEMM).  Instead every wave transposes
+  // 64-row chunks through its own LDS scratch (the staging buffers are free now) and writes
+  // FULL 128-byte lines, 16 B per lane; residual / aux loads use the same coalesced shape.
+  __syncthreads();
+  constexpr int EP = 144;                         // scratch row pitch: 128 B payload + 16 B pad
+  char* ep = smem + wave * (64 * EP);
+  const int rrow = lane >> 3, rch = lane & 7;     // read phase: 8 rows x 8 chunks of 16 B
+  const int wrow0 = m0 + wm * TM * 16, wcol0 = n0 + wn * TN * 16;
+  static_assert(TN == 4, "epilogue assumes 64-column wave tiles");
+#pragma unroll
+  for (int rh = 0; rh < TM / 4; ++rh) {
+    if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU_DUAL) {
+      // bf16 scratch: 64 rows x 64 cols
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          f32x4 v = acc[rh * 4 + i][j];
+          const int col = wcol0 + j * 16 + fk * 4;
+          if (g.bias && col < g.N) v += *reinterpret_cast<const f32x4*>(g.bias + col);
+          const bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+          *reinterpret_cast<bf16x4*>(ep + (i * 16 + frow) * EP + (j * 16 + fk * 4) * 2) = o;
+        }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int lr = it * 8 + rrow;
+        const int row = wrow0 + rh * 64 + lr, col = wcol0 + rch * 8;
+        const bf16x8 hv = *reinterpret_cast<const bf16x8*>(ep + lr * EP + rch * 16);
+        if (row < g.M && col < g.N) {
+          *reinterpret_cast<bf16x8*>((bf16*)g.out + (size_t)row * g.ldc + col) = hv;
+          if constexpr (EPI == EPI_GELU_DUAL) {
+            // GELU is evaluated on the bf16-rounded pre-activation so that backward (which only
+            // has the saved bf16 h) differentiates exactly the function that forward applied.
+            bf16x8 a;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] = f2bf(gelu_f(bf2f(hv[e])));
+            *reinterpret_cast<bf16x8*>((bf16*)g.out2 + (size_t)row * g.ld2 + col) = a;
+          }
+        }
       }
-      if constexpr (EPI == EPI_BF16) {
-        bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-        *reinterpret_cast<bf16x4*>((bf16*)g.out + (size_t)row * g.ldc + col) = o;
-      } else if constexpr (EPI == EPI_F32 || EPI == EPI_F32_BF16) {
-        if (g.resid) {
-          const int rr = g.resid_mod > 0 ? row % g.resid_mod : row;
-          v += *reinterpret_cast<const f32x4*>(g.resid + (size_t)rr * g.ldr + col);
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      // fp32 scratch: 64 rows x 32 cols, two column halves
+#pragma unroll
+      for (int ch = 0; ch < 2; ++ch) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj)
+            *reinterpret_cast<f32x4*>(ep + (i * 16 + frow) * EP + (jj * 16 + fk * 4) * 4) = acc[rh * 4 + i][ch * 2 + jj];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int lr = it * 8 + rrow;
+          const int row = wrow0 + rh * 64 + lr, col = wcol0 + ch * 32 + rch * 4;
+          f32x4 v = *reinterpret_cast<const f32x4*>(ep + lr * EP + rch * 16);
+          if (row < g.M && col < g.N) {
+            if (g.bias) v += *reinterpret_cast<const f32x4*>(g.bias + col);
+            if constexpr (EPI == EPI_F32 || EPI == EPI_F32_BF16) {
+              if (g.resid) {
+                const int rr = g.resid_mod > 0 ? row % g.resid_mod : row;
+                v += *reinterpret_cast<const f32x4*>(g.resid + (size_t)rr * g.ldr + col);
+              }
+              *reinterpret_cast<f32x4*>((float*)g.out + (size_t)row * g.ldc + col) = v;
+              if constexpr (EPI == EPI_F32_BF16) {
+                const bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+                *reinterpret_cast<bf16x4*>((bf16*)g.out2 + (size_t)row * g.ld2 + col) = o;
+              }
+            } else {   // EPI_DGELU
+              const bf16x4 h = *reinterpret_cast<const bf16x4*>(g.aux + (size_t)row * g.ldaux + col);
+              const bf16x4 o = {f2bf(v[0] * dgelu_f(bf2f(h[0]))), f2bf(v[1] * dgelu_f(bf2f(h[1]))),
+                                f2bf(v[2] * dgelu_f(bf2f(h[2]))), f2bf(v[3] * dgelu_f(bf2f(h[3])))};
+              *reinterpret_cast<bf16x4*>((bf16*)g.out + (size_t)row * g.ldc + col) = o;
+            }
+          }
         }
-        *reinterpret_cast<f32x4*>((float*)g.out + (size_t)row * g.ldc + col) = v;
-        if constexpr (EPI == EPI_F32_BF16) {
-          bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-          *reinterpret_cast<bf16x4*>((bf16*)g.out2 + (size_t)row * g.ld2 + col) = o;
-        }
-      } else if constexpr (EPI == EPI_GELU_DUAL) {
-        bf16x4 h = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-        // GELU is evaluated on the bf16-rounded pre-activation so that backward (which only
-        // has the saved bf16 h) differentiates exactly the function that forward applied.
-        bf16x4 a = {f2bf(gelu_f(bf2f(h[0]))), f2bf(gelu_f(bf2f(h[1]))),
-                    f2bf(gelu_f(bf2f(h[2]))), f2bf(gelu_f(bf2f(h[3])))};
-        *reinterpret_cast<bf16x4*>((bf16*)g.out + (size_t)row * g.ldc + col) = h;
-        *reinterpret_cast<bf16x4*>((bf16*)g.out2 + (size_t)row * g.ld2 + col) = a;
-      } else if constexpr (EPI == EPI_DGELU) {
-        const bf16x4 h = *reinterpret_cast<const bf16x4*>(g.aux + (size_t)row * g.ldaux + col);
-        bf16x4 o = {f2bf(v[0] * dgelu_f(bf2f(h[0]))), f2bf(v[1] * dgelu_f(bf2f(h[1]))),
-                    f2bf(v[2] * dgelu_f(bf2f(h[2]))), f2bf(v[3] * dgelu_f(bf2f(h[3])))};
-        *reinterpret_cast<bf16x4*>((bf16*)g.out + (size_t)row * g.ldc + col) = o;
+        __builtin_amdgcn_wave_barrier();
       }
     }
   }
 }
 
-template <int EPI>
-static int launch(const GemmArgs& g, hipStream_t s) {
+static int g_variant = 0, g_dbg = 0;   // 0 = auto, 1 = force 128x128, 2 = force 256x256 (tuning hook)
+
+template <int EPI, int WM, int WN, int TM, int TN>
+static int launch_cfg(const GemmArgs& g, hipStream_t s) {
+  constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+  constexpr int LDS = 2 * (BM + BN) * BK * 2;
   const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<EPI>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<EPI, WM, WN, TM, TN>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
-  hipLaunchKernelGGL(gemm_nt_kernel<EPI>, dim3(ntm * ntn), dim3(256), 2 * STAGE_BYTES, s, g);
+  hipLaunchKernelGGL((gemm_nt_kernel<EPI, WM, WN, TM, TN>), dim3(ntm * ntn), dim3(WM * WN * 64), LDS, s, g);
   return check_launch("gemm_nt");
 }
 
+template <int EPI>
+static int launch(const GemmArgs& g, hipStream_t s) {
+  const bool big = g_variant == 2 || (g_variant == 0 && g.M >= 4096 && g.N % 256 == 0);
+  if (big) return launch_cfg<EPI, 2, 4, 8, 4>(g, s);
+  return launch_cfg<EPI, 2, 2, 4, 4>(g, s);
+}
+
 }  // namespace oat
+
+extern "C" void oat_gemm_set_variant(int v) { oat::g_variant = v & 0xff; oat::g_dbg = v >> 8; }
 
 extern "C" int oat_gemm_nt(const void* A, const void* B, int M, int N, int K, int lda, int ldb,
                            int epi, void* out, int ldc, void* out2, int ld2,
@@ -184,12 +250,12 @@ extern "C" int oat_gemm_nt(const void* A, const void* B, int M, int N, int K, in
   using namespace oat;
   if (M <= 0 || N <= 0 || K <= 0) { set_error("gemm_nt: empty problem"); return -1; }
   if (K % BK != 0) { set_error("gemm_nt: K must be a multiple of 64"); return -2; }
-  if (N % 4 != 0 || lda % 8 != 0 || ldb % 8 != 0 || ldc % 4 != 0) {
-    set_error("gemm_nt: N%4, lda%8, ldb%8, ldc%4 alignment required"); return -3;
+  if (N % 8 != 0 || lda % 8 != 0 || ldb % 8 != 0 || ldc % 8 != 0) {
+    set_error("gemm_nt: N, lda, ldb, ldc must be multiples of 8"); return -3;
   }
   if (!A || !B || !out) { set_error("gemm_nt: null pointer"); return -4; }
   GemmArgs g{(const bf16*)A, (const bf16*)B, M, N, K, lda, ldb, out, ldc, out2, ld2,
-             bias, resid, ldr, resid_mod, (const bf16*)aux, ldaux};
+             bias, resid, ldr, resid_mod, (const bf16*)aux, ldaux, g_dbg};
   hipStream_t s = (hipStream_t)stream;
   switch (epi) {
     case EPI_BF16: return launch<EPI_BF16>(g, s);
