@@ -88,6 +88,38 @@ int oat_attn_time_bwd(const void* qkv, int ldqkv, const void* out, int ldo, cons
 int oat_attn_cls_finalize(const float* cls_side, void* dqkv, int lddqkv, int B, int T, int N, int H, int D,
                           void* stream);
 
+/* ---- text encoder (HF DistilBertModel, called at oa_model.py:113; third-party algorithm) ---------
+ * ids / mask are int64.  Attention: qkv bf16 [B*L, 3*D]; masked keys are skipped. */
+int oat_embed_fwd(const void* ids, const float* word, const float* pos, float* out, int ld, int M, int L,
+                  int D, void* stream);
+int oat_embed_bwd(const void* ids, const float* g, int ld, float* dword_zeroed, int M, int D, void* stream);
+int oat_attn_text_fwd(const void* qkv, int ldqkv, const void* mask, void* out, int ldo, float* lse, int B,
+                      int L, int H, int D, float scale, void* stream);
+int oat_attn_text_bwd(const void* qkv, int ldqkv, const void* mask, const void* out, int ldo,
+                      const float* lse, float* delta_scratch, const void* dout, int lddo, void* dqkv,
+                      int lddqkv, int B, int L, int H, int D, float scale, void* stream);
+/* txt_proj's ReLU (oa_model.py:68) */
+int oat_relu_bf16(const float* x, int ldx, void* y_bf16, int ldy, int M, int D, void* stream);
+int oat_relu_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx, int M, int D, void* stream);
+
+/* ---- loss + optimiser ---------------------------------------------------------------------------
+ * sim_matrix (oa_model.py:192-200) + NormSoftmaxLoss (loss.py:13-25), forward and backward in one
+ * call over the all-gathered embeddings; gradients only for local rows [r0, r0+nloc)
+ * (AllGather_multi.backward, trainer_dist.py:41-45). */
+size_t oat_sim_workspace_floats(int n, int m, int d);
+int oat_sim_matrix_fwd(const float* t, const float* v, int n, int m, int d, float eps, float* sim, float* ws,
+                       void* stream);
+int oat_sim_matrix_bwd(const float* G, const float* ws, int n, int m, int d, float* dt, int t0, int tl,
+                       float* dv, int v0, int vl, void* stream);
+int oat_norm_softmax_loss(const float* sim, int n, float temperature, float* loss, float* G, float* ws_2n,
+                          void* stream);
+size_t oat_infonce_workspace_floats(int n, int d);
+int oat_infonce(const float* t, const float* v, int n, int d, float temperature, float eps, float* loss,
+                float* sim_out, float* dt, float* dv, int r0, int nloc, float* ws, void* stream);
+/* transformers.AdamW (hf_style=1, train_dist_multi.py:66) or torch.optim.AdamW (0) over a flat range */
+int oat_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+              float eps, float weight_decay, int step, int hf_style, float gscale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,43 @@
+"""Shared plumbing for nn.Modules whose forward/backward are HIP launch schedules: parameters stay
+ordinary fp32 nn.Parameters (reference state_dict names), gradients live in ONE persistent flat fp32
+buffer per module whose slices are the Parameters' .grad (kernels write them in place; the flat
+buffer is also what the gradient all-reduce and the fused AdamW operate on)."""
+import torch
+from torch import nn
+
+
+class EngineModule(nn.Module):
+    _skip_prefixes = ()
+
+    def _engine_params(self):
+        names = getattr(self, "_names", None)
+        if names is None:
+            names = [n for n, _ in self.named_parameters() if not n.startswith(tuple(self._skip_prefixes) or ("\0",))]
+            self._names = names
+            self._n_params = len(names)
+        d = dict(self.named_parameters())
+        return [(n, d[n]) for n in names]
+
+    def _param_data(self):
+        return {n: p.data for n, p in self._engine_params()}
+
+    def flat_grad(self):
+        self._grad_views()
+        return self._gradbuf
+
+    def _grad_views(self):
+        pairs = self._engine_params()
+        dev = pairs[0][1].device
+        total = sum(p.numel() for _, p in pairs)
+        buf = getattr(self, "_gradbuf", None)
+        if buf is None or buf.device != dev or buf.numel() != total:
+            buf = torch.zeros(total, dtype=torch.float32, device=dev)
+            self._gradbuf = buf
+        views, off = {}, 0
+        for n, p in pairs:
+            v = buf[off:off + p.numel()].view_as(p)
+            off += p.numel()
+            if p.requires_grad and (p.grad is None or p.grad.data_ptr() != v.data_ptr()):
+                p.grad = v
+            views[n] = v
+        return views

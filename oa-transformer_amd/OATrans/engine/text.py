@@ -1,0 +1,182 @@
+"""DistilBERT forward/backward as an explicit HIP launch schedule.
+
+The reference calls HF transformers' DistilBertModel (third party; call sites
+/root/reference/OATrans/model/oa_model.py:27,113-121).  Its published algorithm - learned
+word + position embeddings -> LayerNorm(1e-12) -> n x post-LN [MHSA with key mask, FFN(GELU)] -
+is executed here with the same GEMM / LayerNorm kernels as the video encoder plus the masked
+attention and embedding kernels of csrc/text.hip.  Dropout is the identity (the parity
+configuration is eval mode; SURVEY.md 'parity traps').
+
+Rows are (b, l) -> b * L + l; fp32 residual stream, bf16 GEMM operands (same conventions as
+engine/video.py).
+"""
+import torch
+
+from ..ops import hip
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class _LayerActs:
+    def __init__(self, Mp, D, Hd, H, dev):
+        z16 = lambda c: torch.zeros(Mp, c, dtype=torch.bfloat16, device=dev)
+        z32 = lambda c: torch.zeros(Mp, c, dtype=torch.float32, device=dev)
+        self.qkv, self.ctx = z16(3 * D), z16(D)
+        self.lse = z32(H)
+        self.s, self.x1, self.f, self.x2 = z32(D), z32(D), z32(D), z32(D)
+        self.x1_16, self.x2_16 = z16(D), z16(D)
+        self.h, self.g = z16(Hd), z16(Hd)
+        self.stats = torch.zeros(4, Mp, dtype=torch.float32, device=dev)
+
+
+class _TextPlan:
+    def __init__(self, B, L, D, Hd, H, n_layers, dev):
+        self.B, self.L, self.M = B, L, B * L
+        self.Mp = Mp = _round_up(self.M, 256)
+        self.layers = [_LayerActs(Mp, D, Hd, H, dev) for _ in range(n_layers)]
+        self.emb = torch.zeros(Mp, D, dtype=torch.float32, device=dev)
+        self.x0 = torch.zeros(Mp, D, dtype=torch.float32, device=dev)
+        self.x0_16 = torch.zeros(Mp, D, dtype=torch.bfloat16, device=dev)
+        self.estats = torch.zeros(2, Mp, dtype=torch.float32, device=dev)
+        self.G = torch.zeros(Mp, D, dtype=torch.float32, device=dev)
+        self.g16 = torch.zeros(Mp, D, dtype=torch.bfloat16, device=dev)
+        self.d_h = torch.zeros(Mp, Hd, dtype=torch.bfloat16, device=dev)
+        self.d_ctx = torch.zeros(Mp, D, dtype=torch.bfloat16, device=dev)
+        self.d_qkv = torch.zeros(Mp, 3 * D, dtype=torch.bfloat16, device=dev)
+        self.delta = torch.zeros(Mp, H, dtype=torch.float32, device=dev)
+        self.gqkv_w = torch.zeros(3 * D, D, dtype=torch.float32, device=dev)
+        self.gqkv_b = torch.zeros(3 * D, dtype=torch.float32, device=dev)
+
+
+class TextEngine:
+    """`params` / `grads` map HF DistilBertModel state_dict names (no `text_model.` prefix)."""
+
+    def __init__(self, n_layers, dim, n_heads, hidden_dim):
+        self.n_layers, self.D, self.H, self.Hd = n_layers, dim, n_heads, hidden_dim
+        if dim // n_heads != 64:
+            raise hip.OatError("the HIP attention kernels are built for head_dim 64")
+        self.scale = 64 ** -0.5
+        self.plans, self.shadow, self.versions = {}, {}, None
+
+    def refresh_shadows(self, params):
+        names = []
+        for i in range(self.n_layers):
+            b = f"transformer.layer.{i}."
+            names += [b + f"attention.{l}.weight" for l in ("q_lin", "k_lin", "v_lin", "out_lin")]
+            names += [b + f"attention.{l}.bias" for l in ("q_lin", "k_lin", "v_lin")]
+            names += [b + "ffn.lin1.weight", b + "ffn.lin2.weight"]
+        versions = tuple(params[n]._version for n in names) + tuple(params[n].data_ptr() for n in names)
+        if versions == self.versions:
+            return
+        dev = params[names[0]].device
+
+        def put(key, w):
+            if key not in self.shadow:
+                self.shadow[key] = (torch.empty(w.shape, dtype=torch.bfloat16, device=dev),
+                                    torch.empty(w.shape[1], w.shape[0], dtype=torch.bfloat16, device=dev))
+            hip.cast_bf16(w.contiguous(), self.shadow[key][0], self.shadow[key][1])
+
+        for i in range(self.n_layers):
+            b = f"transformer.layer.{i}."
+            wqkv = torch.cat([params[b + f"attention.{l}.weight"].detach() for l in ("q_lin", "k_lin", "v_lin")], 0)
+            put(b + "qkv", wqkv)
+            self.shadow[b + "qkv.bias"] = torch.cat(
+                [params[b + f"attention.{l}.bias"].detach() for l in ("q_lin", "k_lin", "v_lin")], 0).contiguous()
+            for l in ("attention.out_lin", "ffn.lin1", "ffn.lin2"):
+                put(b + l, params[b + l + ".weight"].detach())
+        self.versions = versions
+
+    def plan(self, B, L, dev):
+        key = (B, L, str(dev))
+        if key not in self.plans:
+            self.plans[key] = _TextPlan(B, L, self.D, self.Hd, self.H, self.n_layers, dev)
+        return self.plans[key]
+
+    def forward(self, input_ids, attention_mask, params):
+        """-> (last_hidden fp32 view [B, L, D], plan)."""
+        B, L = input_ids.shape
+        D, Hd, H = self.D, self.Hd, self.H
+        self.refresh_shadows(params)
+        pl = self.plan(B, L, input_ids.device)
+        M = pl.M
+        pl.ids = input_ids.contiguous()
+        pl.mask = attention_mask.to(torch.int64).contiguous()
+        hip.embed_fwd(pl.ids, params["embeddings.word_embeddings.weight"],
+                      params["embeddings.position_embeddings.weight"], pl.emb, M, L, D)
+        hip.layernorm_fwd(pl.emb, params["embeddings.LayerNorm.weight"], params["embeddings.LayerNorm.bias"], M, D,
+                          1e-12, y=pl.x0_16, y32=pl.x0, mean=pl.estats[0], rstd=pl.estats[1])
+        x, x16 = pl.x0, pl.x0_16
+        for i, a in enumerate(pl.layers):
+            b = f"transformer.layer.{i}."
+            p = lambda s: params[b + s]
+            w = lambda s: self.shadow[b + s][0]
+            hip.gemm_nt(x16, w("qkv"), M, 3 * D, D, hip.EPI_BF16, a.qkv, bias=self.shadow[b + "qkv.bias"])
+            hip.attn_text_fwd(a.qkv, pl.mask, a.ctx, a.lse, B, L, H, D, self.scale)
+            hip.gemm_nt(a.ctx, w("attention.out_lin"), M, D, D, hip.EPI_F32, a.s, bias=p("attention.out_lin.bias"),
+                        resid=x)
+            hip.layernorm_fwd(a.s, p("sa_layer_norm.weight"), p("sa_layer_norm.bias"), M, D, 1e-12, y=a.x1_16,
+                              y32=a.x1, mean=a.stats[0], rstd=a.stats[1])
+            hip.gemm_nt(a.x1_16, w("ffn.lin1"), M, Hd, D, hip.EPI_GELU_DUAL, a.h, out2=a.g, bias=p("ffn.lin1.bias"))
+            hip.gemm_nt(a.g, w("ffn.lin2"), M, D, Hd, hip.EPI_F32, a.f, bias=p("ffn.lin2.bias"), resid=a.x1)
+            hip.layernorm_fwd(a.f, p("output_layer_norm.weight"), p("output_layer_norm.bias"), M, D, 1e-12,
+                              y=a.x2_16, y32=a.x2, mean=a.stats[2], rstd=a.stats[3])
+            x, x16 = a.x2, a.x2_16
+        return x[:M].view(B, L, D), pl
+
+    def backward(self, pl, params, grads, d_hidden, accumulate=False):
+        """d_hidden: fp32 [B, L, D] gradient of last_hidden_state.  Writes (or accumulates) every
+        text parameter gradient into `grads`."""
+        B, L, M = pl.B, pl.L, pl.M
+        D, Hd, H = self.D, self.Hd, self.H
+        G, g16 = pl.G, pl.g16
+        G[:M].copy_(d_hidden.reshape(M, D))
+        acc = accumulate
+        for i in reversed(range(self.n_layers)):
+            a = pl.layers[i]
+            x16 = pl.layers[i - 1].x2_16 if i > 0 else pl.x0_16
+            b = f"transformer.layer.{i}."
+            p = lambda s: params[b + s]
+            gr = lambda s: grads[b + s]
+            wT = lambda s: self.shadow[b + s][1]
+            # x2 = LN(f), f = x1 + lin2(gelu(lin1(x1)))
+            hip.layernorm_bwd(G, a.f, a.stats[2], a.stats[3], p("output_layer_norm.weight"), M, D, dx=G, dx16=g16,
+                              dgamma=gr("output_layer_norm.weight"), dbeta=gr("output_layer_norm.bias"),
+                              accumulate=acc)                                              # G = dL/df
+            hip.colsum(g16, M, D, gr("ffn.lin2.bias"), accumulate=acc)
+            hip.gemm_tn(g16, a.g, M, D, Hd, gr("ffn.lin2.weight"), accumulate=acc)
+            hip.gemm_nt(g16, wT("ffn.lin2"), M, Hd, D, hip.EPI_DGELU, pl.d_h, aux=a.h)
+            hip.colsum(pl.d_h, M, Hd, gr("ffn.lin1.bias"), accumulate=acc)
+            hip.gemm_tn(pl.d_h, a.x1_16, M, Hd, D, gr("ffn.lin1.weight"), accumulate=acc)
+            hip.gemm_nt(pl.d_h, wT("ffn.lin1"), M, D, Hd, hip.EPI_F32, G, resid=G)          # G = dL/dx1
+            # x1 = LN(s), s = x + out_lin(attn(qkv(x)))
+            hip.layernorm_bwd(G, a.s, a.stats[0], a.stats[1], p("sa_layer_norm.weight"), M, D, dx=G, dx16=g16,
+                              dgamma=gr("sa_layer_norm.weight"), dbeta=gr("sa_layer_norm.bias"), accumulate=acc)
+            hip.colsum(g16, M, D, gr("attention.out_lin.bias"), accumulate=acc)
+            hip.gemm_tn(g16, a.ctx, M, D, D, gr("attention.out_lin.weight"), accumulate=acc)
+            hip.gemm_nt(g16, wT("attention.out_lin"), M, D, D, hip.EPI_BF16, pl.d_ctx)
+            hip.attn_text_bwd(a.qkv, pl.mask, a.ctx, a.lse, pl.delta, pl.d_ctx, pl.d_qkv, B, L, H, D, self.scale)
+            hip.colsum(pl.d_qkv, M, 3 * D, pl.gqkv_b)
+            hip.gemm_tn(pl.d_qkv, x16, M, 3 * D, D, pl.gqkv_w)
+            for k, l in enumerate(("q_lin", "k_lin", "v_lin")):
+                gw, gb = gr(f"attention.{l}.weight"), gr(f"attention.{l}.bias")
+                if acc:
+                    gw.add_(pl.gqkv_w[k * D:(k + 1) * D])
+                    gb.add_(pl.gqkv_b[k * D:(k + 1) * D])
+                else:
+                    gw.copy_(pl.gqkv_w[k * D:(k + 1) * D])
+                    gb.copy_(pl.gqkv_b[k * D:(k + 1) * D])
+            hip.gemm_nt(pl.d_qkv, wT("qkv"), M, D, 3 * D, hip.EPI_F32, G, resid=G)          # G = dL/dx
+        # embeddings: x0 = LN(word[ids] + pos[l])
+        hip.layernorm_bwd(G, pl.emb, pl.estats[0], pl.estats[1], params["embeddings.LayerNorm.weight"], M, D, dx=G,
+                          dgamma=grads["embeddings.LayerNorm.weight"], dbeta=grads["embeddings.LayerNorm.bias"],
+                          accumulate=acc)
+        gword = grads["embeddings.word_embeddings.weight"]
+        if not acc:
+            gword.zero_()
+        hip.embed_bwd(pl.ids, G, gword, M, D)
+        gpos = grads["embeddings.position_embeddings.weight"]
+        if not acc:
+            gpos[L:].zero_()
+        hip.periodic_rowsum(G, B, L, D, gpos[:L], accumulate=acc)

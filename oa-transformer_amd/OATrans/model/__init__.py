@@ -1,0 +1,9 @@
+"""`from OATrans import model as module_arch` (train.py:4, train_dist_multi.py:5) then
+`config.initialize('arch', module_arch)` -> getattr(module, 'FrozenInTime'): the names the entry
+points resolve by reflection live here (the reference's own __init__ is empty)."""
+from .layers import sim_matrix
+from .loss import NormSoftmaxLoss
+from .oa_model import FrozenInTime
+from .video_transformer import SpaceTimeTransformer
+
+__all__ = ["FrozenInTime", "NormSoftmaxLoss", "SpaceTimeTransformer", "sim_matrix"]

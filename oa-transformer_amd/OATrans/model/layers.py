@@ -1,0 +1,110 @@
+"""Small HIP-backed layers shared by the model assemblies: Linear projections
+(txt_proj / vid_proj, /root/reference/OATrans/model/oa_model.py:66-78), sim_matrix and loss."""
+import torch
+from torch import nn
+
+from ..ops import hip
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = (relu(x) if pre_relu else x) @ W^T + b   on the bf16 MFMA GEMM, fp32 in/out."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, pre_relu):
+        x = x.float().contiguous()
+        M, K = x.shape
+        N = weight.shape[0]
+        a16 = torch.zeros(_round_up(M, 64), K, dtype=torch.bfloat16, device=x.device)
+        if pre_relu:
+            hip.relu_bf16(x, a16, M, K)
+        else:
+            hip.cast_bf16(x, a16[:M])
+        w16 = torch.empty(N, K, dtype=torch.bfloat16, device=x.device)
+        wT16 = torch.empty(K, N, dtype=torch.bfloat16, device=x.device)
+        hip.cast_bf16(weight.detach().contiguous(), w16, wT16)
+        y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        hip.gemm_nt(a16, w16, M, N, K, hip.EPI_F32, y, bias=bias.detach() if bias is not None else None)
+        ctx.save_for_backward(x, a16, wT16)
+        ctx.pre_relu, ctx.has_bias = pre_relu, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, a16, wT16 = ctx.saved_tensors
+        dy = dy.float().contiguous()
+        M, N = dy.shape
+        K = x.shape[1]
+        dy16 = torch.zeros(_round_up(M, 64), N, dtype=torch.bfloat16, device=dy.device)
+        hip.cast_bf16(dy, dy16[:M])
+        dW = torch.empty(N, K, dtype=torch.float32, device=dy.device)
+        hip.gemm_tn(dy16, a16, M, N, K, dW)
+        db = None
+        if ctx.has_bias:
+            db = torch.empty(N, dtype=torch.float32, device=dy.device)
+            hip.colsum(dy, M, N, db)
+        dx = torch.empty(M, K, dtype=torch.float32, device=dy.device)
+        hip.gemm_nt(dy16, wT16, M, K, N, hip.EPI_F32, dx)
+        if ctx.pre_relu:
+            hip.relu_bwd(x, dx, dx, M, K)
+        return dx, dW, db, None
+
+
+class HipLinear(nn.Linear):
+    """nn.Linear whose forward/backward run on liboatrans_hip (same parameters / state_dict)."""
+
+    pre_relu = False
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise hip.OatError("HipLinear runs on MI355X only (no CPU path)")
+        return _LinearFn.apply(x, self.weight, self.bias, self.pre_relu)
+
+
+class ReLULinear(nn.Sequential):
+    """txt_proj = Sequential(ReLU, Linear) (oa_model.py:68-70) with the state_dict key '1.*';
+    the ReLU is fused into the GEMM operand cast."""
+
+    def __init__(self, in_features, out_features):
+        lin = HipLinear(in_features, out_features)
+        lin.pre_relu = True
+        super().__init__(nn.Identity(), lin)
+
+
+class _SimFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, eps):
+        a, b = a.float().contiguous(), b.float().contiguous()
+        sim, ws = hip.sim_matrix_fwd(a, b, eps)
+        ctx.ws, ctx.shape = ws, (a.shape[0], b.shape[0], a.shape[1])
+        return sim
+
+    @staticmethod
+    def backward(ctx, g):
+        n, m, d = ctx.shape
+        da, db = hip.sim_matrix_bwd(g.float().contiguous(), ctx.ws, n, m, d)
+        return da, db, None
+
+
+def sim_matrix(a, b, eps=1e-8):
+    """Cosine-similarity matrix with the norm clamped at eps
+    (/root/reference/OATrans/model/oa_model.py:192-200, model.py:164-172)."""
+    if not a.is_cuda:
+        raise hip.OatError("sim_matrix runs on MI355X only (no CPU path); use the oracle for CPU")
+    return _SimFn.apply(a, b, eps)
+
+
+class _NormSoftmaxFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, temperature):
+        loss, G = hip.norm_softmax_loss(x.float().contiguous(), temperature, want_grad=True)
+        ctx.save_for_backward(G)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (G,) = ctx.saved_tensors
+        return G * g, None

@@ -1,0 +1,120 @@
+"""DistilBERT text encoder - parameter container with HF DistilBertModel state_dict names,
+executed by OATrans.engine.text.TextEngine (HIP).  Stands in for the `AutoModel.from_pretrained(
+text_params['model'])` call of the reference (/root/reference/OATrans/model/oa_model.py:27); the
+HF implementation is third-party code, restated in oracle/oatrans_oracle.py."""
+import json
+import os
+from types import SimpleNamespace
+
+import torch
+from torch import nn
+
+from ..engine.module import EngineModule
+from ..engine.text import TextEngine
+from ..ops import hip
+
+DEFAULT_CONFIG = dict(vocab_size=30522, max_position_embeddings=512, n_layers=6, n_heads=12, dim=768, hidden_dim=3072)
+
+
+class _Attn(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.q_lin, self.k_lin, self.v_lin, self.out_lin = (nn.Linear(dim, dim) for _ in range(4))
+
+
+class _FFN(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.lin1, self.lin2 = nn.Linear(dim, hidden), nn.Linear(hidden, dim)
+
+
+class _Layer(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.attention = _Attn(dim)
+        self.sa_layer_norm = nn.LayerNorm(dim, eps=1e-12)
+        self.ffn = _FFN(dim, hidden)
+        self.output_layer_norm = nn.LayerNorm(dim, eps=1e-12)
+
+
+class _Embeddings(nn.Module):
+    def __init__(self, vocab, max_pos, dim):
+        super().__init__()
+        self.word_embeddings = nn.Embedding(vocab, dim)
+        self.position_embeddings = nn.Embedding(max_pos, dim)
+        self.LayerNorm = nn.LayerNorm(dim, eps=1e-12)
+
+
+class _Transformer(nn.Module):
+    def __init__(self, n_layers, dim, hidden):
+        super().__init__()
+        self.layer = nn.ModuleList([_Layer(dim, hidden) for _ in range(n_layers)])
+
+
+class _HiddenFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, input_ids, attention_mask, call_idx, *params):
+        hidden, plan = module._engine.forward(input_ids, attention_mask, module._param_data())
+        ctx.module, ctx.plan, ctx.call_idx = module, plan, call_idx
+        return hidden.clone()
+
+    @staticmethod
+    def backward(ctx, d_hidden):
+        m = ctx.module
+        # a second call in the same step (caption + caption-with-tags, oa_model_global_local.py:161-164)
+        # accumulates into the gradients the first call's backward wrote
+        accumulate = m._bwd_calls > 0
+        m._bwd_calls += 1
+        m._engine.backward(ctx.plan, m._param_data(), m._grad_views(), d_hidden.float().contiguous(), accumulate)
+        return (None, None, None, None) + (None,) * m._n_params
+
+
+class DistilBertHIP(EngineModule):
+    def __init__(self, config=None):
+        super().__init__()
+        cfg = dict(DEFAULT_CONFIG)
+        cfg.update(config or {})
+        self.config = SimpleNamespace(hidden_size=cfg["dim"], **cfg)
+        self.embeddings = _Embeddings(cfg["vocab_size"], cfg["max_position_embeddings"], cfg["dim"])
+        self.transformer = _Transformer(cfg["n_layers"], cfg["dim"], cfg["hidden_dim"])
+        for mod in self.modules():
+            if isinstance(mod, (nn.Linear, nn.Embedding)):
+                nn.init.normal_(mod.weight, std=0.02)               # HF initializer_range
+                if isinstance(mod, nn.Linear):
+                    nn.init.zeros_(mod.bias)
+        self._engine = TextEngine(cfg["n_layers"], cfg["dim"], cfg["n_heads"], cfg["hidden_dim"])
+        self._bwd_calls = 0
+        self._fwd_calls = 0
+
+    @classmethod
+    def from_pretrained(cls, path):
+        """Reads an HF checkpoint directory (config.json + model.safetensors | pytorch_model.bin)."""
+        with open(os.path.join(path, "config.json")) as fh:
+            raw = json.load(fh)
+        m = cls({k: raw[k] for k in DEFAULT_CONFIG if k in raw})
+        st = os.path.join(path, "model.safetensors")
+        if os.path.exists(st):
+            from safetensors.torch import load_file
+            sd = load_file(st)
+        else:
+            sd = torch.load(os.path.join(path, "pytorch_model.bin"), map_location="cpu")
+        sd = {k[len("distilbert."):] if k.startswith("distilbert.") else k: v for k, v in sd.items()}
+        m.load_state_dict(sd, strict=False)
+        return m
+
+    def begin_step(self):
+        """Called once per optimiser step: the next backward overwrites gradients."""
+        self._bwd_calls = 0
+        self._fwd_calls = 0
+
+    def forward(self, input_ids=None, attention_mask=None, **unused):
+        if not input_ids.is_cuda:
+            raise hip.OatError("DistilBertHIP runs on MI355X only (no CPU path); use the oracle for CPU")
+        hip.lib()
+        if attention_mask is None:
+            attention_mask = torch.ones_like(input_ids)
+        params = [p for _, p in self._engine_params()]
+        idx = self._fwd_calls
+        self._fwd_calls += 1
+        hidden = _HiddenFn.apply(self, input_ids, attention_mask, idx, *params)
+        return SimpleNamespace(last_hidden_state=hidden)

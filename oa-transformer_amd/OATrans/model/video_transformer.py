@@ -13,6 +13,7 @@ from functools import partial
 import torch
 from torch import nn
 
+from ..engine.module import EngineModule
 from ..engine.video import VideoEngine
 from ..ops import hip
 
@@ -95,7 +96,9 @@ class _EncoderFn(torch.autograd.Function):
         return (None, None, None) + (None,) * module._n_params
 
 
-class SpaceTimeTransformer(nn.Module):
+class SpaceTimeTransformer(EngineModule):
+    _skip_prefixes = ("head.",)
+
     def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=1000, embed_dim=768, depth=12,
                  num_heads=12, mlp_ratio=4., qkv_bias=True, qk_scale=None, representation_size=None,
                  drop_rate=0., attn_drop_rate=0., drop_path_rate=0., hybrid_backbone=None, norm_layer=None,
@@ -133,8 +136,6 @@ class SpaceTimeTransformer(nn.Module):
         self.need_patch_tokens = True
         self._engine = VideoEngine(depth, embed_dim, num_heads, mlp_ratio, self.patch_embed.patch_size[0], in_chans,
                                    num_frames)
-        self._names = None
-        self._gradbuf = None
 
     def _init_weights(self, m):
         if isinstance(m, nn.Linear):
@@ -148,34 +149,6 @@ class SpaceTimeTransformer(nn.Module):
     @torch.jit.ignore
     def no_weight_decay(self):
         return {'pos_embed', 'cls_token'}
-
-    # ------------------------------------------------------------------ engine plumbing
-    def _engine_params(self):
-        """(name, Parameter) pairs the encoder uses (the classifier head is not on the path)."""
-        if self._names is None:
-            self._names = [n for n, _ in self.named_parameters() if not n.startswith("head.")]
-            self._n_params = len(self._names)
-        d = dict(self.named_parameters())
-        return [(n, d[n]) for n in self._names]
-
-    def _param_data(self):
-        return {n: p.data for n, p in self._engine_params()}
-
-    def _grad_views(self):
-        """Persistent flat fp32 gradient buffer; each Parameter's .grad is a view of it."""
-        pairs = self._engine_params()
-        dev = pairs[0][1].device
-        total = sum(p.numel() for _, p in pairs)
-        if self._gradbuf is None or self._gradbuf.device != dev or self._gradbuf.numel() != total:
-            self._gradbuf = torch.zeros(total, dtype=torch.float32, device=dev)
-        views, off = {}, 0
-        for n, p in pairs:
-            v = self._gradbuf[off:off + p.numel()].view_as(p)
-            off += p.numel()
-            if p.requires_grad and (p.grad is None or p.grad.data_ptr() != v.data_ptr()):
-                p.grad = v
-            views[n] = v
-        return views
 
     def forward_features(self, x, aug=False):
         if not x.is_cuda:

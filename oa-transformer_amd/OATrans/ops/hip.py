@@ -39,6 +39,8 @@ def lib():
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.oat_last_error.restype = ctypes.c_char_p
         _lib.oat_gemm_tn_workspace_bytes.restype = ctypes.c_size_t
+        _lib.oat_infonce_workspace_floats.restype = ctypes.c_size_t
+        _lib.oat_sim_workspace_floats.restype = ctypes.c_size_t
         for name in declared_symbols():
             if not hasattr(_lib, name):
                 raise OatError(f"liboatrans_hip.so lacks symbol {name}")
@@ -209,3 +211,89 @@ def attn_time_bwd(qkv, out, lse, dout, dqkv, cls_side, B, T, N, H, D, scale):
 def attn_cls_finalize(cls_side, dqkv, B, T, N, H, D):
     _check(lib().oat_attn_cls_finalize(_ptr(cls_side), _ptr(dqkv), dqkv.stride(0), B, T, N, H, D, _stream()),
            "oat_attn_cls_finalize")
+
+
+# ----------------------------------------------------------------------------- text encoder / loss / optimiser
+def embed_fwd(ids, word, pos, out, M, L, D):
+    _check(lib().oat_embed_fwd(_ptr(ids), _ptr(word), _ptr(pos), _ptr(out), out.stride(0), M, L, D, _stream()),
+           "oat_embed_fwd")
+
+
+def embed_bwd(ids, g, dword, M, D):
+    _check(lib().oat_embed_bwd(_ptr(ids), _ptr(g), g.stride(0), _ptr(dword), M, D, _stream()), "oat_embed_bwd")
+
+
+def attn_text_fwd(qkv, mask, out, lse, B, L, H, D, scale):
+    _check(lib().oat_attn_text_fwd(_ptr(qkv), qkv.stride(0), _ptr(mask), _ptr(out), out.stride(0), _ptr(lse), B, L,
+                                   H, D, _f(scale), _stream()), "oat_attn_text_fwd")
+
+
+def attn_text_bwd(qkv, mask, out, lse, delta, dout, dqkv, B, L, H, D, scale):
+    _check(lib().oat_attn_text_bwd(_ptr(qkv), qkv.stride(0), _ptr(mask), _ptr(out), out.stride(0), _ptr(lse),
+                                   _ptr(delta), _ptr(dout), dout.stride(0), _ptr(dqkv), dqkv.stride(0), B, L, H, D,
+                                   _f(scale), _stream()), "oat_attn_text_bwd")
+
+
+def relu_bf16(x, y, M, D):
+    _check(lib().oat_relu_bf16(_ptr(x), x.stride(0), _ptr(y), y.stride(0), M, D, _stream()), "oat_relu_bf16")
+
+
+def relu_bwd(x, dy, dx, M, D):
+    _check(lib().oat_relu_bwd(_ptr(x), x.stride(0), _ptr(dy), dy.stride(0), _ptr(dx), dx.stride(0), M, D, _stream()),
+           "oat_relu_bwd")
+
+
+_nce_ws = {}
+
+
+def infonce(t, v, temperature=0.05, eps=1e-8, r0=0, nloc=None, want_sim=False, want_grads=True):
+    """Fused sim_matrix + NormSoftmaxLoss fwd/bwd.  Returns (loss[1], sim|None, dt|None, dv|None)."""
+    n, d = t.shape
+    nloc = n if nloc is None else nloc
+    need = lib().oat_infonce_workspace_floats(n, d)
+    key = (t.device, need)
+    ws = _nce_ws.get(key)
+    if ws is None:
+        ws = torch.empty(need, dtype=torch.float32, device=t.device)
+        _nce_ws[key] = ws
+    loss = torch.empty(1, dtype=torch.float32, device=t.device)
+    sim = torch.empty(n, n, dtype=torch.float32, device=t.device) if want_sim else None
+    dt = torch.empty(nloc, d, dtype=torch.float32, device=t.device) if want_grads else None
+    dv = torch.empty(nloc, d, dtype=torch.float32, device=t.device) if want_grads else None
+    _check(lib().oat_infonce(_ptr(t), _ptr(v), n, d, _f(temperature), _f(eps), _ptr(loss), _ptr(sim), _ptr(dt),
+                             _ptr(dv), r0, nloc, _ptr(ws), _stream()), "oat_infonce")
+    return loss, sim, dt, dv
+
+
+def adamw(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, hf_style=True, gscale=1.0):
+    _check(lib().oat_adamw(_ptr(p), _ptr(g), _ptr(m), _ptr(v), ctypes.c_size_t(p.numel()), _f(lr), _f(beta1),
+                           _f(beta2), _f(eps), _f(weight_decay), int(step), int(hf_style), _f(gscale), _stream()),
+           "oat_adamw")
+
+
+def sim_matrix_fwd(t, v, eps=1e-8):
+    n, d = t.shape
+    m = v.shape[0]
+    ws = torch.empty(lib().oat_sim_workspace_floats(n, m, d), dtype=torch.float32, device=t.device)
+    sim = torch.empty(n, m, dtype=torch.float32, device=t.device)
+    _check(lib().oat_sim_matrix_fwd(_ptr(t), _ptr(v), n, m, d, _f(eps), _ptr(sim), _ptr(ws), _stream()),
+           "oat_sim_matrix_fwd")
+    return sim, ws
+
+
+def sim_matrix_bwd(G, ws, n, m, d):
+    dt = torch.empty(n, d, dtype=torch.float32, device=G.device)
+    dv = torch.empty(m, d, dtype=torch.float32, device=G.device)
+    _check(lib().oat_sim_matrix_bwd(_ptr(G), _ptr(ws), n, m, d, _ptr(dt), 0, n, _ptr(dv), 0, m, _stream()),
+           "oat_sim_matrix_bwd")
+    return dt, dv
+
+
+def norm_softmax_loss(sim, temperature, want_grad=True):
+    n = sim.shape[0]
+    loss = torch.empty(1, dtype=torch.float32, device=sim.device)
+    G = torch.empty_like(sim) if want_grad else None
+    ws = torch.empty(2 * n, dtype=torch.float32, device=sim.device)
+    _check(lib().oat_norm_softmax_loss(_ptr(sim), n, _f(temperature), _ptr(loss), _ptr(G), _ptr(ws), _stream()),
+           "oat_norm_softmax_loss")
+    return loss, G

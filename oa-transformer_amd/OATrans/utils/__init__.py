@@ -1,0 +1,1 @@
+from .util import *  # noqa: F401,F403

@@ -1,0 +1,224 @@
+// Text-encoder specific kernels (DistilBERT, called from oa_model.py:113 in the reference via
+// HF transformers - third-party code, algorithm restated in oracle/oatrans_oracle.py):
+//   embeddings gather (word + position), masked multi-head self-attention fwd / bwd.
+// The linear layers, LayerNorms and GELU reuse gemm_nt / gemm_tn / layernorm kernels.
+//
+// Sequences are short (L <= 512, typically <= 40), so attention is latency-bound VALU work:
+// 8 lanes own one (b, h, query) [forward, backward pass A] or one (b, h, key) [backward pass B],
+// lane p holding dims [8p, 8p+8) of the 64-dim head (same idiom as attn_time.hip).
+// Masked keys (attention_mask == 0) are skipped, which equals HF's masked_fill(finfo.min)
+// whenever a row has at least one unmasked key (always true: token 0 = [CLS]).
+#include "common.h"
+
+namespace oat {
+
+constexpr float X_LOG2E = 1.4426950408889634f;
+constexpr float X_LN2 = 0.6931471805599453f;
+
+OAT_DEV float xdot8(const bf16x8 a, const bf16x8 b) {
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s += bf2f(a[e]) * bf2f(b[e]);
+  return s;
+}
+OAT_DEV float xred8(float v) {
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 4, 64);
+  return v;
+}
+
+// out[m][:] = word[ids[m]][:] + pos[m % L][:]
+__global__ void embed_fwd_kernel(const long long* ids, const float* word, const float* pos, float* out, int ld,
+                                 int M, int L, int D) {
+  const int m = blockIdx.x;
+  const float* w = word + (size_t)ids[m] * D;
+  const float* p = pos + (size_t)(m % L) * D;
+  for (int c = threadIdx.x * 4; c < D; c += blockDim.x * 4)
+    *reinterpret_cast<f32x4*>(out + (size_t)m * ld + c) =
+        *reinterpret_cast<const f32x4*>(w + c) + *reinterpret_cast<const f32x4*>(p + c);
+}
+// dword[ids[m]][:] += g[m][:]   (dword zeroed by the caller)
+__global__ void embed_bwd_kernel(const long long* ids, const float* g, int ld, float* dword, int M, int D) {
+  const int m = blockIdx.x;
+  float* w = dword + (size_t)ids[m] * D;
+  for (int c = threadIdx.x; c < D; c += blockDim.x) atomicAdd(w + c, g[(size_t)m * ld + c]);
+}
+
+struct TextArgs {
+  const bf16* qkv; int ldqkv;
+  const long long* mask;            // [B, L], nonzero = attend
+  bf16* out; int ldo;
+  float* lse;                       // [M, H]
+  float* delta;                     // [M, H]  (backward scratch)
+  const bf16* dout; int lddo;
+  bf16* dqkv; int lddqkv;
+  int B, L, H, D;
+  float scale;
+};
+
+// one 8-lane group per (b, h, i); groups laid out i-fastest
+__global__ __launch_bounds__(256) void attn_text_fwd_kernel(TextArgs a) {
+  const int gid = blockIdx.x * 32 + (threadIdx.x >> 3);
+  const int pl = threadIdx.x & 7;
+  const int total = a.B * a.H * a.L;
+  const bool valid = gid < total;
+  const int gg = valid ? gid : total - 1;
+  const int i = gg % a.L, h = (gg / a.L) % a.H, b = gg / (a.L * a.H);
+  const size_t row = (size_t)b * a.L + i;
+  const int col = h * 64 + pl * 8;
+  const bf16x8 q = *reinterpret_cast<const bf16x8*>(a.qkv + row * a.ldqkv + col);
+  const float c2 = a.scale * X_LOG2E;
+  float m = -INFINITY, l = 0.f, o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int j = 0; j < a.L; ++j) {
+    if (a.mask[(size_t)b * a.L + j] == 0) continue;          // uniform across the 8 lanes
+    const size_t r = (size_t)b * a.L + j;
+    const bf16x8 kk = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + a.D + col);
+    const bf16x8 vv = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + 2 * a.D + col);
+    const float s = xred8(xdot8(q, kk)) * c2;
+    const float mn = fmaxf(m, s);
+    const float alpha = exp2f(m - mn), p = exp2f(s - mn);
+    l = l * alpha + p;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = o[e] * alpha + p * bf2f(vv[e]);
+    m = mn;
+  }
+  if (valid) {
+    const float inv = 1.0f / l;
+    const bf16x8 ob = {f2bf(o[0] * inv), f2bf(o[1] * inv), f2bf(o[2] * inv), f2bf(o[3] * inv),
+                       f2bf(o[4] * inv), f2bf(o[5] * inv), f2bf(o[6] * inv), f2bf(o[7] * inv)};
+    *reinterpret_cast<bf16x8*>(a.out + row * a.ldo + col) = ob;
+    if (pl == 0) a.lse[row * a.H + h] = (m + log2f(l)) * X_LN2;
+  }
+}
+
+// pass A: per query -> delta, dq
+__global__ __launch_bounds__(256) void attn_text_bwd_q_kernel(TextArgs a) {
+  const int gid = blockIdx.x * 32 + (threadIdx.x >> 3);
+  const int pl = threadIdx.x & 7;
+  const int total = a.B * a.H * a.L;
+  const bool valid = gid < total;
+  const int gg = valid ? gid : total - 1;
+  const int i = gg % a.L, h = (gg / a.L) % a.H, b = gg / (a.L * a.H);
+  const size_t row = (size_t)b * a.L + i;
+  const int col = h * 64 + pl * 8;
+  const bf16x8 q = *reinterpret_cast<const bf16x8*>(a.qkv + row * a.ldqkv + col);
+  const bf16x8 go = *reinterpret_cast<const bf16x8*>(a.dout + row * a.lddo + col);
+  const bf16x8 oo = *reinterpret_cast<const bf16x8*>(a.out + row * a.ldo + col);
+  const float delta = xred8(xdot8(go, oo));
+  const float lse2 = a.lse[row * a.H + h] * X_LOG2E;
+  const float c2 = a.scale * X_LOG2E;
+  float dq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int j = 0; j < a.L; ++j) {
+    if (a.mask[(size_t)b * a.L + j] == 0) continue;
+    const size_t r = (size_t)b * a.L + j;
+    const bf16x8 kk = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + a.D + col);
+    const bf16x8 vv = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + 2 * a.D + col);
+    const float p = exp2f(xred8(xdot8(q, kk)) * c2 - lse2);
+    const float ds = p * (xred8(xdot8(go, vv)) - delta) * a.scale;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dq[e] += ds * bf2f(kk[e]);
+  }
+  if (valid) {
+    const bf16x8 ob = {f2bf(dq[0]), f2bf(dq[1]), f2bf(dq[2]), f2bf(dq[3]), f2bf(dq[4]), f2bf(dq[5]), f2bf(dq[6]), f2bf(dq[7])};
+    *reinterpret_cast<bf16x8*>(a.dqkv + row * a.lddqkv + col) = ob;
+    if (pl == 0) a.delta[row * a.H + h] = delta;
+  }
+}
+
+// pass B: per key -> dk, dv (masked keys receive exact zeros)
+__global__ __launch_bounds__(256) void attn_text_bwd_kv_kernel(TextArgs a) {
+  const int gid = blockIdx.x * 32 + (threadIdx.x >> 3);
+  const int pl = threadIdx.x & 7;
+  const int total = a.B * a.H * a.L;
+  const bool valid = gid < total;
+  const int gg = valid ? gid : total - 1;
+  const int j = gg % a.L, h = (gg / a.L) % a.H, b = gg / (a.L * a.H);
+  const size_t row = (size_t)b * a.L + j;
+  const int col = h * 64 + pl * 8;
+  const bf16x8 kk = *reinterpret_cast<const bf16x8*>(a.qkv + row * a.ldqkv + a.D + col);
+  const bf16x8 vv = *reinterpret_cast<const bf16x8*>(a.qkv + row * a.ldqkv + 2 * a.D + col);
+  const bool keep = a.mask[(size_t)b * a.L + j] != 0;
+  const float c2 = a.scale * X_LOG2E;
+  float dk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (keep) {
+    for (int i = 0; i < a.L; ++i) {
+      const size_t r = (size_t)b * a.L + i;
+      const bf16x8 q = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + col);
+      const bf16x8 go = *reinterpret_cast<const bf16x8*>(a.dout + r * a.lddo + col);
+      const float p = exp2f(xred8(xdot8(q, kk)) * c2 - a.lse[r * a.H + h] * X_LOG2E);
+      const float ds = p * (xred8(xdot8(go, vv)) - a.delta[r * a.H + h]) * a.scale;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { dk[e] += ds * bf2f(q[e]); dv[e] += p * bf2f(go[e]); }
+    }
+  }
+  if (valid) {
+    const bf16x8 kb = {f2bf(dk[0]), f2bf(dk[1]), f2bf(dk[2]), f2bf(dk[3]), f2bf(dk[4]), f2bf(dk[5]), f2bf(dk[6]), f2bf(dk[7])};
+    const bf16x8 vb = {f2bf(dv[0]), f2bf(dv[1]), f2bf(dv[2]), f2bf(dv[3]), f2bf(dv[4]), f2bf(dv[5]), f2bf(dv[6]), f2bf(dv[7])};
+    *reinterpret_cast<bf16x8*>(a.dqkv + row * a.lddqkv + a.D + col) = kb;
+    *reinterpret_cast<bf16x8*>(a.dqkv + row * a.lddqkv + 2 * a.D + col) = vb;
+  }
+}
+
+// y = relu(x) as bf16 (txt_proj = ReLU -> Linear, oa_model.py:68) ; backward mask: dx = dy * (x > 0)
+__global__ void relu_bf16_kernel(const float* x, int ldx, bf16* y, int ldy, int M, int D) {
+  const int m = blockIdx.x;
+  for (int c = threadIdx.x; c < D; c += blockDim.x) y[(size_t)m * ldy + c] = f2bf(fmaxf(x[(size_t)m * ldx + c], 0.f));
+}
+__global__ void relu_bwd_kernel(const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx, int M, int D) {
+  const int m = blockIdx.x;
+  for (int c = threadIdx.x; c < D; c += blockDim.x)
+    dx[(size_t)m * lddx + c] = x[(size_t)m * ldx + c] > 0.f ? dy[(size_t)m * lddy + c] : 0.f;
+}
+
+}  // namespace oat
+
+using namespace oat;
+
+extern "C" int oat_embed_fwd(const void* ids, const float* word, const float* pos, float* out, int ld, int M, int L,
+                             int D, void* stream) {
+  if (M <= 0) return 0;
+  if (D % 4 || ld % 4) { set_error("embed_fwd: D%4 required"); return -3; }
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3(M), dim3(192), 0, (hipStream_t)stream, (const long long*)ids, word, pos, out,
+                     ld, M, L, D);
+  return check_launch("embed_fwd");
+}
+extern "C" int oat_embed_bwd(const void* ids, const float* g, int ld, float* dword, int M, int D, void* stream) {
+  if (M <= 0) return 0;
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const long long*)ids, g, ld, dword, M, D);
+  return check_launch("embed_bwd");
+}
+
+extern "C" int oat_attn_text_fwd(const void* qkv, int ldqkv, const void* mask, void* out, int ldo, float* lse, int B,
+                                 int L, int H, int D, float scale, void* stream) {
+  if (D != H * 64) { set_error("attn_text: head_dim must be 64"); return -3; }
+  TextArgs a{(const bf16*)qkv, ldqkv, (const long long*)mask, (bf16*)out, ldo, lse, nullptr, nullptr, 0, nullptr, 0, B, L, H, D, scale};
+  const int groups = B * H * L;
+  hipLaunchKernelGGL(attn_text_fwd_kernel, dim3((groups + 31) / 32), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("attn_text_fwd");
+}
+// delta: fp32 [B*L, H] scratch
+extern "C" int oat_attn_text_bwd(const void* qkv, int ldqkv, const void* mask, const void* out, int ldo,
+                                 const float* lse, float* delta, const void* dout, int lddo, void* dqkv, int lddqkv,
+                                 int B, int L, int H, int D, float scale, void* stream) {
+  if (D != H * 64) { set_error("attn_text: head_dim must be 64"); return -3; }
+  TextArgs a{(const bf16*)qkv, ldqkv, (const long long*)mask, (bf16*)out, ldo, (float*)lse, delta, (const bf16*)dout, lddo,
+             (bf16*)dqkv, lddqkv, B, L, H, D, scale};
+  const int groups = B * H * L;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(attn_text_bwd_q_kernel, dim3((groups + 31) / 32), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(attn_text_bwd_kv_kernel, dim3((groups + 31) / 32), dim3(256), 0, s, a);
+  return check_launch("attn_text_bwd");
+}
+
+extern "C" int oat_relu_bf16(const float* x, int ldx, void* y, int ldy, int M, int D, void* stream) {
+  if (M <= 0) return 0;
+  hipLaunchKernelGGL(relu_bf16_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, x, ldx, (bf16*)y, ldy, M, D);
+  return check_launch("relu_bf16");
+}
+extern "C" int oat_relu_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx, int M, int D,
+                            void* stream) {
+  if (M <= 0) return 0;
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, x, ldx, dy, lddy, dx, lddx, M, D);
+  return check_launch("relu_bwd");
+}
