@@ -6,8 +6,41 @@ import torch
 from torch import nn
 
 
+_WEIGHTS_EPOCH = [0]
+
+
+def bump_weights_epoch():
+    """Called by optimisers that update parameters through raw pointers (no autograd version bump)
+    so that the engines re-cast their bf16 weight shadows."""
+    _WEIGHTS_EPOCH[0] += 1
+
+
 class EngineModule(nn.Module):
     _skip_prefixes = ()
+
+    def _weights_signature(self):
+        pairs = self._engine_params()
+        return (_WEIGHTS_EPOCH[0], sum(p._version for _, p in pairs), pairs[0][1].data_ptr(), pairs[-1][1].data_ptr())
+
+    def flatten_parameters(self):
+        """Re-home every engine parameter into ONE flat fp32 buffer (same order as the flat gradient
+        buffer) so that the optimiser and the gradient all-reduce each see a single range."""
+        pairs = self._engine_params()
+        dev = pairs[0][1].device
+        total = sum(p.numel() for _, p in pairs)
+        flat = torch.empty(total, dtype=torch.float32, device=dev)
+        off = 0
+        for _, p in pairs:
+            v = flat[off:off + p.numel()].view_as(p)
+            v.copy_(p.data)
+            p.data = v
+            off += p.numel()
+        self._flat_param = flat
+        self._gradbuf = None
+        for _, p in pairs:
+            p.grad = None
+        self._grad_views()
+        return flat
 
     def _engine_params(self):
         names = getattr(self, "_names", None)

@@ -86,12 +86,13 @@ class VideoEngine:
         self.shadow_versions = None
 
     # ------------------------------------------------------------------ weights
-    def refresh_shadows(self, params):
-        """bf16 W and W^T copies of every GEMM weight; re-cast only when a master changed."""
+    def refresh_shadows(self, params, sig=None):
+        """bf16 W and W^T copies of every GEMM weight; re-cast only when a master changed
+        (`sig` = EngineModule._weights_signature())."""
         names = [f"blocks.{i}.{l}.weight" for i in range(self.depth) for l in self.LINEARS]
         names.append("patch_embed.proj.weight")
-        versions = tuple(params[n]._version for n in names) + tuple(params[n].data_ptr() for n in names)
-        if versions == self.shadow_versions:
+        versions = sig
+        if sig is not None and versions == self.shadow_versions:
             return
         for n in names:
             w = params[n].detach()
@@ -109,7 +110,7 @@ class VideoEngine:
         return self.plans[key]
 
     # ------------------------------------------------------------------ forward
-    def forward(self, video, params, need_patches=False):
+    def forward(self, video, params, need_patches=False, sig=None):
         """video [B,T,C,R,R] fp32|bf16 -> (cls_normed fp32 [B,D], patches_normed fp32 [B*T*N, D] | None, plan)"""
         B, T, C, R, _ = video.shape
         if T > self.num_frames:
@@ -117,7 +118,7 @@ class VideoEngine:
         g = R // self.ps
         N = g * g
         D, Hd, H = self.D, self.Hd, self.H
-        self.refresh_shadows(params)
+        self.refresh_shadows(params, sig)
         pl = self.plan(B, T, N, video.device)
         M, BTN = pl.M, B * T * N
         video = video.contiguous()

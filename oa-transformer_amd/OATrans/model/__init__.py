@@ -3,7 +3,8 @@
 points resolve by reflection live here (the reference's own __init__ is empty)."""
 from .layers import sim_matrix
 from .loss import NormSoftmaxLoss
+from .metric import t2v_metrics, v2t_metrics
 from .oa_model import FrozenInTime
 from .video_transformer import SpaceTimeTransformer
 
-__all__ = ["FrozenInTime", "NormSoftmaxLoss", "SpaceTimeTransformer", "sim_matrix"]
+__all__ = ["FrozenInTime", "NormSoftmaxLoss", "SpaceTimeTransformer", "sim_matrix", "t2v_metrics", "v2t_metrics"]

@@ -54,7 +54,8 @@ class _Transformer(nn.Module):
 class _HiddenFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, input_ids, attention_mask, call_idx, *params):
-        hidden, plan = module._engine.forward(input_ids, attention_mask, module._param_data())
+        hidden, plan = module._engine.forward(input_ids, attention_mask, module._param_data(),
+                                              module._weights_signature())
         ctx.module, ctx.plan, ctx.call_idx = module, plan, call_idx
         return hidden.clone()
 

@@ -75,7 +75,7 @@ class _EncoderFn(torch.autograd.Function):
     def forward(ctx, module, video, need_patches, *params):
         eng = module._engine
         pd = module._param_data()
-        cls, patches, plan = eng.forward(video, pd, need_patches)
+        cls, patches, plan = eng.forward(video, pd, need_patches, module._weights_signature())
         ctx.module, ctx.plan = module, plan
         ctx.set_materialize_grads(False)
         cls_out = cls.clone()

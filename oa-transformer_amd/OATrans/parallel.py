@@ -1,0 +1,109 @@
+"""Data parallelism for the hot path: one process per GPU, RCCL (torch.distributed 'nccl' on ROCm)
+over xGMI.  Two exchange steps exist:
+
+  * embeddings all-gather with autograd (global-batch negatives):
+      /root/reference/OATrans/trainer/trainer_dist.py:29-45 (AllGather_multi)
+    forward = all_gather in rank order; backward = the LOCAL slice of the incoming gradient, no
+    reduction (every rank computes the same global loss; the parameter-gradient mean then yields
+    (1/W) dL_global/dtheta).  video and text are packed into ONE collective per step.
+  * gradient mean all-reduce (the reference's DistributedDataParallel wrap, base_trainer.py:17-23).
+    The HIP engines write gradients into flat per-module buffers, so the all-reduce runs over a few
+    large contiguous ranges (big messages suit the per-link-bound xGMI ring) on a SIDE stream; the
+    1/W scaling is folded into the fused AdamW (`grad_scale`).
+"""
+import torch
+import torch.distributed as dist
+from torch import nn
+
+
+def world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(), dist.get_rank()
+    return 1, 0
+
+
+class AllGather_multi(torch.autograd.Function):
+    """Same call signature as the reference: AllGather_multi.apply(tensor, n_gpu, args)."""
+
+    @staticmethod
+    def forward(ctx, tensor, n_gpu, args):
+        ctx.rank, ctx.batch_size = args.rank, tensor.shape[0]
+        if args.world_size == 1:
+            return tensor.clone()
+        out = torch.empty((args.world_size * tensor.shape[0],) + tuple(tensor.shape[1:]), dtype=tensor.dtype,
+                          device=tensor.device)
+        dist.all_gather_into_tensor(out, tensor.contiguous())
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        b, r = ctx.batch_size, ctx.rank
+        return grad_output[b * r: b * (r + 1)], None, None
+
+
+def allgather_pair(a, b, args):
+    """One collective for both embedding sets: [B, da + db] -> split after the gather."""
+    packed = AllGather_multi.apply(torch.cat([a, b], dim=1), args.world_size, args)
+    return packed[:, :a.shape[1]], packed[:, a.shape[1]:]
+
+
+class GradSync:
+    """Mean all-reduce of parameter gradients over flat buffers, overlapped on a side stream."""
+
+    def __init__(self, model, bucket_mb=256):
+        self.model = model
+        self.bucket = int(bucket_mb * (1 << 20) // 4)
+        self.stream = torch.cuda.Stream() if torch.cuda.is_available() else None
+
+    def ranges(self):
+        """Maximal contiguous gradient ranges (engine modules expose one each; loose params singly)."""
+        out, cur = [], None
+        for p in self.model.parameters():
+            if p.grad is None:
+                continue
+            ptr, n = p.grad.data_ptr(), p.grad.numel()
+            if cur is not None and ptr == cur[2]:
+                cur[1] += n
+                cur[2] += 4 * n
+            else:
+                cur = [p.grad, n, ptr + 4 * n]
+                out.append(cur)
+        return [torch.as_strided(g, (n,), (1,)) for g, n, _ in out]
+
+    def all_reduce(self, average=True):
+        W, _ = world()
+        if W == 1:
+            return
+        flats = self.ranges()
+        if self.stream is not None and flats[0].is_cuda:
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                self._reduce(flats, W, average)
+            torch.cuda.current_stream().wait_stream(self.stream)
+        else:
+            self._reduce(flats, W, average)
+
+    def _reduce(self, flats, W, average):
+        for f in flats:
+            for s in range(0, f.numel(), self.bucket):
+                chunk = f[s:s + self.bucket]
+                dist.all_reduce(chunk, op=dist.ReduceOp.SUM)
+                if average:
+                    chunk.div_(W)
+
+
+class HipDataParallel(nn.Module):
+    """Stands where the reference puts DistributedDataParallel (base_trainer.py:20-23): exposes
+    `.module`, forwards calls, and owns the gradient synchronisation (torch DDP cannot be used: the
+    engines write .grad in place, so its autograd hooks never fire)."""
+
+    def __init__(self, module):
+        super().__init__()
+        self.module = module
+        self.sync = GradSync(module)
+
+    def forward(self, *a, **kw):
+        return self.module(*a, **kw)
+
+    def sync_gradients(self):
+        self.sync.all_reduce(average=True)
