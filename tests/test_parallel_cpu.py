@@ -1,0 +1,88 @@
+"""N>1 path on CPU with gloo, world_size 2 (the GPU box runs the same code over RCCL):
+AllGather_multi semantics, the packed gather, flat-range gradient mean all-reduce, and the
+(1/W) gradient convention of trainer_dist.py:29-45 + DDP (SURVEY.md 8e 'must match')."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import oatrans_oracle as orc
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, q):
+    import argparse
+    from OATrans.parallel import AllGather_multi, GradSync, allgather_pair
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    args = argparse.Namespace(world_size=world, rank=rank, local_rank=rank)
+    torch.manual_seed(100)                                 # same "model" on every rank
+    W1 = torch.nn.Parameter(torch.randn(16, 8))
+    W2 = torch.nn.Parameter(torch.randn(16, 8))
+    torch.manual_seed(200 + rank)                          # different data per rank
+    xa, xb = torch.randn(3, 8), torch.randn(3, 8)
+    t, v = xa @ W1.t(), xb @ W2.t()
+    # 1. AllGather_multi: rank-order concat forward
+    g = AllGather_multi.apply(t, world, args)
+    assert g.shape == (world * 3, 16) and torch.equal(g[3 * rank:3 * rank + 3], t)
+    # 2. packed gather == two gathers; loss on the global batch
+    v_all, t_all = allgather_pair(v, t, args)
+    assert torch.equal(t_all, g)
+    loss = orc.norm_softmax_loss(orc.sim_matrix(t_all, v_all))
+    loss.backward()
+    # 3. flat-range mean all-reduce over a shared gradient buffer
+    flat = torch.cat([W1.grad.flatten(), W2.grad.flatten()])
+    W1.grad, W2.grad = flat[:128].view(16, 8), flat[128:].view(16, 8)
+    model = torch.nn.ParameterList([W1, W2])
+    sync = GradSync(model)
+    assert len(sync.ranges()) == 1 and sync.ranges()[0].numel() == 256
+    sync.all_reduce(average=True)
+    q.put((rank, loss.item(), W1.grad.clone(), W2.grad.clone(), xa, xb))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gather_and_gradient_convention():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process truth on the concatenated batch
+    torch.manual_seed(100)
+    W1 = torch.randn(16, 8, requires_grad=True)
+    W2 = torch.randn(16, 8, requires_grad=True)
+    xa = torch.cat([r[4] for r in res])
+    xb = torch.cat([r[5] for r in res])
+    loss = orc.norm_softmax_loss(orc.sim_matrix(xa @ W1.t(), xb @ W2.t()))
+    loss.backward()
+    for r in res:
+        assert abs(r[1] - loss.item()) < 1e-5                       # every rank sees the same global loss
+        # slice-only backward + gradient MEAN == (1/W) * dL_global/dtheta
+        assert torch.allclose(r[2], W1.grad / world, atol=1e-5)
+        assert torch.allclose(r[3], W2.grad / world, atol=1e-5)
+    assert torch.equal(res[0][2], res[1][2])
+
+
+def test_single_rank_gather_is_identity():
+    import argparse
+    from OATrans.parallel import AllGather_multi
+    args = argparse.Namespace(world_size=1, rank=0, local_rank=0)
+    x = torch.randn(4, 5, requires_grad=True)
+    y = AllGather_multi.apply(x, 1, args)
+    y.sum().backward()
+    assert torch.equal(y, x) and torch.equal(x.grad, torch.ones_like(x))
