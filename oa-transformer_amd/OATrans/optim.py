@@ -33,11 +33,14 @@ class AdamW(torch.optim.Optimizer):
                     continue
                 n = p.numel()
                 dp, gp = p.data.data_ptr(), p.grad.data_ptr()
-                if cur is not None and dp == cur['dend'] and gp == cur['gend']:
+                ds, gs = p.data.untyped_storage().data_ptr(), p.grad.untyped_storage().data_ptr()
+                # adjacent AND inside the same allocation (neighbouring blocks of the caching allocator
+                # can be address-adjacent without sharing a storage)
+                if cur is not None and dp == cur['dend'] and gp == cur['gend'] and (ds, gs) == cur['stor']:
                     cur['params'].append(p)
                     cur['n'] += n
                 else:
-                    cur = dict(group=gi, params=[p], n=n, d0=dp, g0=gp)
+                    cur = dict(group=gi, params=[p], n=n, d0=dp, g0=gp, stor=(ds, gs))
                     runs.append(cur)
                 cur['dend'], cur['gend'] = dp + 4 * n, gp + 4 * n
         for r in runs:

@@ -62,13 +62,14 @@ class GradSync:
             if p.grad is None:
                 continue
             ptr, n = p.grad.data_ptr(), p.grad.numel()
-            if cur is not None and ptr == cur[2]:
+            stor = p.grad.untyped_storage().data_ptr()
+            if cur is not None and ptr == cur[2] and stor == cur[3]:
                 cur[1] += n
                 cur[2] += 4 * n
             else:
-                cur = [p.grad, n, ptr + 4 * n]
+                cur = [p.grad, n, ptr + 4 * n, stor]
                 out.append(cur)
-        return [torch.as_strided(g, (n,), (1,)) for g, n, _ in out]
+        return [torch.as_strided(g, (n,), (1,)) for g, n, _, _ in out]
 
     def all_reduce(self, average=True):
         W, _ = world()
