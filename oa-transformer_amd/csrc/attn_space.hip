@@ -52,6 +52,7 @@ struct SpaceArgs {
   float scale;
 };
 
+constexpr int SPACE_THREADS = 512;          // 8 waves: two per SIMD hide the MFMA / LDS / exp latency chains
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 
@@ -59,7 +60,7 @@ constexpr float LN2 = 0.6931471805599453f;
 template <int NKT>
 OAT_DEV void load_tile(char* tile, const bf16* src, int ld, int col, size_t base_row, size_t cls_row, int N) {
   constexpr int NKP = NKT * 16;
-  for (int idx = threadIdx.x; idx < NKP * 8; idx += 256) {
+  for (int idx = threadIdx.x; idx < NKP * 8; idx += SPACE_THREADS) {
     const int j = idx >> 3, c = idx & 7;
     bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
     if (j <= N) {
@@ -71,7 +72,7 @@ OAT_DEV void load_tile(char* tile, const bf16* src, int ld, int col, size_t base
 }
 
 template <int NKT>
-__global__ __launch_bounds__(256) void attn_space_fwd_kernel(SpaceArgs a) {
+__global__ __launch_bounds__(SPACE_THREADS) void attn_space_fwd_kernel(SpaceArgs a) {
   constexpr int NKP = NKT * 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Kt = smem;
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256) void attn_space_fwd_kernel(SpaceArgs a) {
   const int g = lane >> 4;
   const float c2 = a.scale * LOG2E;
   const int nqt = (N + 15) / 16;
-  for (int qt = wave; qt < nqt; qt += 4) {
+  for (int qt = wave; qt < nqt; qt += SPACE_THREADS / 64) {
     const int qi = qt * 16 + (lane & 15);
     const size_t qrow = base_row + min(qi, N - 1);
     bf16x8 qf[2];
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(256) void attn_space_fwd_kernel(SpaceArgs a) {
 }
 
 template <int NKT>
-__global__ __launch_bounds__(256) void attn_space_bwd_kernel(SpaceArgs a) {
+__global__ __launch_bounds__(SPACE_THREADS) void attn_space_bwd_kernel(SpaceArgs a) {
   constexpr int NKP = NKT * 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Qt = smem;
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(256) void attn_space_bwd_kernel(SpaceArgs a) {
   load_tile<NKT>(Kt, a.qkv, a.ldqkv, a.D + h * 64, base_row, cls_row, N);
   load_tile<NKT>(Vt, a.qkv, a.ldqkv, 2 * a.D + h * 64, base_row, cls_row, N);
   // dO tile + delta = rowsum(dO * O) + lse (log2 units); 8 lanes per row
-  for (int idx = threadIdx.x; idx < NKP * 8; idx += 256) {
+  for (int idx = threadIdx.x; idx < NKP * 8; idx += SPACE_THREADS) {
     const int j = idx >> 3, c = idx & 7;
     bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
     float d = 0.f;
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(256) void attn_space_bwd_kernel(SpaceArgs a) {
   float* side = a.cls_side + ((size_t)b * a.H + h) * 3 * 64;
 
   // ------------------------------------------------ phase A: lane = query column, produces dQ
-  for (int qt = wave; qt < NKT; qt += 4) {
+  for (int qt = wave; qt < NKT; qt += SPACE_THREADS / 64) {
     if (qt * 16 > N) break;
     const int qi = qt * 16 + (lane & 15);
     const float lq = lse_s[qi], dq_ = del_s[qi];
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(256) void attn_space_bwd_kernel(SpaceArgs a) {
   }
 
   // ------------------------------------------------ phase B: lane = key column, produces dK, dV
-  for (int kt = wave; kt < NKT; kt += 4) {
+  for (int kt = wave; kt < NKT; kt += SPACE_THREADS / 64) {
     if (kt * 16 > N) break;
     const int key = kt * 16 + (lane & 15);
     bf16x8 kf[2], vf[2];
@@ -324,7 +325,7 @@ static int launch_fwd(const SpaceArgs& a, hipStream_t s) {
   const int lds = 2 * NKT * 16 * 128;
   static bool set = false;
   if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_space_fwd_kernel<NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
-  hipLaunchKernelGGL(attn_space_fwd_kernel<NKT>, dim3(a.B * a.T * a.H), dim3(256), lds, s, a);
+  hipLaunchKernelGGL(attn_space_fwd_kernel<NKT>, dim3(a.B * a.T * a.H), dim3(SPACE_THREADS), lds, s, a);
   return check_launch("attn_space_fwd");
 }
 template <int NKT>
@@ -332,7 +333,7 @@ static int launch_bwd(const SpaceArgs& a, hipStream_t s) {
   const int lds = 4 * NKT * 16 * 128 + 2 * NKT * 16 * 4;
   static bool set = false;
   if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_space_bwd_kernel<NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
-  hipLaunchKernelGGL(attn_space_bwd_kernel<NKT>, dim3(a.B * a.T * a.H), dim3(256), lds, s, a);
+  hipLaunchKernelGGL(attn_space_bwd_kernel<NKT>, dim3(a.B * a.T * a.H), dim3(SPACE_THREADS), lds, s, a);
   return check_launch("attn_space_bwd");
 }
 

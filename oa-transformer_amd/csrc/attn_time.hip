@@ -18,6 +18,17 @@ constexpr float T_LOG2E = 1.4426950408889634f;
 constexpr float T_LN2 = 0.6931471805599453f;
 
 OAT_DEV float dot8(const bf16x8 a, const bf16x8 b) {
+  // v_dot2c_f32_bf16: two bf16 products per instruction, fp32 accumulate, no conversion temporaries
+  const bf16x2* a2 = reinterpret_cast<const bf16x2*>(&a);
+  const bf16x2* b2 = reinterpret_cast<const bf16x2*>(&b);
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_fdot2_f32_bf16(a2[e], b2[e], s, false);
+  return s;
+}
+// exact fp32 FMA chain for the FORWARD scores (v_dot2c measurably doubles the sim-matrix error:
+// 3.2e-4 -> 7.1e-4 at ViT-B/16, its accumulate is not round-to-nearest); backward keeps dot2c.
+OAT_DEV float dot8x(const bf16x8 a, const bf16x8 b) {
   float s = 0.f;
 #pragma unroll
   for (int e = 0; e < 8; ++e) s += bf2f(a[e]) * bf2f(b[e]);
@@ -69,7 +80,7 @@ __global__ __launch_bounds__(256) void attn_time_fwd_kernel(TimeArgs a) {
     const bf16x8 q = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + col);
     float s[TT + 1], m = -INFINITY;
 #pragma unroll
-    for (int j = 0; j <= TT; ++j) { s[j] = red8(dot8(q, k[j])) * c2; m = fmaxf(m, s[j]); }
+    for (int j = 0; j <= TT; ++j) { s[j] = red8(dot8x(q, k[j])) * c2; m = fmaxf(m, s[j]); }
     float l = 0.f, o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int j = 0; j <= TT; ++j) {
@@ -108,7 +119,6 @@ __global__ __launch_bounds__(256) void attn_time_bwd_kernel(TimeArgs a) {
   const size_t row0 = (size_t)b * TT * a.N + nn;     // row of frame j = row0 + j * N
   const float c2 = a.scale * T_LOG2E;
   float* side = a.cls_side + ((size_t)b * a.H + h) * 192;
-  float delta[TT + 1], lse2[TT + 1];
   {
     bf16x8 k[TT + 1], v[TT + 1];
 #pragma unroll
@@ -117,20 +127,25 @@ __global__ __launch_bounds__(256) void attn_time_bwd_kernel(TimeArgs a) {
       k[j] = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + a.D + col);
       v[j] = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + 2 * a.D + col);
     }
-#pragma unroll
+    // outer loop deliberately NOT unrolled: keeps the live set at k[], v[] + one query (occupancy)
+#pragma unroll 1
     for (int i = 0; i <= TT; ++i) {
+      // opaque touch: stops the compiler hoisting the 144 bf16->fp32 conversions of k[], v[] out of
+      // this loop (that hoist alone costs 144 VGPRs and pins the kernel at one wave per SIMD)
+#pragma unroll
+      for (int j = 0; j <= TT; ++j) { asm volatile("" : "+v"(k[j])); asm volatile("" : "+v"(v[j])); }
       const size_t r = i < TT ? row0 + (size_t)i * a.N : cls_row;
       const bf16x8 q = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + col);
       const bf16x8 go = *reinterpret_cast<const bf16x8*>(a.dout + r * a.lddo + col);
       const bf16x8 oo = *reinterpret_cast<const bf16x8*>(a.out + r * a.ldo + col);
-      lse2[i] = a.lse[r * a.H + h] * T_LOG2E;
-      delta[i] = red8(dot8(go, oo));
+      const float lse2 = a.lse[r * a.H + h] * T_LOG2E;
+      const float delta = red8(dot8(go, oo));
       float dq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
       for (int j = 0; j <= TT; ++j) {
-        float p = exp2f(red8(dot8(q, k[j])) * c2 - lse2[i]);
+        float p = exp2f(red8(dot8(q, k[j])) * c2 - lse2);
         if (i == TT && j == TT && n != 0) p = 0.f;        // CLS->CLS pair is counted once (n == 0)
-        const float ds = p * (red8(dot8(go, v[j])) - delta[i]) * a.scale;
+        const float ds = p * (red8(dot8(go, v[j])) - delta) * a.scale;
 #pragma unroll
         for (int e = 0; e < 8; ++e) dq[e] += ds * bf2f(k[j][e]);
       }
@@ -152,14 +167,20 @@ __global__ __launch_bounds__(256) void attn_time_bwd_kernel(TimeArgs a) {
   }
   {
     bf16x8 q[TT + 1], go[TT + 1];
+    float delta[TT + 1], lse2[TT + 1];
 #pragma unroll
     for (int i = 0; i <= TT; ++i) {
       const size_t r = i < TT ? row0 + (size_t)i * a.N : cls_row;
       q[i] = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + col);
       go[i] = *reinterpret_cast<const bf16x8*>(a.dout + r * a.lddo + col);
+      const bf16x8 oo = *reinterpret_cast<const bf16x8*>(a.out + r * a.ldo + col);
+      delta[i] = red8(dot8(go[i], oo));
+      lse2[i] = a.lse[r * a.H + h] * T_LOG2E;
     }
-#pragma unroll
+#pragma unroll 1
     for (int j = 0; j <= TT; ++j) {
+#pragma unroll
+      for (int i = 0; i <= TT; ++i) { asm volatile("" : "+v"(q[i])); asm volatile("" : "+v"(go[i])); }
       const size_t r = j < TT ? row0 + (size_t)j * a.N : cls_row;
       const bf16x8 kk = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + a.D + col);
       const bf16x8 vv = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + 2 * a.D + col);
@@ -210,7 +231,7 @@ __global__ __launch_bounds__(256) void attn_cls_fwd_kernel(TimeArgs a) {
     const size_t r = j < S1 ? row0 + j : cls_row;
     const bf16x8 kk = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + a.D + col);
     const bf16x8 vv = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + 2 * a.D + col);
-    const float s = red8(dot8(q, kk)) * c2;
+    const float s = red8(dot8x(q, kk)) * c2;
     const float mn = fmaxf(m, s);
     const float alpha = exp2f(m - mn), p = exp2f(s - mn);
     l = l * alpha + p;

@@ -16,6 +16,15 @@ constexpr float X_LOG2E = 1.4426950408889634f;
 constexpr float X_LN2 = 0.6931471805599453f;
 
 OAT_DEV float xdot8(const bf16x8 a, const bf16x8 b) {
+  // v_dot2c_f32_bf16: two bf16 products per instruction, fp32 accumulate, no conversion temporaries
+  const bf16x2* a2 = reinterpret_cast<const bf16x2*>(&a);
+  const bf16x2* b2 = reinterpret_cast<const bf16x2*>(&b);
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_fdot2_f32_bf16(a2[e], b2[e], s, false);
+  return s;
+}
+OAT_DEV float xdot8x(const bf16x8 a, const bf16x8 b) {      // exact fp32 chain for forward scores
   float s = 0.f;
 #pragma unroll
   for (int e = 0; e < 8; ++e) s += bf2f(a[e]) * bf2f(b[e]);
@@ -75,7 +84,7 @@ __global__ __launch_bounds__(256) void attn_text_fwd_kernel(TextArgs a) {
     const size_t r = (size_t)b * a.L + j;
     const bf16x8 kk = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + a.D + col);
     const bf16x8 vv = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + 2 * a.D + col);
-    const float s = xred8(xdot8(q, kk)) * c2;
+    const float s = xred8(xdot8x(q, kk)) * c2;
     const float mn = fmaxf(m, s);
     const float alpha = exp2f(m - mn), p = exp2f(s - mn);
     l = l * alpha + p;
