@@ -42,7 +42,9 @@ void oat_gemm_set_variant(int v);
  * Rows [M, round_up(M,64)) of P and Q must be readable (contents ignored). */
 size_t oat_gemm_tn_workspace_bytes(int M, int N1, int N2);
 int oat_gemm_tn(const void* P, const void* Q, int M, int N1, int N2, int ldp, int ldq, float* out,
-                int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+                float* bias_out /* [N1] column sums of P, or NULL */, int accumulate, void* workspace,
+                size_t workspace_bytes, void* stream);
+void oat_gemm_tn_set_variant(int v);   /* tuning hook: 0 auto, 1 force 128x128, 2 force 256x256 */
 
 /* ---- LayerNorm (video_transformer.py:164,167,174,346; DistilBERT LayerNorms) ------------- */
 int oat_layernorm_fwd(const float* x, int ldx, const float* gamma, const float* beta, void* y_bf16,

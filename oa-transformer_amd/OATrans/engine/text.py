@@ -144,21 +144,18 @@ class TextEngine:
             hip.layernorm_bwd(G, a.f, a.stats[2], a.stats[3], p("output_layer_norm.weight"), M, D, dx=G, dx16=g16,
                               dgamma=gr("output_layer_norm.weight"), dbeta=gr("output_layer_norm.bias"),
                               accumulate=acc)                                              # G = dL/df
-            hip.colsum(g16, M, D, gr("ffn.lin2.bias"), accumulate=acc)
-            hip.gemm_tn(g16, a.g, M, D, Hd, gr("ffn.lin2.weight"), accumulate=acc)
+            hip.gemm_tn(g16, a.g, M, D, Hd, gr("ffn.lin2.weight"), accumulate=acc, bias_out=gr("ffn.lin2.bias"))
             hip.gemm_nt(g16, wT("ffn.lin2"), M, Hd, D, hip.EPI_DGELU, pl.d_h, aux=a.h)
-            hip.colsum(pl.d_h, M, Hd, gr("ffn.lin1.bias"), accumulate=acc)
-            hip.gemm_tn(pl.d_h, a.x1_16, M, Hd, D, gr("ffn.lin1.weight"), accumulate=acc)
+            hip.gemm_tn(pl.d_h, a.x1_16, M, Hd, D, gr("ffn.lin1.weight"), accumulate=acc, bias_out=gr("ffn.lin1.bias"))
             hip.gemm_nt(pl.d_h, wT("ffn.lin1"), M, D, Hd, hip.EPI_F32, G, resid=G)          # G = dL/dx1
             # x1 = LN(s), s = x + out_lin(attn(qkv(x)))
             hip.layernorm_bwd(G, a.s, a.stats[0], a.stats[1], p("sa_layer_norm.weight"), M, D, dx=G, dx16=g16,
                               dgamma=gr("sa_layer_norm.weight"), dbeta=gr("sa_layer_norm.bias"), accumulate=acc)
-            hip.colsum(g16, M, D, gr("attention.out_lin.bias"), accumulate=acc)
-            hip.gemm_tn(g16, a.ctx, M, D, D, gr("attention.out_lin.weight"), accumulate=acc)
+            hip.gemm_tn(g16, a.ctx, M, D, D, gr("attention.out_lin.weight"), accumulate=acc,
+                        bias_out=gr("attention.out_lin.bias"))
             hip.gemm_nt(g16, wT("attention.out_lin"), M, D, D, hip.EPI_BF16, pl.d_ctx)
             hip.attn_text_bwd(a.qkv, pl.mask, a.ctx, a.lse, pl.delta, pl.d_ctx, pl.d_qkv, B, L, H, D, self.scale)
-            hip.colsum(pl.d_qkv, M, 3 * D, pl.gqkv_b)
-            hip.gemm_tn(pl.d_qkv, x16, M, 3 * D, D, pl.gqkv_w)
+            hip.gemm_tn(pl.d_qkv, x16, M, 3 * D, D, pl.gqkv_w, bias_out=pl.gqkv_b)
             for k, l in enumerate(("q_lin", "k_lin", "v_lin")):
                 gw, gb = gr(f"attention.{l}.weight"), gr(f"attention.{l}.bias")
                 if acc:

@@ -184,43 +184,36 @@ class VideoEngine:
             wT = lambda s: self.shadow[f"blocks.{i}.{s}.weight"][1]
             st = a.stats
             # ---- MLP: out = y + fc2(gelu(fc1(LN2(y))))
-            hip.colsum(g16, M, D, gr("mlp.fc2.bias"))
-            hip.gemm_tn(g16, a.g, M, D, Hd, gr("mlp.fc2.weight"))
+            hip.gemm_tn(g16, a.g, M, D, Hd, gr("mlp.fc2.weight"), bias_out=gr("mlp.fc2.bias"))
             hip.gemm_nt(g16, wT("mlp.fc2"), M, Hd, D, hip.EPI_DGELU, pl.d_h, aux=a.h)
-            hip.colsum(pl.d_h, M, Hd, gr("mlp.fc1.bias"))
-            hip.gemm_tn(pl.d_h, a.a2, M, Hd, D, gr("mlp.fc1.weight"))
+            hip.gemm_tn(pl.d_h, a.a2, M, Hd, D, gr("mlp.fc1.weight"), bias_out=gr("mlp.fc1.bias"))
             hip.gemm_nt(pl.d_h, wT("mlp.fc1"), M, D, Hd, hip.EPI_BF16, pl.d_a)
             hip.layernorm_bwd(pl.d_a, a.y, st[4], st[5], p("norm2.weight"), M, D, dx=G, dx16=g16, dres=G,
                               dgamma=gr("norm2.weight"), dbeta=gr("norm2.bias"))            # G = dL/dy
             # ---- space attention: y = x + proj(attn(LN1(xt)))
-            hip.colsum(g16, M, D, gr("attn.proj.bias"))
-            hip.gemm_tn(g16, a.o_s, M, D, D, gr("attn.proj.weight"))
+            hip.gemm_tn(g16, a.o_s, M, D, D, gr("attn.proj.weight"), bias_out=gr("attn.proj.bias"))
             hip.gemm_nt(g16, wT("attn.proj"), M, D, D, hip.EPI_BF16, pl.d_o)
             pl.side.zero_()
             hip.attn_space_bwd(a.qkv_s, a.o_s, a.lse_s, pl.d_o, pl.d_qkv, pl.side, B, T, N, H, D, self.scale)
             hip.attn_cls_finalize(pl.side, pl.d_qkv, B, T, N, H, D)
-            hip.colsum(pl.d_qkv, M, 3 * D, gr("attn.qkv.bias"))
-            hip.gemm_tn(pl.d_qkv, a.a1, M, 3 * D, D, gr("attn.qkv.weight"))
+            hip.gemm_tn(pl.d_qkv, a.a1, M, 3 * D, D, gr("attn.qkv.weight"), bias_out=gr("attn.qkv.bias"))
             hip.gemm_nt(pl.d_qkv, wT("attn.qkv"), M, D, 3 * D, hip.EPI_BF16, pl.d_a)
             # G <- dL/dy + dL/dxt (both reach x directly); g16 <- dL/dxt alone (feeds the time branch)
             hip.layernorm_bwd(pl.d_a, a.xt, st[2], st[3], p("norm1.weight"), M, D, dx=G, dx16=g16, dres=G,
                               dx16_excl_res=True, dgamma=gr("norm1.weight"), dbeta=gr("norm1.bias"))
             # ---- time attention: xt = x + proj(attn(LN3(x)))
-            hip.colsum(g16, M, D, gr("timeattn.proj.bias"))
-            hip.gemm_tn(g16, a.o_t, M, D, D, gr("timeattn.proj.weight"))
+            hip.gemm_tn(g16, a.o_t, M, D, D, gr("timeattn.proj.weight"), bias_out=gr("timeattn.proj.bias"))
             hip.gemm_nt(g16, wT("timeattn.proj"), M, D, D, hip.EPI_BF16, pl.d_o)
             pl.side.zero_()
             hip.attn_time_bwd(a.qkv_t, a.o_t, a.lse_t, pl.d_o, pl.d_qkv, pl.side, B, T, N, H, D, self.scale)
             hip.attn_cls_finalize(pl.side, pl.d_qkv, B, T, N, H, D)
-            hip.colsum(pl.d_qkv, M, 3 * D, gr("timeattn.qkv.bias"))
-            hip.gemm_tn(pl.d_qkv, a.a3, M, 3 * D, D, gr("timeattn.qkv.weight"))
+            hip.gemm_tn(pl.d_qkv, a.a3, M, 3 * D, D, gr("timeattn.qkv.weight"), bias_out=gr("timeattn.qkv.bias"))
             hip.gemm_nt(pl.d_qkv, wT("timeattn.qkv"), M, D, 3 * D, hip.EPI_BF16, pl.d_a)
             hip.layernorm_bwd(pl.d_a, x, st[0], st[1], p("norm3.weight"), M, D, dx=G, dx16=g16, dres=G,
                               dgamma=gr("norm3.weight"), dbeta=gr("norm3.bias"))            # G = dL/dx
         # ---- token embedding: x0[patch] = cols @ Wp^T + b + pos[1+n] + temporal[f]; x0[cls] = cls + pos[0]
-        hip.colsum(G, BTN, D, grads["patch_embed.proj.bias"])
         gw = grads["patch_embed.proj.weight"]
-        hip.gemm_tn(g16, pl.cols, BTN, D, self.Kp, gw.view(D, self.Kp))
+        hip.gemm_tn(g16, pl.cols, BTN, D, self.Kp, gw.view(D, self.Kp), bias_out=grads["patch_embed.proj.bias"])
         hip.periodic_rowsum(G, B, T * N, D, pl.Gp)
         gpos = grads["pos_embed"].view(N + 1, D)
         hip.periodic_rowsum(pl.Gp, T, N, D, gpos[1:])

@@ -1,23 +1,27 @@
 // bf16 MFMA GEMM, "TN" form (weight gradients):  out[N1,N2] = sum_m P[m,N1]^T * Q[m,N2]
+//                               and optionally     bias[N1]   = sum_m P[m,N1]
 //
 // This is the reduction-over-rows product autograd runs for every nn.Linear weight of the
-// reference (dW = dY^T X; video_transformer.py:102,133,46-50 in backward).  Both operands
-// have the reduction index m as their SLOW (row) index, so MFMA fragments (8 consecutive
-// k per lane) are column slices of the LDS tile: gfx950's ds_read_b64_tr_b16 transpose-read
-// delivers them straight from the row-major image, no transposed copies of activations.
+// reference (dW = dY^T X, db = colsum(dY); video_transformer.py:102,133,46-50 in backward).
+// Both operands have the reduction index m as their SLOW (row) index, so MFMA fragments (8
+// consecutive k per lane) are column slices of the LDS tile: gfx950's ds_read_b64_tr_b16
+// transpose-read delivers them straight from the row-major image - no transposed copies of
+// activations ever touch HBM.
 //
-// v1: 128x128 output tile, 64 rows of m per stage, 4 waves (2x2) x (4x4 MFMA 16x16x32),
-// global_load_lds staging (double-buffered 64 KB), split over m across grid.y with fp32
-// slabs + a deterministic reduce kernel (no atomics).
+// Tile <WM,WN,TM,TN>: (WM*TM*16) x (WN*TN*16) outputs, WM*WN waves, 64 rows of m per stage,
+// global_load_lds staging (double buffered), XOR chunk swizzle on the source address + read.
+//   <2,4,8,4> = 256x256 / 8 waves / 128 KB LDS (big-M weight gradients, half the L2->LDS bytes per
+//   FLOP of the 128^2 tile); <2,2,4,4> = 128x128 / 4 waves / 64 KB (small problems).
+// The m range is split across grid.y; partial products go to fp32 slabs and a deterministic reduce
+// kernel sums them (no atomics).  The bias column sums ride on the matrix pipe: one extra MFMA per
+// (n1-tile, k-step) against an all-ones operand in the workgroups of the first N2 tile.
 // Contract: rows [M, round_up(M,64)) of P and Q must be READABLE (inside the allocation); their
 // contents are ignored (the ragged tail of the last chunk is zeroed in LDS).
 #include "common.h"
 
 namespace oat {
 
-constexpr int TB = 128;            // output tile edge
 constexpr int TK = 64;             // m rows per stage
-constexpr int TSTAGE = 2 * TK * TB * 2;   // P + Q tiles, bytes (32 KB)
 
 OAT_DEV int tn_f(int m) { return ((m & 3) << 1) | (((m >> 3) & 1) << 3); }
 
@@ -25,50 +29,77 @@ struct TnArgs {
   const bf16* P; const bf16* Q;
   int M, N1, N2, ldp, ldq;
   float* slabs;            // [splits][N1][N2]
+  float* bias_slabs;       // [splits][N1] or nullptr
   int chunks_per_split;    // in units of TK rows
+  int splits;
 };
 
-__global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs g) {
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_tn_kernel(TnArgs g) {
+  constexpr int B1 = WM * TM * 16, B2 = WN * TN * 16, NW = WM * WN, NT = NW * 64;
+  constexpr int P_BYTES = TK * B1 * 2, Q_BYTES = TK * B2 * 2, STAGE = P_BYTES + Q_BYTES;
+  constexpr int CP = B1 / 8, CQ = B2 / 8;                  // 16-byte chunks per tile row
+  constexpr int GP = TK * CP / 64 / NW, GQ = TK * CQ / 64 / NW;   // glds instructions per wave per tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int w1 = wave >> 1, w2 = wave & 1;
-  const int nt2 = (g.N2 + TB - 1) / TB;
-  const int t1 = blockIdx.x / nt2, t2 = blockIdx.x % nt2;
-  const int c1 = t1 * TB, c2 = t2 * TB;
-  const int split = blockIdx.y;
+  const int w1 = wave / WN, w2 = wave % WN;
+  // XCD-aware decomposition: hardware places block b on XCD b % 8.  Work items are ordered
+  // split-major (all tiles of one m-split are neighbours: they read the SAME rows of P and Q) and
+  // each XCD takes a contiguous run of that order, so a split's operand rows are fetched from HBM
+  // into one (at most two) XCD L2s and reused by every tile there.  Pure speed choice.
+  const int nt2 = (g.N2 + B2 - 1) / B2;
+  const int ntiles = ((g.N1 + B1 - 1) / B1) * nt2;
+  int wid = blockIdx.x;
+  {
+    const int nwg = gridDim.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = wid & 7, idx = wid >> 3;
+    wid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;   // bijective remap
+  }
+  const int split = wid / ntiles, tile = wid % ntiles;
+  const int t1 = tile / nt2, t2 = tile % nt2;
+  const int c1 = t1 * B1, c2 = t2 * B2;
   const int nchunks_total = (g.M + TK - 1) / TK;
   const int ch0 = split * g.chunks_per_split;
   const int ch1 = min(ch0 + g.chunks_per_split, nchunks_total);
+  const bool do_bias = g.bias_slabs != nullptr && t2 == 0;
 
-  // staging: one wave instruction = 4 rows x 256 B; wave w stages rows [w*16, w*16+16)
-  const int srow = lane >> 4, spc = lane & 15;
-  int p_off[4], q_off[4];
+  // staging: one wave instruction moves 64 chunks = 64/CP rows of the P tile (64/CQ of the Q tile)
+  int p_off[GP], q_off[GQ];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = wave * 16 + i * 4 + srow;          // tile-local row
-    const int lc = spc ^ tn_f(m);
-    const int lp = min(lc, (g.N1 - c1) / 8 - 1);     // clamp ragged columns to a valid chunk
-    const int lq = min(lc, (g.N2 - c2) / 8 - 1);
-    p_off[i] = m * g.ldp + c1 + lp * 8;
-    q_off[i] = m * g.ldq + c2 + lq * 8;
+  for (int i = 0; i < GP; ++i) {
+    const int idx = (wave * GP + i) * 64 + lane;
+    const int m = idx / CP, pc = idx % CP;
+    const int lc = min(pc ^ tn_f(m), (g.N1 - c1) / 8 - 1);      // inverse swizzle; clamp ragged columns
+    p_off[i] = m * g.ldp + c1 + lc * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < GQ; ++i) {
+    const int idx = (wave * GQ + i) * 64 + lane;
+    const int m = idx / CQ, pc = idx % CQ;
+    const int lc = min(pc ^ tn_f(m), (g.N2 - c2) / 8 - 1);
+    q_off[i] = m * g.ldq + c2 + lc * 8;
   }
   auto stage = [&](int buf, int chunk) {
-    char* base = smem + buf * TSTAGE;
+    char* base = smem + buf * STAGE;
     const bf16* Pm = g.P + (size_t)chunk * TK * g.ldp;
     const bf16* Qm = g.Q + (size_t)chunk * TK * g.ldq;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      glds16(Pm + p_off[i], base + (wave * 16 + i * 4) * 256);
-      glds16(Qm + q_off[i], base + TK * 256 + (wave * 16 + i * 4) * 256);
-    }
+    for (int i = 0; i < GP; ++i) glds16(Pm + p_off[i], base + (wave * GP + i) * 1024);
+#pragma unroll
+    for (int i = 0; i < GQ; ++i) glds16(Qm + q_off[i], base + P_BYTES + (wave * GQ + i) * 1024);
   };
 
-  f32x4 acc[4][4];
+  f32x4 acc[TM][TN], accb[TM];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TM; ++i) {
+    accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
 
   // transpose-read addressing: fetch lane s = lane & 15 of 16-lane group gq = lane >> 4
   const int s = lane & 15, gq = lane >> 4;
@@ -79,62 +110,76 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs g) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (ch + 1 < ch1) stage((ch + 1 - ch0) & 1, ch + 1);
-    char* sp = smem + ((ch - ch0) & 1) * TSTAGE;
-    char* sq = sp + TK * 256;
+    char* sp = smem + ((ch - ch0) & 1) * STAGE;
+    char* sq = sp + P_BYTES;
     if (ch == nchunks_total - 1 && g.M - ch * TK < TK) {
       // ragged tail: rows >= M of the last chunk must not contribute (they are readable, not zero)
       const int valid = g.M - ch * TK;
-      for (int idx = tid; idx < (TK - valid) * 16; idx += 256) {
-        const int off = (valid + (idx >> 4)) * 256 + ((idx & 15) << 4);
-        *reinterpret_cast<f32x4*>(sp + off) = f32x4{0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f32x4*>(sq + off) = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
+      for (int idx = tid; idx < (TK - valid) * CP; idx += NT)
+        *reinterpret_cast<f32x4*>(sp + (valid + idx / CP) * (CP * 16) + (idx % CP) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int idx = tid; idx < (TK - valid) * CQ; idx += NT)
+        *reinterpret_cast<f32x4*>(sq + (valid + idx / CQ) * (CQ * 16) + (idx % CQ) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
       __syncthreads();
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 pf[4], qf[4];
+      bf16x8 qf[TN];
+      const int sub = (csub & 1) << 3;
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         const int m = ks * 32 + gq * 8 + half * 4 + rsub;
-        const int rowb = m * 256 + ((csub & 1) << 3);
         const int fm = tn_f(m);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int lc1 = ((w1 * 64 + i * 16) >> 3) + (csub >> 1);
-          const int lc2 = ((w2 * 64 + i * 16) >> 3) + (csub >> 1);
-          const s16x4 a = lds_tr16(sp + rowb + ((lc1 ^ fm) << 4));
-          const s16x4 b = lds_tr16(sq + rowb + ((lc2 ^ fm) << 4));
-          s16x4* pa = reinterpret_cast<s16x4*>(&pf[i]);
-          s16x4* pb = reinterpret_cast<s16x4*>(&qf[i]);
-          pa[half] = a;
-          pb[half] = b;
+        for (int j = 0; j < TN; ++j) {
+          const int lc = ((w2 * TN * 16 + j * 16) >> 3) + (csub >> 1);
+          reinterpret_cast<s16x4*>(&qf[j])[half] = lds_tr16(sq + m * (CQ * 16) + ((lc ^ fm) << 4) + sub);
         }
       }
+      // P fragments in groups of 4 tiles (keeps the live fragment set small)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i0 = 0; i0 < TM; i0 += 4) {
+        bf16x8 pf[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[j], pf[i], acc[i][j], 0, 0, 0);
+        for (int half = 0; half < 2; ++half) {
+          const int m = ks * 32 + gq * 8 + half * 4 + rsub;
+          const int fm = tn_f(m);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int lc = ((w1 * TM * 16 + (i0 + i) * 16) >> 3) + (csub >> 1);
+            reinterpret_cast<s16x4*>(&pf[i])[half] = lds_tr16(sp + m * (CP * 16) + ((lc ^ fm) << 4) + sub);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[j], pf[i], acc[i0 + i][j], 0, 0, 0);
+        if (do_bias && w2 == 0) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            accb[i0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[i], accb[i0 + i], 0, 0, 0);
+        }
+      }
     }
   }
 
   // lane owns out[n1 = .. + (lane & 15)][n2 = .. + (lane >> 4) * 4 + 0..3]
   float* slab = g.slabs + (size_t)split * g.N1 * g.N2;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = c1 + w1 * 64 + i * 16 + (lane & 15);
+  for (int i = 0; i < TM; ++i) {
+    const int r = c1 + w1 * TM * 16 + i * 16 + (lane & 15);
     if (r >= g.N1) continue;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int c = c2 + w2 * 64 + j * 16 + gq * 4;
+    for (int j = 0; j < TN; ++j) {
+      const int c = c2 + w2 * TN * 16 + j * 16 + gq * 4;
       if (c >= g.N2) continue;
       *reinterpret_cast<f32x4*>(slab + (size_t)r * g.N2 + c) = acc[i][j];
     }
+    if (do_bias && w2 == 0 && gq == 0) g.bias_slabs[(size_t)split * g.N1 + r] = accb[i][0];
   }
 }
 
-// out[i] = (accumulate ? out[i] : 0) + sum_s slabs[s][i]     (i over N1*N2, vectorised x4)
+// out[i] = (accumulate ? out[i] : 0) + sum_s slabs[s][i]     (i over n4 float4s)
 __global__ void tn_reduce_kernel(const float* slabs, float* out, int n4, int splits, size_t stride4,
                                  int accumulate) {
   const f32x4* s4 = reinterpret_cast<const f32x4*>(slabs);
@@ -146,44 +191,67 @@ __global__ void tn_reduce_kernel(const float* slabs, float* out, int n4, int spl
   }
 }
 
+static int g_tn_variant = 0;   // 0 auto, 1 force 128^2, 2 force 256^2
+
+template <int WM, int WN, int TM, int TN>
+static int launch_tn(TnArgs g, int splits, float* out, float* bias_out, int accumulate, hipStream_t s) {
+  constexpr int B1 = WM * TM * 16, B2 = WN * TN * 16;
+  constexpr int LDS = 2 * TK * (B1 + B2) * 2;
+  const int tiles = ((g.N1 + B1 - 1) / B1) * ((g.N2 + B2 - 1) / B2);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<WM, WN, TM, TN>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_tn_kernel<WM, WN, TM, TN>), dim3(tiles * splits), dim3(WM * WN * 64), LDS, s, g);
+  int rc = check_launch("gemm_tn");
+  if (rc) return rc;
+  const int n4 = g.N1 * g.N2 / 4;
+  int blocks = (n4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(tn_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)g.slabs, out, n4, splits,
+                     (size_t)g.N1 * g.N2 / 4, accumulate);
+  if (bias_out)
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3((g.N1 / 4 + 255) / 256), dim3(256), 0, s, (const float*)g.bias_slabs,
+                       bias_out, g.N1 / 4, splits, (size_t)g.N1 / 4, accumulate);
+  return check_launch("gemm_tn_reduce");
+}
+
 }  // namespace oat
+
+extern "C" void oat_gemm_tn_set_variant(int v) { oat::g_tn_variant = v; }
 
 extern "C" size_t oat_gemm_tn_workspace_bytes(int M, int N1, int N2) {
   (void)M;
-  // worst case 32 splits
-  return (size_t)32 * N1 * N2 * sizeof(float);
+  return (size_t)32 * ((size_t)N1 * N2 + N1) * sizeof(float);      // worst case 32 splits, + bias slabs
 }
 
+// out[N1,N2] (+)= P^T Q ; bias_out[N1] (+)= column sums of P (NULL to skip)
 extern "C" int oat_gemm_tn(const void* P, const void* Q, int M, int N1, int N2, int ldp, int ldq,
-                           float* out, int accumulate, void* workspace, size_t workspace_bytes,
+                           float* out, float* bias_out, int accumulate, void* workspace, size_t workspace_bytes,
                            void* stream) {
   using namespace oat;
   if (M <= 0 || N1 <= 0 || N2 <= 0) { set_error("gemm_tn: empty problem"); return -1; }
   if (N1 % 8 || N2 % 8 || ldp % 8 || ldq % 8) { set_error("gemm_tn: N1,N2,ldp,ldq must be multiples of 8"); return -3; }
   if (!P || !Q || !out || !workspace) { set_error("gemm_tn: null pointer"); return -4; }
-  const int tiles = ((N1 + TB - 1) / TB) * ((N2 + TB - 1) / TB);
+  const bool big = g_tn_variant == 2 || (g_tn_variant == 0 && M >= 4096 && N1 % 256 == 0 && N2 % 256 == 0);
+  const int B = big ? 256 : 128;
+  const int tiles = ((N1 + B - 1) / B) * ((N2 + B - 1) / B);
   const int nchunks = (M + TK - 1) / TK;
-  int splits = (768 + tiles - 1) / tiles;          // aim at ~3 workgroups per CU
+  const int slots = big ? 256 : 512;                // one 8-wave workgroup per CU, or two 4-wave ones
+  int splits = slots / tiles;                       // largest split count that still fits one round
+  if (splits < 1) splits = 1;
   if (splits > 32) splits = 32;
   if (splits > nchunks) splits = nchunks;
   const int cps = (nchunks + splits - 1) / splits;
   splits = (nchunks + cps - 1) / cps;
-  if ((size_t)splits * N1 * N2 * sizeof(float) > workspace_bytes) { set_error("gemm_tn: workspace too small"); return -6; }
-  TnArgs g{(const bf16*)P, (const bf16*)Q, M, N1, N2, ldp, ldq, (float*)workspace, cps};
+  const size_t need = (size_t)splits * ((size_t)N1 * N2 + N1) * sizeof(float);
+  if (need > workspace_bytes) { set_error("gemm_tn: workspace too small"); return -6; }
+  float* slabs = (float*)workspace;
+  TnArgs g{(const bf16*)P, (const bf16*)Q, M, N1, N2, ldp, ldq, slabs,
+           bias_out ? slabs + (size_t)splits * N1 * N2 : nullptr, cps, splits};
   hipStream_t s = (hipStream_t)stream;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TSTAGE);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, splits), dim3(256), 2 * TSTAGE, s, g);
-  int rc = check_launch("gemm_tn");
-  if (rc) return rc;
-  const int n4 = N1 * N2 / 4;
-  int blocks = (n4 + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(tn_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)workspace, out, n4,
-                     splits, (size_t)N1 * N2 / 4, accumulate);
-  return check_launch("gemm_tn_reduce");
+  if (big) return launch_tn<2, 4, 8, 4>(g, splits, out, bias_out, accumulate, s);
+  return launch_tn<2, 2, 4, 4>(g, splits, out, bias_out, accumulate, s);
 }

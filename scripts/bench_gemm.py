@@ -31,5 +31,9 @@ for (m, n, k) in shapes:
     hip.gemm_set_variant(0)
     # wgrad: out[n,k] = dY[m,n]^T X[m,k]
     P = torch.randn(Mp, n, device="cuda").bfloat16(); out = torch.zeros(n, k, device="cuda")
-    t = timeit(lambda: hip.gemm_tn(P, A, m, n, k, out))
-    print(f"TN      M={m} N1={n} N2={k}: {2*m*n*k/t/1e12:7.1f} TF/s ({t*1e6:7.1f} us)")
+    bo = torch.zeros(n, device="cuda")
+    for tv in (1, 2):
+        hip.gemm_tn_set_variant(tv)
+        t = timeit(lambda: hip.gemm_tn(P, A, m, n, k, out, bias_out=bo))
+        print(f"TN v{tv}   M={m} N1={n} N2={k}: {2*m*n*k/t/1e12:7.1f} TF/s ({t*1e6:7.1f} us)")
+    hip.gemm_tn_set_variant(0)

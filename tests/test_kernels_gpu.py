@@ -106,12 +106,20 @@ def test_gemm_tn(M, N1, N2):
     Q = torch.zeros(Mp, N2, dtype=torch.bfloat16, device=DEV)
     P[:M] = rnd(M, N1, dtype=torch.bfloat16, seed=14)
     Q[:M] = rnd(M, N2, dtype=torch.bfloat16, seed=15)
+    P[M:] = 3.0                                   # rows >= M are readable garbage and must be ignored
+    Q[M:] = -5.0
     out = torch.full((N1, N2), 7.0, device=DEV)
-    hip.gemm_tn(P, Q, M, N1, N2, out)
+    bias = torch.full((N1,), 9.0, device=DEV)
     ref = P[:M].float().t() @ Q[:M].float()
-    close(out, ref, atol=2e-3 * math.sqrt(M), rtol=2e-3, what="gemm_tn")
-    hip.gemm_tn(P, Q, M, N1, N2, out, accumulate=True)
+    bref = P[:M].float().sum(0)
+    for variant in (1, 2, 0):
+        hip.gemm_tn_set_variant(variant)
+        hip.gemm_tn(P, Q, M, N1, N2, out, bias_out=bias)
+        close(out, ref, atol=2e-3 * math.sqrt(M), rtol=2e-3, what=f"gemm_tn v{variant}")
+        close(bias, bref, atol=2e-3 * math.sqrt(M), rtol=2e-3, what=f"gemm_tn bias v{variant}")
+    hip.gemm_tn(P, Q, M, N1, N2, out, accumulate=True, bias_out=bias)
     close(out, 2 * ref, atol=4e-3 * math.sqrt(M), rtol=2e-3, what="gemm_tn accumulate")
+    close(bias, 2 * bref, atol=4e-3 * math.sqrt(M), rtol=2e-3, what="gemm_tn bias accumulate")
 
 
 def test_gemm_tn_asymmetric():
