@@ -16,9 +16,12 @@
 
 namespace oat {
 
-// chunk swizzle for [rows][64 bf16] LDS tiles: conflict-free for ds_read_b128 row fragments
-// (16 consecutive rows) AND for transpose reads (8 consecutive rows x 32 B).
-OAT_DEV int sw8(int row) { const int rp = (row >> 1) & 7; return ((rp & 3) << 1) | (rp >> 2); }
+// chunk swizzle for [rows][64 bf16] LDS tiles.  The permutation {0,2,4,6,5,7,1,3}[(row>>1)&7] was found
+// by exhaustive search over all 8! candidates against the REAL lane groups of both access kinds:
+// ds_read_b128 row fragments (4 non-contiguous 16-lane groups whose lanes carry two different
+// k-chunks) and ds_read_b64_tr_b16 transpose reads (32-lane halves, 8 rows x 32 B): zero conflicts
+// for both (the first hand-derived swizzle measured SQ_LDS_BANK_CONFLICT / IDX_ACTIVE = 0.23-0.30).
+OAT_DEV int sw8(int row) { const int rp = (row >> 1) & 7; return ((rp << 1) + (rp >> 2) * 5) & 7; }
 OAT_DEV int tile_off(int row, int lc) { return row * 128 + ((lc ^ sw8(row)) << 4); }
 
 // row fragment (A/B operand with k = head dim): 16 rows starting at r0, k-step ks (32 dims)
@@ -52,15 +55,18 @@ struct SpaceArgs {
   float scale;
 };
 
-constexpr int SPACE_THREADS = 512;          // 8 waves: two per SIMD hide the MFMA / LDS / exp latency chains
+// forward: 4 waves, 56 KB LDS -> two workgroups per CU overlap each other's prologue;
+// backward: 116 KB LDS pins one workgroup per CU, so it runs 8 waves (two per SIMD) to hide the
+// MFMA / LDS / exp latency chains (measured 899 -> 526 us at B=32, T=8).
+constexpr int FWD_THREADS = 256, BWD_THREADS = 512;
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 
 // stage a [NKP][64] tile from token rows: j < N -> patch row, j == N -> CLS row, else zeros
-template <int NKT>
+template <int NKT, int NTHR>
 OAT_DEV void load_tile(char* tile, const bf16* src, int ld, int col, size_t base_row, size_t cls_row, int N) {
   constexpr int NKP = NKT * 16;
-  for (int idx = threadIdx.x; idx < NKP * 8; idx += SPACE_THREADS) {
+  for (int idx = threadIdx.x; idx < NKP * 8; idx += NTHR) {
     const int j = idx >> 3, c = idx & 7;
     bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
     if (j <= N) {
@@ -72,7 +78,7 @@ OAT_DEV void load_tile(char* tile, const bf16* src, int ld, int col, size_t base
 }
 
 template <int NKT>
-__global__ __launch_bounds__(SPACE_THREADS) void attn_space_fwd_kernel(SpaceArgs a) {
+__global__ __launch_bounds__(FWD_THREADS) void attn_space_fwd_kernel(SpaceArgs a) {
   constexpr int NKP = NKT * 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Kt = smem;
@@ -83,21 +89,27 @@ __global__ __launch_bounds__(SPACE_THREADS) void attn_space_fwd_kernel(SpaceArgs
   const int N = a.N;
   const size_t base_row = (size_t)bf * N;
   const size_t cls_row = (size_t)a.B * a.T * N + b;
-  load_tile<NKT>(Kt, a.qkv, a.ldqkv, a.D + h * 64, base_row, cls_row, N);
-  load_tile<NKT>(Vt, a.qkv, a.ldqkv, 2 * a.D + h * 64, base_row, cls_row, N);
-  __syncthreads();
-
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4;
-  const float c2 = a.scale * LOG2E;
   const int nqt = (N + 15) / 16;
-  for (int qt = wave; qt < nqt; qt += SPACE_THREADS / 64) {
-    const int qi = qt * 16 + (lane & 15);
-    const size_t qrow = base_row + min(qi, N - 1);
-    bf16x8 qf[2];
+  // this wave's first Q fragment is requested before the K/V tiles so its latency hides behind them
+  auto load_q = [&](int qt, bf16x8* dst) {
+    const size_t qrow = base_row + min(qt * 16 + (lane & 15), N - 1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
-      qf[ks] = *reinterpret_cast<const bf16x8*>(a.qkv + qrow * a.ldqkv + h * 64 + ks * 32 + g * 8);
+      dst[ks] = *reinterpret_cast<const bf16x8*>(a.qkv + qrow * a.ldqkv + h * 64 + ks * 32 + g * 8);
+  };
+  bf16x8 qnext[2];
+  load_q(min(wave, nqt - 1), qnext);
+  load_tile<NKT, FWD_THREADS>(Kt, a.qkv, a.ldqkv, a.D + h * 64, base_row, cls_row, N);
+  load_tile<NKT, FWD_THREADS>(Vt, a.qkv, a.ldqkv, 2 * a.D + h * 64, base_row, cls_row, N);
+  __syncthreads();
+
+  const float c2 = a.scale * LOG2E;
+  for (int qt = wave; qt < nqt; qt += FWD_THREADS / 64) {
+    const int qi = qt * 16 + (lane & 15);
+    bf16x8 qf[2] = {qnext[0], qnext[1]};
+    if (qt + FWD_THREADS / 64 < nqt) load_q(qt + FWD_THREADS / 64, qnext);     // prefetch the next tile's Q
     f32x4 st[NKT];
     float m = -INFINITY;
 #pragma unroll
@@ -148,7 +160,7 @@ __global__ __launch_bounds__(SPACE_THREADS) void attn_space_fwd_kernel(SpaceArgs
 }
 
 template <int NKT>
-__global__ __launch_bounds__(SPACE_THREADS) void attn_space_bwd_kernel(SpaceArgs a) {
+__global__ __launch_bounds__(BWD_THREADS) void attn_space_bwd_kernel(SpaceArgs a) {
   constexpr int NKP = NKT * 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Qt = smem;
@@ -163,11 +175,11 @@ __global__ __launch_bounds__(SPACE_THREADS) void attn_space_bwd_kernel(SpaceArgs
   const int N = a.N;
   const size_t base_row = (size_t)bf * N;
   const size_t cls_row = (size_t)a.B * a.T * N + b;
-  load_tile<NKT>(Qt, a.qkv, a.ldqkv, h * 64, base_row, cls_row, N);
-  load_tile<NKT>(Kt, a.qkv, a.ldqkv, a.D + h * 64, base_row, cls_row, N);
-  load_tile<NKT>(Vt, a.qkv, a.ldqkv, 2 * a.D + h * 64, base_row, cls_row, N);
+  load_tile<NKT, BWD_THREADS>(Qt, a.qkv, a.ldqkv, h * 64, base_row, cls_row, N);
+  load_tile<NKT, BWD_THREADS>(Kt, a.qkv, a.ldqkv, a.D + h * 64, base_row, cls_row, N);
+  load_tile<NKT, BWD_THREADS>(Vt, a.qkv, a.ldqkv, 2 * a.D + h * 64, base_row, cls_row, N);
   // dO tile + delta = rowsum(dO * O) + lse (log2 units); 8 lanes per row
-  for (int idx = threadIdx.x; idx < NKP * 8; idx += SPACE_THREADS) {
+  for (int idx = threadIdx.x; idx < NKP * 8; idx += BWD_THREADS) {
     const int j = idx >> 3, c = idx & 7;
     bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
     float d = 0.f;
@@ -196,7 +208,7 @@ __global__ __launch_bounds__(SPACE_THREADS) void attn_space_bwd_kernel(SpaceArgs
   float* side = a.cls_side + ((size_t)b * a.H + h) * 3 * 64;
 
   // ------------------------------------------------ phase A: lane = query column, produces dQ
-  for (int qt = wave; qt < NKT; qt += SPACE_THREADS / 64) {
+  for (int qt = wave; qt < NKT; qt += BWD_THREADS / 64) {
     if (qt * 16 > N) break;
     const int qi = qt * 16 + (lane & 15);
     const float lq = lse_s[qi], dq_ = del_s[qi];
@@ -249,7 +261,7 @@ __global__ __launch_bounds__(SPACE_THREADS) void attn_space_bwd_kernel(SpaceArgs
   }
 
   // ------------------------------------------------ phase B: lane = key column, produces dK, dV
-  for (int kt = wave; kt < NKT; kt += SPACE_THREADS / 64) {
+  for (int kt = wave; kt < NKT; kt += BWD_THREADS / 64) {
     if (kt * 16 > N) break;
     const int key = kt * 16 + (lane & 15);
     bf16x8 kf[2], vf[2];
@@ -325,7 +337,7 @@ static int launch_fwd(const SpaceArgs& a, hipStream_t s) {
   const int lds = 2 * NKT * 16 * 128;
   static bool set = false;
   if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_space_fwd_kernel<NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
-  hipLaunchKernelGGL(attn_space_fwd_kernel<NKT>, dim3(a.B * a.T * a.H), dim3(SPACE_THREADS), lds, s, a);
+  hipLaunchKernelGGL(attn_space_fwd_kernel<NKT>, dim3(a.B * a.T * a.H), dim3(FWD_THREADS), lds, s, a);
   return check_launch("attn_space_fwd");
 }
 template <int NKT>
@@ -333,7 +345,7 @@ static int launch_bwd(const SpaceArgs& a, hipStream_t s) {
   const int lds = 4 * NKT * 16 * 128 + 2 * NKT * 16 * 4;
   static bool set = false;
   if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_space_bwd_kernel<NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
-  hipLaunchKernelGGL(attn_space_bwd_kernel<NKT>, dim3(a.B * a.T * a.H), dim3(SPACE_THREADS), lds, s, a);
+  hipLaunchKernelGGL(attn_space_bwd_kernel<NKT>, dim3(a.B * a.T * a.H), dim3(BWD_THREADS), lds, s, a);
   return check_launch("attn_space_bwd");
 }
 

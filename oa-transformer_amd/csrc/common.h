@@ -60,6 +60,17 @@ OAT_DEV void glds16(const void* gptr, void* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// Same copy issued from inline asm: hipcc does not see it, so it neither counts it nor inserts its own
+// "s_waitcnt vmcnt(0)" in front of later ds_reads (which drains a multi-stage ring every iteration).
+// The CALLER owns the vmcnt accounting: counted s_waitcnt vmcnt(N) + s_barrier before the data is read.
+OAT_DEV void glds16_asm(const void* gptr, void* lds_wave_base) {
+  const uint32_t lds = __builtin_amdgcn_readfirstlane(
+      (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)lds_wave_base));
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gptr), "s"(lds) : "memory");
+}
+
 // LDS transpose read: within each 16-lane group, lane s fetches 4 contiguous bf16 at its own
 // address; output lane i, element j = fetched[lane 4*j + (i >> 2)][i & 3].
 OAT_DEV s16x4 lds_tr16(const void* lds_ptr) {

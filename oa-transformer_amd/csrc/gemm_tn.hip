@@ -21,7 +21,8 @@
 
 namespace oat {
 
-constexpr int TK = 64;             // m rows per stage
+constexpr int TK = 32;             // m rows per stage (one MFMA k-step)
+constexpr int NS = 4;              // LDS ring depth: loads run NS-1 stages ahead of the math
 
 OAT_DEV int tn_f(int m) { return ((m & 3) << 1) | (((m >> 3) & 1) << 3); }
 
@@ -85,9 +86,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_tn_kernel(TnArgs g) {
     const bf16* Pm = g.P + (size_t)chunk * TK * g.ldp;
     const bf16* Qm = g.Q + (size_t)chunk * TK * g.ldq;
 #pragma unroll
-    for (int i = 0; i < GP; ++i) glds16(Pm + p_off[i], base + (wave * GP + i) * 1024);
+    for (int i = 0; i < GP; ++i) glds16_asm(Pm + p_off[i], base + (wave * GP + i) * 1024);
 #pragma unroll
-    for (int i = 0; i < GQ; ++i) glds16(Qm + q_off[i], base + P_BYTES + (wave * GQ + i) * 1024);
+    for (int i = 0; i < GQ; ++i) glds16_asm(Qm + q_off[i], base + P_BYTES + (wave * GQ + i) * 1024);
   };
 
   f32x4 acc[TM][TN], accb[TM];
@@ -105,12 +106,23 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_tn_kernel(TnArgs g) {
   const int s = lane & 15, gq = lane >> 4;
   const int rsub = s >> 2;                 // m offset 0..3 inside the 4-row block
   const int csub = s & 3;                  // 8-byte column group
-  if (ch0 < ch1) stage(0, ch0);
+  // Ring pipeline: the loads of NS-1 stages are in flight while one stage is consumed.  A stage is
+  // published by (own counted vmcnt) + (raw s_barrier): every wave waits for ITS loads of stage i, the
+  // barrier then makes all of them visible and also proves everyone finished reading stage i-1, whose
+  // slot the next prefetch (stage i+NS-1) overwrites.  __syncthreads() is avoided on purpose: with an
+  // LDS-DMA in flight the compiler turns it into vmcnt(0) and drains the pipeline.
+  constexpr int LPS = GP + GQ;                               // glds instructions per thread per stage
+#pragma unroll
+  for (int d = 0; d < NS - 1; ++d)
+    if (ch0 + d < ch1) stage(d, ch0 + d);
   for (int ch = ch0; ch < ch1; ++ch) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (ch + 1 < ch1) stage((ch + 1 - ch0) & 1, ch + 1);
-    char* sp = smem + ((ch - ch0) & 1) * STAGE;
+    const int ahead = min(NS - 2, ch1 - 1 - ch);             // stages issued after this one
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (ch + NS - 1 < ch1) stage((ch + NS - 1 - ch0) % NS, ch + NS - 1);
+    char* sp = smem + ((ch - ch0) % NS) * STAGE;
     char* sq = sp + P_BYTES;
     if (ch == nchunks_total - 1 && g.M - ch * TK < TK) {
       // ragged tail: rows >= M of the last chunk must not contribute (they are readable, not zero)
@@ -121,8 +133,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_tn_kernel(TnArgs g) {
         *reinterpret_cast<f32x4*>(sq + (valid + idx / CQ) * (CQ * 16) + (idx % CQ) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
       __syncthreads();
     }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    {
+      constexpr int ks = 0;
       bf16x8 qf[TN];
       const int sub = (csub & 1) << 3;
 #pragma unroll
@@ -196,7 +208,7 @@ static int g_tn_variant = 0;   // 0 auto, 1 force 128^2, 2 force 256^2
 template <int WM, int WN, int TM, int TN>
 static int launch_tn(TnArgs g, int splits, float* out, float* bias_out, int accumulate, hipStream_t s) {
   constexpr int B1 = WM * TM * 16, B2 = WN * TN * 16;
-  constexpr int LDS = 2 * TK * (B1 + B2) * 2;
+  constexpr int LDS = NS * TK * (B1 + B2) * 2;
   const int tiles = ((g.N1 + B1 - 1) / B1) * ((g.N2 + B2 - 1) / B2);
   static bool attr_set = false;
   if (!attr_set) {

@@ -1,0 +1,25 @@
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oa-transformer_amd")); sys.path.insert(0, ROOT)
+import torch
+from OATrans.ops import hip
+B, T, N, H = int(os.environ.get("B", 32)), 8, 196, 12
+D = H * 64; M = B * T * N + B; Mp = (M + 255) // 256 * 256
+qkv = torch.zeros(Mp, 3 * D, dtype=torch.bfloat16, device="cuda"); qkv[:M] = torch.randn(M, 3 * D, device="cuda").bfloat16()
+out = torch.zeros(Mp, D, dtype=torch.bfloat16, device="cuda"); lse = torch.zeros(Mp, H, device="cuda")
+dout = torch.zeros(Mp, D, dtype=torch.bfloat16, device="cuda"); dout[:M] = torch.randn(M, D, device="cuda").bfloat16()
+dqkv = torch.zeros(Mp, 3 * D, dtype=torch.bfloat16, device="cuda"); side = torch.zeros(B, H, 3, 64, device="cuda")
+def timeit(fn, n=10):
+    for _ in range(2): fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / n * 1e3
+sc = 0.125
+print("space fwd us", timeit(lambda: hip.attn_space_fwd(qkv, out, lse, B, T, N, H, D, sc)))
+print("cls   fwd us", timeit(lambda: hip.attn_cls_fwd(qkv, out, lse, B, T, N, H, D, sc)))
+print("space bwd us", timeit(lambda: hip.attn_space_bwd(qkv, out, lse, dout, dqkv, side, B, T, N, H, D, sc)))
+print("time  fwd us", timeit(lambda: hip.attn_time_fwd(qkv, out, lse, B, T, N, H, D, sc)))
+print("time  bwd us", timeit(lambda: hip.attn_time_bwd(qkv, out, lse, dout, dqkv, side, B, T, N, H, D, sc)))
