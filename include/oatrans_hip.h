@@ -122,6 +122,21 @@ int oat_infonce(const float* t, const float* v, int n, int d, float temperature,
 int oat_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
               float eps, float weight_decay, int step, int hf_style, float gscale, void* stream);
 
+/* ---- object-aware extras (mask-pool / region-sim einsums, BCE, pooled tails) -------------------------
+ * oa_model_global_local.py:178,200 ; oa_model_region_mem.py:117,147-151 ; trainer_region_mem.py:97,166.
+ * C[b,i,j] (+)= act(sum_k A[b,i,k] Bm[b,k,j]) with arbitrary element strides (fp32). */
+int oat_bmm_strided(const float* A, const float* Bm, float* C, int nb, int I, int J, int K, long long sAb,
+                    long long sAi, long long sAk, long long sBb, long long sBk, long long sBj, long long sCb,
+                    long long sCi, long long sCj, int sigmoid, int accumulate, void* stream);
+int oat_sigmoid_bwd(const float* s, const float* ds, float* dz, size_t n, void* stream);
+int oat_bce_sum(const float* p, const float* y, size_t n, float* loss, float* partial256, void* stream);
+int oat_bce_bwd(const float* p, const float* y, const float* g, float* dp, size_t n, void* stream);
+int oat_grouped_broadcast(const float* src, int lds, float* dst, int ldd, int G, int R, int D, float scale,
+                          int accumulate, void* stream);
+int oat_axpby(const float* a, const float* b, float* out, size_t n, float alpha, float beta, void* stream);
+/* tag-token masks built by a Python B x O loop at oa_model_global_local.py:183-196 (ends / n_txt int64) */
+int oat_tag_masks(const void* ends, const void* ntxt, float* out, int B, int O, int L, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -88,18 +88,18 @@ class TextEngine:
                 put(b + l, params[b + l + ".weight"].detach())
         self.versions = versions
 
-    def plan(self, B, L, dev):
-        key = (B, L, str(dev))
+    def plan(self, B, L, dev, slot=0):
+        key = (B, L, str(dev), slot)         # one plan per call within a step (caption / caption+tags passes)
         if key not in self.plans:
             self.plans[key] = _TextPlan(B, L, self.D, self.Hd, self.H, self.n_layers, dev)
         return self.plans[key]
 
-    def forward(self, input_ids, attention_mask, params, sig=None):
+    def forward(self, input_ids, attention_mask, params, sig=None, slot=0):
         """-> (last_hidden fp32 view [B, L, D], plan)."""
         B, L = input_ids.shape
         D, Hd, H = self.D, self.Hd, self.H
         self.refresh_shadows(params, sig)
-        pl = self.plan(B, L, input_ids.device)
+        pl = self.plan(B, L, input_ids.device, slot)
         M = pl.M
         pl.ids = input_ids.contiguous()
         pl.mask = attention_mask.to(torch.int64).contiguous()

@@ -53,6 +53,8 @@ class _Plan:
         self.cls0 = torch.zeros(D, dtype=torch.float32, device=dev)
         self.fstats = torch.zeros(2, Mp, dtype=torch.float32, device=dev)
         self.normed = torch.zeros(Mp, D, dtype=torch.float32, device=dev)
+        self.region = None                      # [B*T*N, D] fp32, allocated on first use (region_mem variant)
+        self.rstats = None
         # backward temporaries (shared by all blocks)
         self.G = torch.zeros(Mp, D, dtype=torch.float32, device=dev)
         self.g16 = torch.zeros(Mp, D, dtype=torch.bfloat16, device=dev)
@@ -110,8 +112,10 @@ class VideoEngine:
         return self.plans[key]
 
     # ------------------------------------------------------------------ forward
-    def forward(self, video, params, need_patches=False, sig=None):
-        """video [B,T,C,R,R] fp32|bf16 -> (cls_normed fp32 [B,D], patches_normed fp32 [B*T*N, D] | None, plan)"""
+    def forward(self, video, params, need_patches=False, sig=None, region_layer=None):
+        """video [B,T,C,R,R] fp32|bf16 -> (cls_normed fp32 [B,D], patches_normed fp32 [B*T*N, D] | None, plan).
+        region_layer=K additionally leaves region_norm(x after block K)[patch rows] in plan.region
+        (oa_video_transformer_region.py:364-376)."""
         B, T, C, R, _ = video.shape
         if T > self.num_frames:
             raise ValueError(f"{T} frames > num_frames={self.num_frames}")     # video_transformer.py:73
@@ -147,6 +151,13 @@ class VideoEngine:
             hip.gemm_nt(a.a2, w("mlp.fc1"), M, Hd, D, hip.EPI_GELU_DUAL, a.h, out2=a.g, bias=p("mlp.fc1.bias"))
             hip.gemm_nt(a.g, w("mlp.fc2"), M, D, Hd, hip.EPI_F32, a.out, bias=p("mlp.fc2.bias"), resid=a.y)
             x = a.out
+            if region_layer is not None and i + 1 == region_layer:
+                if pl.region is None:
+                    pl.region = torch.zeros(BTN, D, dtype=torch.float32, device=video.device)
+                    pl.rstats = torch.zeros(2, BTN, dtype=torch.float32, device=video.device)
+                hip.layernorm_fwd(x, params["region_norm.weight"], params["region_norm.bias"], BTN, D, 1e-6,
+                                  y32=pl.region, mean=pl.rstats[0], rstd=pl.rstats[1])
+        pl.region_layer = region_layer
         pl.x_final = x
         pl.need_patches = need_patches
         if need_patches:
@@ -158,9 +169,10 @@ class VideoEngine:
         return pl.normed[BTN:M], None, pl
 
     # ------------------------------------------------------------------ backward
-    def backward(self, pl, params, grads, d_cls, d_patches=None):
+    def backward(self, pl, params, grads, d_cls, d_patches=None, d_region=None):
         """Writes every video parameter gradient into `grads`.  d_cls fp32 [B,D]; d_patches fp32
-        [B*T*N, D] or None (contract class oa_model.FrozenInTime discards patch outputs)."""
+        [B*T*N, D] or None (contract class oa_model.FrozenInTime discards patch outputs); d_region fp32
+        [B*T*N, D] = gradient of plan.region (enters the residual stream below block `region_layer`)."""
         B, T, N = pl.B, pl.T, pl.N
         D, Hd, H = self.D, self.Hd, self.H
         M, BTN = pl.M, B * T * N
@@ -176,8 +188,18 @@ class VideoEngine:
             hip.layernorm_bwd(d_cls.contiguous(), pl.x_final[BTN:], pl.fstats[0][BTN:], pl.fstats[1][BTN:],
                               params["norm.weight"], B, D, dx=G[BTN:], dx16=g16[BTN:], dgamma=grads["norm.weight"],
                               dbeta=grads["norm.bias"])
+        rl = getattr(pl, "region_layer", None)
+        if rl is not None:
+            for k in ("region_norm.weight", "region_norm.bias"):
+                if d_region is None:
+                    grads[k].zero_()
         for i in reversed(range(self.depth)):
             a = pl.blocks[i]
+            if rl is not None and d_region is not None and i + 1 == rl:
+                # region tokens branch off the output of block rl-1: add their gradient to the stream
+                hip.layernorm_bwd(d_region.contiguous(), a.out, pl.rstats[0], pl.rstats[1], params["region_norm.weight"],
+                                  BTN, D, dx=G, dx16=g16, dres=G, dgamma=grads["region_norm.weight"],
+                                  dbeta=grads["region_norm.bias"])
             x = pl.blocks[i - 1].out if i > 0 else pl.x0
             p = lambda s: params[f"blocks.{i}.{s}"]
             gr = lambda s: grads[f"blocks.{i}.{s}"]

@@ -6,5 +6,6 @@ from .loss import NormSoftmaxLoss
 from .metric import t2v_metrics, v2t_metrics
 from .oa_model import FrozenInTime
 from .video_transformer import SpaceTimeTransformer
+from . import oa_model_global_local, oa_model_region_mem  # noqa: F401  (module_arch = model.oa_model_global_local, train_dist_multi_global_local.py:7)
 
 __all__ = ["FrozenInTime", "NormSoftmaxLoss", "SpaceTimeTransformer", "sim_matrix", "t2v_metrics", "v2t_metrics"]

@@ -61,16 +61,20 @@ class HipLinear(nn.Linear):
     def forward(self, x):
         if not x.is_cuda:
             raise hip.OatError("HipLinear runs on MI355X only (no CPU path)")
-        return _LinearFn.apply(x, self.weight, self.bias, self.pre_relu)
+        lead = x.shape[:-1]
+        y = _LinearFn.apply(x.reshape(-1, x.shape[-1]), self.weight, self.bias, self.pre_relu)
+        return y.reshape(*lead, y.shape[-1])
 
 
 class ReLULinear(nn.Sequential):
     """txt_proj = Sequential(ReLU, Linear) (oa_model.py:68-70) with the state_dict key '1.*';
     the ReLU is fused into the GEMM operand cast."""
 
-    def __init__(self, in_features, out_features):
+    def __init__(self, in_features, out_features, xavier=False):
         lin = HipLinear(in_features, out_features)
         lin.pre_relu = True
+        if xavier:
+            nn.init.xavier_uniform_(lin.weight)          # oa_model_region_mem.py:12-14
         super().__init__(nn.Identity(), lin)
 
 

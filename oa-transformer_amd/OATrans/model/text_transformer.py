@@ -55,7 +55,7 @@ class _HiddenFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, input_ids, attention_mask, call_idx, *params):
         hidden, plan = module._engine.forward(input_ids, attention_mask, module._param_data(),
-                                              module._weights_signature())
+                                              module._weights_signature(), slot=call_idx)
         ctx.module, ctx.plan, ctx.call_idx = module, plan, call_idx
         return hidden.clone()
 

@@ -72,28 +72,29 @@ class _EncoderFn(torch.autograd.Function):
     so the function returns None for them."""
 
     @staticmethod
-    def forward(ctx, module, video, need_patches, *params):
+    def forward(ctx, module, video, need_patches, region_layer, *params):
         eng = module._engine
         pd = module._param_data()
-        cls, patches, plan = eng.forward(video, pd, need_patches, module._weights_signature())
+        cls, patches, plan = eng.forward(video, pd, need_patches, module._weights_signature(), region_layer)
         ctx.module, ctx.plan = module, plan
         ctx.set_materialize_grads(False)
-        cls_out = cls.clone()
-        if need_patches:
-            B = video.shape[0]
-            return cls_out, patches.view(B, -1, patches.shape[-1])
-        return cls_out, None
+        B, D = video.shape[0], cls.shape[-1]
+        # outputs are views of plan buffers that the next step overwrites; consumers use them within the step
+        return (cls.clone(), patches.view(B, -1, D) if need_patches else None,
+                plan.region.view(B, -1, D) if region_layer is not None else None)
 
     @staticmethod
-    def backward(ctx, d_cls, d_patches):
+    def backward(ctx, d_cls, d_patches, d_region):
         module, plan = ctx.module, ctx.plan
         D = module.embed_dim
         if d_cls is None:
             d_cls = torch.zeros(plan.B, D, device=plan.G.device)
         if d_patches is not None:
             d_patches = d_patches.reshape(-1, D).float()
-        module._engine.backward(plan, module._param_data(), module._grad_views(), d_cls.float(), d_patches)
-        return (None, None, None) + (None,) * module._n_params
+        if d_region is not None:
+            d_region = d_region.reshape(-1, D).float()
+        module._engine.backward(plan, module._param_data(), module._grad_views(), d_cls.float(), d_patches, d_region)
+        return (None, None, None, None) + (None,) * module._n_params
 
 
 class SpaceTimeTransformer(EngineModule):
@@ -134,6 +135,7 @@ class SpaceTimeTransformer(EngineModule):
         if num_frames == 1:
             self.apply(self._init_weights)
         self.need_patch_tokens = True
+        self.region_layer = None
         self._engine = VideoEngine(depth, embed_dim, num_heads, mlp_ratio, self.patch_embed.patch_size[0], in_chans,
                                    num_frames)
 
@@ -155,7 +157,9 @@ class SpaceTimeTransformer(EngineModule):
             raise hip.OatError("SpaceTimeTransformer runs on MI355X only (no CPU path); use the oracle for CPU")
         hip.lib()
         params = [p for _, p in self._engine_params()]
-        cls, patches = _EncoderFn.apply(self, x, bool(self.need_patch_tokens), *params)
+        cls, patches, region = _EncoderFn.apply(self, x, bool(self.need_patch_tokens), self.region_layer, *params)
+        if self.region_layer is not None:
+            return cls, patches, region
         return cls, patches
 
     def forward(self, x, aug=False):

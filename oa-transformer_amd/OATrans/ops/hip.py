@@ -301,3 +301,46 @@ def norm_softmax_loss(sim, temperature, want_grad=True):
     _check(lib().oat_norm_softmax_loss(_ptr(sim), n, _f(temperature), _ptr(loss), _ptr(G), _ptr(ws), _stream()),
            "oat_norm_softmax_loss")
     return loss, G
+
+
+# ----------------------------------------------------------------------------- object-aware extras
+def bmm_strided(A, Bm, C, nb, I, J, K, sA, sB, sC, sigmoid=False, accumulate=False):
+    """C[b,i,j] (+)= act(sum_k A[b,i,k] * Bm[b,k,j]); sA=(b,i,k) sB=(b,k,j) sC=(b,i,j) element strides."""
+    ll = ctypes.c_longlong
+    _check(lib().oat_bmm_strided(_ptr(A), _ptr(Bm), _ptr(C), nb, I, J, K, ll(sA[0]), ll(sA[1]), ll(sA[2]), ll(sB[0]),
+                                 ll(sB[1]), ll(sB[2]), ll(sC[0]), ll(sC[1]), ll(sC[2]), int(sigmoid), int(accumulate),
+                                 _stream()), "oat_bmm_strided")
+
+
+def sigmoid_bwd(s, ds, dz):
+    _check(lib().oat_sigmoid_bwd(_ptr(s), _ptr(ds), _ptr(dz), ctypes.c_size_t(s.numel()), _stream()), "oat_sigmoid_bwd")
+
+
+def bce_sum(p, y):
+    loss = torch.empty(1, dtype=torch.float32, device=p.device)
+    part = torch.empty(256, dtype=torch.float32, device=p.device)
+    _check(lib().oat_bce_sum(_ptr(p), _ptr(y), ctypes.c_size_t(p.numel()), _ptr(loss), _ptr(part), _stream()),
+           "oat_bce_sum")
+    return loss
+
+
+def bce_bwd(p, y, g, dp):
+    _check(lib().oat_bce_bwd(_ptr(p), _ptr(y), _ptr(g), _ptr(dp), ctypes.c_size_t(p.numel()), _stream()), "oat_bce_bwd")
+
+
+def grouped_broadcast(src, dst, G, R, D, scale=1.0, accumulate=False):
+    _check(lib().oat_grouped_broadcast(_ptr(src), src.stride(0), _ptr(dst), dst.stride(0), G, R, D, _f(scale),
+                                       int(accumulate), _stream()), "oat_grouped_broadcast")
+
+
+def axpby(a, b, out, alpha, beta=0.0):
+    _check(lib().oat_axpby(_ptr(a), _ptr(b), _ptr(out), ctypes.c_size_t(out.numel()), _f(alpha), _f(beta), _stream()),
+           "oat_axpby")
+
+
+def tag_masks(ends, ntxt, L):
+    B, O = ends.shape
+    out = torch.empty(B, O, L, dtype=torch.float32, device=ends.device)
+    _check(lib().oat_tag_masks(_ptr(ends.contiguous()), _ptr(ntxt.contiguous()), _ptr(out), B, O, L, _stream()),
+           "oat_tag_masks")
+    return out

@@ -1,0 +1,162 @@
+// Object-aware extras: tiny batched contractions and element-wise losses.
+//   mask-pool   einsum('b o l, b l c -> b o c')   /root/reference/OATrans/model/oa_model_global_local.py:178,200
+//   region-sim  sigmoid(einsum('b k f, b n f -> b k n'))   /root/reference/OATrans/model/oa_model_region_mem.py:147-151
+//   BCELoss(reduction='sum')                      /root/reference/OATrans/trainer/trainer_region_mem.py:97,166
+//   patch-mean pooling of the GL / region tails   oa_video_transformer_global_local.py:356, oa_model_region_mem.py:117
+// All of them are < 0.02 % of the step's FLOPs: one generic fp32 strided batched matmul (any transposition
+// is a stride choice, so forward and both backward products share it) plus element-wise kernels.
+#include "common.h"
+
+namespace oat {
+
+struct BmmArgs {
+  const float* A; const float* Bm; float* C;
+  int nb, I, J, K;
+  long long sAb, sAi, sAk, sBb, sBk, sBj, sCb, sCi, sCj;
+  int sigmoid, accumulate;
+};
+
+// C[b,i,j] (+)= act( sum_k A[b,i,k] * Bm[b,k,j] ) ; 16x16 outputs per block, K tiled by 16 through LDS
+__global__ __launch_bounds__(256) void bmm_strided_kernel(BmmArgs a) {
+  __shared__ float sa[16][17], sb[16][17];
+  const int b = blockIdx.z;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int i = blockIdx.y * 16 + ty, j = blockIdx.x * 16 + tx;
+  const float* A = a.A + (long long)b * a.sAb;
+  const float* Bm = a.Bm + (long long)b * a.sBb;
+  float acc = 0.f;
+  for (int k0 = 0; k0 < a.K; k0 += 16) {
+    const int ka = k0 + tx, kb = k0 + ty;
+    sa[ty][tx] = (i < a.I && ka < a.K) ? A[(long long)i * a.sAi + (long long)ka * a.sAk] : 0.f;
+    sb[ty][tx] = (kb < a.K && j < a.J) ? Bm[(long long)kb * a.sBk + (long long)j * a.sBj] : 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc += sa[ty][k] * sb[k][tx];
+    __syncthreads();
+  }
+  if (i < a.I && j < a.J) {
+    float* c = a.C + (long long)b * a.sCb + (long long)i * a.sCi + (long long)j * a.sCj;
+    if (a.sigmoid) acc = 1.f / (1.f + __expf(-acc));
+    *c = a.accumulate ? *c + acc : acc;
+  }
+}
+
+// dz = ds * s * (1 - s)
+__global__ void sigmoid_bwd_kernel(const float* s, const float* ds, float* dz, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    dz[i] = ds[i] * s[i] * (1.f - s[i]);
+}
+
+// BCELoss(reduction='sum'): -(y log p + (1-y) log(1-p)), logs clamped at -100 like torch
+__global__ void bce_sum_kernel(const float* p, const float* y, size_t n, float* partial) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float lp = fmaxf(logf(p[i]), -100.f), lq = fmaxf(logf(1.f - p[i]), -100.f);
+    s -= y[i] * lp + (1.f - y[i]) * lq;
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void sum_partials_kernel(const float* partial, int n, float* out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += partial[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = red[0] + red[1] + red[2] + red[3];
+}
+// dp = g * (p - y) / max(p (1 - p), 1e-12)
+__global__ void bce_bwd_kernel(const float* p, const float* y, const float* g, float* dp, size_t n) {
+  const float gg = g[0];
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    dp[i] = gg * (p[i] - y[i]) / fmaxf(p[i] * (1.f - p[i]), 1e-12f);
+}
+
+// dst[g*R + r][:] (+)= scale * src[g][:]     (backward of a per-group mean / sum over rows)
+__global__ void grouped_broadcast_kernel(const float* src, int lds_, float* dst, int ldd, int R, int D, float scale,
+                                         int accumulate) {
+  const size_t row = blockIdx.x;
+  const float* s = src + (row / R) * lds_;
+  float* d = dst + row * ldd;
+  for (int c = threadIdx.x * 4; c < D; c += blockDim.x * 4) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(s + c) * scale;
+    if (accumulate) v += *reinterpret_cast<const f32x4*>(d + c);
+    *reinterpret_cast<f32x4*>(d + c) = v;
+  }
+}
+
+// out[i] = alpha * a[i] + beta * b[i]   (fp32; the 1/2 CLS + 1/2 patch-mean mixes of the OA tails)
+__global__ void axpby_kernel(const float* a, const float* b, float* out, size_t n, float alpha, float beta) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = alpha * a[i] + (b ? beta * b[i] : 0.f);
+}
+
+}  // namespace oat
+
+using namespace oat;
+
+extern "C" int oat_bmm_strided(const float* A, const float* Bm, float* C, int nb, int I, int J, int K, long long sAb,
+                               long long sAi, long long sAk, long long sBb, long long sBk, long long sBj, long long sCb,
+                               long long sCi, long long sCj, int sigmoid, int accumulate, void* stream) {
+  if (nb <= 0 || I <= 0 || J <= 0 || K <= 0) { set_error("bmm_strided: empty problem"); return -1; }
+  if (nb > 65535) { set_error("bmm_strided: batch > 65535"); return -3; }
+  BmmArgs a{A, Bm, C, nb, I, J, K, sAb, sAi, sAk, sBb, sBk, sBj, sCb, sCi, sCj, sigmoid, accumulate};
+  hipLaunchKernelGGL(bmm_strided_kernel, dim3((J + 15) / 16, (I + 15) / 16, nb), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("bmm_strided");
+}
+extern "C" int oat_sigmoid_bwd(const float* s, const float* ds, float* dz, size_t n, void* stream) {
+  if (n == 0) return 0;
+  int blocks = (int)((n + 255) / 256); if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, s, ds, dz, n);
+  return check_launch("sigmoid_bwd");
+}
+// partial: workspace of 256 floats
+extern "C" int oat_bce_sum(const float* p, const float* y, size_t n, float* loss, float* partial, void* stream) {
+  if (n == 0) { set_error("bce_sum: empty"); return -1; }
+  int blocks = (int)((n + 255) / 256); if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(bce_sum_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, y, n, partial);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, blocks, loss);
+  return check_launch("bce_sum");
+}
+extern "C" int oat_bce_bwd(const float* p, const float* y, const float* g, float* dp, size_t n, void* stream) {
+  if (n == 0) return 0;
+  int blocks = (int)((n + 255) / 256); if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(bce_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, y, g, dp, n);
+  return check_launch("bce_bwd");
+}
+extern "C" int oat_grouped_broadcast(const float* src, int lds_, float* dst, int ldd, int G, int R, int D, float scale,
+                                     int accumulate, void* stream) {
+  if (G <= 0 || R <= 0) return 0;
+  if (D % 4 || lds_ % 4 || ldd % 4) { set_error("grouped_broadcast: D%4 required"); return -3; }
+  hipLaunchKernelGGL(grouped_broadcast_kernel, dim3((unsigned)((size_t)G * R)), dim3(192), 0, (hipStream_t)stream, src,
+                     lds_, dst, ldd, R, D, scale, accumulate);
+  return check_launch("grouped_broadcast");
+}
+extern "C" int oat_axpby(const float* a, const float* b, float* out, size_t n, float alpha, float beta, void* stream) {
+  if (n == 0) return 0;
+  int blocks = (int)((n + 255) / 256); if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(axpby_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b, out, n, alpha, beta);
+  return check_launch("axpby");
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// tag-token masks (oa_model_global_local.py:183-196 builds them with a Python loop over B x O on the host):
+// out[b][o][l] = 1 for  n_txt[b]-1+end[b][o-1] <= l < n_txt[b]-1+end[b][o]   (end[b][-1] = 0), else 0
+namespace oat {
+__global__ void tag_masks_kernel(const long long* ends, const long long* ntxt, float* out, int B, int O, int L) {
+  const int b = blockIdx.x / O, o = blockIdx.x % O;
+  const long long base = ntxt[b] - 1;
+  const long long lo = base + (o > 0 ? ends[(size_t)b * O + o - 1] : 0), hi = base + ends[(size_t)b * O + o];
+  for (int l = threadIdx.x; l < L; l += blockDim.x) out[((size_t)b * O + o) * L + l] = (l >= lo && l < hi) ? 1.f : 0.f;
+}
+}  // namespace oat
+extern "C" int oat_tag_masks(const void* ends, const void* ntxt, float* out, int B, int O, int L, void* stream) {
+  if (B <= 0 || O <= 0 || L <= 0) return 0;
+  hipLaunchKernelGGL(oat::tag_masks_kernel, dim3(B * O), dim3(64), 0, (hipStream_t)stream, (const long long*)ends,
+                     (const long long*)ntxt, out, B, O, L);
+  return oat::check_launch("tag_masks");
+}

@@ -216,3 +216,89 @@ def region_sim(text_regions, object_regions):
 def gl_tail(x_normed):
     """oa_video_transformer_global_local.py:356-359: (1/2 CLS + 1/2 mean patches, patches)."""
     return 0.5 * x_normed[:, 0] + 0.5 * x_normed[:, 1:].mean(dim=1), x_normed[:, 1:]
+
+
+# --------------------------------------------------------------------------- OA variants (SURVEY 8a a16-a18)
+def _encoder_stream(video, p, num_heads, pre, tap=None):
+    x, T, N = video_tokens(video, p, pre)
+    depth = 1 + max(int(k[len(pre) + 7:].split(".")[0]) for k in p if k.startswith(pre + "blocks."))
+    tapped = None
+    for i in range(depth):
+        x = space_time_block(x, p, i, T, N, num_heads, pre)
+        if tap is not None and i + 1 == tap:
+            tapped = x
+    return x, tapped
+
+
+def video_encoder_region(video, p, num_heads=12, pre="video_model.", region_layer=6):
+    """oa_video_transformer_region.py:364-376: (norm(x)[:,0], region_norm(x after block 6)[:,1:])."""
+    x, tapped = _encoder_stream(video, p, num_heads, pre, tap=region_layer)
+    return _ln(x, p, pre + "norm", 1e-6)[:, 0], _ln(tapped, p, pre + "region_norm", 1e-6)[:, 1:]
+
+
+def video_encoder_gl(video, p, num_heads=12, pre="video_model."):
+    """oa_video_transformer_global_local.py:356-359."""
+    x, _ = _encoder_stream(video, p, num_heads, pre)
+    return gl_tail(_ln(x, p, pre + "norm", 1e-6))
+
+
+def _relu_lin(x, p, name):
+    return F.linear(F.relu(x), p[name + ".1.weight"], p[name + ".1.bias"])
+
+
+def region_mem_forward(p, video, input_ids, attention_mask, text_region_embedding, num_heads=12, text_heads=12):
+    """oa_model_region_mem.FrozenInTime.forward (oa_model_region_mem.py:105-123,141-151)."""
+    t = _relu_lin(distilbert(input_ids, attention_mask, p, n_heads=text_heads)[:, 0], p, "txt_proj")
+    B = video.shape[0]
+    v = video.reshape(B * 2, -1, *video.shape[2:])
+    cls, region = video_encoder_region(v, p, num_heads)
+    proj = lambda z: F.linear(z, p["vid_proj.0.weight"], p["vid_proj.0.bias"])
+    emb, reg = proj(cls), proj(region)
+    obj_region, vid_emb, vid_region = reg[0::2], emb[1::2], reg[1::2]
+    treg = _relu_lin(text_region_embedding, p, "txt_proj_2")
+    video_emb = (vid_emb + vid_region.mean(dim=1)) / 2
+    return t, video_emb, region_sim(treg, obj_region)
+
+
+def region_mem_loss(t, v, rsim, patch_mask, temperature=0.05):
+    """trainer_region_mem.py:151-167: NCE + 0.1 * BCE_sum / rows."""
+    loss = norm_softmax_loss(sim_matrix(t, v), temperature)
+    rs = rsim.reshape(-1, rsim.shape[-1])
+    pm = patch_mask.reshape(-1, patch_mask.shape[-1]).float()
+    return loss + 0.1 * F.binary_cross_entropy(rs, pm, reduction="sum") / rs.shape[0]
+
+
+def tag_masks(object_token_masks, n_txt, L):
+    """oa_model_global_local.py:183-196 (Python double loop in the reference): tag k of sample j covers
+    pad-text positions [n_txt-1+end_{k-1}, n_txt-1+end_k)."""
+    ends = object_token_masks.long()
+    starts = torch.cat([torch.zeros_like(ends[:, :1]), ends[:, :-1]], dim=1)
+    pos = torch.arange(L)[None, None, :]
+    base = (n_txt.long() - 1)[:, None, None]
+    return ((pos >= base + starts[:, :, None]) & (pos < base + ends[:, :, None])).float()
+
+
+def gl_forward(p, video, text, pad_text, patch_masks, object_token_masks, num_heads=12, text_heads=12):
+    """oa_model_global_local.FrozenInTime.forward (oa_model_global_local.py:149-208, :210-221)."""
+    def compute_text(ids, mask):
+        h = distilbert(ids, mask, p, n_heads=text_heads)
+        return _relu_lin(h[:, 0] + h[:, 1:].mean(dim=1), p, "txt_proj"), h
+    t, ttok = compute_text(*text)
+    pt, ptok = compute_text(*pad_text)
+    B = video.shape[0]
+    v = video.reshape(B * 2, -1, *video.shape[2:])
+    emb, region = video_encoder_gl(v, p, num_heads)
+    emb = F.linear(emb, p["vid_proj.0.weight"], p["vid_proj.0.bias"])
+    obj_emb, obj_region, vid_emb, vid_region = emb[0::2], region[0::2], emb[1::2], region[1::2]
+    region_feat = mask_pool(patch_masks.float(), obj_region)
+    tm = tag_masks(object_token_masks, text[1].sum(dim=1), ptok.shape[1])
+    tags_feat = mask_pool(tm, ptok)
+    region_feat = F.linear(region_feat, p["vid_local_proj.0.weight"], p["vid_local_proj.0.bias"])
+    tags_feat = _relu_lin(tags_feat, p, "text_local_proj")
+    return t, pt, vid_emb, obj_emb, region_feat, tags_feat
+
+
+def gl_loss(t, pt, v, region_feat, tags_feat, temperature=0.05):
+    """trainer_global_local.py:187-211."""
+    return (norm_softmax_loss(sim_matrix(t, v), temperature) + norm_softmax_loss(sim_matrix(pt, v), temperature)
+            + norm_softmax_loss(sim_matrix(region_feat.mean(dim=1), tags_feat.mean(dim=1)), temperature))

@@ -225,13 +225,141 @@ def gen_full(FrozenInTime, sim_matrix, NormSoftmaxLoss, T, B=2, L=12):
                 T=T, B=B, L=L, mask=mask)
 
 
+def _oa_inputs(B=2, F=2, L=8, Lp=12, O=3, K=5):
+    video = si.seeded_tensor(SEED, "oa.video", (B, F, 3, 224, 224))
+    ids = si.seeded_ints(SEED, "oa.ids", (B, L), 1000, 30000)
+    ids[:, 0] = 101
+    mask = torch.ones(B, L, dtype=torch.int64)
+    mask[1, L - 2:] = 0
+    pids = si.seeded_ints(SEED, "oa.pids", (B, Lp), 1000, 30000)
+    pids[:, 0] = 101
+    pmask = torch.ones(B, Lp, dtype=torch.int64)
+    pmask[1, Lp - 1:] = 0
+    patch_masks = (si.seeded_tensor(SEED, "oa.pm", (B, O, 196)) > 0.3).float()
+    region_masks = (si.seeded_tensor(SEED, "oa.rm", (B, K, 196)) > 0.5).float()
+    otm = torch.tensor([[1, 3, 4], [2, 3, 5]], dtype=torch.int64)[:B, :O]      # cumulative tag-token ends
+    treg = si.seeded_tensor(SEED, "oa.treg", (B, K, 512))
+    return dict(video=video, ids=ids, mask=mask, pids=pids, pmask=pmask, patch_masks=patch_masks,
+                region_masks=region_masks, otm=otm, treg=treg)
+
+
+def _probe(module):
+    probe = {}
+    for k, prm in module.named_parameters():
+        if prm.grad is None:
+            continue
+        g = prm.grad.flatten()
+        idx = si.seeded_ints(SEED, "probe." + k, (8,), 0, g.numel())
+        probe[k] = dict(idx=idx, val=g[idx].clone(), norm=g.norm().clone())
+    return probe
+
+
+def _pretrained_dir():
+    from transformers import DistilBertConfig, DistilBertModel
+    os.makedirs("pretrained", exist_ok=True)
+    DistilBertModel(DistilBertConfig()).save_pretrained("pretrained/distilbert-base-uncased")
+    torch.save({}, "pretrained/jx_vit_base_p16_224-80ecf9dd.pth")
+
+
+def gen_region_mem(NormSoftmaxLoss, sim_matrix):
+    """The reference's own oa_model_region_mem.FrozenInTime at ViT-B/16 geometry, F=2 (one object frame +
+    one video frame), with the region loss of trainer_region_mem.py:151-167."""
+    from OATrans.model.oa_model_region_mem import FrozenInTime
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        try:
+            _pretrained_dir()
+            m = FrozenInTime(video_params=dict(model="SpaceTimeTransformer", arch_config="base_patch16_224", num_frames=1,
+                                               pretrained=True, time_init="rand"),
+                             object_params=dict(model="", input_objects=False),
+                             text_params=dict(model="pretrained/distilbert-base-uncased", pretrained=True, input="text"),
+                             projection="minimal", load_checkpoint="")
+        finally:
+            os.chdir(cwd)
+    sd = si.frozen_state_dict(SEED, dict(num_frames=1), {})
+    sd.update(si.seeded_state_dict({"video_model.region_norm.weight": (768,), "video_model.region_norm.bias": (768,),
+                                    "video_model.object_embed.weight": (768, 2054), "video_model.object_embed.bias": (768,),
+                                    "txt_proj_2.1.weight": (256, 512), "txt_proj_2.1.bias": (256,)}, SEED))
+    r = m.load_state_dict(sd, strict=False)
+    assert not r.unexpected_keys and not r.missing_keys, r
+    m.eval()
+    d = _oa_inputs()
+    t, v, rsim = m({"video": d["video"], "text": {"input_ids": d["ids"], "attention_mask": d["mask"]},
+                    "text_region_embedding": d["treg"]})
+    loss = NormSoftmaxLoss()(sim_matrix(t, v))
+    rs, pm = rsim.view(-1, rsim.size(-1)), d["region_masks"].view(-1, 196)
+    loss = loss + 0.1 * torch.nn.BCELoss(reduction='sum')(rs, pm) / rs.size(0)
+    loss.backward()
+    return dict(text=t.detach(), video=v.detach(), region_sim=rsim.detach(), loss=loss.detach(), grad_probe=_probe(m))
+
+
+def gen_global_local(NormSoftmaxLoss, sim_matrix):
+    """The reference's oa_model_global_local.FrozenInTime (needs cwd-style imports + an Identity shim for the
+    undefined CrossModalityFusion) with the 3-term loss of trainer_global_local.py:187-211."""
+    import OATrans.base as refbase
+    sys.path.insert(0, f"{REF}/OATrans")
+    for name in ("cv2",):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["base"] = refbase
+    spec = importlib.util.spec_from_file_location("model.oa_video_transformer_global_local",
+                                                  f"{REF}/OATrans/model/oa_video_transformer_global_local.py")
+    vt = importlib.util.module_from_spec(spec)
+    pkg = types.ModuleType("model")
+    pkg.__path__ = []
+    sys.modules["model"] = pkg
+    sys.modules["model.oa_video_transformer_global_local"] = vt
+    spec.loader.exec_module(vt)
+    spec = importlib.util.spec_from_file_location("ref_oa_gl", f"{REF}/OATrans/model/oa_model_global_local.py")
+    gl = importlib.util.module_from_spec(spec)
+    gl.CrossModalityFusion = nn.Identity          # undefined in the reference; never used in forward
+    gl.__dict__["CrossModalityFusion"] = nn.Identity
+    spec.loader.exec_module(gl)
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        try:
+            _pretrained_dir()
+            m = gl.FrozenInTime(video_params=dict(model="SpaceTimeTransformer", arch_config="base_patch16_224", num_frames=1,
+                                                  pretrained=True, time_init="rand", two_outputs=False),
+                                object_params=dict(model="", input_objects=False),
+                                text_params=dict(model="pretrained/distilbert-base-uncased", pretrained=True, input="text"),
+                                projection="minimal", load_checkpoint="")
+        finally:
+            os.chdir(cwd)
+    sd = si.frozen_state_dict(SEED, dict(num_frames=1), {})
+    sd.update(si.seeded_state_dict({"video_model.object_embed.weight": (768, 2054), "video_model.object_embed.bias": (768,),
+                                    "text_local_proj.1.weight": (256, 768), "text_local_proj.1.bias": (256,),
+                                    "vid_local_proj.0.weight": (256, 768), "vid_local_proj.0.bias": (256,)}, SEED))
+    r = m.load_state_dict(sd, strict=False)
+    assert not r.unexpected_keys and not r.missing_keys, r
+    m.eval()
+    m.set_device("cpu")
+    d = _oa_inputs()
+    t, pt, v, ov, extra = m({"video": d["video"], "text": {"input_ids": d["ids"], "attention_mask": d["mask"]},
+                             "pad_text": {"input_ids": d["pids"], "attention_mask": d["pmask"]},
+                             "patch_masks": d["patch_masks"], "object_token_masks": d["otm"],
+                             "object_token_len": d["otm"][:, -1]})
+    region_feat, tags_feat = extra[4], extra[5]
+    L = NormSoftmaxLoss()
+    loss = L(sim_matrix(t, v)) + L(sim_matrix(pt, v)) + L(sim_matrix(region_feat.mean(1), tags_feat.mean(1)))
+    loss.backward()
+    return dict(text=t.detach(), pad_text=pt.detach(), video=v.detach(), object_video=ov.detach(),
+                region_feat=region_feat.detach(), tags_feat=tags_feat.detach(), loss=loss.detach(), grad_probe=_probe(m))
+
+
 def main():
     import_reference()
     from OATrans.model.video_transformer import SpaceTimeTransformer
     from OATrans.model.oa_model import FrozenInTime, sim_matrix
     from OATrans.model.loss import NormSoftmaxLoss
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["small", "loss", "full"]
+    which = sys.argv[1:] or ["small", "loss", "full", "oa"]
+    if "oa" in which:
+        torch.save(gen_region_mem(NormSoftmaxLoss, sim_matrix), os.path.join(HERE, "oa_region_mem.pt"))
+        print("region_mem done")
+        torch.save(gen_global_local(NormSoftmaxLoss, sim_matrix), os.path.join(HERE, "oa_global_local.pt"))
+        print("global_local done")
     if "small" in which:
         torch.save(gen_small_video(SpaceTimeTransformer), os.path.join(HERE, "small_video.pt"))
         torch.save(gen_small_chain(SpaceTimeTransformer, sim_matrix, NormSoftmaxLoss),
