@@ -41,9 +41,12 @@ def build(args, device):
     from OATrans.optim import AdamW
     from OATrans.parallel import HipDataParallel
     torch.manual_seed(1234)
-    model = module_arch.FrozenInTime(
-        video_params=dict(model="SpaceTimeTransformer", arch_config="base_patch16_224", num_frames=args.frames,
-                          pretrained=True, time_init="rand"),
+    cls = {"frozen": module_arch.FrozenInTime, "region_mem": module_arch.oa_model_region_mem.FrozenInTime,
+           "global_local": module_arch.oa_model_global_local.FrozenInTime}[args.variant]
+    model = cls(
+        video_params=dict(model="SpaceTimeTransformer", arch_config="base_patch16_224",
+                          num_frames=args.frames if args.variant == "frozen" else max(1, args.frames // 2),
+                          pretrained=True, time_init="rand", two_outputs=False),
         object_params=dict(model="", input_objects=False),
         text_params=dict(model="pretrained/distilbert-base-uncased", pretrained=True, input="text"),
         projection="minimal", load_checkpoint="")
@@ -69,7 +72,16 @@ def synthetic_batch(args, rank, device):
     video = torch.randn(B, T, 3, 224, 224, generator=g).to(torch.bfloat16).to(device)
     ids = torch.randint(1000, 30000, (B, L), generator=g)
     ids[:, 0], ids[:, -1] = 101, 102
-    return {"video": video, "text": {"input_ids": ids.to(device), "attention_mask": torch.ones(B, L, dtype=torch.int64, device=device)}}
+    batch = {"video": video, "text": {"input_ids": ids.to(device), "attention_mask": torch.ones(B, L, dtype=torch.int64, device=device)}}
+    if args.variant != "frozen":
+        from OATrans.data_loader.data_loader import MultiDistTextObjectVideoDataLoader
+        O = 5 if args.variant == "region_mem" else 10
+        dl = MultiDistTextObjectVideoDataLoader("Synthetic", {"max_length": L}, {"input_res": 224, "num_frames": 1}, "",
+                                                batch_size=B, object_params={"input_objects": True, "num_objects": O})
+        extra = dl.make_batch(4321 + rank, device)
+        for k in ("patch_masks", "object_token_masks", "object_token_len", "pad_text", "text_region_embedding"):
+            batch[k] = extra[k]
+    return batch
 
 
 def instrumented_gemm_profile(step_fn):
@@ -143,6 +155,10 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
     ap.add_argument("--frames", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--variant", choices=["frozen", "region_mem", "global_local"], default="frozen",
+                    help="frozen = oa_model.FrozenInTime (headline); the OA variants view the F input frames as 2B clips of "
+                         "F/2 frames (object stream + video stream); their mask-pool / region-BCE shapes are only valid "
+                         "for F = 2, exactly as in the reference")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", 1))
     rank = int(os.environ.get("RANK", 0))
@@ -154,13 +170,14 @@ def main():
     if world > 1:
         dist.init_process_group(backend="nccl", init_method="tcp://{}:{}".format(
             os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ.get("MASTER_PORT", "29500")), rank=rank, world_size=world)
-    from OATrans.trainer.step import hot_step
+    from OATrans.trainer.step import global_local_step, hot_step, region_mem_step
+    step_impl = {"frozen": hot_step, "region_mem": region_mem_step, "global_local": global_local_step}[args.variant]
     dp, opt, loss_fn = build(args, device)
     data = synthetic_batch(args, rank, device)
     step_args = argparse.Namespace(world_size=world, rank=rank, local_rank=local)
 
     def step():
-        return hot_step(dp, loss_fn, opt, data, step_args)
+        return step_impl(dp, loss_fn, opt, data, step_args)
 
     for _ in range(args.warmup):
         step()
@@ -187,7 +204,7 @@ def main():
         "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"{args.frames}-frame 224^2 ViT-B/16 SpaceTimeTransformer + DistilBERT-base (oa_model.FrozenInTime), "
+        "config": {"workload": f"[{args.variant}] {args.frames}-frame 224^2 ViT-B/16 SpaceTimeTransformer + DistilBERT-base (oa_model.FrozenInTime), "
                                f"bs {args.batch}/GPU, Lt 32, fwd+bwd+AdamW, InfoNCE over all-gathered embeddings",
                    "per_gpu_batch": args.batch, "global_batch": world * args.batch, "frames": args.frames,
                    "parallelism": f"dp{world}", "gflop_per_pair": round(gf_pair, 1)},
@@ -208,7 +225,7 @@ def main():
                                "traffic": None, "launches_per_step": d["n"],
                                "avg_launch_us": round(d["ms"] / d["n"] * 1e3, 1),
                                "gflop_per_launch": round(d["flops"] / d["n"] / 1e9, 1)}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.variant == "frozen":
             # torch CPU kernels collapse when all 256 SMT threads of the GPU box are used (measured 325 s /
             # iteration vs ~9 s on 8 threads), so the baseline uses 8 threads, the count BASELINE.md quotes
             threads = min(8, os.cpu_count() or 1)

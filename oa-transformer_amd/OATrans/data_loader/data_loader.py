@@ -33,6 +33,7 @@ class _SyntheticLoader:
         self.split = split
         self.video_params = dict(video_params)
         self.text_params = dict(text_params or {})
+        self.object_params = dict(object_params or {})
         self.args = args
         self.world_size = getattr(args, 'world_size', 1) if args is not None else 1
         self.rank = getattr(args, 'rank', 0) if args is not None else 0
@@ -53,9 +54,37 @@ class _SyntheticLoader:
         ids[:, 0], ids[:, -1] = 101, 102
         batch = {'video': video, 'text': {'input_ids': ids, 'attention_mask': torch.ones(B, L, dtype=torch.int64)},
                  'meta': {'paths': [f'synthetic/{seed}/{i}' for i in range(B)], 'dataset': [self.dataset_name] * B}}
+        op = self.object_params
+        if op.get('input_objects') or op.get('pseudo_labels') or op.get('input_object_bboxs'):
+            # object-aware fields in the formats the reference datasets emit:
+            #   patch_masks        [B, O, 196] 0/1 - boxes rasterised on the 14x14 patch grid
+            #                      (base_dataset_global_local.py:348-356); region_mem uses O = 5 (:233-247)
+            #   object_token_masks [B, O] cumulative tag-token ends, object_token_len [B]
+            #   pad_text           caption + object tags, pre-tokenised
+            #   text_region_embedding [B, 5, 512] (CLIP text features of 5 sampled classes)
+            O, g14 = int(op.get('num_objects', 10)), 14
+            x0 = torch.randint(0, g14 - 1, (B, O), generator=g)
+            y0 = torch.randint(0, g14 - 1, (B, O), generator=g)
+            x1 = x0 + 1 + torch.randint(0, g14, (B, O), generator=g) % (g14 - x0)
+            y1 = y0 + 1 + torch.randint(0, g14, (B, O), generator=g) % (g14 - y0)
+            xs = torch.arange(g14)[None, None, :]
+            in_x = (xs >= x0[..., None]) & (xs < x1[..., None])
+            in_y = (xs >= y0[..., None]) & (xs < y1[..., None])
+            batch['patch_masks'] = (in_y[..., :, None] & in_x[..., None, :]).reshape(B, O, g14 * g14).float()
+            ntok = torch.randint(1, 4, (B, O), generator=g)
+            batch['object_token_masks'] = ntok.cumsum(dim=1)
+            batch['object_token_len'] = batch['object_token_masks'][:, -1].clone()
+            Lp = L + int(3 * O)
+            pids = torch.randint(1000, 30000, (B, Lp), generator=g)
+            pids[:, 0] = 101
+            batch['pad_text'] = {'input_ids': pids, 'attention_mask': torch.ones(B, Lp, dtype=torch.int64)}
+            batch['text_region_embedding'] = torch.randn(B, 5, 512, generator=g)
         if device is not None:
-            batch['video'] = batch['video'].to(device)
-            batch['text'] = {k: v.to(device) for k, v in batch['text'].items()}
+            for k, v in list(batch.items()):
+                if isinstance(v, torch.Tensor):
+                    batch[k] = v.to(device)
+                elif isinstance(v, dict) and k != 'meta':
+                    batch[k] = {kk: vv.to(device) for kk, vv in v.items()}
         return batch
 
     def __iter__(self):

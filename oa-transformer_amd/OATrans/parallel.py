@@ -47,6 +47,20 @@ def allgather_pair(a, b, args):
     return packed[:, :a.shape[1]], packed[:, a.shape[1]:]
 
 
+def allgather_packed(tensors, args):
+    """ONE collective for any number of per-sample tensors [B, ...]: flatten each to [B, -1], concatenate,
+    gather with the slice-only backward, split and restore shapes (the reference issues one NCCL call per
+    tensor: 6 in trainer_global_local.py:171-182, 4 in trainer_region_mem.py:152-155)."""
+    flat = [t.reshape(t.shape[0], -1).float() for t in tensors]
+    widths = [f.shape[1] for f in flat]
+    packed = AllGather_multi.apply(torch.cat(flat, dim=1), args.world_size, args)
+    outs, off = [], 0
+    for t, w in zip(tensors, widths):
+        outs.append(packed[:, off:off + w].reshape((packed.shape[0],) + tuple(t.shape[1:])))
+        off += w
+    return outs
+
+
 class GradSync:
     """Mean all-reduce of parameter gradients over flat buffers, overlapped on a side stream."""
 

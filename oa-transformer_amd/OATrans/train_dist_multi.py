@@ -80,7 +80,7 @@ def run(config, args):
     torch.distributed.destroy_process_group()
 
 
-if __name__ == '__main__':
+def parse_cli():
     parser = argparse.ArgumentParser(description='OA-Transformer on MI355X')
     parser.add_argument('-c', '--config', default=None, type=str, help='config file path (default: None)')
     parser.add_argument('-r', '--resume', default=None, type=str, help='path to latest checkpoint (default: None)')
@@ -100,5 +100,9 @@ if __name__ == '__main__':
         CustomArgs(['--lr', '--learning_rate'], type=float, target=('optimizer', 'args', 'lr')),
         CustomArgs(['--bs', '--batch_size'], type=int, target=('data_loader', 'args', 'batch_size')),
     ]
-    config = ConfigParser(parser, options)
+    return ConfigParser(parser, options)
+
+
+if __name__ == '__main__':
+    config = parse_cli()
     run(config, config.args)

@@ -2,10 +2,12 @@
 trainers, bench.py and the smoke test so that what is benchmarked is what trains."""
 try:
     from OATrans.model.layers import sim_matrix
-    from OATrans.parallel import allgather_pair
+    from OATrans.model.oa_layers import bce_sum, mean_rows
+    from OATrans.parallel import allgather_packed, allgather_pair
 except ImportError:
     from model.layers import sim_matrix
-    from parallel import allgather_pair
+    from model.oa_layers import bce_sum, mean_rows
+    from parallel import allgather_packed, allgather_pair
 
 
 def hot_step(model_dp, loss_fn, optimizer, data, args):
@@ -22,3 +24,42 @@ def hot_step(model_dp, loss_fn, optimizer, data, args):
     model_dp.sync_gradients()
     optimizer.step()
     return loss.detach()
+
+
+def _finish(model_dp, optimizer, loss):
+    loss.backward()
+    model_dp.sync_gradients()
+    optimizer.step()
+    return loss.detach()
+
+
+def region_mem_step(model_dp, loss_fn, optimizer, data, args):
+    """trainer_region_mem.py:139-171: InfoNCE(text, video) + 0.1 * BCE_sum(region_sim, patch_mask) / rows,
+    over the all-gathered batch."""
+    core = model_dp.module
+    core.begin_step()
+    optimizer.zero_grad()
+    text, video, rsim = model_dp(data, aug=True)
+    patch_mask = data['patch_masks'].float()
+    if patch_mask.dim() == 4:
+        patch_mask = patch_mask.squeeze(1)
+    video, text, rsim, patch_mask = allgather_packed([video, text, rsim, patch_mask], args)
+    loss = loss_fn(sim_matrix(text, video))
+    rs = rsim.reshape(-1, rsim.shape[-1])
+    pm = patch_mask.reshape(-1, patch_mask.shape[-1])
+    loss = loss + 0.1 * bce_sum(rs, pm) / rs.shape[0]
+    return _finish(model_dp, optimizer, loss)
+
+
+def global_local_step(model_dp, loss_fn, optimizer, data, args):
+    """trainer_global_local.py:144-215: NCE(text, video) + NCE(pad_text, video) + NCE(mean_o region, mean_o tags)."""
+    core = model_dp.module
+    core.begin_step()
+    optimizer.zero_grad()
+    text, pad_text, video, pad_video, extra = model_dp(data)
+    region_feat, tags_feat = extra[4], extra[5]
+    video, pad_text, pad_video, text, region_feat, tags_feat = allgather_packed(
+        [video, pad_text, pad_video, text, region_feat, tags_feat], args)
+    loss = loss_fn(sim_matrix(text, video)) + loss_fn(sim_matrix(pad_text, video))
+    loss = loss + loss_fn(sim_matrix(mean_rows(region_feat), mean_rows(tags_feat)))
+    return _finish(model_dp, optimizer, loss)

@@ -1,0 +1,26 @@
+"""Global+local trainer (/root/reference/OATrans/trainer/trainer_global_local.py): three InfoNCE terms over
+six gathered tensors (one packed collective here).  The reference leaves torch.autograd.set_detect_anomaly
+on at import (:16) - a debugging leftover that is not reproduced."""
+try:
+    from OATrans.trainer.step import global_local_step
+    from OATrans.trainer.trainer_dist import Multi_Trainer_dist as _Base
+except ImportError:
+    from trainer.step import global_local_step
+    from trainer.trainer_dist import Multi_Trainer_dist as _Base
+
+
+class Multi_Trainer_dist(_Base):
+    def _to_device(self, data):
+        data = super()._to_device(data)
+        if self.tokenizer is not None and not isinstance(data['pad_text'], dict):
+            data['pad_text'] = self.tokenizer(data['pad_text'], return_tensors='pt', padding=True, truncation=True)
+        data['pad_text'] = {k: v.to(self.device) for k, v in data['pad_text'].items()}
+        for k in ('patch_masks', 'object_token_masks', 'object_token_len'):
+            data[k] = data[k].to(self.device)
+        return data
+
+    def train_step(self, data):
+        return global_local_step(self.model, self.loss, self.optimizer, data, self.args)
+
+    def _valid_epoch(self, epoch):
+        return {}
