@@ -62,18 +62,20 @@ constexpr int FWD_THREADS = 256, BWD_THREADS = 512;
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 
-// stage a [NKP][64] tile from token rows: j < N -> patch row, j == N -> CLS row, else zeros
+// stage a [NKP][64] tile from token rows with LDS-DMA: j < N -> patch row, j == N -> CLS row, j > N ->
+// alias of the CLS row (padding rows are never used un-masked: their scores are -inf / their P is 0, so they
+// only need to be finite).  All slabs of a tile are in flight at once (the earlier load->wait->ds_write loop
+// serialised ~7 HBM latencies per tile); the bank swizzle is applied on the per-lane SOURCE address.
 template <int NKT, int NTHR>
 OAT_DEV void load_tile(char* tile, const bf16* src, int ld, int col, size_t base_row, size_t cls_row, int N) {
-  constexpr int NKP = NKT * 16;
-  for (int idx = threadIdx.x; idx < NKP * 8; idx += NTHR) {
-    const int j = idx >> 3, c = idx & 7;
-    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (j <= N) {
-      const size_t r = j < N ? base_row + j : cls_row;
-      v = *reinterpret_cast<const bf16x8*>(src + r * ld + col + c * 8);
-    }
-    *reinterpret_cast<bf16x8*>(tile + tile_off(j, c)) = v;
+  constexpr int NSLAB = NKT * 2;                    // 8 rows (1 KB) per wave instruction
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (int slab = wave; slab < NSLAB; slab += NTHR / 64) {
+    const int j = slab * 8 + (lane >> 3);
+    const int lc = (lane & 7) ^ sw8(j);
+    const size_t r = j < N ? base_row + j : cls_row;
+    glds16(src + r * ld + col + lc * 8, tile + slab * 1024);
   }
 }
 
@@ -178,26 +180,34 @@ __global__ __launch_bounds__(BWD_THREADS) void attn_space_bwd_kernel(SpaceArgs a
   load_tile<NKT, BWD_THREADS>(Qt, a.qkv, a.ldqkv, h * 64, base_row, cls_row, N);
   load_tile<NKT, BWD_THREADS>(Kt, a.qkv, a.ldqkv, a.D + h * 64, base_row, cls_row, N);
   load_tile<NKT, BWD_THREADS>(Vt, a.qkv, a.ldqkv, 2 * a.D + h * 64, base_row, cls_row, N);
-  // dO tile + delta = rowsum(dO * O) + lse (log2 units); 8 lanes per row
-  for (int idx = threadIdx.x; idx < NKP * 8; idx += BWD_THREADS) {
-    const int j = idx >> 3, c = idx & 7;
-    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-    float d = 0.f;
-    size_t r = 0;
-    if (j <= N) {
-      r = j < N ? base_row + j : cls_row;
-      v = *reinterpret_cast<const bf16x8*>(a.dout + r * a.lddo + h * 64 + c * 8);
-      const bf16x8 o = *reinterpret_cast<const bf16x8*>(a.out + r * a.ldo + h * 64 + c * 8);
+  load_tile<NKT, BWD_THREADS>(Dt, a.dout, a.lddo, h * 64, base_row, cls_row, N);
+  // delta = rowsum(dO * O) and lse (log2 units), 8 lanes per row; all loads issued before the first use
+  {
+    constexpr int ITER = (NKP * 8 + BWD_THREADS - 1) / BWD_THREADS;
+    bf16x8 gv[ITER], ov[ITER];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) d += bf2f(v[e]) * bf2f(o[e]);
+    for (int it = 0; it < ITER; ++it) {
+      const int idx = it * BWD_THREADS + threadIdx.x;
+      const int j = min(idx >> 3, N), c = idx & 7;
+      const size_t r = j < N ? base_row + j : cls_row;
+      gv[it] = *reinterpret_cast<const bf16x8*>(a.dout + r * a.lddo + h * 64 + c * 8);
+      ov[it] = *reinterpret_cast<const bf16x8*>(a.out + r * a.ldo + h * 64 + c * 8);
     }
-    *reinterpret_cast<bf16x8*>(Dt + tile_off(j, c)) = v;
-    d += __shfl_xor(d, 1, 64);
-    d += __shfl_xor(d, 2, 64);
-    d += __shfl_xor(d, 4, 64);
-    if (c == 0) {
-      del_s[j] = d;
-      lse_s[j] = j <= N ? a.lse[r * a.H + h] * LOG2E : 0.f;
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int idx = it * BWD_THREADS + threadIdx.x;
+      const int j = idx >> 3, c = idx & 7;
+      float d = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) d += bf2f(gv[it][e]) * bf2f(ov[it][e]);
+      d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0xB1, 0xF, 0xF, true));
+      d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x4E, 0xF, 0xF, true));
+      d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x141, 0xF, 0xF, true));
+      if (c == 0 && j < NKP) {
+        const size_t r = j < N ? base_row + j : cls_row;
+        del_s[j] = j <= N ? d : 0.f;
+        lse_s[j] = j <= N ? a.lse[r * a.H + h] * LOG2E : 0.f;
+      }
     }
   }
   __syncthreads();

@@ -30,10 +30,12 @@ OAT_DEV float xdot8x(const bf16x8 a, const bf16x8 b) {      // exact fp32 chain 
   for (int e = 0; e < 8; ++e) s += bf2f(a[e]) * bf2f(b[e]);
   return s;
 }
+// sum over the 8 lanes of a problem group, result in all 8: three v_add_f32_dpp (quad_perm xor 1, xor 2,
+// row_half_mirror) instead of three ds_bpermute round trips through the LDS crossbar
 OAT_DEV float xred8(float v) {
-  v += __shfl_xor(v, 1, 64);
-  v += __shfl_xor(v, 2, 64);
-  v += __shfl_xor(v, 4, 64);
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
   return v;
 }
 
