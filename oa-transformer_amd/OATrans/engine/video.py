@@ -55,14 +55,18 @@ class _Plan:
         self.normed = torch.zeros(Mp, D, dtype=torch.float32, device=dev)
         self.region = None                      # [B*T*N, D] fp32, allocated on first use (region_mem variant)
         self.rstats = None
-        # backward temporaries (shared by all blocks)
+        # backward temporaries.  Weight gradients (gemm_tn) run on a SIDE stream concurrently with the
+        # data-gradient chain, so every bf16 dY that a weight gradient reads lives in a small ring:
+        #   ga[3]  : block-input gradient (written one block ahead by LN3-backward)
+        #   sets[2]: d_h, dy16, d_qkv_s, dxt16, d_qkv_t of even / odd blocks
+        z16 = lambda c: torch.zeros(Mp, c, dtype=torch.bfloat16, device=dev)
         self.G = torch.zeros(Mp, D, dtype=torch.float32, device=dev)
-        self.g16 = torch.zeros(Mp, D, dtype=torch.bfloat16, device=dev)
-        self.d_h = torch.zeros(Mp, Hd, dtype=torch.bfloat16, device=dev)
-        self.d_a = torch.zeros(Mp, D, dtype=torch.bfloat16, device=dev)
-        self.d_o = torch.zeros(Mp, D, dtype=torch.bfloat16, device=dev)
-        self.d_qkv = torch.zeros(Mp, 3 * D, dtype=torch.bfloat16, device=dev)
-        self.side = torch.zeros(B, H, 3, 64, dtype=torch.float32, device=dev)
+        self.ga = [z16(D) for _ in range(3)]
+        self.sets = [dict(d_h=z16(Hd), gb=z16(D), d_qkv_s=z16(3 * D), gc=z16(D), d_qkv_t=z16(3 * D)) for _ in range(2)]
+        self.d_a = z16(D)
+        self.d_o = z16(D)
+        self.tn_ws = torch.empty(hip.lib().oat_gemm_tn_workspace_bytes(0, 3 * D, Hd) // 4 // 8, dtype=torch.float32, device=dev)
+        self.cls_side = torch.zeros(B, H, 3, 64, dtype=torch.float32, device=dev)
         self.Gp = torch.zeros(T * N, D, dtype=torch.float32, device=dev)
 
 
@@ -86,6 +90,7 @@ class VideoEngine:
         self.plans = {}
         self.shadow = {}
         self.shadow_versions = None
+        self.side = None                 # HIP stream for weight gradients (created lazily on the device)
 
     # ------------------------------------------------------------------ weights
     def refresh_shadows(self, params, sig=None):
@@ -172,11 +177,32 @@ class VideoEngine:
     def backward(self, pl, params, grads, d_cls, d_patches=None, d_region=None):
         """Writes every video parameter gradient into `grads`.  d_cls fp32 [B,D]; d_patches fp32
         [B*T*N, D] or None (contract class oa_model.FrozenInTime discards patch outputs); d_region fp32
-        [B*T*N, D] = gradient of plan.region (enters the residual stream below block `region_layer`)."""
+        [B*T*N, D] = gradient of plan.region (enters the residual stream below block `region_layer`).
+
+        Two HIP streams: the data-gradient chain (dgrad GEMMs, LayerNorm / attention backward) stays on the
+        current stream; every weight gradient (gemm_tn + fused bias sums) goes to a side stream as soon as
+        its dY exists.  The chain never depends on a weight gradient, so the MFMA-bound wgrad GEMMs fill
+        the HBM-bound stretches (LN backward, attention backward, fp32 epilogues) of the chain."""
         B, T, N = pl.B, pl.T, pl.N
         D, Hd, H = self.D, self.Hd, self.H
         M, BTN = pl.M, B * T * N
-        G, g16 = pl.G, pl.g16
+        G = pl.G
+        main = torch.cuda.current_stream()
+        if self.side is None:
+            self.side = torch.cuda.Stream()
+        side = self.side
+        side.wait_stream(main)               # side may not start before this step's forward is done
+        done = {}                            # block index -> event: its wgrads finished on the side stream
+
+        def wgrad(P, Q, n1, n2, w, b, rows=M):
+            ev = torch.cuda.Event()
+            ev.record(main)                  # P was produced by everything enqueued on main so far
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                hip.gemm_tn(P, Q, rows, n1, n2, w, bias_out=b, ws=pl.tn_ws)
+
+        top = self.depth - 1
+        g16 = pl.ga[top % 3]
         # final norm
         if pl.need_patches and d_patches is not None:
             dn = torch.cat([d_patches, d_cls], dim=0).contiguous()
@@ -189,53 +215,63 @@ class VideoEngine:
                               params["norm.weight"], B, D, dx=G[BTN:], dx16=g16[BTN:], dgamma=grads["norm.weight"],
                               dbeta=grads["norm.bias"])
         rl = getattr(pl, "region_layer", None)
-        if rl is not None:
+        if rl is not None and d_region is None:
             for k in ("region_norm.weight", "region_norm.bias"):
-                if d_region is None:
-                    grads[k].zero_()
+                grads[k].zero_()
         for i in reversed(range(self.depth)):
             a = pl.blocks[i]
+            st8 = pl.sets[i % 2]
+            ga = pl.ga[i % 3]                              # dL/d(block output), bf16
+            ga_next = pl.ga[(i - 1) % 3]                   # written by this block's LN3 backward
+            if i + 2 in done:
+                main.wait_event(done[i + 2])               # ring slot i%2 (and ga[(i-1)%3]) is free again
             if rl is not None and d_region is not None and i + 1 == rl:
                 # region tokens branch off the output of block rl-1: add their gradient to the stream
                 hip.layernorm_bwd(d_region.contiguous(), a.out, pl.rstats[0], pl.rstats[1], params["region_norm.weight"],
-                                  BTN, D, dx=G, dx16=g16, dres=G, dgamma=grads["region_norm.weight"],
+                                  BTN, D, dx=G, dx16=ga, dres=G, dgamma=grads["region_norm.weight"],
                                   dbeta=grads["region_norm.bias"])
             x = pl.blocks[i - 1].out if i > 0 else pl.x0
             p = lambda s: params[f"blocks.{i}.{s}"]
             gr = lambda s: grads[f"blocks.{i}.{s}"]
             wT = lambda s: self.shadow[f"blocks.{i}.{s}.weight"][1]
             st = a.stats
+            d_h, gb, d_qkv_s, gc, d_qkv_t = st8["d_h"], st8["gb"], st8["d_qkv_s"], st8["gc"], st8["d_qkv_t"]
             # ---- MLP: out = y + fc2(gelu(fc1(LN2(y))))
-            hip.gemm_tn(g16, a.g, M, D, Hd, gr("mlp.fc2.weight"), bias_out=gr("mlp.fc2.bias"))
-            hip.gemm_nt(g16, wT("mlp.fc2"), M, Hd, D, hip.EPI_DGELU, pl.d_h, aux=a.h)
-            hip.gemm_tn(pl.d_h, a.a2, M, Hd, D, gr("mlp.fc1.weight"), bias_out=gr("mlp.fc1.bias"))
-            hip.gemm_nt(pl.d_h, wT("mlp.fc1"), M, D, Hd, hip.EPI_BF16, pl.d_a)
-            hip.layernorm_bwd(pl.d_a, a.y, st[4], st[5], p("norm2.weight"), M, D, dx=G, dx16=g16, dres=G,
+            wgrad(ga, a.g, D, Hd, gr("mlp.fc2.weight"), gr("mlp.fc2.bias"))
+            hip.gemm_nt(ga, wT("mlp.fc2"), M, Hd, D, hip.EPI_DGELU, d_h, aux=a.h)
+            wgrad(d_h, a.a2, Hd, D, gr("mlp.fc1.weight"), gr("mlp.fc1.bias"))
+            hip.gemm_nt(d_h, wT("mlp.fc1"), M, D, Hd, hip.EPI_BF16, pl.d_a)
+            hip.layernorm_bwd(pl.d_a, a.y, st[4], st[5], p("norm2.weight"), M, D, dx=G, dx16=gb, dres=G,
                               dgamma=gr("norm2.weight"), dbeta=gr("norm2.bias"))            # G = dL/dy
             # ---- space attention: y = x + proj(attn(LN1(xt)))
-            hip.gemm_tn(g16, a.o_s, M, D, D, gr("attn.proj.weight"), bias_out=gr("attn.proj.bias"))
-            hip.gemm_nt(g16, wT("attn.proj"), M, D, D, hip.EPI_BF16, pl.d_o)
-            pl.side.zero_()
-            hip.attn_space_bwd(a.qkv_s, a.o_s, a.lse_s, pl.d_o, pl.d_qkv, pl.side, B, T, N, H, D, self.scale)
-            hip.attn_cls_finalize(pl.side, pl.d_qkv, B, T, N, H, D)
-            hip.gemm_tn(pl.d_qkv, a.a1, M, 3 * D, D, gr("attn.qkv.weight"), bias_out=gr("attn.qkv.bias"))
-            hip.gemm_nt(pl.d_qkv, wT("attn.qkv"), M, D, 3 * D, hip.EPI_BF16, pl.d_a)
-            # G <- dL/dy + dL/dxt (both reach x directly); g16 <- dL/dxt alone (feeds the time branch)
-            hip.layernorm_bwd(pl.d_a, a.xt, st[2], st[3], p("norm1.weight"), M, D, dx=G, dx16=g16, dres=G,
+            wgrad(gb, a.o_s, D, D, gr("attn.proj.weight"), gr("attn.proj.bias"))
+            hip.gemm_nt(gb, wT("attn.proj"), M, D, D, hip.EPI_BF16, pl.d_o)
+            pl.cls_side.zero_()
+            hip.attn_space_bwd(a.qkv_s, a.o_s, a.lse_s, pl.d_o, d_qkv_s, pl.cls_side, B, T, N, H, D, self.scale)
+            hip.attn_cls_finalize(pl.cls_side, d_qkv_s, B, T, N, H, D)
+            wgrad(d_qkv_s, a.a1, 3 * D, D, gr("attn.qkv.weight"), gr("attn.qkv.bias"))
+            hip.gemm_nt(d_qkv_s, wT("attn.qkv"), M, D, 3 * D, hip.EPI_BF16, pl.d_a)
+            # G <- dL/dy + dL/dxt (both reach x directly); gc <- dL/dxt alone (feeds the time branch)
+            hip.layernorm_bwd(pl.d_a, a.xt, st[2], st[3], p("norm1.weight"), M, D, dx=G, dx16=gc, dres=G,
                               dx16_excl_res=True, dgamma=gr("norm1.weight"), dbeta=gr("norm1.bias"))
             # ---- time attention: xt = x + proj(attn(LN3(x)))
-            hip.gemm_tn(g16, a.o_t, M, D, D, gr("timeattn.proj.weight"), bias_out=gr("timeattn.proj.bias"))
-            hip.gemm_nt(g16, wT("timeattn.proj"), M, D, D, hip.EPI_BF16, pl.d_o)
-            pl.side.zero_()
-            hip.attn_time_bwd(a.qkv_t, a.o_t, a.lse_t, pl.d_o, pl.d_qkv, pl.side, B, T, N, H, D, self.scale)
-            hip.attn_cls_finalize(pl.side, pl.d_qkv, B, T, N, H, D)
-            hip.gemm_tn(pl.d_qkv, a.a3, M, 3 * D, D, gr("timeattn.qkv.weight"), bias_out=gr("timeattn.qkv.bias"))
-            hip.gemm_nt(pl.d_qkv, wT("timeattn.qkv"), M, D, 3 * D, hip.EPI_BF16, pl.d_a)
-            hip.layernorm_bwd(pl.d_a, x, st[0], st[1], p("norm3.weight"), M, D, dx=G, dx16=g16, dres=G,
+            wgrad(gc, a.o_t, D, D, gr("timeattn.proj.weight"), gr("timeattn.proj.bias"))
+            hip.gemm_nt(gc, wT("timeattn.proj"), M, D, D, hip.EPI_BF16, pl.d_o)
+            pl.cls_side.zero_()
+            hip.attn_time_bwd(a.qkv_t, a.o_t, a.lse_t, pl.d_o, d_qkv_t, pl.cls_side, B, T, N, H, D, self.scale)
+            hip.attn_cls_finalize(pl.cls_side, d_qkv_t, B, T, N, H, D)
+            wgrad(d_qkv_t, a.a3, 3 * D, D, gr("timeattn.qkv.weight"), gr("timeattn.qkv.bias"))
+            hip.gemm_nt(d_qkv_t, wT("timeattn.qkv"), M, D, 3 * D, hip.EPI_BF16, pl.d_a)
+            hip.layernorm_bwd(pl.d_a, x, st[0], st[1], p("norm3.weight"), M, D, dx=G, dx16=ga_next, dres=G,
                               dgamma=gr("norm3.weight"), dbeta=gr("norm3.bias"))            # G = dL/dx
+            ev = torch.cuda.Event()
+            with torch.cuda.stream(side):
+                ev.record(side)
+            done[i] = ev
         # ---- token embedding: x0[patch] = cols @ Wp^T + b + pos[1+n] + temporal[f]; x0[cls] = cls + pos[0]
+        g16 = pl.ga[(-1) % 3]
         gw = grads["patch_embed.proj.weight"]
-        hip.gemm_tn(g16, pl.cols, BTN, D, self.Kp, gw.view(D, self.Kp), bias_out=grads["patch_embed.proj.bias"])
+        wgrad(g16, pl.cols, D, self.Kp, gw.view(D, self.Kp), grads["patch_embed.proj.bias"], rows=BTN)
         hip.periodic_rowsum(G, B, T * N, D, pl.Gp)
         gpos = grads["pos_embed"].view(N + 1, D)
         hip.periodic_rowsum(pl.Gp, T, N, D, gpos[1:])
@@ -245,3 +281,4 @@ class VideoEngine:
         hip.grouped_rowsum(pl.Gp, T, N, D, gt[:T])
         hip.grouped_rowsum(G[BTN:], 1, B, D, grads["cls_token"].view(1, D))
         gpos[:1].copy_(grads["cls_token"].view(1, D))
+        main.wait_stream(side)               # every weight gradient is complete before the caller continues

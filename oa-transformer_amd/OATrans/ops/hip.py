@@ -102,9 +102,12 @@ def tn_workspace(device, N1, N2):
     return ws
 
 
-def gemm_tn(P, Q, M, N1, N2, out, accumulate=False, ldp=None, ldq=None, bias_out=None):
-    """out[N1,N2] (+)= P[:M,:N1]^T @ Q[:M,:N2]  (weight gradient); bias_out[N1] (+)= colsum(P)."""
-    ws = tn_workspace(out.device, N1, N2)
+def gemm_tn(P, Q, M, N1, N2, out, accumulate=False, ldp=None, ldq=None, bias_out=None, ws=None):
+    """out[N1,N2] (+)= P[:M,:N1]^T @ Q[:M,:N2]  (weight gradient); bias_out[N1] (+)= colsum(P).
+    `ws`: caller-owned fp32 slab workspace (a launch stream needs its own; default = a per-device one
+    for the current stream)."""
+    if ws is None:
+        ws = tn_workspace(out.device, N1, N2)
     rc = lib().oat_gemm_tn(_ptr(P), _ptr(Q), M, N1, N2, ldp or P.stride(0), ldq or Q.stride(0), _ptr(out),
                            _ptr(bias_out), int(accumulate), _ptr(ws), ctypes.c_size_t(ws.numel() * 4), _stream())
     _check(rc, "oat_gemm_tn")
