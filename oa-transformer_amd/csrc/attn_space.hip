@@ -217,119 +217,169 @@ __global__ __launch_bounds__(BWD_THREADS) void attn_space_bwd_kernel(SpaceArgs a
   const float c2 = a.scale * LOG2E;
   float* side = a.cls_side + ((size_t)b * a.H + h) * 3 * 64;
 
-  // ------------------------------------------------ phase A: lane = query column, produces dQ
-  for (int qt = wave; qt < NKT; qt += BWD_THREADS / 64) {
-    if (qt * 16 > N) break;
-    const int qi = qt * 16 + (lane & 15);
-    const float lq = lse_s[qi], dq_ = del_s[qi];
-    bf16x8 qf[2], df[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) { qf[ks] = row_frag(Qt, qt * 16, ks, lane); df[ks] = row_frag(Dt, qt * 16, ks, lane); }
-    f32x4 ds[NKT];
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-      f32x4 s = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Kt, kt * 16, ks, lane), qf[ks], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Vt, kt * 16, ks, lane), df[ks], dp, 0, 0, 0);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = kt * 16 + g * 4 + r;
-        bool ok = key <= N && qi <= N;
-        if (qi == N && key == N && f != 0) ok = false;      // CLS->CLS pair is counted once (frame 0)
-        const float p = ok ? exp2f(s[r] * c2 - lq) : 0.f;
-        ds[kt][r] = p * (dp[r] - dq_);
-      }
-    }
-    f32x4 dq[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0, 0, 0, 0};
-#pragma unroll
-    for (int u = 0; u < NKT / 2; ++u) {
-      const bf16x8 sb = {f2bf(ds[2 * u][0]), f2bf(ds[2 * u][1]), f2bf(ds[2 * u][2]), f2bf(ds[2 * u][3]),
-                         f2bf(ds[2 * u + 1][0]), f2bf(ds[2 * u + 1][1]), f2bf(ds[2 * u + 1][2]), f2bf(ds[2 * u + 1][3])};
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
-        dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Kt, u * 32, dt, lane), sb, dq[dt], 0, 0, 0);
-    }
-    if (qi < N) {
-      bf16* drow = a.dqkv + (base_row + qi) * a.lddqkv + h * 64 + g * 4;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        const bf16x4 o = {f2bf(dq[dt][0] * a.scale), f2bf(dq[dt][1] * a.scale), f2bf(dq[dt][2] * a.scale),
-                          f2bf(dq[dt][3] * a.scale)};
-        *reinterpret_cast<bf16x4*>(drow + dt * 16) = o;
-      }
-    } else if (qi == N) {
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) atomicAdd(side + dt * 16 + g * 4 + r, dq[dt][r] * a.scale);
-    }
-  }
+  // Both phases process TWO 16-wide tiles per wave so that every LDS fragment (row fragments and
+  // transpose-read fragments) feeds two MFMA chains: half the LDS traffic per MFMA and two independent
+  // dependency chains per wave (the kernel is latency-bound at two waves per SIMD).
+  auto pack8 = [](const f32x4& a, const f32x4& b) {
+    return bf16x8{f2bf(a[0]), f2bf(a[1]), f2bf(a[2]), f2bf(a[3]), f2bf(b[0]), f2bf(b[1]), f2bf(b[2]), f2bf(b[3])};
+  };
+  const int ntile = N / 16 + 1;                         // tiles that contain a real row (index <= N)
 
-  // ------------------------------------------------ phase B: lane = key column, produces dK, dV
-  for (int kt = wave; kt < NKT; kt += BWD_THREADS / 64) {
-    if (kt * 16 > N) break;
-    const int key = kt * 16 + (lane & 15);
-    bf16x8 kf[2], vf[2];
+  // ------------------------------------------------ phase A: lane = query column, produces dQ
+  // streamed over key pairs: dS of keys [32u, 32u+32) is consumed by the dQ MFMAs right away
+  for (int pr = wave; pr * 2 < ntile; pr += BWD_THREADS / 64) {
+    const int qt0 = pr * 2;
+    const bool two = qt0 + 1 < ntile;                   // wave-uniform
+    const int qiA = qt0 * 16 + (lane & 15), qiB = qiA + 16;
+    const float lqA = lse_s[qiA], dlA = del_s[qiA], lqB = lse_s[qiB], dlB = del_s[qiB];
+    bf16x8 qfA[2], dfA[2], qfB[2], dfB[2];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) { kf[ks] = row_frag(Kt, kt * 16, ks, lane); vf[ks] = row_frag(Vt, kt * 16, ks, lane); }
-    f32x4 dk[4], dv[4];
+    for (int ks = 0; ks < 2; ++ks) {
+      qfA[ks] = row_frag(Qt, qt0 * 16, ks, lane); dfA[ks] = row_frag(Dt, qt0 * 16, ks, lane);
+      qfB[ks] = row_frag(Qt, qt0 * 16 + 16, ks, lane); dfB[ks] = row_frag(Dt, qt0 * 16 + 16, ks, lane);
+    }
+    f32x4 dqA[4], dqB[4];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0, 0, 0, 0}; dv[dt] = f32x4{0, 0, 0, 0}; }
+    for (int dt = 0; dt < 4; ++dt) { dqA[dt] = f32x4{0, 0, 0, 0}; dqB[dt] = f32x4{0, 0, 0, 0}; }
 #pragma unroll 1
     for (int u = 0; u < NKT / 2; ++u) {
       if (u * 32 > N) break;
-      float pv[8], sv[8];
+      f32x4 dsA[2], dsB[2];
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        const int q0 = u * 32 + half * 16;
-        f32x4 s = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
+      for (int hf = 0; hf < 2; ++hf) {
+        const int kt = 2 * u + hf;
+        f32x4 sA = {0, 0, 0, 0}, pA = {0, 0, 0, 0}, sB = {0, 0, 0, 0}, pB = {0, 0, 0, 0};
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-          s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Qt, q0, ks, lane), kf[ks], s, 0, 0, 0);
-          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Dt, q0, ks, lane), vf[ks], dp, 0, 0, 0);
+          const bf16x8 kf = row_frag(Kt, kt * 16, ks, lane), vf = row_frag(Vt, kt * 16, ks, lane);
+          sA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qfA[ks], sA, 0, 0, 0);
+          pA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dfA[ks], pA, 0, 0, 0);
+          if (two) {
+            sB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qfB[ks], sB, 0, 0, 0);
+            pB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dfB[ks], pB, 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kt * 16 + g * 4 + r;
+          const bool clsdup = key == N && f != 0;       // CLS->CLS pair is counted once (frame 0)
+          const bool okA = key <= N && qiA <= N && !(qiA == N && clsdup);
+          const bool okB = key <= N && qiB <= N && !(qiB == N && clsdup);
+          dsA[hf][r] = okA ? exp2f(sA[r] * c2 - lqA) * (pA[r] - dlA) : 0.f;
+          dsB[hf][r] = (two && okB) ? exp2f(sB[r] * c2 - lqB) * (pB[r] - dlB) : 0.f;
+        }
+      }
+      const bf16x8 sbA = pack8(dsA[0], dsA[1]), sbB = pack8(dsB[0], dsB[1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const bf16x8 tf = tr_frag(Kt, u * 32, dt, lane);
+        dqA[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tf, sbA, dqA[dt], 0, 0, 0);
+        if (two) dqB[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tf, sbB, dqB[dt], 0, 0, 0);
+      }
+    }
+    auto put_q = [&](int qi, const f32x4 (&dq)[4]) {
+      if (qi < N) {
+        bf16* drow = a.dqkv + (base_row + qi) * a.lddqkv + h * 64 + g * 4;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const bf16x4 o = {f2bf(dq[dt][0] * a.scale), f2bf(dq[dt][1] * a.scale), f2bf(dq[dt][2] * a.scale),
+                            f2bf(dq[dt][3] * a.scale)};
+          *reinterpret_cast<bf16x4*>(drow + dt * 16) = o;
+        }
+      } else if (qi == N) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) atomicAdd(side + dt * 16 + g * 4 + r, dq[dt][r] * a.scale);
+      }
+    };
+    put_q(qiA, dqA);
+    if (two) put_q(qiB, dqB);
+  }
+
+  // ------------------------------------------------ phase B: lane = key column, produces dK, dV
+  for (int pr = wave; pr * 2 < ntile; pr += BWD_THREADS / 64) {
+    const int kt0 = pr * 2;
+    const bool two = kt0 + 1 < ntile;
+    const int keyA = kt0 * 16 + (lane & 15), keyB = keyA + 16;
+    bf16x8 kfA[2], vfA[2], kfB[2], vfB[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      kfA[ks] = row_frag(Kt, kt0 * 16, ks, lane); vfA[ks] = row_frag(Vt, kt0 * 16, ks, lane);
+      kfB[ks] = row_frag(Kt, kt0 * 16 + 16, ks, lane); vfB[ks] = row_frag(Vt, kt0 * 16 + 16, ks, lane);
+    }
+    f32x4 dkA[4], dvA[4], dkB[4], dvB[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      dkA[dt] = f32x4{0, 0, 0, 0}; dvA[dt] = f32x4{0, 0, 0, 0}; dkB[dt] = f32x4{0, 0, 0, 0}; dvB[dt] = f32x4{0, 0, 0, 0};
+    }
+#pragma unroll 1
+    for (int u = 0; u < NKT / 2; ++u) {
+      if (u * 32 > N) break;
+      f32x4 pvA[2], svA[2], pvB[2], svB[2];
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int q0 = u * 32 + hf * 16;
+        f32x4 sA = {0, 0, 0, 0}, pA = {0, 0, 0, 0}, sB = {0, 0, 0, 0}, pB = {0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const bf16x8 qf = row_frag(Qt, q0, ks, lane), df = row_frag(Dt, q0, ks, lane);
+          sA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kfA[ks], sA, 0, 0, 0);
+          pA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, vfA[ks], pA, 0, 0, 0);
+          if (two) {
+            sB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kfB[ks], sB, 0, 0, 0);
+            pB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, vfB[ks], pB, 0, 0, 0);
+          }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int qi = q0 + g * 4 + r;
-          bool ok = key <= N && qi <= N;
-          if (qi == N && key == N && f != 0) ok = false;
-          const float p = ok ? exp2f(s[r] * c2 - lse_s[qi]) : 0.f;
-          pv[half * 4 + r] = p;
-          sv[half * 4 + r] = p * (dp[r] - del_s[qi]);
+          const float lq = lse_s[qi], dl = del_s[qi];
+          const bool clsq = qi == N && f != 0;
+          const bool okA = keyA <= N && qi <= N && !(clsq && keyA == N);
+          const bool okB = two && keyB <= N && qi <= N && !(clsq && keyB == N);
+          const float a_ = okA ? exp2f(sA[r] * c2 - lq) : 0.f;
+          const float b_ = okB ? exp2f(sB[r] * c2 - lq) : 0.f;
+          pvA[hf][r] = a_; svA[hf][r] = a_ * (pA[r] - dl);
+          pvB[hf][r] = b_; svB[hf][r] = b_ * (pB[r] - dl);
         }
       }
-      const bf16x8 pb = {f2bf(pv[0]), f2bf(pv[1]), f2bf(pv[2]), f2bf(pv[3]), f2bf(pv[4]), f2bf(pv[5]), f2bf(pv[6]), f2bf(pv[7])};
-      const bf16x8 sb = {f2bf(sv[0]), f2bf(sv[1]), f2bf(sv[2]), f2bf(sv[3]), f2bf(sv[4]), f2bf(sv[5]), f2bf(sv[6]), f2bf(sv[7])};
+      const bf16x8 pbA = pack8(pvA[0], pvA[1]), sbA = pack8(svA[0], svA[1]);
+      const bf16x8 pbB = pack8(pvB[0], pvB[1]), sbB = pack8(svB[0], svB[1]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Dt, u * 32, dt, lane), pb, dv[dt], 0, 0, 0);
-        dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Qt, u * 32, dt, lane), sb, dk[dt], 0, 0, 0);
-      }
-    }
-    if (key < N) {
-      bf16* drow = a.dqkv + (base_row + key) * a.lddqkv + h * 64 + g * 4;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        const bf16x4 ok_ = {f2bf(dk[dt][0] * a.scale), f2bf(dk[dt][1] * a.scale), f2bf(dk[dt][2] * a.scale),
-                            f2bf(dk[dt][3] * a.scale)};
-        const bf16x4 ov = {f2bf(dv[dt][0]), f2bf(dv[dt][1]), f2bf(dv[dt][2]), f2bf(dv[dt][3])};
-        *reinterpret_cast<bf16x4*>(drow + a.D + dt * 16) = ok_;
-        *reinterpret_cast<bf16x4*>(drow + 2 * a.D + dt * 16) = ov;
-      }
-    } else if (key == N) {
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          atomicAdd(side + 64 + dt * 16 + g * 4 + r, dk[dt][r] * a.scale);
-          atomicAdd(side + 128 + dt * 16 + g * 4 + r, dv[dt][r]);
+        const bf16x8 td = tr_frag(Dt, u * 32, dt, lane), tq = tr_frag(Qt, u * 32, dt, lane);
+        dvA[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(td, pbA, dvA[dt], 0, 0, 0);
+        dkA[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tq, sbA, dkA[dt], 0, 0, 0);
+        if (two) {
+          dvB[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(td, pbB, dvB[dt], 0, 0, 0);
+          dkB[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tq, sbB, dkB[dt], 0, 0, 0);
         }
+      }
     }
+    auto put_kv = [&](int key, const f32x4 (&dk)[4], const f32x4 (&dv)[4]) {
+      if (key < N) {
+        bf16* drow = a.dqkv + (base_row + key) * a.lddqkv + h * 64 + g * 4;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const bf16x4 ok_ = {f2bf(dk[dt][0] * a.scale), f2bf(dk[dt][1] * a.scale), f2bf(dk[dt][2] * a.scale),
+                              f2bf(dk[dt][3] * a.scale)};
+          const bf16x4 ov = {f2bf(dv[dt][0]), f2bf(dv[dt][1]), f2bf(dv[dt][2]), f2bf(dv[dt][3])};
+          *reinterpret_cast<bf16x4*>(drow + a.D + dt * 16) = ok_;
+          *reinterpret_cast<bf16x4*>(drow + 2 * a.D + dt * 16) = ov;
+        }
+      } else if (key == N) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            atomicAdd(side + 64 + dt * 16 + g * 4 + r, dk[dt][r] * a.scale);
+            atomicAdd(side + 128 + dt * 16 + g * 4 + r, dv[dt][r]);
+          }
+      }
+    };
+    put_kv(keyA, dkA, dvA);
+    if (two) put_kv(keyB, dkB, dvB);
   }
 }
 
