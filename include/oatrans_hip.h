@@ -50,6 +50,10 @@ void oat_gemm_tn_set_variant(int v);   /* tuning hook: 0 auto, 1 force 128x128, 
 int oat_layernorm_fwd(const float* x, int ldx, const float* gamma, const float* beta, void* y_bf16,
                       int ldy, float* y_f32, int ldy32, float* mean, float* rstd, int M, int D,
                       float eps, void* stream);
+/* s = x + add16 (bf16 branch output); sum32 = s (new fp32 residual stream, may alias x); y = LN(s) */
+int oat_add_layernorm_fwd(const float* x, int ldx, const void* add16, int ldadd, float* sum32, int ldsum,
+                          const float* gamma, const float* beta, void* y_bf16, int ldy, float* y_f32, int ldy32,
+                          float* mean, float* rstd, int M, int D, float eps, void* stream);
 int oat_ln_bwd_blocks(int M);   /* partial workspace = blocks * 2 * D floats */
 int oat_layernorm_bwd(const void* dy, int dy_is_bf16, int lddy, const float* x, int ldx,
                       const float* mean, const float* rstd, const float* gamma, const float* dres,

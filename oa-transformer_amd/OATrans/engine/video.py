@@ -65,6 +65,7 @@ class _Plan:
         self.sets = [dict(d_h=z16(Hd), gb=z16(D), d_qkv_s=z16(3 * D), gc=z16(D), d_qkv_t=z16(3 * D)) for _ in range(2)]
         self.d_a = z16(D)
         self.d_o = z16(D)
+        self.branch16 = z16(D)           # forward: bf16 branch output awaiting its fused add + LayerNorm
         self.tn_ws = torch.empty(hip.lib().oat_gemm_tn_workspace_bytes(0, 3 * D, Hd) // 4 // 8, dtype=torch.float32, device=dev)
         self.cls_side = torch.zeros(B, H, 3, 64, dtype=torch.float32, device=dev)
         self.Gp = torch.zeros(T * N, D, dtype=torch.float32, device=dev)
@@ -136,42 +137,64 @@ class VideoEngine:
         hip.gemm_nt(pl.cols, self.shadow["patch_embed.proj.weight"][0], BTN, D, self.Kp, hip.EPI_F32, pl.x0,
                     bias=params["patch_embed.proj.bias"], resid=pl.table, resid_mod=T * N)
         hip.broadcast_rows(pl.cls0, pl.x0[BTN:], B, D)
-        x = pl.x0
+        # Residual adds are fused into the NEXT LayerNorm (oat_add_layernorm_fwd): the three projection /
+        # fc2 GEMMs of a block write their branch output as bf16 and the streaming LN kernel forms
+        # x + branch, stores the new fp32 stream and the normalised bf16 operand in one pass.
+        br = pl.branch16
+        x = pl.x0                      # stream entering block i (fully materialised)
+        pend = None                    # (y, m16) of the previous block: out = y + m16 not yet formed
         for i, a in enumerate(pl.blocks):
             p = lambda s: params[f"blocks.{i}.{s}"]
             w = lambda s: self.shadow[f"blocks.{i}.{s}.weight"][0]
             st = a.stats
-            hip.layernorm_fwd(x, p("norm3.weight"), p("norm3.bias"), M, D, 1e-6, y=a.a3, mean=st[0], rstd=st[1])
+            if pend is None:
+                hip.layernorm_fwd(x, p("norm3.weight"), p("norm3.bias"), M, D, 1e-6, y=a.a3, mean=st[0], rstd=st[1])
+            else:
+                prev = pl.blocks[i - 1]
+                hip.add_layernorm_fwd(prev.y, br, prev.out, p("norm3.weight"), p("norm3.bias"), M, D, 1e-6, y=a.a3,
+                                      mean=st[0], rstd=st[1])
+                x = prev.out
+                if region_layer is not None and i == region_layer:
+                    self._region_tap(pl, params, x, BTN, D, video.device)
             hip.gemm_nt(a.a3, w("timeattn.qkv"), M, 3 * D, D, hip.EPI_BF16, a.qkv_t, bias=p("timeattn.qkv.bias"))
             hip.attn_time_fwd(a.qkv_t, a.o_t, a.lse_t, B, T, N, H, D, self.scale)
             hip.attn_cls_fwd(a.qkv_t, a.o_t, a.lse_t, B, T, N, H, D, self.scale)
-            hip.gemm_nt(a.o_t, w("timeattn.proj"), M, D, D, hip.EPI_F32, a.xt, bias=p("timeattn.proj.bias"), resid=x)
-            hip.layernorm_fwd(a.xt, p("norm1.weight"), p("norm1.bias"), M, D, 1e-6, y=a.a1, mean=st[2], rstd=st[3])
+            hip.gemm_nt(a.o_t, w("timeattn.proj"), M, D, D, hip.EPI_BF16, br, bias=p("timeattn.proj.bias"))
+            hip.add_layernorm_fwd(x, br, a.xt, p("norm1.weight"), p("norm1.bias"), M, D, 1e-6, y=a.a1, mean=st[2],
+                                  rstd=st[3])                                       # xt = x + time
             hip.gemm_nt(a.a1, w("attn.qkv"), M, 3 * D, D, hip.EPI_BF16, a.qkv_s, bias=p("attn.qkv.bias"))
             hip.attn_space_fwd(a.qkv_s, a.o_s, a.lse_s, B, T, N, H, D, self.scale)
             hip.attn_cls_fwd(a.qkv_s, a.o_s, a.lse_s, B, T, N, H, D, self.scale)
+            hip.gemm_nt(a.o_s, w("attn.proj"), M, D, D, hip.EPI_BF16, br, bias=p("attn.proj.bias"))
             # space residual comes from x, NOT from x + time (video_transformer.py:170)
-            hip.gemm_nt(a.o_s, w("attn.proj"), M, D, D, hip.EPI_F32, a.y, bias=p("attn.proj.bias"), resid=x)
-            hip.layernorm_fwd(a.y, p("norm2.weight"), p("norm2.bias"), M, D, 1e-6, y=a.a2, mean=st[4], rstd=st[5])
+            hip.add_layernorm_fwd(x, br, a.y, p("norm2.weight"), p("norm2.bias"), M, D, 1e-6, y=a.a2, mean=st[4],
+                                  rstd=st[5])                                       # y = x + space
             hip.gemm_nt(a.a2, w("mlp.fc1"), M, Hd, D, hip.EPI_GELU_DUAL, a.h, out2=a.g, bias=p("mlp.fc1.bias"))
-            hip.gemm_nt(a.g, w("mlp.fc2"), M, D, Hd, hip.EPI_F32, a.out, bias=p("mlp.fc2.bias"), resid=a.y)
-            x = a.out
-            if region_layer is not None and i + 1 == region_layer:
-                if pl.region is None:
-                    pl.region = torch.zeros(BTN, D, dtype=torch.float32, device=video.device)
-                    pl.rstats = torch.zeros(2, BTN, dtype=torch.float32, device=video.device)
-                hip.layernorm_fwd(x, params["region_norm.weight"], params["region_norm.bias"], BTN, D, 1e-6,
-                                  y32=pl.region, mean=pl.rstats[0], rstd=pl.rstats[1])
+            hip.gemm_nt(a.g, w("mlp.fc2"), M, D, Hd, hip.EPI_BF16, br, bias=p("mlp.fc2.bias"))
+            pend = a                                                                # out = y + br, formed lazily
+        last = pl.blocks[-1]
         pl.region_layer = region_layer
-        pl.x_final = x
+        pl.x_final = last.out
         pl.need_patches = need_patches
-        if need_patches:
-            hip.layernorm_fwd(x, params["norm.weight"], params["norm.bias"], M, D, 1e-6, y32=pl.normed,
-                              mean=pl.fstats[0], rstd=pl.fstats[1])
-            return pl.normed[BTN:M], pl.normed[:BTN], pl
-        hip.layernorm_fwd(x[BTN:], params["norm.weight"], params["norm.bias"], B, D, 1e-6, y32=pl.normed[BTN:],
-                          mean=pl.fstats[0][BTN:], rstd=pl.fstats[1][BTN:])
+        tap_last = region_layer is not None and region_layer == self.depth
+        if need_patches or tap_last:
+            hip.add_layernorm_fwd(last.y, br, last.out, params["norm.weight"], params["norm.bias"], M, D, 1e-6,
+                                  y32=pl.normed, mean=pl.fstats[0], rstd=pl.fstats[1])
+            if tap_last:
+                self._region_tap(pl, params, last.out, BTN, D, video.device)
+            return pl.normed[BTN:M], (pl.normed[:BTN] if need_patches else None), pl
+        # contract class: only the CLS rows of the last block's output are ever consumed
+        hip.add_layernorm_fwd(last.y[BTN:], br[BTN:], last.out[BTN:], params["norm.weight"], params["norm.bias"], B, D,
+                              1e-6, y32=pl.normed[BTN:], mean=pl.fstats[0][BTN:], rstd=pl.fstats[1][BTN:])
         return pl.normed[BTN:M], None, pl
+
+    def _region_tap(self, pl, params, x, BTN, D, dev):
+        """region_norm(x after block K)[patch rows] (oa_video_transformer_region.py:364-376)."""
+        if pl.region is None:
+            pl.region = torch.zeros(BTN, D, dtype=torch.float32, device=dev)
+            pl.rstats = torch.zeros(2, BTN, dtype=torch.float32, device=dev)
+        hip.layernorm_fwd(x, params["region_norm.weight"], params["region_norm.bias"], BTN, D, 1e-6, y32=pl.region,
+                          mean=pl.rstats[0], rstd=pl.rstats[1])
 
     # ------------------------------------------------------------------ backward
     def backward(self, pl, params, grads, d_cls, d_patches=None, d_region=None):

@@ -121,6 +121,16 @@ def layernorm_fwd(x, gamma, beta, M, D, eps, y=None, y32=None, mean=None, rstd=N
     _check(rc, "oat_layernorm_fwd")
 
 
+def add_layernorm_fwd(x, add16, sum32, gamma, beta, M, D, eps, y=None, y32=None, mean=None, rstd=None):
+    """sum32 = x + add16 ; y = LN(sum32)  (fused residual add + LayerNorm)."""
+    rc = lib().oat_add_layernorm_fwd(_ptr(x), x.stride(0), _ptr(add16), add16.stride(0), _ptr(sum32),
+                                     sum32.stride(0) if sum32 is not None else 0, _ptr(gamma), _ptr(beta), _ptr(y),
+                                     y.stride(0) if y is not None else 0, _ptr(y32),
+                                     y32.stride(0) if y32 is not None else 0, _ptr(mean), _ptr(rstd), M, D, _f(eps),
+                                     _stream())
+    _check(rc, "oat_add_layernorm_fwd")
+
+
 _part_ws = {}
 
 
