@@ -157,14 +157,12 @@ class VideoEngine:
                 if region_layer is not None and i == region_layer:
                     self._region_tap(pl, params, x, BTN, D, video.device)
             hip.gemm_nt(a.a3, w("timeattn.qkv"), M, 3 * D, D, hip.EPI_BF16, a.qkv_t, bias=p("timeattn.qkv.bias"))
-            hip.attn_time_fwd(a.qkv_t, a.o_t, a.lse_t, B, T, N, H, D, self.scale)
-            hip.attn_cls_fwd(a.qkv_t, a.o_t, a.lse_t, B, T, N, H, D, self.scale)
+            self._attention(hip.attn_time_fwd, a.qkv_t, a.o_t, a.lse_t, B, T, N)
             hip.gemm_nt(a.o_t, w("timeattn.proj"), M, D, D, hip.EPI_BF16, br, bias=p("timeattn.proj.bias"))
             hip.add_layernorm_fwd(x, br, a.xt, p("norm1.weight"), p("norm1.bias"), M, D, 1e-6, y=a.a1, mean=st[2],
                                   rstd=st[3])                                       # xt = x + time
             hip.gemm_nt(a.a1, w("attn.qkv"), M, 3 * D, D, hip.EPI_BF16, a.qkv_s, bias=p("attn.qkv.bias"))
-            hip.attn_space_fwd(a.qkv_s, a.o_s, a.lse_s, B, T, N, H, D, self.scale)
-            hip.attn_cls_fwd(a.qkv_s, a.o_s, a.lse_s, B, T, N, H, D, self.scale)
+            self._attention(hip.attn_space_fwd, a.qkv_s, a.o_s, a.lse_s, B, T, N)
             hip.gemm_nt(a.o_s, w("attn.proj"), M, D, D, hip.EPI_BF16, br, bias=p("attn.proj.bias"))
             # space residual comes from x, NOT from x + time (video_transformer.py:170)
             hip.add_layernorm_fwd(x, br, a.y, p("norm2.weight"), p("norm2.bias"), M, D, 1e-6, y=a.a2, mean=st[4],
@@ -187,6 +185,22 @@ class VideoEngine:
         hip.add_layernorm_fwd(last.y[BTN:], br[BTN:], last.out[BTN:], params["norm.weight"], params["norm.bias"], B, D,
                               1e-6, y32=pl.normed[BTN:], mean=pl.fstats[0][BTN:], rstd=pl.fstats[1][BTN:])
         return pl.normed[BTN:M], None, pl
+
+    def _attention(self, patch_kernel, qkv, out, lse, B, T, N):
+        """Patch attention on the current stream, the independent CLS-query attention (it only writes the
+        CLS rows of out / lse) concurrently on the side stream."""
+        main = torch.cuda.current_stream()
+        if self.side is None:
+            self.side = torch.cuda.Stream()
+        ev = torch.cuda.Event()
+        ev.record(main)                                  # qkv is complete
+        self.side.wait_event(ev)
+        with torch.cuda.stream(self.side):
+            hip.attn_cls_fwd(qkv, out, lse, B, T, N, self.H, self.D, self.scale)
+            done = torch.cuda.Event()
+            done.record(self.side)
+        patch_kernel(qkv, out, lse, B, T, N, self.H, self.D, self.scale)
+        main.wait_event(done)
 
     def _region_tap(self, pl, params, x, BTN, D, dev):
         """region_norm(x after block K)[patch rows] (oa_video_transformer_region.py:364-376)."""

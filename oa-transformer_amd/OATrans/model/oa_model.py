@@ -84,8 +84,18 @@ class FrozenInTime(BaseModel):
         self.text_model.begin_step()
 
     def forward(self, data, aug=False, return_embeds=True):
-        text_embeddings = self.compute_text(data['text'])
+        # the two towers are independent until the loss: the (small, launch-bound) text tower runs on its
+        # own HIP stream under the video tower; autograd replays each tower's backward on its forward stream
+        main = torch.cuda.current_stream()
+        if getattr(self, "_text_stream", None) is None:
+            self._text_stream = torch.cuda.Stream()
+        side = self._text_stream
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            text_embeddings = self.compute_text(data['text'])
         video_embeddings = self.compute_video(data['video'], aug=aug)
+        main.wait_stream(side)
+        text_embeddings.record_stream(main)
         if return_embeds:
             return text_embeddings, video_embeddings
         return sim_matrix(text_embeddings, video_embeddings)

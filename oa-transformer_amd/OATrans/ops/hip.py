@@ -93,12 +93,18 @@ def gemm_tn_set_variant(v):
 _tn_ws = {}
 
 
+def _stream_key(device):
+    """Workspaces are per (device, stream): kernels of different HIP streams may run concurrently."""
+    return (str(device), torch.cuda.current_stream().cuda_stream)
+
+
 def tn_workspace(device, N1, N2):
     need = lib().oat_gemm_tn_workspace_bytes(0, N1, N2)
-    ws = _tn_ws.get(device)
+    key = _stream_key(device)
+    ws = _tn_ws.get(key)
     if ws is None or ws.numel() * 4 < need:
         ws = torch.empty(need // 4, dtype=torch.float32, device=device)
-        _tn_ws[device] = ws
+        _tn_ws[key] = ws
     return ws
 
 
@@ -135,10 +141,11 @@ _part_ws = {}
 
 
 def _partials(device, n):
-    ws = _part_ws.get(device)
+    key = _stream_key(device)
+    ws = _part_ws.get(key)
     if ws is None or ws.numel() < n:
         ws = torch.empty(n, dtype=torch.float32, device=device)
-        _part_ws[device] = ws
+        _part_ws[key] = ws
     return ws
 
 
@@ -268,7 +275,7 @@ def infonce(t, v, temperature=0.05, eps=1e-8, r0=0, nloc=None, want_sim=False, w
     n, d = t.shape
     nloc = n if nloc is None else nloc
     need = lib().oat_infonce_workspace_floats(n, d)
-    key = (t.device, need)
+    key = (_stream_key(t.device), need)
     ws = _nce_ws.get(key)
     if ws is None:
         ws = torch.empty(need, dtype=torch.float32, device=t.device)
