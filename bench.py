@@ -187,6 +187,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    host_elapsed = time.perf_counter() - t0            # host-side enqueue time (GPU still running)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -211,6 +212,7 @@ def main():
         "step_algorithmic_tflops_per_gpu": round(value / world * gf_pair / 1e3, 1),
         "step_mfma_frac": round(value / world * gf_pair / 1e3 / BF16_DENSE_PEAK_TFLOPS, 4),
         "final_loss": round(loss_val, 4),
+        "host_enqueue_ms_per_step": round(host_elapsed / args.steps * 1e3, 2),
     }
     if rank == 0:
         by, _ = instrumented_gemm_profile(step)
