@@ -4,9 +4,9 @@ This is the MI355X-native execution of
   /root/reference/OATrans/model/video_transformer.py:303-351 (forward_features)
   /root/reference/OATrans/model/video_transformer.py:161-176 (SpaceTimeBlock.forward)
 and of the autograd graph PyTorch would record for them.  Nothing here traces or compiles:
-forward and backward are fixed launch sequences of liboatrans_hip.so entry points on the
-current HIP stream, over activation buffers sized once per (B, T) "plan" (288 GB of HBM3E
-holds every saved activation of a bs-64 8-frame step, so nothing is recomputed).
+forward and backward are fixed launch sequences of liboatrans_hip.so entry points over activation
+buffers sized once per shape ("plan"; 288 GB of HBM3E holds every saved activation of a bs-64
+8-frame step, so nothing is recomputed).
 
 HBM layout
   token rows  : patch (b,f,n) -> row (b*T+f)*N + n ; CLS(b) -> row B*T*N + b ; M = B*T*N + B
@@ -15,7 +15,19 @@ HBM layout
   GEMM inputs : bf16 [Mp, D|3D|4D]    (LN outputs, qkv, attention outputs, MLP hidden)
   weights     : fp32 masters (nn.Parameters, reference state_dict names) + bf16 shadows
                 W [out,in] (forward "NT" operand) and W^T [in,out] (data-gradient operand)
+
+Concurrency (HIP streams and events, no graph compiler)
+  * LANES: a large batch is split into two half-batches that walk the network on two streams, interleaved
+    block by block.  The HBM- or latency-bound kernels of one lane (LayerNorm, attention, GEMM epilogues)
+    overlap the MFMA-bound GEMM main loops of the other.  Lane 1 is chained behind lane 0 wherever both
+    write the same gradient buffer (lane 0 overwrites, lane 1 accumulates: a fixed order, so results are
+    deterministic), which also keeps the two lanes out of phase.
+  * weight gradients (gemm_tn + fused bias sums) go to a third stream as soon as their dY exists: the
+    data-gradient chain never depends on them.
+  * the CLS-query attention (independent of the patch attention) runs beside it on a side stream.
 """
+import os
+
 import torch
 
 from ..ops import hip
@@ -41,11 +53,14 @@ class _BlockActs:
 
 
 class _Plan:
+    """Buffers of one lane (one half-batch, or the whole batch when lanes are off)."""
+
     def __init__(self, B, T, N, D, Hd, H, depth, Kp, dev):
         self.B, self.T, self.N = B, T, N
         self.M = B * T * N + B
         self.Mp = _round_up(self.M, 256)
         Mp = self.Mp
+        z16 = lambda c: torch.zeros(Mp, c, dtype=torch.bfloat16, device=dev)
         self.blocks = [_BlockActs(Mp, D, Hd, H, dev) for _ in range(depth)]
         self.x0 = torch.zeros(Mp, D, dtype=torch.float32, device=dev)
         self.cols = torch.zeros(_round_up(B * T * N, 256), Kp, dtype=torch.bfloat16, device=dev)
@@ -55,20 +70,46 @@ class _Plan:
         self.normed = torch.zeros(Mp, D, dtype=torch.float32, device=dev)
         self.region = None                      # [B*T*N, D] fp32, allocated on first use (region_mem variant)
         self.rstats = None
-        # backward temporaries.  Weight gradients (gemm_tn) run on a SIDE stream concurrently with the
-        # data-gradient chain, so every bf16 dY that a weight gradient reads lives in a small ring:
+        self.branch16 = z16(D)                  # forward: bf16 branch output awaiting its fused add + LayerNorm
+        # backward temporaries.  Weight gradients read their dY from small rings so the chain can run ahead:
         #   ga[3]  : block-input gradient (written one block ahead by LN3-backward)
         #   sets[2]: d_h, dy16, d_qkv_s, dxt16, d_qkv_t of even / odd blocks
-        z16 = lambda c: torch.zeros(Mp, c, dtype=torch.bfloat16, device=dev)
         self.G = torch.zeros(Mp, D, dtype=torch.float32, device=dev)
         self.ga = [z16(D) for _ in range(3)]
         self.sets = [dict(d_h=z16(Hd), gb=z16(D), d_qkv_s=z16(3 * D), gc=z16(D), d_qkv_t=z16(3 * D)) for _ in range(2)]
         self.d_a = z16(D)
         self.d_o = z16(D)
-        self.branch16 = z16(D)           # forward: bf16 branch output awaiting its fused add + LayerNorm
-        self.tn_ws = torch.empty(hip.lib().oat_gemm_tn_workspace_bytes(0, 3 * D, Hd) // 4 // 8, dtype=torch.float32, device=dev)
         self.cls_side = torch.zeros(B, H, 3, 64, dtype=torch.float32, device=dev)
         self.Gp = torch.zeros(T * N, D, dtype=torch.float32, device=dev)
+        self.stream = self.side = self.video = self.x_final = None      # set per call
+
+
+class _Run:
+    """What a forward leaves for its backward: the lane plans (1 or 2) and the output flags."""
+
+    def __init__(self, lanes, need_patches, region_layer):
+        self.lanes, self.need_patches, self.region_layer = lanes, need_patches, region_layer
+        self.B = sum(pl.B for pl in lanes)
+        self.G = lanes[0].G
+
+    @property
+    def region(self):
+        return self.lanes[0].region
+
+    @property
+    def blocks(self):
+        return self.lanes[0].blocks
+
+
+class _Lane:
+    """Backward-pass state of one lane."""
+
+    def __init__(self, pl, index, d_cls, d_patches, d_region):
+        self.pl, self.index = pl, index
+        self.d_cls, self.d_patches, self.d_region = d_cls, d_patches, d_region
+        self.done = {}            # block index -> event: its weight gradients finished on the wgrad stream
+        self.order = []           # lane 0: events recorded after each gradient its own stream writes
+        self.follow = None        # lane 1: lane 0's `order`
 
 
 class VideoEngine:
@@ -91,16 +132,18 @@ class VideoEngine:
         self.plans = {}
         self.shadow = {}
         self.shadow_versions = None
-        self.side = None                 # HIP stream for weight gradients (created lazily on the device)
+        self.lanes = int(os.environ.get("OAT_LANES", "1"))   # half-batches on two streams (1 = off)
+        self.min_lane_rows = 8192        # token rows per lane below which splitting only adds launches
+        self._streams = None
+        self._tn_ws = None
 
-    # ------------------------------------------------------------------ weights
+    # ------------------------------------------------------------------ weights / plans / streams
     def refresh_shadows(self, params, sig=None):
         """bf16 W and W^T copies of every GEMM weight; re-cast only when a master changed
         (`sig` = EngineModule._weights_signature())."""
         names = [f"blocks.{i}.{l}.weight" for i in range(self.depth) for l in self.LINEARS]
         names.append("patch_embed.proj.weight")
-        versions = sig
-        if sig is not None and versions == self.shadow_versions:
+        if sig is not None and sig == self.shadow_versions:
             return
         for n in names:
             w = params[n].detach()
@@ -109,213 +152,311 @@ class VideoEngine:
                 self.shadow[n] = (torch.empty_like(w2, dtype=torch.bfloat16),
                                   torch.empty(w2.shape[1], w2.shape[0], dtype=torch.bfloat16, device=w.device))
             hip.cast_bf16(w2, self.shadow[n][0], self.shadow[n][1])
-        self.shadow_versions = versions
+        self.shadow_versions = sig
 
-    def plan(self, B, T, N, dev):
-        key = (B, T, N, str(dev))
+    def plan(self, B, T, N, dev, slot=0):
+        key = (B, T, N, str(dev), slot)
         if key not in self.plans:
             self.plans[key] = _Plan(B, T, N, self.D, self.Hd, self.H, self.depth, self.Kp, dev)
         return self.plans[key]
 
+    def _get_streams(self, dev):
+        if self._streams is None:
+            self._streams = dict(lane1=torch.cuda.Stream(), wgrad=torch.cuda.Stream(),
+                                 side=[torch.cuda.Stream(), torch.cuda.Stream()])
+            self._tn_ws = torch.empty(hip.lib().oat_gemm_tn_workspace_bytes(0, 3 * self.D, self.Hd) // 4 // 8,
+                                      dtype=torch.float32, device=dev)
+        return self._streams
+
     # ------------------------------------------------------------------ forward
     def forward(self, video, params, need_patches=False, sig=None, region_layer=None):
-        """video [B,T,C,R,R] fp32|bf16 -> (cls_normed fp32 [B,D], patches_normed fp32 [B*T*N, D] | None, plan).
-        region_layer=K additionally leaves region_norm(x after block K)[patch rows] in plan.region
+        """video [B,T,C,R,R] fp32|bf16 -> (cls_normed fp32 [B,D], patches_normed fp32 [B*T*N, D] | None, run).
+        region_layer=K additionally leaves region_norm(x after block K)[patch rows] in run.region
         (oa_video_transformer_region.py:364-376)."""
         B, T, C, R, _ = video.shape
         if T > self.num_frames:
             raise ValueError(f"{T} frames > num_frames={self.num_frames}")     # video_transformer.py:73
         g = R // self.ps
         N = g * g
-        D, Hd, H = self.D, self.Hd, self.H
         self.refresh_shadows(params, sig)
-        pl = self.plan(B, T, N, video.device)
-        M, BTN = pl.M, B * T * N
+        dev = video.device
+        st = self._get_streams(dev)
+        main = torch.cuda.current_stream()
+        two = (self.lanes == 2 and not need_patches and region_layer is None and B % 2 == 0
+               and (B // 2) * (T * N + 1) >= self.min_lane_rows)
         video = video.contiguous()
-        hip.im2col(video, pl.cols, B * T, C, R, self.ps)
+        lanes = []
+        for h in range(2 if two else 1):
+            Bh = B // 2 if two else B
+            pl = self.plan(Bh, T, N, dev, slot=h)
+            pl.stream = main if h == 0 else st["lane1"]
+            pl.side = st["side"][h]
+            pl.video = video[h * Bh:(h + 1) * Bh]
+            lanes.append(pl)
+        if two:
+            st["lane1"].wait_stream(main)
+        for pl in lanes:
+            with torch.cuda.stream(pl.stream):
+                self._embed(pl, params, C, R)
+        pend = [None] * len(lanes)
+        for i in range(self.depth):
+            for h, pl in enumerate(lanes):
+                with torch.cuda.stream(pl.stream):
+                    pend[h] = self._block_fwd(pl, i, params, pend[h], region_layer)
+        run = _Run(lanes, need_patches, region_layer)
+        outs = []
+        for pl in lanes:
+            with torch.cuda.stream(pl.stream):
+                outs.append(self._final_fwd(pl, params, need_patches, region_layer))
+        for pl in lanes:
+            pl.video = None
+        if two:
+            main.wait_stream(st["lane1"])
+            return torch.cat([o[0] for o in outs], dim=0), None, run
+        return outs[0][0], outs[0][1], run
+
+    def _embed(self, pl, params, C, R):
+        B, T, N, D = pl.B, pl.T, pl.N, self.D
+        BTN = B * T * N
+        hip.im2col(pl.video, pl.cols, B * T, C, R, self.ps)
         hip.pos_table(params["pos_embed"], params["temporal_embed"], params["cls_token"], pl.table, pl.cls0, T, N, D)
         hip.gemm_nt(pl.cols, self.shadow["patch_embed.proj.weight"][0], BTN, D, self.Kp, hip.EPI_F32, pl.x0,
                     bias=params["patch_embed.proj.bias"], resid=pl.table, resid_mod=T * N)
         hip.broadcast_rows(pl.cls0, pl.x0[BTN:], B, D)
-        # Residual adds are fused into the NEXT LayerNorm (oat_add_layernorm_fwd): the three projection /
-        # fc2 GEMMs of a block write their branch output as bf16 and the streaming LN kernel forms
-        # x + branch, stores the new fp32 stream and the normalised bf16 operand in one pass.
-        br = pl.branch16
-        x = pl.x0                      # stream entering block i (fully materialised)
-        pend = None                    # (y, m16) of the previous block: out = y + m16 not yet formed
-        for i, a in enumerate(pl.blocks):
-            p = lambda s: params[f"blocks.{i}.{s}"]
-            w = lambda s: self.shadow[f"blocks.{i}.{s}.weight"][0]
-            st = a.stats
-            if pend is None:
-                hip.layernorm_fwd(x, p("norm3.weight"), p("norm3.bias"), M, D, 1e-6, y=a.a3, mean=st[0], rstd=st[1])
-            else:
-                prev = pl.blocks[i - 1]
-                hip.add_layernorm_fwd(prev.y, br, prev.out, p("norm3.weight"), p("norm3.bias"), M, D, 1e-6, y=a.a3,
-                                      mean=st[0], rstd=st[1])
-                x = prev.out
-                if region_layer is not None and i == region_layer:
-                    self._region_tap(pl, params, x, BTN, D, video.device)
-            hip.gemm_nt(a.a3, w("timeattn.qkv"), M, 3 * D, D, hip.EPI_BF16, a.qkv_t, bias=p("timeattn.qkv.bias"))
-            self._attention(hip.attn_time_fwd, a.qkv_t, a.o_t, a.lse_t, B, T, N)
-            hip.gemm_nt(a.o_t, w("timeattn.proj"), M, D, D, hip.EPI_BF16, br, bias=p("timeattn.proj.bias"))
-            hip.add_layernorm_fwd(x, br, a.xt, p("norm1.weight"), p("norm1.bias"), M, D, 1e-6, y=a.a1, mean=st[2],
-                                  rstd=st[3])                                       # xt = x + time
-            hip.gemm_nt(a.a1, w("attn.qkv"), M, 3 * D, D, hip.EPI_BF16, a.qkv_s, bias=p("attn.qkv.bias"))
-            self._attention(hip.attn_space_fwd, a.qkv_s, a.o_s, a.lse_s, B, T, N)
-            hip.gemm_nt(a.o_s, w("attn.proj"), M, D, D, hip.EPI_BF16, br, bias=p("attn.proj.bias"))
-            # space residual comes from x, NOT from x + time (video_transformer.py:170)
-            hip.add_layernorm_fwd(x, br, a.y, p("norm2.weight"), p("norm2.bias"), M, D, 1e-6, y=a.a2, mean=st[4],
-                                  rstd=st[5])                                       # y = x + space
-            hip.gemm_nt(a.a2, w("mlp.fc1"), M, Hd, D, hip.EPI_GELU_DUAL, a.h, out2=a.g, bias=p("mlp.fc1.bias"))
-            hip.gemm_nt(a.g, w("mlp.fc2"), M, D, Hd, hip.EPI_BF16, br, bias=p("mlp.fc2.bias"))
-            pend = a                                                                # out = y + br, formed lazily
-        last = pl.blocks[-1]
-        pl.region_layer = region_layer
+
+    def _block_fwd(self, pl, i, params, pend, region_layer):
+        """Residual adds are fused into the NEXT LayerNorm (oat_add_layernorm_fwd): the projection / fc2 GEMMs
+        write their branch output as bf16 and the streaming LN kernel forms x + branch, stores the new fp32
+        stream and the normalised bf16 operand in one pass.  `pend` = the previous block, whose
+        out = y + branch is still to be formed."""
+        M, D, Hd = pl.M, self.D, self.Hd
+        a, br = pl.blocks[i], pl.branch16
+        p = lambda s: params[f"blocks.{i}.{s}"]
+        w = lambda s: self.shadow[f"blocks.{i}.{s}.weight"][0]
+        st = a.stats
+        if pend is None:
+            x = pl.x0
+            hip.layernorm_fwd(x, p("norm3.weight"), p("norm3.bias"), M, D, 1e-6, y=a.a3, mean=st[0], rstd=st[1])
+        else:
+            hip.add_layernorm_fwd(pend.y, br, pend.out, p("norm3.weight"), p("norm3.bias"), M, D, 1e-6, y=a.a3,
+                                  mean=st[0], rstd=st[1])
+            x = pend.out
+            if region_layer is not None and i == region_layer:
+                self._region_tap(pl, params, x)
+        hip.gemm_nt(a.a3, w("timeattn.qkv"), M, 3 * D, D, hip.EPI_BF16, a.qkv_t, bias=p("timeattn.qkv.bias"))
+        self._attention(pl, hip.attn_time_fwd, a.qkv_t, a.o_t, a.lse_t)
+        hip.gemm_nt(a.o_t, w("timeattn.proj"), M, D, D, hip.EPI_BF16, br, bias=p("timeattn.proj.bias"))
+        hip.add_layernorm_fwd(x, br, a.xt, p("norm1.weight"), p("norm1.bias"), M, D, 1e-6, y=a.a1, mean=st[2],
+                              rstd=st[3])                                           # xt = x + time
+        hip.gemm_nt(a.a1, w("attn.qkv"), M, 3 * D, D, hip.EPI_BF16, a.qkv_s, bias=p("attn.qkv.bias"))
+        self._attention(pl, hip.attn_space_fwd, a.qkv_s, a.o_s, a.lse_s)
+        hip.gemm_nt(a.o_s, w("attn.proj"), M, D, D, hip.EPI_BF16, br, bias=p("attn.proj.bias"))
+        # space residual comes from x, NOT from x + time (video_transformer.py:170)
+        hip.add_layernorm_fwd(x, br, a.y, p("norm2.weight"), p("norm2.bias"), M, D, 1e-6, y=a.a2, mean=st[4],
+                              rstd=st[5])                                           # y = x + space
+        hip.gemm_nt(a.a2, w("mlp.fc1"), M, Hd, D, hip.EPI_GELU_DUAL, a.h, out2=a.g, bias=p("mlp.fc1.bias"))
+        hip.gemm_nt(a.g, w("mlp.fc2"), M, D, Hd, hip.EPI_BF16, br, bias=p("mlp.fc2.bias"))
+        return a                                                                    # out = y + br, formed lazily
+
+    def _final_fwd(self, pl, params, need_patches, region_layer):
+        B, M, D = pl.B, pl.M, self.D
+        BTN = M - B
+        last, br = pl.blocks[-1], pl.branch16
         pl.x_final = last.out
-        pl.need_patches = need_patches
         tap_last = region_layer is not None and region_layer == self.depth
         if need_patches or tap_last:
             hip.add_layernorm_fwd(last.y, br, last.out, params["norm.weight"], params["norm.bias"], M, D, 1e-6,
                                   y32=pl.normed, mean=pl.fstats[0], rstd=pl.fstats[1])
             if tap_last:
-                self._region_tap(pl, params, last.out, BTN, D, video.device)
-            return pl.normed[BTN:M], (pl.normed[:BTN] if need_patches else None), pl
+                self._region_tap(pl, params, last.out)
+            return pl.normed[BTN:M], (pl.normed[:BTN] if need_patches else None)
         # contract class: only the CLS rows of the last block's output are ever consumed
         hip.add_layernorm_fwd(last.y[BTN:], br[BTN:], last.out[BTN:], params["norm.weight"], params["norm.bias"], B, D,
                               1e-6, y32=pl.normed[BTN:], mean=pl.fstats[0][BTN:], rstd=pl.fstats[1][BTN:])
-        return pl.normed[BTN:M], None, pl
+        return pl.normed[BTN:M], None
 
-    def _attention(self, patch_kernel, qkv, out, lse, B, T, N):
-        """Patch attention on the current stream, the independent CLS-query attention (it only writes the
-        CLS rows of out / lse) concurrently on the side stream."""
-        main = torch.cuda.current_stream()
-        if self.side is None:
-            self.side = torch.cuda.Stream()
+    def _attention(self, pl, patch_kernel, qkv, out, lse):
+        """Patch attention on the lane's stream, the independent CLS-query attention (it only writes the
+        CLS rows of out / lse) concurrently on the lane's side stream."""
+        cur = torch.cuda.current_stream()
         ev = torch.cuda.Event()
-        ev.record(main)                                  # qkv is complete
-        self.side.wait_event(ev)
-        with torch.cuda.stream(self.side):
-            hip.attn_cls_fwd(qkv, out, lse, B, T, N, self.H, self.D, self.scale)
+        ev.record(cur)                                   # qkv is complete
+        pl.side.wait_event(ev)
+        with torch.cuda.stream(pl.side):
+            hip.attn_cls_fwd(qkv, out, lse, pl.B, pl.T, pl.N, self.H, self.D, self.scale)
             done = torch.cuda.Event()
-            done.record(self.side)
-        patch_kernel(qkv, out, lse, B, T, N, self.H, self.D, self.scale)
-        main.wait_event(done)
+            done.record(pl.side)
+        patch_kernel(qkv, out, lse, pl.B, pl.T, pl.N, self.H, self.D, self.scale)
+        cur.wait_event(done)
 
-    def _region_tap(self, pl, params, x, BTN, D, dev):
+    def _region_tap(self, pl, params, x):
         """region_norm(x after block K)[patch rows] (oa_video_transformer_region.py:364-376)."""
+        BTN, D = pl.M - pl.B, self.D
         if pl.region is None:
-            pl.region = torch.zeros(BTN, D, dtype=torch.float32, device=dev)
-            pl.rstats = torch.zeros(2, BTN, dtype=torch.float32, device=dev)
+            pl.region = torch.zeros(BTN, D, dtype=torch.float32, device=x.device)
+            pl.rstats = torch.zeros(2, BTN, dtype=torch.float32, device=x.device)
         hip.layernorm_fwd(x, params["region_norm.weight"], params["region_norm.bias"], BTN, D, 1e-6, y32=pl.region,
                           mean=pl.rstats[0], rstd=pl.rstats[1])
 
     # ------------------------------------------------------------------ backward
-    def backward(self, pl, params, grads, d_cls, d_patches=None, d_region=None):
-        """Writes every video parameter gradient into `grads`.  d_cls fp32 [B,D]; d_patches fp32
-        [B*T*N, D] or None (contract class oa_model.FrozenInTime discards patch outputs); d_region fp32
-        [B*T*N, D] = gradient of plan.region (enters the residual stream below block `region_layer`).
+    def backward(self, run, params, grads, d_cls, d_patches=None, d_region=None):
+        """Writes every video parameter gradient into `grads`.  d_cls fp32 [B,D]; d_patches fp32 [B*T*N, D] or
+        None (contract class oa_model.FrozenInTime discards patch outputs); d_region fp32 [B*T*N, D] =
+        gradient of run.region (enters the residual stream below block `region_layer`).
 
-        Two HIP streams: the data-gradient chain (dgrad GEMMs, LayerNorm / attention backward) stays on the
-        current stream; every weight gradient (gemm_tn + fused bias sums) goes to a side stream as soon as
-        its dY exists.  The chain never depends on a weight gradient, so the MFMA-bound wgrad GEMMs fill
-        the HBM-bound stretches (LN backward, attention backward, fp32 epilogues) of the chain."""
-        B, T, N = pl.B, pl.T, pl.N
-        D, Hd, H = self.D, self.Hd, self.H
-        M, BTN = pl.M, B * T * N
-        G = pl.G
-        main = torch.cuda.current_stream()
-        if self.side is None:
-            self.side = torch.cuda.Stream()
-        side = self.side
-        side.wait_stream(main)               # side may not start before this step's forward is done
-        done = {}                            # block index -> event: its wgrads finished on the side stream
+        Streams: each lane's data-gradient chain (dgrad GEMMs, LayerNorm / attention backward) runs on the
+        lane's stream; every weight gradient goes to the shared wgrad stream as soon as its dY exists (lane 0
+        overwrites, lane 1 accumulates - one stream, so the order is fixed).  The chain never depends on a
+        weight gradient, so the MFMA-bound wgrad GEMMs fill the HBM-bound stretches of the chains.  Gradients
+        the chains write themselves (LayerNorm gains, positional tables) are ordered lane 0 -> lane 1 by events."""
+        st = self._get_streams(run.G.device)
+        main, wg = torch.cuda.current_stream(), st["wgrad"]
+        two = len(run.lanes) == 2
+        if two:
+            st["lane1"].wait_stream(main)    # d_cls was produced on the caller's stream
+        wg.wait_stream(main)                 # no weight gradient before this step's forward is done
+        d_cls = d_cls.contiguous()
+        lanes, off = [], 0
+        for h, pl in enumerate(run.lanes):
+            lanes.append(_Lane(pl, h, d_cls[off:off + pl.B], d_patches, d_region))
+            off += pl.B
+        if two:
+            lanes[1].follow = lanes[0].order
+        for ln in lanes:
+            with torch.cuda.stream(ln.pl.stream):
+                self._final_bwd(ln, run, params, grads)
+        for i in reversed(range(self.depth)):
+            for ln in lanes:
+                with torch.cuda.stream(ln.pl.stream):
+                    self._block_bwd(ln, i, run, params, grads, wg)
+        for ln in lanes:
+            with torch.cuda.stream(ln.pl.stream):
+                self._embed_bwd(ln, grads, wg)
+        if two:
+            main.wait_stream(st["lane1"])
+        main.wait_stream(wg)                 # every weight gradient is complete before the caller continues
 
-        def wgrad(P, Q, n1, n2, w, b, rows=M):
+    def _own_grad(self, ln, fn):
+        """Run `fn(accumulate)` - kernels that write parameter gradients from the lane's own stream - so that
+        lane 0 overwrites first and lane 1 accumulates after it."""
+        cur = torch.cuda.current_stream()
+        if ln.index == 0:
+            fn(False)
             ev = torch.cuda.Event()
-            ev.record(main)                  # P was produced by everything enqueued on main so far
-            side.wait_event(ev)
-            with torch.cuda.stream(side):
-                hip.gemm_tn(P, Q, rows, n1, n2, w, bias_out=b, ws=pl.tn_ws)
+            ev.record(cur)
+            ln.order.append(ev)
+        else:
+            cur.wait_event(ln.follow.pop(0))     # recorded already: lane 0 is always enqueued first
+            fn(True)
 
-        top = self.depth - 1
-        g16 = pl.ga[top % 3]
-        # final norm
-        if pl.need_patches and d_patches is not None:
-            dn = torch.cat([d_patches, d_cls], dim=0).contiguous()
-            hip.layernorm_bwd(dn, pl.x_final, pl.fstats[0], pl.fstats[1], params["norm.weight"], M, D, dx=G, dx16=g16,
-                              dgamma=grads["norm.weight"], dbeta=grads["norm.bias"])
+    def _wgrad(self, ln, wg, P, Q, rows, n1, n2, w, b):
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())   # P was produced by everything enqueued on this lane so far
+        wg.wait_event(ev)
+        with torch.cuda.stream(wg):
+            hip.gemm_tn(P, Q, rows, n1, n2, w, bias_out=b, ws=self._tn_ws, accumulate=(ln.index == 1))
+
+    def _final_bwd(self, ln, run, params, grads):
+        pl, D = ln.pl, self.D
+        B, M = pl.B, pl.M
+        BTN = M - B
+        G = pl.G
+        g16 = pl.ga[(self.depth - 1) % 3]
+        if run.need_patches and ln.d_patches is not None:
+            dn = torch.cat([ln.d_patches, ln.d_cls], dim=0).contiguous()
+            self._own_grad(ln, lambda acc: hip.layernorm_bwd(
+                dn, pl.x_final, pl.fstats[0], pl.fstats[1], params["norm.weight"], M, D, dx=G, dx16=g16,
+                dgamma=grads["norm.weight"], dbeta=grads["norm.bias"], accumulate=acc))
         else:
             G[:BTN].zero_()
             g16[:BTN].zero_()
-            hip.layernorm_bwd(d_cls.contiguous(), pl.x_final[BTN:], pl.fstats[0][BTN:], pl.fstats[1][BTN:],
-                              params["norm.weight"], B, D, dx=G[BTN:], dx16=g16[BTN:], dgamma=grads["norm.weight"],
-                              dbeta=grads["norm.bias"])
-        rl = getattr(pl, "region_layer", None)
-        if rl is not None and d_region is None:
+            self._own_grad(ln, lambda acc: hip.layernorm_bwd(
+                ln.d_cls, pl.x_final[BTN:], pl.fstats[0][BTN:], pl.fstats[1][BTN:], params["norm.weight"], B, D,
+                dx=G[BTN:], dx16=g16[BTN:], dgamma=grads["norm.weight"], dbeta=grads["norm.bias"], accumulate=acc))
+        if run.region_layer is not None and ln.d_region is None:
             for k in ("region_norm.weight", "region_norm.bias"):
                 grads[k].zero_()
-        for i in reversed(range(self.depth)):
-            a = pl.blocks[i]
-            st8 = pl.sets[i % 2]
-            ga = pl.ga[i % 3]                              # dL/d(block output), bf16
-            ga_next = pl.ga[(i - 1) % 3]                   # written by this block's LN3 backward
-            if i + 2 in done:
-                main.wait_event(done[i + 2])               # ring slot i%2 (and ga[(i-1)%3]) is free again
-            if rl is not None and d_region is not None and i + 1 == rl:
-                # region tokens branch off the output of block rl-1: add their gradient to the stream
-                hip.layernorm_bwd(d_region.contiguous(), a.out, pl.rstats[0], pl.rstats[1], params["region_norm.weight"],
-                                  BTN, D, dx=G, dx16=ga, dres=G, dgamma=grads["region_norm.weight"],
-                                  dbeta=grads["region_norm.bias"])
-            x = pl.blocks[i - 1].out if i > 0 else pl.x0
-            p = lambda s: params[f"blocks.{i}.{s}"]
-            gr = lambda s: grads[f"blocks.{i}.{s}"]
-            wT = lambda s: self.shadow[f"blocks.{i}.{s}.weight"][1]
-            st = a.stats
-            d_h, gb, d_qkv_s, gc, d_qkv_t = st8["d_h"], st8["gb"], st8["d_qkv_s"], st8["gc"], st8["d_qkv_t"]
-            # ---- MLP: out = y + fc2(gelu(fc1(LN2(y))))
-            wgrad(ga, a.g, D, Hd, gr("mlp.fc2.weight"), gr("mlp.fc2.bias"))
-            hip.gemm_nt(ga, wT("mlp.fc2"), M, Hd, D, hip.EPI_DGELU, d_h, aux=a.h)
-            wgrad(d_h, a.a2, Hd, D, gr("mlp.fc1.weight"), gr("mlp.fc1.bias"))
-            hip.gemm_nt(d_h, wT("mlp.fc1"), M, D, Hd, hip.EPI_BF16, pl.d_a)
-            hip.layernorm_bwd(pl.d_a, a.y, st[4], st[5], p("norm2.weight"), M, D, dx=G, dx16=gb, dres=G,
-                              dgamma=gr("norm2.weight"), dbeta=gr("norm2.bias"))            # G = dL/dy
-            # ---- space attention: y = x + proj(attn(LN1(xt)))
-            wgrad(gb, a.o_s, D, D, gr("attn.proj.weight"), gr("attn.proj.bias"))
-            hip.gemm_nt(gb, wT("attn.proj"), M, D, D, hip.EPI_BF16, pl.d_o)
-            pl.cls_side.zero_()
-            hip.attn_space_bwd(a.qkv_s, a.o_s, a.lse_s, pl.d_o, d_qkv_s, pl.cls_side, B, T, N, H, D, self.scale)
-            hip.attn_cls_finalize(pl.cls_side, d_qkv_s, B, T, N, H, D)
-            wgrad(d_qkv_s, a.a1, 3 * D, D, gr("attn.qkv.weight"), gr("attn.qkv.bias"))
-            hip.gemm_nt(d_qkv_s, wT("attn.qkv"), M, D, 3 * D, hip.EPI_BF16, pl.d_a)
-            # G <- dL/dy + dL/dxt (both reach x directly); gc <- dL/dxt alone (feeds the time branch)
-            hip.layernorm_bwd(pl.d_a, a.xt, st[2], st[3], p("norm1.weight"), M, D, dx=G, dx16=gc, dres=G,
-                              dx16_excl_res=True, dgamma=gr("norm1.weight"), dbeta=gr("norm1.bias"))
-            # ---- time attention: xt = x + proj(attn(LN3(x)))
-            wgrad(gc, a.o_t, D, D, gr("timeattn.proj.weight"), gr("timeattn.proj.bias"))
-            hip.gemm_nt(gc, wT("timeattn.proj"), M, D, D, hip.EPI_BF16, pl.d_o)
-            pl.cls_side.zero_()
-            hip.attn_time_bwd(a.qkv_t, a.o_t, a.lse_t, pl.d_o, d_qkv_t, pl.cls_side, B, T, N, H, D, self.scale)
-            hip.attn_cls_finalize(pl.cls_side, d_qkv_t, B, T, N, H, D)
-            wgrad(d_qkv_t, a.a3, 3 * D, D, gr("timeattn.qkv.weight"), gr("timeattn.qkv.bias"))
-            hip.gemm_nt(d_qkv_t, wT("timeattn.qkv"), M, D, 3 * D, hip.EPI_BF16, pl.d_a)
-            hip.layernorm_bwd(pl.d_a, x, st[0], st[1], p("norm3.weight"), M, D, dx=G, dx16=ga_next, dres=G,
-                              dgamma=gr("norm3.weight"), dbeta=gr("norm3.bias"))            # G = dL/dx
-            ev = torch.cuda.Event()
-            with torch.cuda.stream(side):
-                ev.record(side)
-            done[i] = ev
-        # ---- token embedding: x0[patch] = cols @ Wp^T + b + pos[1+n] + temporal[f]; x0[cls] = cls + pos[0]
-        g16 = pl.ga[(-1) % 3]
+
+    def _block_bwd(self, ln, i, run, params, grads, wg):
+        pl = ln.pl
+        B, T, N, M = pl.B, pl.T, pl.N, pl.M
+        D, Hd, H = self.D, self.Hd, self.H
+        BTN = M - B
+        G = pl.G
+        cur = torch.cuda.current_stream()
+        a = pl.blocks[i]
+        st8 = pl.sets[i % 2]
+        ga, ga_next = pl.ga[i % 3], pl.ga[(i - 1) % 3]     # dL/d(block output) bf16 ; written by this block's LN3 bwd
+        if i + 2 in ln.done:
+            cur.wait_event(ln.done[i + 2])                 # ring slot i%2 (and ga[(i-1)%3]) is free again
+        rl = run.region_layer
+        if rl is not None and ln.d_region is not None and i + 1 == rl:
+            # region tokens branch off the output of block rl-1: add their gradient to the stream
+            hip.layernorm_bwd(ln.d_region.contiguous(), a.out, pl.rstats[0], pl.rstats[1], params["region_norm.weight"],
+                              BTN, D, dx=G, dx16=ga, dres=G, dgamma=grads["region_norm.weight"],
+                              dbeta=grads["region_norm.bias"])
+        x = pl.blocks[i - 1].out if i > 0 else pl.x0
+        p = lambda s: params[f"blocks.{i}.{s}"]
+        gr = lambda s: grads[f"blocks.{i}.{s}"]
+        wT = lambda s: self.shadow[f"blocks.{i}.{s}.weight"][1]
+        st = a.stats
+        d_h, gb, d_qkv_s, gc, d_qkv_t = st8["d_h"], st8["gb"], st8["d_qkv_s"], st8["gc"], st8["d_qkv_t"]
+        # ---- MLP: out = y + fc2(gelu(fc1(LN2(y))))
+        self._wgrad(ln, wg, ga, a.g, M, D, Hd, gr("mlp.fc2.weight"), gr("mlp.fc2.bias"))
+        hip.gemm_nt(ga, wT("mlp.fc2"), M, Hd, D, hip.EPI_DGELU, d_h, aux=a.h)
+        self._wgrad(ln, wg, d_h, a.a2, M, Hd, D, gr("mlp.fc1.weight"), gr("mlp.fc1.bias"))
+        hip.gemm_nt(d_h, wT("mlp.fc1"), M, D, Hd, hip.EPI_BF16, pl.d_a)
+        self._own_grad(ln, lambda acc: hip.layernorm_bwd(
+            pl.d_a, a.y, st[4], st[5], p("norm2.weight"), M, D, dx=G, dx16=gb, dres=G,
+            dgamma=gr("norm2.weight"), dbeta=gr("norm2.bias"), accumulate=acc))              # G = dL/dy
+        # ---- space attention: y = x + proj(attn(LN1(xt)))
+        self._wgrad(ln, wg, gb, a.o_s, M, D, D, gr("attn.proj.weight"), gr("attn.proj.bias"))
+        hip.gemm_nt(gb, wT("attn.proj"), M, D, D, hip.EPI_BF16, pl.d_o)
+        pl.cls_side.zero_()
+        hip.attn_space_bwd(a.qkv_s, a.o_s, a.lse_s, pl.d_o, d_qkv_s, pl.cls_side, B, T, N, H, D, self.scale)
+        hip.attn_cls_finalize(pl.cls_side, d_qkv_s, B, T, N, H, D)
+        self._wgrad(ln, wg, d_qkv_s, a.a1, M, 3 * D, D, gr("attn.qkv.weight"), gr("attn.qkv.bias"))
+        hip.gemm_nt(d_qkv_s, wT("attn.qkv"), M, D, 3 * D, hip.EPI_BF16, pl.d_a)
+        # G <- dL/dy + dL/dxt (both reach x directly); gc <- dL/dxt alone (feeds the time branch)
+        self._own_grad(ln, lambda acc: hip.layernorm_bwd(
+            pl.d_a, a.xt, st[2], st[3], p("norm1.weight"), M, D, dx=G, dx16=gc, dres=G, dx16_excl_res=True,
+            dgamma=gr("norm1.weight"), dbeta=gr("norm1.bias"), accumulate=acc))
+        # ---- time attention: xt = x + proj(attn(LN3(x)))
+        self._wgrad(ln, wg, gc, a.o_t, M, D, D, gr("timeattn.proj.weight"), gr("timeattn.proj.bias"))
+        hip.gemm_nt(gc, wT("timeattn.proj"), M, D, D, hip.EPI_BF16, pl.d_o)
+        pl.cls_side.zero_()
+        hip.attn_time_bwd(a.qkv_t, a.o_t, a.lse_t, pl.d_o, d_qkv_t, pl.cls_side, B, T, N, H, D, self.scale)
+        hip.attn_cls_finalize(pl.cls_side, d_qkv_t, B, T, N, H, D)
+        self._wgrad(ln, wg, d_qkv_t, a.a3, M, 3 * D, D, gr("timeattn.qkv.weight"), gr("timeattn.qkv.bias"))
+        hip.gemm_nt(d_qkv_t, wT("timeattn.qkv"), M, D, 3 * D, hip.EPI_BF16, pl.d_a)
+        self._own_grad(ln, lambda acc: hip.layernorm_bwd(
+            pl.d_a, x, st[0], st[1], p("norm3.weight"), M, D, dx=G, dx16=ga_next, dres=G,
+            dgamma=gr("norm3.weight"), dbeta=gr("norm3.bias"), accumulate=acc))              # G = dL/dx
+        ev = torch.cuda.Event()
+        with torch.cuda.stream(wg):
+            ev.record(wg)
+        ln.done[i] = ev
+
+    def _embed_bwd(self, ln, grads, wg):
+        """x0[patch] = cols @ Wp^T + b + pos[1+n] + temporal[f] ; x0[cls] = cls + pos[0]"""
+        pl, D = ln.pl, self.D
+        B, T, N, M = pl.B, pl.T, pl.N, pl.M
+        BTN = M - B
+        G = pl.G
         gw = grads["patch_embed.proj.weight"]
-        wgrad(g16, pl.cols, D, self.Kp, gw.view(D, self.Kp), grads["patch_embed.proj.bias"], rows=BTN)
+        self._wgrad(ln, wg, pl.ga[(-1) % 3], pl.cols, BTN, D, self.Kp, gw.view(D, self.Kp),
+                    grads["patch_embed.proj.bias"])
         hip.periodic_rowsum(G, B, T * N, D, pl.Gp)
         gpos = grads["pos_embed"].view(N + 1, D)
-        hip.periodic_rowsum(pl.Gp, T, N, D, gpos[1:])
         gt = grads["temporal_embed"].view(-1, D)
-        if T < gt.shape[0]:
-            gt[T:].zero_()
-        hip.grouped_rowsum(pl.Gp, T, N, D, gt[:T])
-        hip.grouped_rowsum(G[BTN:], 1, B, D, grads["cls_token"].view(1, D))
-        gpos[:1].copy_(grads["cls_token"].view(1, D))
-        main.wait_stream(side)               # every weight gradient is complete before the caller continues
+        gcls = grads["cls_token"].view(1, D)
+
+        def tables(acc):
+            hip.periodic_rowsum(pl.Gp, T, N, D, gpos[1:], accumulate=acc)
+            if T < gt.shape[0] and not acc:
+                gt[T:].zero_()
+            hip.grouped_rowsum(pl.Gp, T, N, D, gt[:T], accumulate=acc)
+            hip.grouped_rowsum(G[BTN:], 1, B, D, gcls, accumulate=acc)
+            gpos[:1].copy_(gcls)             # pos_embed[0] only ever meets the CLS token
+
+        self._own_grad(ln, tables)
