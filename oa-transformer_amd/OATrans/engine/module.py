@@ -54,6 +54,33 @@ class EngineModule(nn.Module):
     def _param_data(self):
         return {n: p.data for n, p in self._engine_params()}
 
+    grad_ready_hook = None      # set by parallel.GradSync: hook(module, lo, hi) once flat_grad()[lo:hi] is enqueued
+
+    def _announce(self, prefixes):
+        """Tell the gradient all-reduce that every parameter whose name starts with one of `prefixes` has its
+        final gradient enqueued on the current stream.  Only a CONTIGUOUS run of the flat buffer is announced;
+        anything else is left to the reduction after backward."""
+        hook = self.grad_ready_hook
+        if hook is None:
+            return
+        cache = self.__dict__.setdefault("_announce_cache", {})
+        if prefixes not in cache:
+            lo = hi = None
+            off = 0
+            table = []
+            for n, p in self._engine_params():
+                if n.startswith(prefixes):
+                    lo = off if lo is None else lo
+                    hi = off + p.numel()
+                table.append((n, off, off + p.numel()))
+                off += p.numel()
+            if lo is None or any(a >= lo and b <= hi and not n.startswith(prefixes) for n, a, b in table):
+                lo = hi = None
+            cache[prefixes] = (lo, hi)
+        lo, hi = cache[prefixes]
+        if lo is not None:
+            hook(self, lo, hi)
+
     def flat_grad(self):
         self._grad_views()
         return self._gradbuf

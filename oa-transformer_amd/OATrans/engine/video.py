@@ -299,7 +299,7 @@ class VideoEngine:
                           mean=pl.rstats[0], rstd=pl.rstats[1])
 
     # ------------------------------------------------------------------ backward
-    def backward(self, run, params, grads, d_cls, d_patches=None, d_region=None):
+    def backward(self, run, params, grads, d_cls, d_patches=None, d_region=None, ready=None):
         """Writes every video parameter gradient into `grads`.  d_cls fp32 [B,D]; d_patches fp32 [B*T*N, D] or
         None (contract class oa_model.FrozenInTime discards patch outputs); d_region fp32 [B*T*N, D] =
         gradient of run.region (enters the residual stream below block `region_layer`).
@@ -308,7 +308,11 @@ class VideoEngine:
         lane's stream; every weight gradient goes to the shared wgrad stream as soon as its dY exists (lane 0
         overwrites, lane 1 accumulates - one stream, so the order is fixed).  The chain never depends on a
         weight gradient, so the MFMA-bound wgrad GEMMs fill the HBM-bound stretches of the chains.  Gradients
-        the chains write themselves (LayerNorm gains, positional tables) are ordered lane 0 -> lane 1 by events."""
+        the chains write themselves (LayerNorm gains, positional tables) are ordered lane 0 -> lane 1 by events.
+
+        `ready(prefixes)` (optional) is called - with the wgrad stream current and ordered after everything
+        that writes them - as soon as all gradients of the parameters named by `prefixes` are enqueued: one call
+        per block, top to bottom, so the gradient all-reduce can start while backward is still running."""
         st = self._get_streams(run.G.device)
         main, wg = torch.cuda.current_stream(), st["wgrad"]
         two = len(run.lanes) == 2
@@ -325,16 +329,30 @@ class VideoEngine:
         for ln in lanes:
             with torch.cuda.stream(ln.pl.stream):
                 self._final_bwd(ln, run, params, grads)
+        if run.region_layer is not None:
+            ready = None                     # region_norm gradients arrive out of block order: reduce after backward
         for i in reversed(range(self.depth)):
             for ln in lanes:
                 with torch.cuda.stream(ln.pl.stream):
                     self._block_bwd(ln, i, run, params, grads, wg)
+            self._announce(lanes[-1], wg, ready, (f"blocks.{i}.", "norm.") if i == self.depth - 1 else (f"blocks.{i}.",))
         for ln in lanes:
             with torch.cuda.stream(ln.pl.stream):
                 self._embed_bwd(ln, grads, wg)
+        self._announce(lanes[-1], wg, ready, ("cls_token", "pos_embed", "temporal_embed", "patch_embed."))
         if two:
             main.wait_stream(st["lane1"])
         main.wait_stream(wg)                 # every weight gradient is complete before the caller continues
+
+    @staticmethod
+    def _announce(last_lane, wg, ready, prefixes):
+        if ready is None:
+            return
+        ev = torch.cuda.Event()
+        ev.record(last_lane.pl.stream)       # LayerNorm / table gradients of the last lane are enqueued
+        wg.wait_event(ev)
+        with torch.cuda.stream(wg):
+            ready(prefixes)
 
     def _own_grad(self, ln, fn):
         """Run `fn(accumulate)` - kernels that write parameter gradients from the lane's own stream - so that

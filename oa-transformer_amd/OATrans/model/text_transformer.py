@@ -67,6 +67,8 @@ class _HiddenFn(torch.autograd.Function):
         accumulate = m._bwd_calls > 0
         m._bwd_calls += 1
         m._engine.backward(ctx.plan, m._param_data(), m._grad_views(), d_hidden.float().contiguous(), accumulate)
+        if m._bwd_calls == m._fwd_calls:
+            m._announce(("",))               # last backward of the step: the whole flat gradient is final
         return (None, None, None, None) + (None,) * m._n_params
 
 

@@ -93,7 +93,9 @@ class _EncoderFn(torch.autograd.Function):
             d_patches = d_patches.reshape(-1, D).float()
         if d_region is not None:
             d_region = d_region.reshape(-1, D).float()
-        module._engine.backward(plan, module._param_data(), module._grad_views(), d_cls.float(), d_patches, d_region)
+        ready = module._announce if module.grad_ready_hook is not None else None
+        module._engine.backward(plan, module._param_data(), module._grad_views(), d_cls.float(), d_patches, d_region,
+                                ready=ready)
         return (None, None, None, None) + (None,) * module._n_params
 
 

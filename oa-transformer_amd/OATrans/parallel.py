@@ -8,8 +8,8 @@ over xGMI.  Two exchange steps exist:
     (1/W) dL_global/dtheta).  video and text are packed into ONE collective per step.
   * gradient mean all-reduce (the reference's DistributedDataParallel wrap, base_trainer.py:17-23).
     The HIP engines write gradients into flat per-module buffers, so the all-reduce runs over a few
-    large contiguous ranges (big messages suit the per-link-bound xGMI ring) on a SIDE stream; the
-    1/W scaling is folded into the fused AdamW (`grad_scale`).
+    large contiguous ranges (big messages suit the per-link-bound xGMI ring), started while backward is
+    still running (GradSync.on_ready) so that the exchange hides behind the remaining backward kernels.
 """
 import torch
 import torch.distributed as dist
@@ -62,12 +62,36 @@ def allgather_packed(tensors, args):
 
 
 class GradSync:
-    """Mean all-reduce of parameter gradients over flat buffers, overlapped on a side stream."""
+    """Mean all-reduce of parameter gradients over flat buffers.
 
-    def __init__(self, model, bucket_mb=256):
+    overlap=True: the engine modules announce gradient ranges as soon as the kernels writing them are
+    enqueued (`grad_ready_hook`, one ViT block = 28 MB at a time, the whole text tower at once); each range
+    is all-reduced asynchronously on RCCL's stream while the rest of backward runs.  xGMI is point-to-point,
+    so at 2 GPUs one link carries the whole 600 MB exchange: hidden behind backward it costs nothing, after
+    backward it would cost ~10 ms.  `all_reduce()` (after backward) reduces whatever was not announced,
+    waits for the asynchronous work and applies the 1/W mean.  Every rank issues the same collectives in the
+    same order (the launch schedule is deterministic)."""
+
+    def __init__(self, model, bucket_mb=256, overlap=True, force=False):
         self.model = model
+        self.force = force           # issue the collectives even in a 1-rank group (exercises the RCCL path on one GPU)
         self.bucket = int(bucket_mb * (1 << 20) // 4)
         self.stream = torch.cuda.Stream() if torch.cuda.is_available() else None
+        self._pending = []           # async work handles of this step
+        self._covered = []           # [byte_lo, byte_hi) address ranges already handed to RCCL this step
+        if overlap:
+            for m in model.modules():
+                if hasattr(m, "flat_grad") and hasattr(m, "_engine_params"):
+                    m.grad_ready_hook = self.on_ready
+
+    def on_ready(self, module, lo, hi):
+        """flat_grad()[lo:hi] of `module` is final once the work enqueued so far on the CURRENT stream is done."""
+        W, _ = world()
+        if (W == 1 and not self.force) or hi <= lo:
+            return
+        flat = module.flat_grad()[lo:hi]
+        self._pending.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
+        self._covered.append((flat.data_ptr(), flat.data_ptr() + 4 * flat.numel()))
 
     def ranges(self):
         """Maximal contiguous gradient ranges (engine modules expose one each; loose params singly)."""
@@ -85,26 +109,42 @@ class GradSync:
                 out.append(cur)
         return [torch.as_strided(g, (n,), (1,)) for g, n, _, _ in out]
 
+    def _uncovered(self, flat):
+        """Pieces of `flat` outside every range announced through on_ready this step."""
+        a, b = flat.data_ptr(), flat.data_ptr() + 4 * flat.numel()
+        pieces, pos = [], a
+        for lo, hi in sorted(c for c in self._covered if c[1] > a and c[0] < b):
+            if lo > pos:
+                pieces.append((pos, lo))
+            pos = max(pos, hi)
+        if pos < b:
+            pieces.append((pos, b))
+        return [flat[(lo - a) // 4:(hi - a) // 4] for lo, hi in pieces]
+
     def all_reduce(self, average=True):
         W, _ = world()
-        if W == 1:
+        if W == 1 and not self.force:
             return
         flats = self.ranges()
+        rest = [piece for f in flats for piece in self._uncovered(f)]
         if self.stream is not None and flats[0].is_cuda:
             self.stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.stream):
-                self._reduce(flats, W, average)
+                self._reduce(rest)
             torch.cuda.current_stream().wait_stream(self.stream)
         else:
-            self._reduce(flats, W, average)
+            self._reduce(rest)
+        for work in self._pending:
+            work.wait()                      # device-side: the current stream waits for RCCL's stream
+        self._pending, self._covered = [], []
+        if average:
+            for f in flats:
+                f.div_(W)
 
-    def _reduce(self, flats, W, average):
+    def _reduce(self, flats):
         for f in flats:
             for s in range(0, f.numel(), self.bucket):
-                chunk = f[s:s + self.bucket]
-                dist.all_reduce(chunk, op=dist.ReduceOp.SUM)
-                if average:
-                    chunk.div_(W)
+                dist.all_reduce(f[s:s + self.bucket], op=dist.ReduceOp.SUM)
 
 
 class HipDataParallel(nn.Module):

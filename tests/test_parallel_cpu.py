@@ -86,3 +86,66 @@ def test_single_rank_gather_is_identity():
     y = AllGather_multi.apply(x, 1, args)
     y.sum().backward()
     assert torch.equal(y, x) and torch.equal(x.grad, torch.ones_like(x))
+
+
+class _FlatToy(torch.nn.Module):
+    """CPU stand-in for an engine module: parameters 'blocks.0.w', 'blocks.1.w', 'norm.w' over one flat
+    gradient buffer (the real EngineModule plumbing, no kernels)."""
+
+    def __new__(cls):
+        from OATrans.engine.module import EngineModule
+
+        class Toy(EngineModule):
+            def __init__(self):
+                super().__init__()
+                self.blocks = torch.nn.ModuleList([torch.nn.Linear(4, 4, bias=False) for _ in range(2)])
+                self.norm = torch.nn.LayerNorm(4)
+        return Toy()
+
+
+def _overlap_worker(rank, world, port, q):
+    from OATrans.parallel import GradSync
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    torch.manual_seed(1)
+    toy = _FlatToy()
+    loose = torch.nn.Parameter(torch.zeros(5))
+    model = torch.nn.ModuleDict({"toy": toy})
+    model.register_parameter("loose", loose)
+    sync = GradSync(model, overlap=True)
+    assert toy.grad_ready_hook is not None
+    views = toy._grad_views()
+    loose.grad = torch.zeros(5)
+    for step in range(2):                                   # second step: state was reset by all_reduce()
+        for i, (n, v) in enumerate(views.items()):
+            v.fill_(float((rank + 1) * (i + 1) + step))
+        loose.grad.fill_(float(10 * (rank + 1)))
+        toy._announce(("blocks.1.", "norm."))               # top block + final norm: contiguous tail
+        toy._announce(("blocks.0.", "norm."))               # NOT contiguous (blocks.1 lies between): ignored
+        assert len(sync._pending) == 1
+        toy._announce(("blocks.0.",))
+        assert len(sync._pending) == 2
+        sync.all_reduce(average=True)
+        assert not sync._pending and not sync._covered
+        for i, (n, v) in enumerate(views.items()):
+            want = sum((r + 1) * (i + 1) + step for r in range(world)) / world
+            assert torch.allclose(v, torch.full_like(v, want)), (n, v, want)     # reduced exactly once
+        assert torch.allclose(loose.grad, torch.full((5,), sum(10.0 * (r + 1) for r in range(world)) / world))
+    q.put(rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_overlapped_gradient_sync():
+    """Ranges announced during backward are all-reduced asynchronously; the final sync covers the rest and
+    every element is averaged exactly once (parallel.GradSync.on_ready / _uncovered)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got == [0, 1]
