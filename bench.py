@@ -115,6 +115,19 @@ def instrumented_gemm_profile(step_fn):
     return by, len(mods)
 
 
+def pmc_traffic(kernel, args):
+    """HBM-side bytes per launch of the dominant kernel.  PMC counters cannot be sampled from inside this
+    process, so this is the committed rocprofv3 measurement of the same command and workload
+    (profiles/round1b_pmc_hbm_traffic.md: separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections);
+    null when the workload differs from the measured one."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1b_pmc_traffic.json")
+    if not os.path.exists(path) or (args.variant, args.batch, args.frames) != ("frozen", 32, 8):
+        return None
+    with open(path) as fh:
+        rec = json.load(fh)
+    return rec["bytes_per_launch"] if rec.get("kernel") == kernel else None
+
+
 def cpu_baseline(frames, threads):
     """fp32 CPU oracle (port of the reference arithmetic) on a bounded sample: bs 2, fwd+bwd."""
     from OATrans.utils import seeded_init as si
@@ -224,7 +237,7 @@ def main():
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "kernel": names.get(epi, str(epi)), "achieved": round(ach, 1),
                                "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / BF16_DENSE_PEAK_TFLOPS, 4),
-                               "traffic": None, "launches_per_step": d["n"],
+                               "traffic": pmc_traffic(names.get(epi, str(epi)), args), "launches_per_step": d["n"],
                                "avg_launch_us": round(d["ms"] / d["n"] * 1e3, 1),
                                "gflop_per_launch": round(d["flops"] / d["n"] / 1e9, 1)}
         if world == 1 and not args.no_cpu_baseline and args.variant == "frozen":

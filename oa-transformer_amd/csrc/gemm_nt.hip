@@ -6,10 +6,10 @@
 //   vid_proj/txt_proj  /root/reference/OATrans/model/oa_model.py:68-74
 // and their data-gradients in backward (B = W^T shadow).
 //
-// gfx950 design (v1, "2-phase"): 128x128x64 tile, 256 threads = 4 waves (2x2), each wave
-// a 64x64 sub-tile = 4x4 MFMA 16x16x32 tiles (64 fp32 accumulators / lane).  Both operands
-// are K-contiguous, so A and B fragments are one ds_read_b128 each.  Tiles are staged with
-// 16-byte global_load_lds (no VGPR round trip) into a double-buffered 64 KB LDS image; the
+// gfx950 design: 256x256x64 tile, 512 threads = 8 waves (2x4), each wave a 128x64 sub-tile = 8x4 MFMA
+// 16x16x32 tiles (128 fp32 accumulators / lane); a 128x128x64 / 4-wave configuration serves small
+// problems.  Both operands are K-contiguous, so A and B fragments are one ds_read_b128 each.  Tiles are
+// staged with 16-byte global_load_lds (no VGPR round trip) into an LDS ring (see the kernel comment); the
 // LDS image is lane-linear, so the bank-conflict swizzle (chunk ^= (row >> 1) & 7 inside a
 // 128-byte row) is applied to the per-lane GLOBAL source address and again on the read.
 // MFMA operands are swapped (acc = mfma(Bfrag, Afrag)) so each lane owns 4 CONSECUTIVE
@@ -44,10 +44,16 @@ OAT_DEV int swz(int r, int lc) { return r * 128 + ((lc ^ ((r >> 1) & 7)) << 4); 
 
 // WM x WN waves, each owning TM x TN MFMA tiles of 16x16:  <2,2,4,4> = 128x128 / 4 waves,
 // <2,4,8,4> = 256x256 / 8 waves (one workgroup per CU, 128 KB LDS).
-template <int EPI, int WM, int WN, int TM, int TN>
+//
+// Staging pipeline: B (weights: re-read by every workgroup, L2-resident) is double-buffered; A (activations:
+// streamed once from HBM / Infinity Cache, ~2 us away under load) gets NSA = 3 stages in the 256x256
+// configuration (3 x 32 KB + 2 x 32 KB = all 160 KB of LDS), so its loads are issued TWO K-steps ahead.
+// The LDS-DMA loads are issued from inline asm (the compiler would otherwise drain them with vmcnt(0)
+// before the first ds_read) and published by a counted s_waitcnt + raw s_barrier.
+template <int EPI, int WM, int WN, int TM, int TN, int NSA, bool SPREAD>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16, NW = WM * WN;
-  constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
   constexpr int GA = BM / 8 / NW, GB = BN / 8 / NW;       // glds instructions per wave per tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -83,12 +89,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
     const int lc = (lane & 7) ^ ((r >> 1) & 7);
     b_src[i] = g.B + (size_t)min(n0 + r, g.N - 1) * g.ldb + lc * 8;
   }
-  auto stage = [&](int buf, int k0) {
-    char* base = smem + buf * STAGE_BYTES;
+  char* const sA0 = smem;
+  char* const sB0 = smem + NSA * A_BYTES;
+  auto stageA = [&](int buf, int k0) {
 #pragma unroll
-    for (int i = 0; i < GA; ++i) glds16(a_src[i] + k0, base + (wave * GA + i) * 8 * 128);
+    for (int i = 0; i < GA; ++i) glds16_asm(a_src[i] + k0, sA0 + buf * A_BYTES + (wave * GA + i) * 1024);
+  };
+  auto stageB = [&](int buf, int k0) {
 #pragma unroll
-    for (int i = 0; i < GB; ++i) glds16(b_src[i] + k0, base + BM * 128 + (wave * GB + i) * 8 * 128);
+    for (int i = 0; i < GB; ++i) glds16_asm(b_src[i] + k0, sB0 + buf * B_BYTES + (wave * GB + i) * 1024);
   };
 
   f32x4 acc[TM][TN];
@@ -98,14 +107,27 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = g.K / BK;
-  stage(0, 0);
+  stageA(0, 0);
+  stageB(0, 0);
+  if (NSA == 3 && nk > 1) stageA(1, BK);
   const int frow = lane & 15, fk = lane >> 4;
+  int abuf = 0;                                   // kt % NSA
   for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + 1 < nk) stage((kt + 1) & 1, (kt + 1) * BK);
-    const char* sa = smem + (kt & 1) * STAGE_BYTES;
-    const char* sb = sa + BM * 128;
+    // in flight after this wait: only A(kt+1) (issued last), everything older - A(kt), B(kt) - has landed
+    if (NSA == 3 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GA) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                 // stage kt visible; everyone is done reading stage kt-1
+    const bool moreB = kt + 1 < nk, moreA = NSA == 3 ? kt + 2 < nk : kt + 1 < nk;
+    const int bbuf_n = (kt + 1) & 1;
+    const int abuf_n = NSA == 3 ? (abuf == 0 ? 2 : abuf - 1) : (kt + 1) & 1;      // (kt + 2) % 3 | (kt + 1) % 2
+    const int ka_n = (NSA == 3 ? kt + 2 : kt + 1) * BK;
+    if (!SPREAD) {
+      if (moreB) stageB(bbuf_n, (kt + 1) * BK);
+      if (moreA) stageA(abuf_n, ka_n);
+    }
+    const char* sa = sA0 + abuf * A_BYTES;
+    const char* sb = sB0 + (kt & 1) * B_BYTES;
+    abuf = abuf + 1 == NSA ? 0 : abuf + 1;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       bf16x8 af[TM], bfr[TN];
@@ -116,10 +138,28 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
       for (int i = 0; i < TM; ++i)
         af[i] = *reinterpret_cast<const bf16x8*>(sa + swz(wm * TM * 16 + i * 16 + frow, kk * 4 + fk));
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        if constexpr (SPREAD) {
+          // one LDS-DMA piece per SLOT MFMA groups: a piece blocks its wave's issue port for 60-180 cycles;
+          // spread through the MFMA stream that time is hidden behind matrix work instead of stalling both
+          // waves of a SIMD together right after the barrier
+          constexpr int SLOTS = 2 * TM, NP = GA + GB, EVERY = SLOTS / NP;
+          const int slot = kk * TM + i;
+          if (EVERY > 0 && slot % EVERY == EVERY - 1 && slot / EVERY < NP) {
+            const int pc = slot / EVERY;
+            __builtin_amdgcn_sched_barrier(0);
+            if (pc < GB) {
+              if (moreB) glds16_asm(b_src[pc] + (kt + 1) * BK, sB0 + bbuf_n * B_BYTES + (wave * GB + pc) * 1024);
+            } else {
+              if (moreA) glds16_asm(a_src[pc - GB] + ka_n, sA0 + abuf_n * A_BYTES + (wave * GA + pc - GB) * 1024);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
     }
   }
 
@@ -217,26 +257,26 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
 
 static int g_variant = 0, g_dbg = 0;   // 0 = auto, 1 = force 128x128, 2 = force 256x256 (tuning hook)
 
-template <int EPI, int WM, int WN, int TM, int TN>
+template <int EPI, int WM, int WN, int TM, int TN, int NSA, bool SPREAD>
 static int launch_cfg(const GemmArgs& g, hipStream_t s) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
-  constexpr int LDS = 2 * (BM + BN) * BK * 2;
+  constexpr int LDS = (NSA * BM + 2 * BN) * BK * 2;
   const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<EPI, WM, WN, TM, TN>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<EPI, WM, WN, TM, TN, NSA, SPREAD>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_nt_kernel<EPI, WM, WN, TM, TN>), dim3(ntm * ntn), dim3(WM * WN * 64), LDS, s, g);
+  hipLaunchKernelGGL((gemm_nt_kernel<EPI, WM, WN, TM, TN, NSA, SPREAD>), dim3(ntm * ntn), dim3(WM * WN * 64), LDS, s, g);
   return check_launch("gemm_nt");
 }
 
 template <int EPI>
 static int launch(const GemmArgs& g, hipStream_t s) {
   const bool big = g_variant == 2 || (g_variant == 0 && g.M >= 4096 && g.N % 256 == 0);
-  if (big) return launch_cfg<EPI, 2, 4, 8, 4>(g, s);
-  return launch_cfg<EPI, 2, 2, 4, 4>(g, s);
+  if (big) return launch_cfg<EPI, 2, 4, 8, 4, 3, true>(g, s);
+  return launch_cfg<EPI, 2, 2, 4, 4, 2, false>(g, s);
 }
 
 }  // namespace oat
