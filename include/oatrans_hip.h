@@ -82,6 +82,7 @@ int oat_attn_space_fwd(const void* qkv, int ldqkv, void* out, int ldo, float* ls
                        int H, int D, float scale, void* stream);
 int oat_attn_time_fwd(const void* qkv, int ldqkv, void* out, int ldo, float* lse, int B, int T, int N,
                       int H, int D, float scale, void* stream);
+void oat_attn_time_set_variant(int v);   /* tuning hook: 0 auto (single-read LDS kernel for T <= 8), 1 force two-pass */
 int oat_attn_cls_fwd(const void* qkv, int ldqkv, void* out, int ldo, float* lse, int B, int T, int N,
                      int H, int D, float scale, void* stream);
 /* cls_side: fp32 [B,H,3,64], zero on entry; finish with oat_attn_cls_finalize. */

@@ -215,6 +215,114 @@ __global__ __launch_bounds__(256) void attn_time_bwd_kernel(TimeArgs a) {
   }
 }
 
+// Single-read backward for T <= 8.  Same math as the two-pass kernel, but pass A parks every query row it
+// loads (q_i, dO_i as packed bf16, delta_i, lse_i) in a per-wave LDS slab and K, V stay in registers, so pass B
+// (key-major, inner query loop rolled, reading its own lane's slots back) touches HBM only to store dK / dV:
+// 620 MB per launch instead of 1073 MB (PMC), and the kernel is HBM-bound.  Every lane re-reads only what
+// its own wave wrote, in program order: no barrier.  p <= 1 always, so the raw v_exp_f32 (no denormal range
+// scaling) is exact enough and saves four VALU instructions per score.
+template <int TT>
+__global__ __launch_bounds__(256) void attn_time_bwd_lds_kernel(TimeArgs a) {
+  constexpr int R = TT + 1;
+  constexpr int WAVE_LDS = R * 64 * 16 * 2 + 8 * R * 2 * 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int ng = (a.N + 7) / 8;
+  if (wid >= a.B * a.H * ng) return;
+  char* base = smem + (threadIdx.x >> 6) * WAVE_LDS;
+  bf16x8* sq = reinterpret_cast<bf16x8*>(base);
+  bf16x8* sgo = sq + R * 64;
+  float* sdl = reinterpret_cast<float*>(sgo + R * 64) + (lane >> 3) * R * 2;     // [i][delta, lse2] of this problem
+  const int bh = wid / ng, b = bh / a.H, h = bh % a.H;
+  const int n = (wid % ng) * 8 + (lane >> 3);
+  const int pl = lane & 7;
+  const bool valid = n < a.N;
+  const int nn = valid ? n : a.N - 1;
+  const size_t cls_row = (size_t)a.B * a.T * a.N + b;
+  const int col = h * 64 + pl * 8;
+  const size_t row0 = (size_t)b * TT * a.N + nn;
+  const float c2 = a.scale * T_LOG2E;
+  float* side = a.cls_side + ((size_t)b * a.H + h) * 192;
+  bf16x8 k[R], v[R];
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const size_t r = j < TT ? row0 + (size_t)j * a.N : cls_row;
+    k[j] = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + a.D + col);
+    v[j] = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + 2 * a.D + col);
+  }
+  // ---- pass A: dQ_i; park q_i, dO_i, delta_i, lse_i
+#pragma unroll 1
+  for (int i = 0; i < R; ++i) {
+#pragma unroll
+    for (int j = 0; j < R; ++j) { asm volatile("" : "+v"(k[j])); asm volatile("" : "+v"(v[j])); }
+    const size_t r = i < TT ? row0 + (size_t)i * a.N : cls_row;
+    const bf16x8 q = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + col);
+    const bf16x8 go = *reinterpret_cast<const bf16x8*>(a.dout + r * a.lddo + col);
+    const bf16x8 oo = *reinterpret_cast<const bf16x8*>(a.out + r * a.ldo + col);
+    const float lse2 = a.lse[r * a.H + h] * T_LOG2E;
+    const float delta = red8(dot8(go, oo));
+    sq[i * 64 + lane] = q;
+    sgo[i * 64 + lane] = go;
+    if (pl == 0) { sdl[i * 2] = delta; sdl[i * 2 + 1] = lse2; }
+    float dq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      float p = __builtin_amdgcn_exp2f(red8(dot8(q, k[j])) * c2 - lse2);
+      if (i == TT && j == TT && n != 0) p = 0.f;        // CLS->CLS pair is counted once (n == 0)
+      const float ds = p * (red8(dot8(go, v[j])) - delta) * a.scale;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dq[e] += ds * bf2f(k[j][e]);
+    }
+    if (i < TT) {
+      if (valid) {
+        const bf16x8 ob = {f2bf(dq[0]), f2bf(dq[1]), f2bf(dq[2]), f2bf(dq[3]), f2bf(dq[4]), f2bf(dq[5]), f2bf(dq[6]), f2bf(dq[7])};
+        *reinterpret_cast<bf16x8*>(a.dqkv + r * a.lddqkv + col) = ob;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float t = valid ? dq[e] : 0.f;
+        t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
+        if (lane < 8) atomicAdd(side + pl * 8 + e, t);
+      }
+    }
+  }
+  // ---- pass B: dK_j, dV_j from registers (k, v) and LDS (queries)
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const bf16x8 kk = k[j], vv = v[j];
+    float dk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 1
+    for (int i = 0; i < R; ++i) {
+      const bf16x8 q = sq[i * 64 + lane], go = sgo[i * 64 + lane];
+      const float delta = sdl[i * 2], lse2 = sdl[i * 2 + 1];
+      float p = __builtin_amdgcn_exp2f(red8(dot8(q, kk)) * c2 - lse2);
+      if (i == TT && j == TT && n != 0) p = 0.f;
+      const float ds = p * (red8(dot8(go, vv)) - delta) * a.scale;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { dk[e] += ds * bf2f(q[e]); dv[e] += p * bf2f(go[e]); }
+    }
+    const size_t r = j < TT ? row0 + (size_t)j * a.N : cls_row;
+    if (j < TT) {
+      if (valid) {
+        const bf16x8 kb = {f2bf(dk[0]), f2bf(dk[1]), f2bf(dk[2]), f2bf(dk[3]), f2bf(dk[4]), f2bf(dk[5]), f2bf(dk[6]), f2bf(dk[7])};
+        const bf16x8 vb = {f2bf(dv[0]), f2bf(dv[1]), f2bf(dv[2]), f2bf(dv[3]), f2bf(dv[4]), f2bf(dv[5]), f2bf(dv[6]), f2bf(dv[7])};
+        *reinterpret_cast<bf16x8*>(a.dqkv + r * a.lddqkv + a.D + col) = kb;
+        *reinterpret_cast<bf16x8*>(a.dqkv + r * a.lddqkv + 2 * a.D + col) = vb;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float tk = valid ? dk[e] : 0.f, tv = valid ? dv[e] : 0.f;
+        tk += __shfl_xor(tk, 8, 64); tk += __shfl_xor(tk, 16, 64); tk += __shfl_xor(tk, 32, 64);
+        tv += __shfl_xor(tv, 8, 64); tv += __shfl_xor(tv, 16, 64); tv += __shfl_xor(tv, 32, 64);
+        if (lane < 8) { atomicAdd(side + 64 + pl * 8 + e, tk); atomicAdd(side + 128 + pl * 8 + e, tv); }
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------- CLS query over all keys
 // one workgroup per (b,h): 32 groups of 8 lanes stride over the 1 + T*N keys with an online
 // softmax each, then merge through LDS.  Writes out[cls row] and lse[cls row].
@@ -263,6 +371,9 @@ __global__ __launch_bounds__(256) void attn_cls_fwd_kernel(TimeArgs a) {
 
 using namespace oat;
 
+static int g_time_two_pass = 0;   // tuning hook: 1 = force the two-pass backward for every T
+extern "C" void oat_attn_time_set_variant(int v) { g_time_two_pass = v; }
+
 #define OAT_TIME_DISPATCH(KERNEL)                                                                     \
   switch (T) {                                                                                        \
     case 1: hipLaunchKernelGGL(KERNEL<1>, dim3(blocks), dim3(256), 0, s, a); break;                   \
@@ -294,6 +405,21 @@ extern "C" int oat_attn_time_bwd(const void* qkv, int ldqkv, const void* out, in
   hipStream_t s = (hipStream_t)stream;
   const int waves = B * H * ((N + 7) / 8);
   const int blocks = (waves + 3) / 4;
+  if (T <= 8 && !g_time_two_pass) {
+#define OAT_TIME_LDS(TT) \
+    case TT: { \
+      constexpr int LDS = 4 * ((TT + 1) * 64 * 32 + 8 * (TT + 1) * 8); \
+      static bool attr = false; \
+      if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_time_bwd_lds_kernel<TT>), \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; } \
+      hipLaunchKernelGGL(attn_time_bwd_lds_kernel<TT>, dim3(blocks), dim3(256), LDS, s, a); break; }
+    switch (T) {
+      OAT_TIME_LDS(1) OAT_TIME_LDS(2) OAT_TIME_LDS(3) OAT_TIME_LDS(4) OAT_TIME_LDS(8)
+      default: set_error("attn_time: supported frame counts are 1,2,3,4,8,16"); return -3;
+    }
+#undef OAT_TIME_LDS
+    return check_launch("attn_time_bwd");
+  }
   OAT_TIME_DISPATCH(attn_time_bwd_kernel)
   return check_launch("attn_time_bwd");
 }

@@ -23,3 +23,11 @@ print("cls   fwd us", timeit(lambda: hip.attn_cls_fwd(qkv, out, lse, B, T, N, H,
 print("space bwd us", timeit(lambda: hip.attn_space_bwd(qkv, out, lse, dout, dqkv, side, B, T, N, H, D, sc)))
 print("time  fwd us", timeit(lambda: hip.attn_time_fwd(qkv, out, lse, B, T, N, H, D, sc)))
 print("time  bwd us", timeit(lambda: hip.attn_time_bwd(qkv, out, lse, dout, dqkv, side, B, T, N, H, D, sc)))
+hip.attn_cls_fwd(qkv, out, lse, B, T, N, H, D, sc); hip.attn_time_fwd(qkv, out, lse, B, T, N, H, D, sc)
+for rep in range(2):
+    for var in (1, 0):
+        hip.lib().oat_attn_time_set_variant(var)
+        side.zero_()
+        t = timeit(lambda: hip.attn_time_bwd(qkv, out, lse, dout, dqkv, side, B, T, N, H, D, sc))
+        print(f"time bwd variant {var} ({'two-pass' if var else 'single-read LDS'}): {t:.1f} us  checksum {dqkv.float().abs().sum().item():.6e}")
+hip.lib().oat_attn_time_set_variant(0)
