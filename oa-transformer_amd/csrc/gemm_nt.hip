@@ -214,6 +214,35 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
         }
       }
       __builtin_amdgcn_wave_barrier();
+    } else if constexpr (EPI == EPI_DGELU && BM == 256) {
+      // fp32 scratch, 64 rows x 64 cols (272-B pitch; 8 waves x 17 KB fit the 160 KB ring): a lane then owns 8
+      // consecutive columns, so the saved pre-activation is read and dH written in full 128-byte lines
+      constexpr int EW = 272;
+      char* ew = smem + wave * (64 * EW);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          *reinterpret_cast<f32x4*>(ew + (i * 16 + frow) * EW + (j * 16 + fk * 4) * 4) = acc[rh * 4 + i][j];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int lr = it * 8 + rrow;
+        const int row = wrow0 + rh * 64 + lr, col = wcol0 + rch * 8;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(ew + lr * EW + rch * 32);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(ew + lr * EW + rch * 32 + 16);
+        if (row < g.M && col < g.N) {
+          const bf16x8 h = *reinterpret_cast<const bf16x8*>(g.aux + (size_t)row * g.ldaux + col);
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            o[e] = f2bf((v0[e] + (g.bias ? g.bias[col + e] : 0.f)) * dgelu_f(bf2f(h[e])));
+            o[4 + e] = f2bf((v1[e] + (g.bias ? g.bias[col + 4 + e] : 0.f)) * dgelu_f(bf2f(h[4 + e])));
+          }
+          *reinterpret_cast<bf16x8*>((bf16*)g.out + (size_t)row * g.ldc + col) = o;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
     } else {
       // fp32 scratch: 64 rows x 32 cols, two column halves
 #pragma unroll
