@@ -71,21 +71,33 @@ class TextEngine:
         if sig is not None and versions == self.versions:
             return
         dev = params[names[0]].device
+        D = self.D
+        srcs = [params[n].detach() for n in names if n.endswith(".weight")]
+        key = tuple(w.data_ptr() for w in srcs)
+        if getattr(self, "_cast", None) is None or self._cast.key != key:
+            entries = []
 
-        def put(key, w):
-            if key not in self.shadow:
-                self.shadow[key] = (torch.empty(w.shape, dtype=torch.bfloat16, device=dev),
-                                    torch.empty(w.shape[1], w.shape[0], dtype=torch.bfloat16, device=dev))
-            hip.cast_bf16(w.contiguous(), self.shadow[key][0], self.shadow[key][1])
+            def shadow(k, rows, cols):
+                self.shadow[k] = (torch.empty(rows, cols, dtype=torch.bfloat16, device=dev),
+                                  torch.empty(cols, rows, dtype=torch.bfloat16, device=dev))
+                return self.shadow[k]
 
+            for i in range(self.n_layers):
+                b = f"transformer.layer.{i}."
+                w, wT = shadow(b + "qkv", 3 * D, D)             # q|k|v rows concatenated by the cast itself
+                for j, l in enumerate(("q_lin", "k_lin", "v_lin")):
+                    entries.append((params[b + f"attention.{l}.weight"].detach(), w[j * D:(j + 1) * D],
+                                    wT[:, j * D:(j + 1) * D], D, 3 * D))
+                for l in ("attention.out_lin", "ffn.lin1", "ffn.lin2"):
+                    src = params[b + l + ".weight"].detach()
+                    w, wT = shadow(b + l, src.shape[0], src.shape[1])
+                    entries.append((src, w, wT, src.shape[1], src.shape[0]))
+            self._cast = hip.CastTable(entries)
+        self._cast.run()
         for i in range(self.n_layers):
             b = f"transformer.layer.{i}."
-            wqkv = torch.cat([params[b + f"attention.{l}.weight"].detach() for l in ("q_lin", "k_lin", "v_lin")], 0)
-            put(b + "qkv", wqkv)
             self.shadow[b + "qkv.bias"] = torch.cat(
-                [params[b + f"attention.{l}.bias"].detach() for l in ("q_lin", "k_lin", "v_lin")], 0).contiguous()
-            for l in ("attention.out_lin", "ffn.lin1", "ffn.lin2"):
-                put(b + l, params[b + l + ".weight"].detach())
+                [params[b + f"attention.{l}.bias"].detach() for l in ("q_lin", "k_lin", "v_lin")], 0)
         self.versions = versions
 
     def plan(self, B, L, dev, slot=0):

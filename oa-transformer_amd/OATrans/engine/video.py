@@ -132,6 +132,7 @@ class VideoEngine:
         self.plans = {}
         self.shadow = {}
         self.shadow_versions = None
+        self._cast = None
         self.lanes = int(os.environ.get("OAT_LANES", "1"))   # half-batches on two streams (1 = off)
         self.min_lane_rows = 8192        # token rows per lane below which splitting only adds launches
         self._streams = None
@@ -145,13 +146,16 @@ class VideoEngine:
         names.append("patch_embed.proj.weight")
         if sig is not None and sig == self.shadow_versions:
             return
-        for n in names:
-            w = params[n].detach()
-            w2 = w.reshape(w.shape[0], -1)
-            if n not in self.shadow:
-                self.shadow[n] = (torch.empty_like(w2, dtype=torch.bfloat16),
-                                  torch.empty(w2.shape[1], w2.shape[0], dtype=torch.bfloat16, device=w.device))
-            hip.cast_bf16(w2, self.shadow[n][0], self.shadow[n][1])
+        srcs = [params[n].detach().reshape(params[n].shape[0], -1) for n in names]
+        key = tuple(w.data_ptr() for w in srcs)
+        if self._cast is None or self._cast.key != key:           # masters moved (first call, .to(), flatten)
+            entries = []
+            for n, w in zip(names, srcs):
+                self.shadow[n] = (torch.empty_like(w, dtype=torch.bfloat16),
+                                  torch.empty(w.shape[1], w.shape[0], dtype=torch.bfloat16, device=w.device))
+                entries.append((w, self.shadow[n][0], self.shadow[n][1], w.shape[1], w.shape[0]))
+            self._cast = hip.CastTable(entries)
+        self._cast.run()                                          # all 73 W / W^T shadows in one launch
         self.shadow_versions = sig
 
     def plan(self, B, T, N, dev, slot=0):
@@ -161,9 +165,12 @@ class VideoEngine:
         return self.plans[key]
 
     def _get_streams(self, dev):
+        """Streams are created only when used: HIP multiplexes streams onto a few hardware queues
+        (GPU_MAX_HW_QUEUES, default 4) and two streams that share a queue run in enqueue order."""
         if self._streams is None:
-            self._streams = dict(lane1=torch.cuda.Stream(), wgrad=torch.cuda.Stream(),
-                                 side=[torch.cuda.Stream(), torch.cuda.Stream()])
+            two = self.lanes == 2
+            self._streams = dict(lane1=torch.cuda.Stream() if two else None, wgrad=torch.cuda.Stream(),
+                                 side=[torch.cuda.Stream(), torch.cuda.Stream() if two else None])
             self._tn_ws = torch.empty(hip.lib().oat_gemm_tn_workspace_bytes(0, 3 * self.D, self.Hd) // 4 // 8,
                                       dtype=torch.float32, device=dev)
         return self._streams

@@ -90,10 +90,12 @@ class FrozenInTime(BaseModel):
         if getattr(self, "_text_stream", None) is None:
             self._text_stream = torch.cuda.Stream()
         side = self._text_stream
-        side.wait_stream(main)
+        side.wait_stream(main)           # the text stream starts after what is on `main` NOW (the optimiser step)
+        # host enqueue order: the video tower is the critical path, so its launches are queued first and the
+        # (launch-bound) text tower is queued behind them; on the GPU it runs underneath the video tower
+        video_embeddings = self.compute_video(data['video'], aug=aug)
         with torch.cuda.stream(side):
             text_embeddings = self.compute_text(data['text'])
-        video_embeddings = self.compute_video(data['video'], aug=aug)
         main.wait_stream(side)
         text_embeddings.record_stream(main)
         if return_embeds:

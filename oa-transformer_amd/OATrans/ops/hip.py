@@ -200,6 +200,27 @@ def cast_bf16(src, dst=None, dstT=None):
     _check(lib().oat_cast_bf16(_ptr(src), _ptr(dst), _ptr(dstT), R, C, _stream()), "oat_cast_bf16")
 
 
+class CastTable:
+    """Device descriptor table for oat_cast_bf16_multi, built once per set of (master, shadow) buffers.
+    entries: (src fp32 [R, C] contiguous, dst bf16 | None, dstT bf16 | None, ldd, ldT) - dst / dstT may be row or
+    column slices of larger shadows (ldd / ldT = their leading dimensions)."""
+
+    def __init__(self, entries):
+        rows, tiles = [], 0
+        for src, dst, dstT, ldd, ldT in entries:
+            R, C = src.shape
+            rows.append([src.data_ptr(), dst.data_ptr() if dst is not None else 0,
+                         dstT.data_ptr() if dstT is not None else 0, R, C, ldd, ldT, tiles])
+            tiles += ((R + 31) // 32) * ((C + 31) // 32)
+        self.n, self.tiles = len(rows), tiles
+        self.key = tuple(r[0] for r in rows)
+        self.table = torch.tensor(rows, dtype=torch.int64).to(entries[0][0].device)
+        self.keep = entries                      # the table holds raw pointers: keep the tensors alive
+
+    def run(self):
+        _check(lib().oat_cast_bf16_multi(_ptr(self.table), self.n, self.tiles, _stream()), "oat_cast_bf16_multi")
+
+
 def _attn_fwd(fn, name, qkv, out, lse, B, T, N, H, D, scale):
     _check(fn(_ptr(qkv), qkv.stride(0), _ptr(out), out.stride(0), _ptr(lse), B, T, N, H, D, _f(scale), _stream()),
            name)

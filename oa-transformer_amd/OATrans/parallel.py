@@ -76,7 +76,6 @@ class GradSync:
         self.model = model
         self.force = force           # issue the collectives even in a 1-rank group (exercises the RCCL path on one GPU)
         self.bucket = int(bucket_mb * (1 << 20) // 4)
-        self.stream = torch.cuda.Stream() if torch.cuda.is_available() else None
         self._pending = []           # async work handles of this step
         self._covered = []           # [byte_lo, byte_hi) address ranges already handed to RCCL this step
         if overlap:
@@ -127,13 +126,7 @@ class GradSync:
             return
         flats = self.ranges()
         rest = [piece for f in flats for piece in self._uncovered(f)]
-        if self.stream is not None and flats[0].is_cuda:
-            self.stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self.stream):
-                self._reduce(rest)
-            torch.cuda.current_stream().wait_stream(self.stream)
-        else:
-            self._reduce(rest)
+        self._reduce(rest)               # the few loose ranges: on the current stream (RCCL runs them on its own)
         for work in self._pending:
             work.wait()                      # device-side: the current stream waits for RCCL's stream
         self._pending, self._covered = [], []

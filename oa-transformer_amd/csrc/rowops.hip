@@ -296,6 +296,36 @@ __global__ void cast_bf16_kernel(const float* src, bf16* dst, bf16* dstT, int R,
   }
 }
 
+// Every weight shadow of a module in ONE launch.  desc[m] = {src, dst, dstT, R, C, ldd, ldT, first_tile}: 32x32
+// tiles of matrix m start at block first_tile; dst / dstT may carry their own leading dimension, so the casts can
+// also assemble concatenated shadows (DistilBERT's q|k|v weights) without a separate copy.
+struct CastDesc { const float* src; bf16* dst; bf16* dstT; long long R, C, ldd, ldT, first_tile; };
+__global__ void cast_bf16_multi_kernel(const CastDesc* desc, int n) {
+  __shared__ float tile[32][33];
+  int lo = 0, hi = n - 1;                               // last matrix whose first_tile <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (desc[mid].first_tile <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const CastDesc d = desc[lo];
+  const int R = (int)d.R, C = (int)d.C;
+  const int t = blockIdx.x - (int)d.first_tile, tpr = (C + 31) / 32;
+  const int c0 = (t % tpr) * 32, r0 = (t / tpr) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    float v = 0.f;
+    if (r < R && c < C) { v = d.src[(size_t)r * C + c]; if (d.dst) d.dst[(size_t)r * d.ldd + c] = f2bf(v); }
+    tile[i][tx] = v;
+  }
+  if (!d.dstT) return;
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + tx;
+    if (r < R && c < C) d.dstT[(size_t)c * d.ldT + r] = f2bf(tile[tx][i]);
+  }
+}
+
 }  // namespace oat
 
 using namespace oat;
@@ -401,6 +431,13 @@ extern "C" int oat_broadcast_rows(const float* src, float* dst, int ld, int R, i
   if (R <= 0) return 0;
   hipLaunchKernelGGL(broadcast_rows_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, src, dst, ld, R, D);
   return check_launch("broadcast_rows");
+}
+extern "C" int oat_cast_bf16_multi(const void* desc, int n_matrices, int total_tiles, void* stream) {
+  if (n_matrices <= 0 || total_tiles <= 0) return 0;
+  if (!desc) { set_error("cast_bf16_multi: null descriptor table"); return -4; }
+  hipLaunchKernelGGL(cast_bf16_multi_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream,
+                     (const CastDesc*)desc, n_matrices);
+  return check_launch("cast_bf16_multi");
 }
 extern "C" int oat_cast_bf16(const float* src, void* dst, void* dstT, int R, int C, void* stream) {
   if (R <= 0 || C <= 0) return 0;
