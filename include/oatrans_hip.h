@@ -35,7 +35,9 @@ int oat_gemm_nt(const void* A, const void* B, int M, int N, int K, int lda, int 
                 void* out, int ldc, void* out2, int ld2, const float* bias, const float* resid,
                 int ldr, int resid_mod, const void* aux, int ldaux, void* stream);
 
-/* tuning hook: 0 = auto tile choice, 1 = force 128x128 (4 waves), 2 = force 256x256 (8 waves) */
+/* tuning hook.  bits 0-7: 0 = auto tile choice, 1 = force 128x128 (4 waves), 2 = force 256x256 (8 waves),
+ * 3 = 256x256 with 4 hand-pipelined waves; bits 8-15: ablation flags (1 = skip the epilogue);
+ * bits 16-31: grid of the persistent 256x256 launch (0 = one workgroup per CU, 0xffff = one per tile) */
 void oat_gemm_set_variant(int v);
 
 /* out[N1,N2] (fp32, (+)=) sum_m P[m,N1]^T Q[m,N2]  - weight gradients of every nn.Linear.

@@ -15,6 +15,7 @@
 // MFMA operands are swapped (acc = mfma(Bfrag, Afrag)) so each lane owns 4 CONSECUTIVE
 // output columns of one row: bias/residual loads are float4 and stores are 8/16 bytes.
 #include "common.h"
+#include <type_traits>
 
 namespace oat {
 
@@ -39,6 +40,12 @@ struct GemmArgs {
 
 constexpr int BK = 64;
 
+// MFMA with the accumulator pinned to AGPRs.  With 256 accumulator registers per lane (128x128 wave tile) hipcc
+// otherwise selects the VGPR form and shuttles every result through v_accvgpr_write / _read.
+OAT_DEV void mfma_agpr(f32x4& c, const bf16x8 a, const bf16x8 b) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+
 // physical byte offset of logical 16B-chunk `lc` (0..7) of row r in a [rows][64 bf16] tile
 OAT_DEV int swz(int r, int lc) { return r * 128 + ((lc ^ ((r >> 1) & 7)) << 4); }
 
@@ -50,7 +57,7 @@ OAT_DEV int swz(int r, int lc) { return r * 128 + ((lc ^ ((r >> 1) & 7)) << 4); 
 // configuration (3 x 32 KB + 2 x 32 KB = all 160 KB of LDS), so its loads are issued TWO K-steps ahead.
 // The LDS-DMA loads are issued from inline asm (the compiler would otherwise drain them with vmcnt(0)
 // before the first ds_read) and published by a counted s_waitcnt + raw s_barrier.
-template <int EPI, int WM, int WN, int TM, int TN, int NSA, bool SPREAD>
+template <int EPI, int WM, int WN, int TM, int TN, int NSA, bool SPREAD, bool PIPE = false>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16, NW = WM * WN;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
@@ -64,9 +71,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
   // XCD-aware tile order: consecutive ids on one XCD share the A row-panel (M-major walk of N).
   const int ntn = (g.N + BN - 1) / BN;
   const int ntm = (g.M + BM - 1) / BM;
-  int bid = blockIdx.x;
+  // Persistent launch (gridDim.x < number of tiles): workgroup w walks tiles w, w + gridDim.x, ... - exactly the
+  // tiles the hardware would have dispatched to that slot - so the store drain of one tile overlaps the
+  // prologue loads of the next instead of an idle CU waiting for the old workgroup to retire.
+  const int nwg = ntm * ntn;
+  for (int tile = blockIdx.x; tile < nwg; tile += gridDim.x) {
+  int bid = tile;
   {
-    const int nwg = ntm * ntn;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;   // bijective remap
   }
@@ -107,10 +118,86 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = g.K / BK;
+  const int frow = lane & 15, fk = lane >> 4;
+  if constexpr (PIPE) {
+    // One wave per SIMD (4 waves x 128x128): nothing hides a wave's own LDS latency or its barrier, so the
+    // loop is software-pipelined by hand.  Fragments are double-buffered in registers (set 0 = k-half 0, set 1 =
+    // k-half 1); every group of 4 MFMAs carries one ds_read_b128 of the NEXT half and - in the second half -
+    // one LDS-DMA piece of a later stage.  The stage hand-over (counted vmcnt + barrier) sits in the MIDDLE of a
+    // K-step: stage kt is fully in registers by then, so its slots are refilled right away (W two steps ahead in
+    // a 2-slot ring, A three steps ahead in a 3-slot ring).
+    static_assert(NSA == 3 && TM == 8 && TN == 8 && GA + GB == 16, "pipelined loop is built for 4 waves of 128x128");
+    bf16x8 fa[2][TM], fb[2][TN];
+    auto ld_item = [&](int set, const char* sa, const char* sb, int kk, int it) {
+      // item order = order of first use by the next half: B0..3, A0, B4..7, A1..A7
+      if (it < 4) fb[set][it] = *reinterpret_cast<const bf16x8*>(sb + swz(wn * TN * 16 + it * 16 + frow, kk * 4 + fk));
+      else if (it == 4) fa[set][0] = *reinterpret_cast<const bf16x8*>(sa + swz(wm * TM * 16 + frow, kk * 4 + fk));
+      else if (it < 9) fb[set][it - 1] = *reinterpret_cast<const bf16x8*>(sb + swz(wn * TN * 16 + (it - 1) * 16 + frow, kk * 4 + fk));
+      else fa[set][it - 8] = *reinterpret_cast<const bf16x8*>(sa + swz(wm * TM * 16 + (it - 8) * 16 + frow, kk * 4 + fk));
+    };
+    stageA(0, 0);
+    stageB(0, 0);
+    if (nk > 1) { stageA(1, BK); stageB(1, BK); }
+    if (nk > 2) stageA(2, 2 * BK);
+    if (nk > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * GA + GB) : "memory");
+    else if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GA + GB) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int it = 0; it < 16; ++it) ld_item(0, sA0, sB0, 0, it);
+    int abuf = 0;
+    // one K-step; MORE / MOREB / MOREA (is there a stage kt+1 / kt+2 / kt+3) are compile-time so that the
+    // steady-state body carries no branches between the MFMA groups - the last three steps are peeled
+    auto kstep = [&](int kt, auto more_c, auto moreb_c, auto morea_c) {
+      constexpr bool more = decltype(more_c)::value, moreB = decltype(moreb_c)::value, moreA = decltype(morea_c)::value;
+      const int abuf1 = abuf == 2 ? 0 : abuf + 1;
+      const char* sa = sA0 + abuf * A_BYTES;
+      const char* sb = sB0 + (kt & 1) * B_BYTES;
+      const char* sa1 = sA0 + abuf1 * A_BYTES;
+      const char* sb1 = sB0 + ((kt + 1) & 1) * B_BYTES;
+      // ---- first half: MFMAs on set 0, fetch k-half 1 of this stage into set 1
+#pragma unroll
+      for (int gq = 0; gq < 16; ++gq) {
+        const int i = gq >> 1, j0 = (gq & 1) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mfma_agpr(acc[i][j0 + j], fb[0][j0 + j], fa[0][i]);
+        ld_item(1, sa, sb, 1, gq);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // ---- hand-over: stage kt+1 landed for everyone, stage kt no longer read by anyone
+      if constexpr (more) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (moreB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GA) : "memory");     // only A(kt+2) may still fly
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+      // ---- second half: MFMAs on set 1, fetch k-half 0 of stage kt+1 into set 0, refill the freed slots
+#pragma unroll
+      for (int gq = 0; gq < 16; ++gq) {
+        const int i = gq >> 1, j0 = (gq & 1) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mfma_agpr(acc[i][j0 + j], fb[1][j0 + j], fa[1][i]);
+        if constexpr (more) ld_item(0, sa1, sb1, 0, gq);
+        if (gq < GB) {
+          if constexpr (moreB) glds16_asm(b_src[gq] + (kt + 2) * BK, sB0 + (kt & 1) * B_BYTES + (wave * GB + gq) * 1024);
+        } else {
+          if constexpr (moreA) glds16_asm(a_src[gq - GB] + (kt + 3) * BK, sA0 + abuf * A_BYTES + (wave * GA + gq - GB) * 1024);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      abuf = abuf1;
+    };
+    using T_ = std::true_type; using F_ = std::false_type;
+    int kt = 0;
+    for (; kt + 3 < nk; ++kt) kstep(kt, T_{}, T_{}, T_{});
+    if (kt + 2 < nk) { kstep(kt, T_{}, T_{}, F_{}); ++kt; }
+    if (kt + 1 < nk) { kstep(kt, T_{}, F_{}, F_{}); ++kt; }
+    kstep(kt, F_{}, F_{}, F_{});
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // MFMA -> accvgpr_read wait states (asm MFMAs are opaque)
+  } else {
   stageA(0, 0);
   stageB(0, 0);
   if (NSA == 3 && nk > 1) stageA(1, BK);
-  const int frow = lane & 15, fk = lane >> 4;
   int abuf = 0;                                   // kt % NSA
   for (int kt = 0; kt < nk; ++kt) {
     // in flight after this wait: only A(kt+1) (issued last), everything older - A(kt), B(kt) - has landed
@@ -163,12 +250,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
     }
   }
 
+  }
+
   if (g.dbg & 1) {   // tuning experiment: keep the accumulators live but skip the epilogue
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(acc[i][j]));
-    return;
+    __syncthreads();
+    continue;
   }
   // ---- epilogue.  Each lane owns C[row = .. + (lane & 15)][col = .. + (lane >> 4) * 4 + 0..3]
   // (4 columns = 8..16 B): storing that directly gives 32-64 B fragments per row and an
@@ -179,17 +269,21 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
   constexpr int EP = 144;                         // scratch row pitch: 128 B payload + 16 B pad
   char* ep = smem + wave * (64 * EP);
   const int rrow = lane >> 3, rch = lane & 7;     // read phase: 8 rows x 8 chunks of 16 B
-  const int wrow0 = m0 + wm * TM * 16, wcol0 = n0 + wn * TN * 16;
-  static_assert(TN == 4, "epilogue assumes 64-column wave tiles");
+  const int wrow0 = m0 + wm * TM * 16;
+  static_assert(TN % 4 == 0, "epilogue works on 64-column groups of the wave tile");
+  const int wcol00 = n0 + wn * TN * 16;
 #pragma unroll
-  for (int rh = 0; rh < TM / 4; ++rh) {
+  for (int rh = 0; rh < TM / 4; ++rh)
+#pragma unroll
+  for (int cg = 0; cg < TN / 4; ++cg) {
+    const int wcol0 = wcol00 + cg * 64;
     if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU_DUAL) {
       // bf16 scratch: 64 rows x 64 cols
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          f32x4 v = acc[rh * 4 + i][j];
+          f32x4 v = acc[rh * 4 + i][cg * 4 + j];
           const int col = wcol0 + j * 16 + fk * 4;
           if (g.bias && col < g.N) v += *reinterpret_cast<const f32x4*>(g.bias + col);
           const bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
@@ -223,7 +317,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          *reinterpret_cast<f32x4*>(ew + (i * 16 + frow) * EW + (j * 16 + fk * 4) * 4) = acc[rh * 4 + i][j];
+          *reinterpret_cast<f32x4*>(ew + (i * 16 + frow) * EW + (j * 16 + fk * 4) * 4) = acc[rh * 4 + i][cg * 4 + j];
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
@@ -251,7 +345,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int jj = 0; jj < 2; ++jj)
-            *reinterpret_cast<f32x4*>(ep + (i * 16 + frow) * EP + (jj * 16 + fk * 4) * 4) = acc[rh * 4 + i][ch * 2 + jj];
+            *reinterpret_cast<f32x4*>(ep + (i * 16 + frow) * EP + (jj * 16 + fk * 4) * 4) = acc[rh * 4 + i][cg * 4 + ch * 2 + jj];
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
@@ -282,35 +376,55 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
       }
     }
   }
+  if (tile + (int)gridDim.x < nwg) {      // the epilogue scratch lives in the staging ring the next tile refills
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  }   // tile loop
 }
 
-static int g_variant = 0, g_dbg = 0;   // 0 = auto, 1 = force 128x128, 2 = force 256x256 (tuning hook)
+// tuning hook: variant 0 = auto, 1 = force 128x128, 2 = force 256x256, 3 = 4-wave pipelined 256x256;
+// persist 0 = one workgroup per CU, 0xffff = one workgroup per tile, else the grid size
+static int g_variant = 0, g_dbg = 0, g_persist = 0;
 
-template <int EPI, int WM, int WN, int TM, int TN, int NSA, bool SPREAD>
+template <int EPI, int WM, int WN, int TM, int TN, int NSA, bool SPREAD, bool PIPE = false>
 static int launch_cfg(const GemmArgs& g, hipStream_t s) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
   constexpr int LDS = (NSA * BM + 2 * BN) * BK * 2;
   const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<EPI, WM, WN, TM, TN, NSA, SPREAD>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<EPI, WM, WN, TM, TN, NSA, SPREAD, PIPE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_nt_kernel<EPI, WM, WN, TM, TN, NSA, SPREAD>), dim3(ntm * ntn), dim3(WM * WN * 64), LDS, s, g);
+  int grid = ntm * ntn;
+  if (BM == 256 && g_persist != 0xffff) {        // persistent: one workgroup per CU walks the tiles (+1.8 % per step)
+    static int cus = 0;
+    if (cus == 0) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+      if (cus <= 0) cus = 256;
+    }
+    const int slots = g_persist > 0 ? g_persist : cus;
+    if (grid > slots) grid = slots;
+  }
+  hipLaunchKernelGGL((gemm_nt_kernel<EPI, WM, WN, TM, TN, NSA, SPREAD, PIPE>), dim3(grid), dim3(WM * WN * 64), LDS, s, g);
   return check_launch("gemm_nt");
 }
 
 template <int EPI>
 static int launch(const GemmArgs& g, hipStream_t s) {
-  const bool big = g_variant == 2 || (g_variant == 0 && g.M >= 4096 && g.N % 256 == 0);
+  const bool big = g_variant >= 2 || (g_variant == 0 && g.M >= 4096 && g.N % 256 == 0);
+  if (big && g_variant == 3) return launch_cfg<EPI, 2, 2, 8, 8, 3, false, true>(g, s);   // 4 waves x 128x128, hand-pipelined
   if (big) return launch_cfg<EPI, 2, 4, 8, 4, 3, true>(g, s);
   return launch_cfg<EPI, 2, 2, 4, 4, 2, false>(g, s);
 }
 
 }  // namespace oat
 
-extern "C" void oat_gemm_set_variant(int v) { oat::g_variant = v & 0xff; oat::g_dbg = v >> 8; }
+extern "C" void oat_gemm_set_variant(int v) { oat::g_variant = v & 0xff; oat::g_dbg = (v >> 8) & 0xff; oat::g_persist = (v >> 16) & 0xffff; }
 
 extern "C" int oat_gemm_nt(const void* A, const void* B, int M, int N, int K, int lda, int ldb,
                            int epi, void* out, int ldc, void* out2, int ld2,

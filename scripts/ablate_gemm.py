@@ -18,8 +18,9 @@ for (m, n, k) in [(M, 768, 3072), (M, 2304, 768), (M, 768, 768), (M, 3072, 768),
     A = torch.randn(Mp, k, device="cuda").bfloat16(); B = (torch.randn(n, k, device="cuda") * k ** -0.5).bfloat16()
     bias = torch.randn(n, device="cuda"); out16 = torch.zeros(Mp, n, device="cuda", dtype=torch.bfloat16)
     for rep in range(2):
-        for dbg in (32, 32 + (2 << 8), 32 + (4 << 8), 32 + (6 << 8), 32 + (8 << 8)):
-            hip.gemm_set_variant(2 | (dbg << 8))
+      for VAR in (2, 2 | (256 << 16), 2 | (248 << 16)):
+        for dbg in (0,):
+            hip.gemm_set_variant(VAR | (dbg << 8))
             t = timeit(lambda: hip.gemm_nt(A, B, m, n, k, hip.EPI_BF16, out16, bias=bias))
-            print(f"N={n} K={k} dbg={dbg:5d}: {2*m*n*k/t/1e12:7.1f} TF/s ({t*1e6:7.1f} us)")
+            print(f"N={n} K={k} variant={VAR & 0xff} persist={VAR >> 16}: {2*m*n*k/t/1e12:7.1f} TF/s ({t*1e6:7.1f} us)")
 hip.gemm_set_variant(0)
