@@ -75,12 +75,16 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
   // tiles the hardware would have dispatched to that slot - so the store drain of one tile overlaps the
   // prologue loads of the next instead of an idle CU waiting for the old workgroup to retire.
   const int nwg = ntm * ntn;
+  auto remap = [&](int t) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = t & 7, idx = t >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;   // bijective
+  };
+  // PREF: while a tile's epilogue runs (scratch in the upper 96 KB of the ring), the first two A stages of the
+  // workgroup's NEXT tile are already streaming into A slots 0 and 1.
+  constexpr bool PREF = !PIPE && NSA == 3 && EPI != EPI_DGELU;
+  bool prefetched = false;
   for (int tile = blockIdx.x; tile < nwg; tile += gridDim.x) {
-  int bid = tile;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;   // bijective remap
-  }
+  const int bid = remap(tile);
   const int tm = bid / ntn, tn = bid % ntn;
   const int m0 = tm * BM, n0 = tn * BN;
 
@@ -119,6 +123,16 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
 
   const int nk = g.K / BK;
   const int frow = lane & 15, fk = lane >> 4;
+  // bias of this lane's output columns, requested before the main loop: fetched in the epilogue it costs one
+  // exposed global-load latency per tile (22 of 193 us at N = 2304, K = 768)
+  f32x4 bias_v[TN];
+  if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU_DUAL) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * TN * 16 + j * 16 + fk * 4;
+      bias_v[j] = (g.bias && col < g.N) ? *reinterpret_cast<const f32x4*>(g.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
   if constexpr (PIPE) {
     // One wave per SIMD (4 waves x 128x128): nothing hides a wave's own LDS latency or its barrier, so the
     // loop is software-pipelined by hand.  Fragments are double-buffered in registers (set 0 = k-half 0, set 1 =
@@ -195,13 +209,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
     kstep(kt, F_{}, F_{}, F_{});
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // MFMA -> accvgpr_read wait states (asm MFMAs are opaque)
   } else {
-  stageA(0, 0);
+  const bool have_a = PREF && prefetched;         // A(0), A(1) were issued during the previous tile's epilogue
+  if (!have_a) stageA(0, 0);
   stageB(0, 0);
-  if (NSA == 3 && nk > 1) stageA(1, BK);
+  if (NSA == 3 && nk > 1 && !have_a) stageA(1, BK);
   int abuf = 0;                                   // kt % NSA
   for (int kt = 0; kt < nk; ++kt) {
     // in flight after this wait: only A(kt+1) (issued last), everything older - A(kt), B(kt) - has landed
-    if (NSA == 3 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GA) : "memory");
+    // (after a prefetch B(0) is the youngest load, so step 0 waits for everything)
+    if (NSA == 3 && kt + 1 < nk && !(have_a && kt == 0)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GA) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                 // stage kt visible; everyone is done reading stage kt-1
     const bool moreB = kt + 1 < nk, moreA = NSA == 3 ? kt + 2 < nk : kt + 1 < nk;
@@ -266,8 +282,24 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
   // 64-row chunks through its own LDS scratch (the staging buffers are free now) and writes
   // FULL 128-byte lines, 16 B per lane; residual / aux loads use the same coalesced shape.
   __syncthreads();
+  prefetched = false;
+  if constexpr (PREF) {
+    const int tile_n = tile + (int)gridDim.x;
+    if (tile_n < nwg && nk > 1 && !(g.dbg & 2)) {
+      const int m0n = (remap(tile_n) / ntn) * BM;
+#pragma unroll
+      for (int i = 0; i < GA; ++i) {
+        const int r = (wave * GA + i) * 8 + srow;
+        const int lc = (lane & 7) ^ ((r >> 1) & 7);
+        a_src[i] = g.A + (size_t)min(m0n + r, g.M - 1) * g.lda + lc * 8;
+      }
+      stageA(0, 0);
+      stageA(1, BK);
+      prefetched = true;
+    }
+  }
   constexpr int EP = 144;                         // scratch row pitch: 128 B payload + 16 B pad
-  char* ep = smem + wave * (64 * EP);
+  char* ep = smem + (PREF ? 2 * A_BYTES : 0) + wave * (64 * EP);
   const int rrow = lane >> 3, rch = lane & 7;     // read phase: 8 rows x 8 chunks of 16 B
   const int wrow0 = m0 + wm * TM * 16;
   static_assert(TN % 4 == 0, "epilogue works on 64-column groups of the wave tile");
@@ -283,9 +315,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          f32x4 v = acc[rh * 4 + i][cg * 4 + j];
-          const int col = wcol0 + j * 16 + fk * 4;
-          if (g.bias && col < g.N) v += *reinterpret_cast<const f32x4*>(g.bias + col);
+          const f32x4 v = acc[rh * 4 + i][cg * 4 + j] + bias_v[cg * 4 + j];
           const bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
           *reinterpret_cast<bf16x4*>(ep + (i * 16 + frow) * EP + (j * 16 + fk * 4) * 2) = o;
         }
@@ -296,7 +326,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
         const int row = wrow0 + rh * 64 + lr, col = wcol0 + rch * 8;
         const bf16x8 hv = *reinterpret_cast<const bf16x8*>(ep + lr * EP + rch * 16);
         if (row < g.M && col < g.N) {
-          *reinterpret_cast<bf16x8*>((bf16*)g.out + (size_t)row * g.ldc + col) = hv;
+          const int orow = (g.dbg & 4) ? (row & 1023) : row;      // ablation: all row panels overwrite the first 1024 rows
+          if (!(g.dbg & 8)) *reinterpret_cast<bf16x8*>((bf16*)g.out + (size_t)orow * g.ldc + col) = hv;
+          else asm volatile("" ::"v"(hv));
           if constexpr (EPI == EPI_GELU_DUAL) {
             // GELU is evaluated on the bf16-rounded pre-activation so that backward (which only
             // has the saved bf16 h) differentiates exactly the function that forward applied.
