@@ -78,6 +78,13 @@ class GradSync:
         self.bucket = int(bucket_mb * (1 << 20) // 4)
         self._pending = []           # async work handles of this step
         self._covered = []           # [byte_lo, byte_hi) address ranges already handed to RCCL this step
+        W, _ = world()
+        if W > 1 and torch.cuda.is_available():
+            # RCCL's kernels hold CUs for the length of a collective.  A persistent GEMM launch (one workgroup per
+            # CU walking its tiles) that finds some CUs taken runs its remaining workgroups AFTER the others - up to
+            # twice the time; one workgroup per tile adapts to whatever CUs are free (1.4 % slower on an idle GPU).
+            from .ops import hip
+            hip.gemm_set_variant(0xffff << 16)
         if overlap:
             for m in model.modules():
                 if hasattr(m, "flat_grad") and hasattr(m, "_engine_params"):

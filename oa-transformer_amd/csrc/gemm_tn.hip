@@ -33,6 +33,7 @@ struct TnArgs {
   float* bias_slabs;       // [splits][N1] or nullptr
   int chunks_per_split;    // in units of TK rows
   int splits;
+  int dbg;                 // ablation bits: 1 = no global loads after the first stages, 2 = no slab store
 };
 
 template <int WM, int WN, int TM, int TN>
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_tn_kernel(TnArgs g) {
     else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (ch + NS - 1 < ch1) stage((ch + NS - 1 - ch0) % NS, ch + NS - 1);
+    if (ch + NS - 1 < ch1 && !(g.dbg & 1)) stage((ch + NS - 1 - ch0) % NS, ch + NS - 1);
     char* sp = smem + ((ch - ch0) % NS) * STAGE;
     char* sq = sp + P_BYTES;
     if (ch == nchunks_total - 1 && g.M - ch * TK < TK) {
@@ -185,7 +186,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_tn_kernel(TnArgs g) {
     for (int j = 0; j < TN; ++j) {
       const int c = c2 + w2 * TN * 16 + j * 16 + gq * 4;
       if (c >= g.N2) continue;
-      *reinterpret_cast<f32x4*>(slab + (size_t)r * g.N2 + c) = acc[i][j];
+      if (!(g.dbg & 2)) *reinterpret_cast<f32x4*>(slab + (size_t)r * g.N2 + c) = acc[i][j];
+      else asm volatile("" ::"v"(acc[i][j]));
     }
     if (do_bias && w2 == 0 && gq == 0) g.bias_slabs[(size_t)split * g.N1 + r] = accb[i][0];
   }
@@ -203,7 +205,7 @@ __global__ void tn_reduce_kernel(const float* slabs, float* out, int n4, int spl
   }
 }
 
-static int g_tn_variant = 0;   // 0 auto, 1 force 128^2, 2 force 256^2
+static int g_tn_variant = 0, g_tn_dbg = 0;   // 0 auto, 1 force 128^2, 2 force 256^2
 
 template <int WM, int WN, int TM, int TN>
 static int launch_tn(TnArgs g, int splits, float* out, float* bias_out, int accumulate, hipStream_t s) {
@@ -232,7 +234,7 @@ static int launch_tn(TnArgs g, int splits, float* out, float* bias_out, int accu
 
 }  // namespace oat
 
-extern "C" void oat_gemm_tn_set_variant(int v) { oat::g_tn_variant = v; }
+extern "C" void oat_gemm_tn_set_variant(int v) { oat::g_tn_variant = v & 0xff; oat::g_tn_dbg = v >> 8; }
 
 extern "C" size_t oat_gemm_tn_workspace_bytes(int M, int N1, int N2) {
   (void)M;
@@ -262,7 +264,7 @@ extern "C" int oat_gemm_tn(const void* P, const void* Q, int M, int N1, int N2, 
   if (need > workspace_bytes) { set_error("gemm_tn: workspace too small"); return -6; }
   float* slabs = (float*)workspace;
   TnArgs g{(const bf16*)P, (const bf16*)Q, M, N1, N2, ldp, ldq, slabs,
-           bias_out ? slabs + (size_t)splits * N1 * N2 : nullptr, cps, splits};
+           bias_out ? slabs + (size_t)splits * N1 * N2 : nullptr, cps, splits, g_tn_dbg};
   hipStream_t s = (hipStream_t)stream;
   if (big) return launch_tn<2, 4, 8, 4>(g, splits, out, bias_out, accumulate, s);
   return launch_tn<2, 2, 4, 4>(g, splits, out, bias_out, accumulate, s);
