@@ -64,7 +64,16 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_tn_kernel(TnArgs g) {
   const int nchunks_total = (g.M + TK - 1) / TK;
   const int ch0 = split * g.chunks_per_split;
   const int ch1 = min(ch0 + g.chunks_per_split, nchunks_total);
-  const bool do_bias = g.bias_slabs != nullptr && t2 == 0;
+  // bias column sums (an all-ones MFMA operand) are spread over the nt2 workgroups and WN waves that hold the
+  // same P tile, so that no wave carries more than ~2 extra MFMAs per chunk (all 8 on the t2 = 0, w2 = 0 waves
+  // made those workgroups - and with them the launch - 10 % slower)
+  unsigned bias_own = 0;                     // bit i: this wave sums P tile (w1, i)
+  if (g.bias_slabs != nullptr) {
+    const int owners = nt2 * WN;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+      if ((w1 * TM + i) % owners == t2 * WN + w2) bias_own |= 1u << i;
+  }
 
   // staging: one wave instruction moves 64 chunks = 64/CP rows of the P tile (64/CQ of the Q tile)
   int p_off[GP], q_off[GQ];
@@ -167,10 +176,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_tn_kernel(TnArgs g) {
 #pragma unroll
           for (int j = 0; j < TN; ++j)
             acc[i0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[j], pf[i], acc[i0 + i][j], 0, 0, 0);
-        if (do_bias && w2 == 0) {
+        if (bias_own) {
 #pragma unroll
           for (int i = 0; i < 4; ++i)
-            accb[i0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[i], accb[i0 + i], 0, 0, 0);
+            if (bias_own >> (i0 + i) & 1)
+              accb[i0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[i], accb[i0 + i], 0, 0, 0);
         }
       }
     }
@@ -189,19 +199,23 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_tn_kernel(TnArgs g) {
       if (!(g.dbg & 2)) *reinterpret_cast<f32x4*>(slab + (size_t)r * g.N2 + c) = acc[i][j];
       else asm volatile("" ::"v"(acc[i][j]));
     }
-    if (do_bias && w2 == 0 && gq == 0) g.bias_slabs[(size_t)split * g.N1 + r] = accb[i][0];
+    if ((bias_own >> i & 1) && gq == 0) g.bias_slabs[(size_t)split * g.N1 + r] = accb[i][0];
   }
 }
 
-// out[i] = (accumulate ? out[i] : 0) + sum_s slabs[s][i]     (i over n4 float4s)
+// out[i] = (accumulate ? out[i] : 0) + sum_s slabs[s][i] (i over n4 float4s) and, in the same launch, the same
+// reduction of the bias slabs (nb4 float4s; the items after n4)
 __global__ void tn_reduce_kernel(const float* slabs, float* out, int n4, int splits, size_t stride4,
-                                 int accumulate) {
-  const f32x4* s4 = reinterpret_cast<const f32x4*>(slabs);
-  f32x4* o4 = reinterpret_cast<f32x4*>(out);
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
-    f32x4 v = accumulate ? o4[i] : f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < splits; ++s) v += s4[(size_t)s * stride4 + i];
-    o4[i] = v;
+                                 const float* bslabs, float* bout, int nb4, int accumulate) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4 + nb4; i += gridDim.x * blockDim.x) {
+    const bool isb = i >= n4;
+    const int k = isb ? i - n4 : i;
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(isb ? bslabs : slabs);
+    f32x4* o4 = reinterpret_cast<f32x4*>(isb ? bout : out);
+    const size_t st = isb ? (size_t)nb4 : stride4;
+    f32x4 v = accumulate ? o4[k] : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < splits; ++s) v += s4[(size_t)s * st + k];
+    o4[k] = v;
   }
 }
 
@@ -221,14 +235,11 @@ static int launch_tn(TnArgs g, int splits, float* out, float* bias_out, int accu
   hipLaunchKernelGGL((gemm_tn_kernel<WM, WN, TM, TN>), dim3(tiles * splits), dim3(WM * WN * 64), LDS, s, g);
   int rc = check_launch("gemm_tn");
   if (rc) return rc;
-  const int n4 = g.N1 * g.N2 / 4;
-  int blocks = (n4 + 255) / 256;
+  const int n4 = g.N1 * g.N2 / 4, nb4 = bias_out ? g.N1 / 4 : 0;
+  int blocks = (n4 + nb4 + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(tn_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)g.slabs, out, n4, splits,
-                     (size_t)g.N1 * g.N2 / 4, accumulate);
-  if (bias_out)
-    hipLaunchKernelGGL(tn_reduce_kernel, dim3((g.N1 / 4 + 255) / 256), dim3(256), 0, s, (const float*)g.bias_slabs,
-                       bias_out, g.N1 / 4, splits, (size_t)g.N1 / 4, accumulate);
+                     (size_t)g.N1 * g.N2 / 4, (const float*)g.bias_slabs, bias_out, nb4, accumulate);
   return check_launch("gemm_tn_reduce");
 }
 
