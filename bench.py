@@ -61,7 +61,7 @@ def build(args, device):
     for m in (model.video_model, model.text_model):
         m.flatten_parameters()
     dp = HipDataParallel(model)
-    opt = AdamW([p for p in model.parameters() if p.requires_grad], lr=2e-4)
+    opt = AdamW([p for p in model.parameters() if p.requires_grad], lr=args.lr)
     loss_fn = module_arch.NormSoftmaxLoss()
     return dp, opt, loss_fn
 
@@ -167,6 +167,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
     ap.add_argument("--frames", type=int, default=8)
+    ap.add_argument("--lr", type=float, default=2e-5,
+                    help="AdamW step size (the reference config uses 2e-4 on PRETRAINED towers; random-init towers on one repeated "
+                         "synthetic batch spike at that value, which says nothing about throughput but makes final_loss useless)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", choices=["frozen", "region_mem", "global_local"], default="frozen",
                     help="frozen = oa_model.FrozenInTime (headline); the OA variants view the F input frames as 2B clips of "

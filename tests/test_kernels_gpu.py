@@ -283,3 +283,25 @@ def test_attention_fwd_bwd(mode, B, T, N, H):
     gs = gref.abs().max().item()
     close(dqkv[:M], gref, atol=2e-2 * gs, rtol=3e-2, what=f"{mode} attention bwd")
     assert torch.count_nonzero(dqkv[M:]) == 0
+
+
+def test_cast_bf16_multi_assembles_concatenated_shadows():
+    """oat_cast_bf16_multi: several masters -> bf16 W / W^T in ONE launch, including row / column slices of a
+    concatenated shadow (how DistilBERT's q|k|v weight is assembled).  Bit-exact vs torch casts."""
+    from OATrans.ops import hip
+    torch.manual_seed(0)
+    q, k, v = (torch.randn(96, 64, device="cuda") for _ in range(3))
+    w1 = torch.randn(200, 72, device="cuda")          # ragged: not multiples of the 32x32 tile
+    cat = torch.zeros(288, 64, dtype=torch.bfloat16, device="cuda")
+    catT = torch.zeros(64, 288, dtype=torch.bfloat16, device="cuda")
+    s1 = torch.zeros(200, 72, dtype=torch.bfloat16, device="cuda")
+    s1T = torch.zeros(72, 200, dtype=torch.bfloat16, device="cuda")
+    only_t = torch.zeros(64, 96, dtype=torch.bfloat16, device="cuda")
+    entries = [(m, cat[j * 96:(j + 1) * 96], catT[:, j * 96:(j + 1) * 96], 64, 288) for j, m in enumerate((q, k, v))]
+    entries += [(w1, s1, s1T, 72, 200), (q, None, only_t, 0, 96)]
+    hip.CastTable(entries).run()
+    torch.cuda.synchronize()
+    ref = torch.cat([q, k, v], 0).bfloat16()
+    assert torch.equal(cat, ref) and torch.equal(catT, ref.t().contiguous())
+    assert torch.equal(s1, w1.bfloat16()) and torch.equal(s1T, w1.bfloat16().t().contiguous())
+    assert torch.equal(only_t, q.bfloat16().t().contiguous())
