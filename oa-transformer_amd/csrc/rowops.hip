@@ -7,6 +7,7 @@
 //   VideoPatchEmbed conv     :69-75            (im2col feeding the patch GEMM)
 //   cls/pos/temporal tables  :313-324
 #include "common.h"
+#include <stdlib.h>
 
 namespace oat {
 
@@ -353,7 +354,12 @@ extern "C" int oat_add_layernorm_fwd(const float* x, int ldx, const void* add16,
   return ln_fwd_launch(x, ldx, gamma, beta, y, ldy, y32, ldy32, mean, rstd, M, D, eps, add16, ldadd, sum32, ldsum, stream);
 }
 
-extern "C" int oat_ln_bwd_blocks(int M) { int b = (M + 3) / 4; return b > 512 ? 512 : b; }
+static int ln_bwd_cap() {
+  static int cap = 0;
+  if (cap == 0) { const char* e = getenv("OAT_LN_BWD_BLOCKS"); cap = e ? atoi(e) : 1024; if (cap < 1) cap = 1024; }
+  return cap;
+}
+extern "C" int oat_ln_bwd_blocks(int M) { int b = (M + 3) / 4; const int cap = ln_bwd_cap(); return b > cap ? cap : b; }
 
 // part: fp32 workspace of oat_ln_bwd_blocks(M) * 2 * D floats (or NULL to skip dgamma/dbeta)
 extern "C" int oat_layernorm_bwd(const void* dy, int dy_is_bf16, int lddy, const float* x, int ldx,
