@@ -41,7 +41,8 @@ int oat_gemm_nt(const void* A, const void* B, int M, int N, int K, int lda, int 
 void oat_gemm_set_variant(int v);
 
 /* out[N1,N2] (fp32, (+)=) sum_m P[m,N1]^T Q[m,N2]  - weight gradients of every nn.Linear.
- * Rows [M, round_up(M,64)) of P and Q must be readable (contents ignored). */
+ * Rows [M, round_up(M,64)) of P and Q must be readable (contents ignored).
+ * workspace: fp32 split-M slabs; oat_gemm_tn_workspace_bytes(M, ..) is exact for that launch, M <= 0 the worst case. */
 size_t oat_gemm_tn_workspace_bytes(int M, int N1, int N2);
 int oat_gemm_tn(const void* P, const void* Q, int M, int N1, int N2, int ldp, int ldq, float* out,
                 float* bias_out /* [N1] column sums of P, or NULL */, int accumulate, void* workspace,

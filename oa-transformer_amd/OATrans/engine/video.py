@@ -171,8 +171,6 @@ class VideoEngine:
             two = self.lanes == 2
             self._streams = dict(lane1=torch.cuda.Stream() if two else None, wgrad=torch.cuda.Stream(),
                                  side=[torch.cuda.Stream(), torch.cuda.Stream() if two else None])
-            self._tn_ws = torch.empty(hip.lib().oat_gemm_tn_workspace_bytes(0, 3 * self.D, self.Hd) // 4 // 8,
-                                      dtype=torch.float32, device=dev)
         return self._streams
 
     # ------------------------------------------------------------------ forward
@@ -378,6 +376,10 @@ class VideoEngine:
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())   # P was produced by everything enqueued on this lane so far
         wg.wait_event(ev)
+        need = hip.lib().oat_gemm_tn_workspace_bytes(rows, n1, n2) // 4     # exact for this (rows, shape)
+        if self._tn_ws is None or self._tn_ws.numel() < need:
+            with torch.cuda.stream(wg):                 # one slab workspace for the (serial) wgrad stream, grown on demand
+                self._tn_ws = torch.empty(need, dtype=torch.float32, device=P.device)
         with torch.cuda.stream(wg):
             hip.gemm_tn(P, Q, rows, n1, n2, w, bias_out=b, ws=self._tn_ws, accumulate=(ln.index == 1))
 

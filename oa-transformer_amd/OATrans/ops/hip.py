@@ -100,8 +100,8 @@ def _stream_key(device):
     return (str(device), torch.cuda.current_stream().cuda_stream)
 
 
-def tn_workspace(device, N1, N2):
-    need = lib().oat_gemm_tn_workspace_bytes(0, N1, N2)
+def tn_workspace(device, M, N1, N2):
+    need = lib().oat_gemm_tn_workspace_bytes(M, N1, N2)
     key = _stream_key(device)
     ws = _tn_ws.get(key)
     if ws is None or ws.numel() * 4 < need:
@@ -115,7 +115,7 @@ def gemm_tn(P, Q, M, N1, N2, out, accumulate=False, ldp=None, ldq=None, bias_out
     `ws`: caller-owned fp32 slab workspace (a launch stream needs its own; default = a per-device one
     for the current stream)."""
     if ws is None:
-        ws = tn_workspace(out.device, N1, N2)
+        ws = tn_workspace(out.device, M, N1, N2)
     rc = lib().oat_gemm_tn(_ptr(P), _ptr(Q), M, N1, N2, ldp or P.stride(0), ldq or Q.stride(0), _ptr(out),
                            _ptr(bias_out), int(accumulate), _ptr(ws), ctypes.c_size_t(ws.numel() * 4), _stream())
     _check(rc, "oat_gemm_tn")

@@ -161,15 +161,19 @@ __global__ __launch_bounds__(FWD_THREADS) void attn_space_fwd_kernel(SpaceArgs a
   }
 }
 
-template <int NKT>
+// BIG (frames of 224..447 patches, e.g. 336^2 / 16 -> 441): four [NKP][64] tiles no longer fit the LDS, but
+// neither phase needs all four.  Phase A (dQ) streams over K and V and touches Q / dO only as the per-wave row
+// fragments; phase B (dK, dV) is the mirror image.  So LDS holds TWO tiles: K, V during phase A, then - after a
+// barrier - Q, dO for phase B, and the per-wave row fragments come straight from global memory.
+template <int NKT, bool BIG>
 __global__ __launch_bounds__(BWD_THREADS) void attn_space_bwd_kernel(SpaceArgs a) {
   constexpr int NKP = NKT * 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Qt = smem;
-  char* Kt = smem + NKP * 128;
-  char* Vt = smem + 2 * NKP * 128;
-  char* Dt = smem + 3 * NKP * 128;                       // dO tile
-  float* lse_s = reinterpret_cast<float*>(smem + 4 * NKP * 128);
+  char* Kt = smem;
+  char* Vt = smem + NKP * 128;
+  char* Qt = BIG ? Kt : smem + 2 * NKP * 128;            // BIG: aliases, valid in phase B only
+  char* Dt = BIG ? Vt : smem + 3 * NKP * 128;            // dO tile
+  float* lse_s = reinterpret_cast<float*>(smem + (BIG ? 2 : 4) * NKP * 128);
   float* del_s = lse_s + NKP;
   const int h = blockIdx.x % a.H;
   const int bf = blockIdx.x / a.H;
@@ -177,10 +181,16 @@ __global__ __launch_bounds__(BWD_THREADS) void attn_space_bwd_kernel(SpaceArgs a
   const int N = a.N;
   const size_t base_row = (size_t)bf * N;
   const size_t cls_row = (size_t)a.B * a.T * N + b;
-  load_tile<NKT, BWD_THREADS>(Qt, a.qkv, a.ldqkv, h * 64, base_row, cls_row, N);
+  if (!BIG) load_tile<NKT, BWD_THREADS>(Qt, a.qkv, a.ldqkv, h * 64, base_row, cls_row, N);
   load_tile<NKT, BWD_THREADS>(Kt, a.qkv, a.ldqkv, a.D + h * 64, base_row, cls_row, N);
   load_tile<NKT, BWD_THREADS>(Vt, a.qkv, a.ldqkv, 2 * a.D + h * 64, base_row, cls_row, N);
-  load_tile<NKT, BWD_THREADS>(Dt, a.dout, a.lddo, h * 64, base_row, cls_row, N);
+  if (!BIG) load_tile<NKT, BWD_THREADS>(Dt, a.dout, a.lddo, h * 64, base_row, cls_row, N);
+  // row fragment of a token-row matrix straight from global memory (same element order as row_frag on a tile)
+  auto grow_frag = [&](const bf16* src, int ld, int col, int r0, int ks, int lane_) {
+    const int j = r0 + (lane_ & 15);
+    const size_t r = j < N ? base_row + j : cls_row;
+    return *reinterpret_cast<const bf16x8*>(src + r * ld + col + (ks * 4 + (lane_ >> 4)) * 8);
+  };
   // delta = rowsum(dO * O) and lse (log2 units), 8 lanes per row; all loads issued before the first use
   {
     constexpr int ITER = (NKP * 8 + BWD_THREADS - 1) / BWD_THREADS;
@@ -235,8 +245,13 @@ __global__ __launch_bounds__(BWD_THREADS) void attn_space_bwd_kernel(SpaceArgs a
     bf16x8 qfA[2], dfA[2], qfB[2], dfB[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      qfA[ks] = row_frag(Qt, qt0 * 16, ks, lane); dfA[ks] = row_frag(Dt, qt0 * 16, ks, lane);
-      qfB[ks] = row_frag(Qt, qt0 * 16 + 16, ks, lane); dfB[ks] = row_frag(Dt, qt0 * 16 + 16, ks, lane);
+      if constexpr (BIG) {
+        qfA[ks] = grow_frag(a.qkv, a.ldqkv, h * 64, qt0 * 16, ks, lane); dfA[ks] = grow_frag(a.dout, a.lddo, h * 64, qt0 * 16, ks, lane);
+        qfB[ks] = grow_frag(a.qkv, a.ldqkv, h * 64, qt0 * 16 + 16, ks, lane); dfB[ks] = grow_frag(a.dout, a.lddo, h * 64, qt0 * 16 + 16, ks, lane);
+      } else {
+        qfA[ks] = row_frag(Qt, qt0 * 16, ks, lane); dfA[ks] = row_frag(Dt, qt0 * 16, ks, lane);
+        qfB[ks] = row_frag(Qt, qt0 * 16 + 16, ks, lane); dfB[ks] = row_frag(Dt, qt0 * 16 + 16, ks, lane);
+      }
     }
     f32x4 dqA[4], dqB[4];
 #pragma unroll
@@ -298,6 +313,12 @@ __global__ __launch_bounds__(BWD_THREADS) void attn_space_bwd_kernel(SpaceArgs a
   }
 
   // ------------------------------------------------ phase B: lane = key column, produces dK, dV
+  if constexpr (BIG) {
+    __syncthreads();                                      // every wave is done with K, V in LDS
+    load_tile<NKT, BWD_THREADS>(Qt, a.qkv, a.ldqkv, h * 64, base_row, cls_row, N);
+    load_tile<NKT, BWD_THREADS>(Dt, a.dout, a.lddo, h * 64, base_row, cls_row, N);
+    __syncthreads();
+  }
   for (int pr = wave; pr * 2 < ntile; pr += BWD_THREADS / 64) {
     const int kt0 = pr * 2;
     const bool two = kt0 + 1 < ntile;
@@ -305,8 +326,13 @@ __global__ __launch_bounds__(BWD_THREADS) void attn_space_bwd_kernel(SpaceArgs a
     bf16x8 kfA[2], vfA[2], kfB[2], vfB[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      kfA[ks] = row_frag(Kt, kt0 * 16, ks, lane); vfA[ks] = row_frag(Vt, kt0 * 16, ks, lane);
-      kfB[ks] = row_frag(Kt, kt0 * 16 + 16, ks, lane); vfB[ks] = row_frag(Vt, kt0 * 16 + 16, ks, lane);
+      if constexpr (BIG) {
+        kfA[ks] = grow_frag(a.qkv, a.ldqkv, a.D + h * 64, kt0 * 16, ks, lane); vfA[ks] = grow_frag(a.qkv, a.ldqkv, 2 * a.D + h * 64, kt0 * 16, ks, lane);
+        kfB[ks] = grow_frag(a.qkv, a.ldqkv, a.D + h * 64, kt0 * 16 + 16, ks, lane); vfB[ks] = grow_frag(a.qkv, a.ldqkv, 2 * a.D + h * 64, kt0 * 16 + 16, ks, lane);
+      } else {
+        kfA[ks] = row_frag(Kt, kt0 * 16, ks, lane); vfA[ks] = row_frag(Vt, kt0 * 16, ks, lane);
+        kfB[ks] = row_frag(Kt, kt0 * 16 + 16, ks, lane); vfB[ks] = row_frag(Vt, kt0 * 16 + 16, ks, lane);
+      }
     }
     f32x4 dkA[4], dvA[4], dkB[4], dvB[4];
 #pragma unroll
@@ -400,18 +426,18 @@ static int launch_fwd(const SpaceArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(attn_space_fwd_kernel<NKT>, dim3(a.B * a.T * a.H), dim3(FWD_THREADS), lds, s, a);
   return check_launch("attn_space_fwd");
 }
-template <int NKT>
+template <int NKT, bool BIG = false>
 static int launch_bwd(const SpaceArgs& a, hipStream_t s) {
-  const int lds = 4 * NKT * 16 * 128 + 2 * NKT * 16 * 4;
+  const int lds = (BIG ? 2 : 4) * NKT * 16 * 128 + 2 * NKT * 16 * 4;
   static bool set = false;
-  if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_space_bwd_kernel<NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
-  hipLaunchKernelGGL(attn_space_bwd_kernel<NKT>, dim3(a.B * a.T * a.H), dim3(BWD_THREADS), lds, s, a);
+  if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_space_bwd_kernel<NKT, BIG>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
+  hipLaunchKernelGGL((attn_space_bwd_kernel<NKT, BIG>), dim3(a.B * a.T * a.H), dim3(BWD_THREADS), lds, s, a);
   return check_launch("attn_space_bwd");
 }
 
 static int pick_nkt(int N) {
   const int need = (N + 1 + 31) / 32 * 2;     // even number of 16-key tiles
-  const int opts[] = {2, 4, 8, 14};
+  const int opts[] = {2, 4, 8, 14, 28};
   for (int o : opts) if (o >= need) return o;
   return -1;
 }
@@ -424,14 +450,15 @@ extern "C" int oat_attn_space_fwd(const void* qkv, int ldqkv, void* out, int ldo
                                   int H, int D, float scale, void* stream) {
   if (D != H * 64) { set_error("attn_space: head_dim must be 64"); return -3; }
   const int nkt = pick_nkt(N);
-  if (nkt < 0) { set_error("attn_space: patches per frame > 223 not supported by this build"); return -3; }
+  if (nkt < 0) { set_error("attn_space: patches per frame > 447 not supported by this build"); return -3; }
   SpaceArgs a{(const bf16*)qkv, ldqkv, (bf16*)out, ldo, lse, nullptr, 0, nullptr, 0, nullptr, B, T, N, H, D, scale};
   hipStream_t s = (hipStream_t)stream;
   switch (nkt) {
     case 2: return launch_fwd<2>(a, s);
     case 4: return launch_fwd<4>(a, s);
     case 8: return launch_fwd<8>(a, s);
-    default: return launch_fwd<14>(a, s);
+    case 14: return launch_fwd<14>(a, s);
+    default: return launch_fwd<28>(a, s);
   }
 }
 
@@ -442,7 +469,7 @@ extern "C" int oat_attn_space_bwd(const void* qkv, int ldqkv, const void* out, i
                                   int N, int H, int D, float scale, void* stream) {
   if (D != H * 64) { set_error("attn_space: head_dim must be 64"); return -3; }
   const int nkt = pick_nkt(N);
-  if (nkt < 0) { set_error("attn_space: patches per frame > 223 not supported by this build"); return -3; }
+  if (nkt < 0) { set_error("attn_space: patches per frame > 447 not supported by this build"); return -3; }
   SpaceArgs a{(const bf16*)qkv, ldqkv, (bf16*)out, ldo, (float*)lse, (const bf16*)dout, lddo, (bf16*)dqkv, lddqkv,
               cls_side, B, T, N, H, D, scale};
   hipStream_t s = (hipStream_t)stream;
@@ -450,7 +477,8 @@ extern "C" int oat_attn_space_bwd(const void* qkv, int ldqkv, const void* out, i
     case 2: return launch_bwd<2>(a, s);
     case 4: return launch_bwd<4>(a, s);
     case 8: return launch_bwd<8>(a, s);
-    default: return launch_bwd<14>(a, s);
+    case 14: return launch_bwd<14>(a, s);
+    default: return launch_bwd<28, true>(a, s);
   }
 }
 

@@ -247,19 +247,9 @@ static int launch_tn(TnArgs g, int splits, float* out, float* bias_out, int accu
 
 extern "C" void oat_gemm_tn_set_variant(int v) { oat::g_tn_variant = v & 0xff; oat::g_tn_dbg = v >> 8; }
 
-extern "C" size_t oat_gemm_tn_workspace_bytes(int M, int N1, int N2) {
-  (void)M;
-  return (size_t)32 * ((size_t)N1 * N2 + N1) * sizeof(float);      // worst case 32 splits, + bias slabs
-}
-
-// out[N1,N2] (+)= P^T Q ; bias_out[N1] (+)= column sums of P (NULL to skip)
-extern "C" int oat_gemm_tn(const void* P, const void* Q, int M, int N1, int N2, int ldp, int ldq,
-                           float* out, float* bias_out, int accumulate, void* workspace, size_t workspace_bytes,
-                           void* stream) {
+// tile shape and split count of a launch (shared by the launcher and the workspace query)
+static void tn_plan(int M, int N1, int N2, bool* big_, int* splits_, int* cps_) {
   using namespace oat;
-  if (M <= 0 || N1 <= 0 || N2 <= 0) { set_error("gemm_tn: empty problem"); return -1; }
-  if (N1 % 8 || N2 % 8 || ldp % 8 || ldq % 8) { set_error("gemm_tn: N1,N2,ldp,ldq must be multiples of 8"); return -3; }
-  if (!P || !Q || !out || !workspace) { set_error("gemm_tn: null pointer"); return -4; }
   const bool big = g_tn_variant == 2 || (g_tn_variant == 0 && M >= 4096 && N1 % 256 == 0 && N2 % 256 == 0);
   const int B = big ? 256 : 128;
   const int tiles = ((N1 + B - 1) / B) * ((N2 + B - 1) / B);
@@ -271,6 +261,27 @@ extern "C" int oat_gemm_tn(const void* P, const void* Q, int M, int N1, int N2, 
   if (splits > nchunks) splits = nchunks;
   const int cps = (nchunks + splits - 1) / splits;
   splits = (nchunks + cps - 1) / cps;
+  *big_ = big; *splits_ = splits; *cps_ = cps;
+}
+
+// M > 0: exact need of that launch; M <= 0: worst case over every M (32 splits)
+extern "C" size_t oat_gemm_tn_workspace_bytes(int M, int N1, int N2) {
+  int splits = 32, cps = 0;
+  bool big = false;
+  if (M > 0) tn_plan(M, N1, N2, &big, &splits, &cps);
+  return (size_t)splits * ((size_t)N1 * N2 + N1) * sizeof(float);      // weight slabs + bias slabs
+}
+
+// out[N1,N2] (+)= P^T Q ; bias_out[N1] (+)= column sums of P (NULL to skip)
+extern "C" int oat_gemm_tn(const void* P, const void* Q, int M, int N1, int N2, int ldp, int ldq,
+                           float* out, float* bias_out, int accumulate, void* workspace, size_t workspace_bytes,
+                           void* stream) {
+  using namespace oat;
+  if (M <= 0 || N1 <= 0 || N2 <= 0) { set_error("gemm_tn: empty problem"); return -1; }
+  if (N1 % 8 || N2 % 8 || ldp % 8 || ldq % 8) { set_error("gemm_tn: N1,N2,ldp,ldq must be multiples of 8"); return -3; }
+  if (!P || !Q || !out || !workspace) { set_error("gemm_tn: null pointer"); return -4; }
+  bool big; int splits, cps;
+  tn_plan(M, N1, N2, &big, &splits, &cps);
   const size_t need = (size_t)splits * ((size_t)N1 * N2 + N1) * sizeof(float);
   if (need > workspace_bytes) { set_error("gemm_tn: workspace too small"); return -6; }
   float* slabs = (float*)workspace;

@@ -138,3 +138,30 @@ def test_two_lanes_match_single_lane():
     for k, g1 in res[0][1].items():
         e = rel(res[1][1][k], g1)
         assert e < 1e-4, (k, e)
+
+
+def test_336_geometry_vs_oracle():
+    """336^2 frames (441 patches per frame: BASELINE config 5's geometry) run the two-stage-LDS space attention
+    (csrc/attn_space.hip, NKT = 28).  Encoder outputs and every parameter gradient against the CPU oracle."""
+    from OATrans.model.video_transformer import SpaceTimeTransformer
+    from oracle import oatrans_oracle as orc
+    geo = dict(embed_dim=128, depth=2, mlp_ratio=4, num_frames=2, patches_per_frame=441, patch=16)
+    m = SpaceTimeTransformer(img_size=336, patch_size=16, embed_dim=128, depth=2, num_heads=2, num_frames=2, time_init="rand")
+    m.head = torch.nn.Identity()
+    sd = si.seeded_state_dict(si.video_param_shapes(**geo), SEED, "video_model.")
+    r = m.load_state_dict({k[len("video_model."):]: v for k, v in sd.items()}, strict=False)
+    assert not r.unexpected_keys and not r.missing_keys, r
+    m = m.cuda()
+    video = si.seeded_tensor(SEED, "in.video.336", (2, 2, 3, 336, 336)).cuda()
+    cls, patches = m(video)
+    gc = si.seeded_tensor(SEED, "g.cls.336", cls.shape)
+    gp = si.seeded_tensor(SEED, "g.patches.336", patches.shape, std=0.05)
+    ((cls * gc.cuda()).sum() + (patches * gp.cuda()).sum()).backward()
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ocls, opatches = orc.video_encoder(video.cpu(), p, num_heads=2)
+    ((ocls * gc).sum() + (opatches * gp).sum()).backward()
+    assert rel(cls, ocls) < 1e-2 and rel(patches, opatches) < 1e-2, (rel(cls, ocls), rel(patches, opatches))
+    for k, prm in m.named_parameters():
+        ref = p["video_model." + k].grad
+        e, c = rel(prm.grad, ref), cosine(prm.grad, ref)
+        assert e < 3e-2 and c > 0.999, (k, e, c)
