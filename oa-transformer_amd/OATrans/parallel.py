@@ -83,7 +83,10 @@ class GradSync:
             # RCCL's kernels hold CUs for the length of a collective.  A persistent GEMM launch (one workgroup per
             # CU walking its tiles) that finds some CUs taken runs its remaining workgroups AFTER the others - up to
             # twice the time; one workgroup per tile adapts to whatever CUs are free (1.4 % slower on an idle GPU).
-            from .ops import hip
+            try:
+                from .ops import hip
+            except ImportError:                      # entry points run from inside OATrans/ import us as a top-level module
+                from ops import hip
             hip.gemm_set_variant(0xffff << 16)
         if overlap:
             for m in model.modules():
