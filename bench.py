@@ -176,6 +176,10 @@ def main():
                          "F/2 frames (object stream + video stream); their mask-pool / region-BCE shapes are only valid "
                          "for F = 2, exactly as in the reference")
     args = ap.parse_args()
+    if args.variant != "frozen" and args.frames != 2:
+        print(f"### --variant {args.variant}: patch masks live on one frame's 14x14 grid, so the OA clips are single-frame "
+              "(2 input frames = object frame + video frame, SURVEY.md 8a a16); running with --frames 2", file=sys.stderr)
+        args.frames = 2
     world = int(os.environ.get("WORLD_SIZE", 1))
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -216,12 +220,13 @@ def main():
     pairs = world * args.batch * args.steps
     value = pairs / elapsed
     gf_pair = flops_per_pair(args.frames) / 1e9
+    cls_name = {"frozen": "oa_model", "region_mem": "oa_model_region_mem", "global_local": "oa_model_global_local"}[args.variant]
     out = {
         "metric": "video-text pairs/sec fwd+bwd, 8-frame ViT-B/16, 1/2/4/8 MI355X",
         "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"[{args.variant}] {args.frames}-frame 224^2 ViT-B/16 SpaceTimeTransformer + DistilBERT-base (oa_model.FrozenInTime), "
+        "config": {"workload": f"[{args.variant}] {args.frames}-frame 224^2 ViT-B/16 SpaceTimeTransformer + DistilBERT-base ({cls_name}.FrozenInTime), "
                                f"bs {args.batch}/GPU, Lt 32, fwd+bwd+AdamW, InfoNCE over all-gathered embeddings",
                    "per_gpu_batch": args.batch, "global_batch": world * args.batch, "frames": args.frames,
                    "parallelism": f"dp{world}", "gflop_per_pair": round(gf_pair, 1)},

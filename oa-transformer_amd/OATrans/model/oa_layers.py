@@ -106,12 +106,21 @@ class _BmmFn(torch.autograd.Function):
 def mask_pool(masks, feats):
     """einsum('b o l, b l c -> b o c') (oa_model_global_local.py:178,200)"""
     _need_cuda(feats, "mask_pool")
+    if masks.dim() != 3 or feats.dim() != 3 or masks.shape[0] != feats.shape[0] or masks.shape[2] != feats.shape[1]:
+        # the reference's einsum raises on the same inputs: patch masks live on ONE frame's 14x14 grid, so the OA
+        # clips must be single-frame (2-frame loader batches; SURVEY.md 8a a16)
+        raise RuntimeError(f"mask_pool: einsum('b o l, b l c -> b o c') needs masks [B,O,L] and feats [B,L,C]; got "
+                           f"{tuple(masks.shape)} and {tuple(feats.shape)}")
     return _BmmFn.apply(masks, feats, False, False)
 
 
 def region_sim(text_regions, object_regions):
     """sigmoid(einsum('b k f, b n f -> b k n')) (oa_model_region_mem.py:147-151)"""
     _need_cuda(object_regions, "region_sim")
+    if text_regions.dim() != 3 or object_regions.dim() != 3 or text_regions.shape[0] != object_regions.shape[0] \
+            or text_regions.shape[2] != object_regions.shape[2]:
+        raise RuntimeError(f"region_sim: einsum('b k f, b n f -> b k n') got {tuple(text_regions.shape)} and "
+                           f"{tuple(object_regions.shape)}")
     return _BmmFn.apply(text_regions, object_regions, True, True)
 
 
@@ -133,4 +142,7 @@ class _BceSumFn(torch.autograd.Function):
 def bce_sum(p, y):
     """nn.BCELoss(reduction='sum') (trainer_region_mem.py:97,166)"""
     _need_cuda(p, "bce_sum")
+    if p.shape != y.shape:        # F.binary_cross_entropy raises the same way (target size != input size)
+        raise ValueError(f"Using a target size ({tuple(y.shape)}) that is different to the input size ({tuple(p.shape)}) "
+                         "is deprecated. Please ensure they have the same size.")
     return _BceSumFn.apply(p, y)
