@@ -36,6 +36,7 @@ struct GemmArgs {
   const float* resid; int ldr; int resid_mod;
   const bf16* aux; int ldaux;
   int dbg;
+  int row0;            // first row of this launch inside the caller's problem (tail launches; used by resid_mod)
 };
 
 constexpr int BK = 64;
@@ -388,7 +389,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
             if (g.bias) v += *reinterpret_cast<const f32x4*>(g.bias + col);
             if constexpr (EPI == EPI_F32 || EPI == EPI_F32_BF16) {
               if (g.resid) {
-                const int rr = g.resid_mod > 0 ? row % g.resid_mod : row;
+                const int rr = g.resid_mod > 0 ? (row + g.row0) % g.resid_mod : row;
                 v += *reinterpret_cast<const f32x4*>(g.resid + (size_t)rr * g.ldr + col);
               }
               *reinterpret_cast<f32x4*>((float*)g.out + (size_t)row * g.ldc + col) = v;
@@ -419,6 +420,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
 // persist 0 = one workgroup per CU, 0xffff = one workgroup per tile, else the grid size
 static int g_variant = 0, g_dbg = 0, g_persist = 0;
 
+static int cu_count() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
+
 template <int EPI, int WM, int WN, int TM, int TN, int NSA, bool SPREAD, bool PIPE = false>
 static int launch_cfg(const GemmArgs& g, hipStream_t s) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
@@ -432,14 +444,7 @@ static int launch_cfg(const GemmArgs& g, hipStream_t s) {
   }
   int grid = ntm * ntn;
   if (BM == 256 && g_persist != 0xffff) {        // persistent: one workgroup per CU walks the tiles (+1.8 % per step)
-    static int cus = 0;
-    if (cus == 0) {
-      int dev = 0;
-      hipDeviceProp_t prop;
-      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-      if (cus <= 0) cus = 256;
-    }
-    const int slots = g_persist > 0 ? g_persist : cus;
+    const int slots = g_persist > 0 ? g_persist : cu_count();
     if (grid > slots) grid = slots;
   }
   hipLaunchKernelGGL((gemm_nt_kernel<EPI, WM, WN, TM, TN, NSA, SPREAD, PIPE>), dim3(grid), dim3(WM * WN * 64), LDS, s, g);
@@ -450,7 +455,36 @@ template <int EPI>
 static int launch(const GemmArgs& g, hipStream_t s) {
   const bool big = g_variant >= 2 || (g_variant == 0 && g.M >= 4096 && g.N % 256 == 0);
   if (big && g_variant == 3) return launch_cfg<EPI, 2, 2, 8, 8, 3, false, true>(g, s);   // 4 waves x 128x128, hand-pipelined
-  if (big) return launch_cfg<EPI, 2, 4, 8, 4, 3, true>(g, s);
+  if (big) {
+    // Tail split.  256x256 tiles leave the last round of workgroups mostly empty when tiles % CUs is small (N = 768 at
+    // M = 50208: 591 tiles = 2.31 rounds -> a third round with 79 of 256 CUs busy).  The row panels of the full rounds
+    // go to the 256x256 kernel, the remaining rows to the 128x128 configuration (two workgroups per CU), whose quarter
+    // tiles fill the machine once more: same per-element arithmetic, bit-identical results, no workspace.
+    const int ntm = (g.M + 255) / 256, ntn = (g.N + 255) / 256, cus = cu_count();
+    const int T = ntm * ntn, R = T / cus, r = T - R * cus;
+    const int panels_main = R * cus / ntn;
+    // Measured: +5...9 % per launch at R = 2 (-1.6 % at R = 9) on an idle GPU, but -1 % for the training step, where
+    // the weight-gradient stream already fills that third round and an exact two-round fit has no slack when a few
+    // CUs are busy at launch.  Opt-in (ablation bit 64).
+    if ((g_dbg & 64) && R >= 1 && R <= 4 && r > 0 && r * 10 < cus * 7 && panels_main >= 1 && panels_main < ntm) {
+      const int M1 = panels_main * 256;
+      GemmArgs a = g;
+      a.M = M1;
+      int rc = launch_cfg<EPI, 2, 4, 8, 4, 3, true>(a, s);
+      if (rc) return rc;
+      GemmArgs b = g;
+      const size_t osz = (EPI == EPI_F32 || EPI == EPI_F32_BF16) ? 4 : 2;
+      b.M = g.M - M1;
+      b.row0 = g.row0 + M1;
+      b.A = g.A + (size_t)M1 * g.lda;
+      b.out = (char*)g.out + (size_t)M1 * g.ldc * osz;
+      if (g.out2) b.out2 = (char*)g.out2 + (size_t)M1 * g.ld2 * 2;
+      if (g.aux) b.aux = g.aux + (size_t)M1 * g.ldaux;
+      if (g.resid && g.resid_mod <= 0) b.resid = g.resid + (size_t)M1 * g.ldr;
+      return launch_cfg<EPI, 2, 2, 4, 4, 2, false>(b, s);
+    }
+    return launch_cfg<EPI, 2, 4, 8, 4, 3, true>(g, s);
+  }
   return launch_cfg<EPI, 2, 2, 4, 4, 2, false>(g, s);
 }
 
@@ -470,7 +504,7 @@ extern "C" int oat_gemm_nt(const void* A, const void* B, int M, int N, int K, in
   }
   if (!A || !B || !out) { set_error("gemm_nt: null pointer"); return -4; }
   GemmArgs g{(const bf16*)A, (const bf16*)B, M, N, K, lda, ldb, out, ldc, out2, ld2,
-             bias, resid, ldr, resid_mod, (const bf16*)aux, ldaux, g_dbg};
+             bias, resid, ldr, resid_mod, (const bf16*)aux, ldaux, g_dbg, 0};
   hipStream_t s = (hipStream_t)stream;
   switch (epi) {
     case EPI_BF16: return launch<EPI_BF16>(g, s);
