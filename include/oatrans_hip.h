@@ -150,6 +150,11 @@ int oat_grouped_broadcast(const float* src, int lds, float* dst, int ldd, int G,
 int oat_axpby(const float* a, const float* b, float* out, size_t n, float alpha, float beta, void* stream);
 /* tag-token masks built by a Python B x O loop at oa_model_global_local.py:183-196 (ends / n_txt int64) */
 int oat_tag_masks(const void* ends, const void* ntxt, float* out, int B, int O, int L, void* stream);
+/* bbox -> patch-grid masks built by numpy loops in the reference's datasets (base_dataset_global_local.py:348-356:
+ * one mask per box, box_class = sel_class = NULL, O == NB; base_dataset_region_mem.py:233-247: mask o = union of the
+ * boxes whose class equals sel_class[b,o]).  bbox fp32 [B,NB,ldb>=4] = x0,y0,x1,y1 in [0,1]; out fp32 [B,O,P*P]. */
+int oat_patch_masks(const float* bbox, int ldb, const int* box_class, const int* sel_class, float* out, int B, int NB,
+                    int O, int P, void* stream);
 
 #ifdef __cplusplus
 }

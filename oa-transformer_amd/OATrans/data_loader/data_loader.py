@@ -71,6 +71,9 @@ class _SyntheticLoader:
             in_x = (xs >= x0[..., None]) & (xs < x1[..., None])
             in_y = (xs >= y0[..., None]) & (xs < y1[..., None])
             batch['patch_masks'] = (in_y[..., :, None] & in_x[..., None, :]).reshape(B, O, g14 * g14).float()
+            # the same boxes in the wire format of the object extractor (x0, y0, x1, y1 normalised to the frame,
+            # a quarter cell inside the grid lines): on a GPU the masks are produced from these by oat_patch_masks
+            batch['bboxs'] = torch.stack([x0 + 0.25, y0 + 0.25, x1 - 0.25, y1 - 0.25], dim=-1).float() / g14
             ntok = torch.randint(1, 4, (B, O), generator=g)
             batch['object_token_masks'] = ntok.cumsum(dim=1)
             batch['object_token_len'] = batch['object_token_masks'][:, -1].clone()
@@ -79,6 +82,12 @@ class _SyntheticLoader:
             pids[:, 0] = 101
             batch['pad_text'] = {'input_ids': pids, 'attention_mask': torch.ones(B, Lp, dtype=torch.int64)}
             batch['text_region_embedding'] = torch.randn(B, 5, 512, generator=g)
+        if device is not None and torch.device(device).type == 'cuda' and 'bboxs' in batch:
+            try:
+                from OATrans.ops import hip
+            except ImportError:
+                from ops import hip
+            batch['patch_masks'] = hip.patch_masks(batch['bboxs'].to(device), g14)      # bbox -> mask on the device
         if device is not None:
             for k, v in list(batch.items()):
                 if isinstance(v, torch.Tensor):

@@ -387,3 +387,18 @@ def tag_masks(ends, ntxt, L):
     _check(lib().oat_tag_masks(_ptr(ends.contiguous()), _ptr(ntxt.contiguous()), _ptr(out), B, O, L, _stream()),
            "oat_tag_masks")
     return out
+
+
+def patch_masks(bbox, P=14, box_class=None, sel_class=None):
+    """bbox fp32 [B, NB, >=4] -> fp32 [B, O, P*P] patch-grid masks (see oat_patch_masks)."""
+    bbox = bbox.float().contiguous()
+    B, NB, ldb = bbox.shape
+    if box_class is not None:
+        box_class, sel_class = box_class.to(torch.int32).contiguous(), sel_class.to(torch.int32).contiguous()
+        O = sel_class.shape[1]
+    else:
+        O = NB
+    out = torch.empty(B, O, P * P, dtype=torch.float32, device=bbox.device)
+    _check(lib().oat_patch_masks(_ptr(bbox), ldb, _ptr(box_class), _ptr(sel_class), _ptr(out), B, NB, O, P, _stream()),
+           "oat_patch_masks")
+    return out

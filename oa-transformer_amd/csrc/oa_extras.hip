@@ -154,6 +154,45 @@ __global__ void tag_masks_kernel(const long long* ends, const long long* ntxt, f
   for (int l = threadIdx.x; l < L; l += blockDim.x) out[((size_t)b * O + o) * L + l] = (l >= lo && l < hi) ? 1.f : 0.f;
 }
 }  // namespace oat
+// bbox -> patch-grid masks (the dataset-side numpy loops of base_dataset_global_local.py:348-356 and
+// base_dataset_region_mem.py:233-247): out[b, o, r * P + c] = 1 iff some box nb that belongs to mask o
+// (nb == o without classes; box_class[b, nb] == sel_class[b, o] with) covers cell (r, c):
+// int(y0 * P) <= r < ceil(y1 * P) and int(x0 * P) <= c < ceil(x1 * P), with numpy's slice rules for the bounds.
+namespace oat {
+__device__ __forceinline__ int np_bound(int v, int P) { if (v < 0) v += P; return v < 0 ? 0 : (v > P ? P : v); }
+__global__ void patch_masks_kernel(const float* bbox, int ldb, const int* box_class, const int* sel_class, float* out,
+                                   int NB, int O, int P) {
+  const int b = blockIdx.x / O, o = blockIdx.x % O;
+  const int cell = threadIdx.x;
+  if (cell >= P * P) return;
+  const int r = cell / P, c = cell % P;
+  float v = 0.f;
+  const int lo = box_class ? 0 : o, hi = box_class ? NB : o + 1;
+  for (int nb = lo; nb < hi; ++nb) {
+    if (box_class && box_class[(size_t)b * NB + nb] != sel_class[(size_t)b * O + o]) continue;
+    const float* bx = bbox + ((size_t)b * NB + nb) * ldb;
+    const float x0 = bx[0] * (float)P, y0 = bx[1] * (float)P, x1 = bx[2] * (float)P, y1 = bx[3] * (float)P;
+    const int c0 = np_bound((int)x0, P), c1 = np_bound((int)ceilf(x1), P);
+    const int r0 = np_bound((int)y0, P), r1 = np_bound((int)ceilf(y1), P);
+    if (r >= r0 && r < r1 && c >= c0 && c < c1) v = 1.f;
+  }
+  out[((size_t)b * O + o) * P * P + cell] = v;
+}
+}  // namespace oat
+
+extern "C" int oat_patch_masks(const float* bbox, int ldb, const int* box_class, const int* sel_class, float* out, int B,
+                               int NB, int O, int P, void* stream) {
+  using namespace oat;
+  if (B <= 0 || O <= 0) return 0;
+  if (!bbox || !out || ldb < 4) { set_error("patch_masks: null pointer or ldb < 4"); return -4; }
+  if (P <= 0 || P * P > 1024) { set_error("patch_masks: patch grid must be 1..32 cells per side"); return -3; }
+  if ((box_class == nullptr) != (sel_class == nullptr)) { set_error("patch_masks: box_class and sel_class go together"); return -4; }
+  if (!box_class && O != NB) { set_error("patch_masks: one mask per box needs O == NB"); return -3; }
+  hipLaunchKernelGGL(patch_masks_kernel, dim3(B * O), dim3((P * P + 63) / 64 * 64), 0, (hipStream_t)stream, bbox, ldb,
+                     box_class, sel_class, out, NB, O, P);
+  return check_launch("patch_masks");
+}
+
 extern "C" int oat_tag_masks(const void* ends, const void* ntxt, float* out, int B, int O, int L, void* stream) {
   if (B <= 0 || O <= 0 || L <= 0) return 0;
   hipLaunchKernelGGL(oat::tag_masks_kernel, dim3(B * O), dim3(64), 0, (hipStream_t)stream, (const long long*)ends,

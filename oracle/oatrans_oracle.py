@@ -302,3 +302,28 @@ def gl_loss(t, pt, v, region_feat, tags_feat, temperature=0.05):
     """trainer_global_local.py:187-211."""
     return (norm_softmax_loss(sim_matrix(t, v), temperature) + norm_softmax_loss(sim_matrix(pt, v), temperature)
             + norm_softmax_loss(sim_matrix(region_feat.mean(dim=1), tags_feat.mean(dim=1)), temperature))
+
+
+def patch_masks_from_bbox(bboxs, patch_rows=14, box_class=None, sel_class=None):
+    """bbox -> patch-grid masks, float32 [O, patch_rows**2].
+
+    bboxs [NB, >=4] = (x0, y0, x1, y1) normalised to the frame.  Restates
+      /root/reference/OATrans/base/base_dataset_global_local.py:348-356  (one mask per box: box_class is None)
+      /root/reference/OATrans/base/base_dataset_region_mem.py:233-247    (mask j = union of the boxes whose class is
+                                                                         sel_class[j]; the random choice of the 5
+                                                                         classes stays with the caller)
+    including numpy's slice semantics (int() truncation of the start, ceil of the stop, clamping to the grid)."""
+    import math
+    b = bboxs[:, :4].to(torch.float32) * patch_rows
+    nb = b.shape[0]
+    out_n = nb if box_class is None else len(sel_class)
+    m = torch.zeros(out_n, patch_rows, patch_rows)
+    for o in range(out_n):
+        for i in range(nb):
+            if box_class is not None and int(box_class[i]) != int(sel_class[o]):
+                continue
+            if box_class is None and i != o:
+                continue
+            x0, y0, x1, y1 = (float(v) for v in b[i])
+            m[o, int(y0):math.ceil(y1), int(x0):math.ceil(x1)] = 1
+    return m.reshape(out_n, patch_rows * patch_rows)

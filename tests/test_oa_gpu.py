@@ -171,3 +171,31 @@ def test_oa_training_steps_run_and_learn(variant):
     print(variant, losses)
     assert all(l == l and abs(l) < 1e6 for l in losses)
     assert losses[-1] < losses[0]
+
+
+def test_patch_masks_kernel_vs_reference_golden(golden_dir):
+    """oat_patch_masks (bbox -> patch-grid masks on the device) is bit-exact against the reference's numpy loops."""
+    import os
+    from OATrans.ops import hip
+    g = torch.load(os.path.join(golden_dir, "oa_patch_masks.pt"), map_location="cpu", weights_only=False)
+    for c in g["global_local"]:
+        got = hip.patch_masks(c["bbox"][None].cuda())
+        assert torch.equal(got[0].cpu(), c["masks"])
+    for c in g["region_mem"]:
+        got = hip.patch_masks(c["bbox"][None].cuda(), box_class=c["box_class"][None].cuda(), sel_class=c["sel_class"][None].cuda())
+        assert torch.equal(got[0].cpu(), c["masks"])
+    # a batch of two samples at once
+    a, b = g["global_local"][2], g["global_local"][2]
+    got = hip.patch_masks(torch.stack([a["bbox"], b["bbox"].flip(0)]).cuda())
+    assert torch.equal(got[0].cpu(), a["masks"]) and torch.equal(got[1].cpu(), b["masks"].flip(0))
+
+
+def test_loader_device_masks_equal_host_rasterisation():
+    """The synthetic loader rasterises its boxes on the host (CPU batches) and through oat_patch_masks (GPU batches):
+    identical masks."""
+    from OATrans.data_loader.data_loader import MultiDistTextObjectVideoDataLoader
+    dl = MultiDistTextObjectVideoDataLoader("Synthetic", {"max_length": 8}, {"input_res": 32, "num_frames": 2}, "", batch_size=3,
+                                            object_params={"input_objects": True, "num_objects": 7})
+    host = dl.make_batch(11)
+    dev = dl.make_batch(11, torch.device("cuda"))
+    assert dev["patch_masks"].is_cuda and torch.equal(dev["patch_masks"].cpu(), host["patch_masks"])

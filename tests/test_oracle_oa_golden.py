@@ -108,3 +108,16 @@ def test_tag_masks_matches_the_reference_loop():
             ref[j][k][int(n_txt[j]) - 1 + start:int(n_txt[j]) - 1 + int(otm[j][k])] = 1
             start = int(otm[j][k])
     assert torch.equal(tm, ref)
+
+
+def test_patch_masks_from_bbox_vs_reference(golden_dir):
+    """bbox -> 14x14 patch masks: the oracle against vectors produced by the reference's own method bodies
+    (tests/golden/make_golden_masks.py)."""
+    import os
+    import torch
+    from oracle import oatrans_oracle as orc
+    g = torch.load(os.path.join(golden_dir, "oa_patch_masks.pt"), map_location="cpu", weights_only=False)
+    for c in g["global_local"]:
+        assert torch.equal(orc.patch_masks_from_bbox(c["bbox"]), c["masks"])
+    for c in g["region_mem"]:
+        assert torch.equal(orc.patch_masks_from_bbox(c["bbox"], box_class=c["box_class"], sel_class=c["sel_class"]), c["masks"])
