@@ -104,15 +104,21 @@ def test_state_dict_data_parallel_fix():
     assert list(state_dict_data_parallel_fix({"a.w": 1}, cur)) == ["a.w"]
 
 
-def test_retrieval_metrics():
+def test_retrieval_metrics_vs_reference_golden(golden_dir):
+    """t2v / v2t metrics against the outputs of the reference's own metric.py (tests/golden/make_golden_metrics.py):
+    optimistic ties for t2v, averaged ties for v2t, R1 = exact rank 0, several captions per video, query masks."""
+    import os
     from OATrans.model.metric import t2v_metrics, v2t_metrics
-    sims = np.eye(10) + 0.01 * np.random.RandomState(0).randn(10, 10)
-    m = t2v_metrics(sims)
-    assert m["R1"] == 100.0 and m["MedR"] == 1.0 and m["MeanR"] == 1.0
-    sims = np.arange(16, dtype=float).reshape(4, 4)      # best column is always the last one
-    m = t2v_metrics(sims)
-    assert m["R1"] == 25.0 and m["R5"] == 100.0 and m["MedR"] == 2.5
-    assert v2t_metrics(sims)["R1"] == 25.0
+    cases = torch.load(os.path.join(golden_dir, "metrics.pt"), map_location="cpu", weights_only=False)
+    assert len(cases) >= 6
+    for c in cases:
+        sims = c["sims"].numpy()
+        masks = None if c["masks"] is None else c["masks"].numpy()
+        for fn, want in ((t2v_metrics, c["t2v"]), (v2t_metrics, c["v2t"])):
+            got = fn(sims.copy(), None if masks is None else masks.copy())
+            assert set(got) == set(want), c["name"]
+            for k in want:
+                assert abs(got[k] - want[k]) <= 1e-9 * max(1.0, abs(want[k])), (c["name"], fn.__name__, k, got[k], want[k])
 
 
 def test_seeded_generator_is_a_pure_function_of_name():
