@@ -46,7 +46,9 @@ def _worker(rank, world, port, q):
     sync = GradSync(model)
     assert len(sync.ranges()) == 1 and sync.ranges()[0].numel() == 256
     sync.all_reduce(average=True)
-    q.put((rank, loss.item(), W1.grad.clone(), W2.grad.clone(), xa, xb))
+    # numpy, not torch tensors: torch shares tensor storage by file descriptor, which fails if this process exits
+    # before the parent has unpickled the message
+    q.put((rank, loss.item(), W1.grad.numpy().copy(), W2.grad.numpy().copy(), xa.numpy().copy(), xb.numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -59,6 +61,7 @@ def test_two_rank_gather_and_gradient_convention():
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda r: r[0])
+    res = [(r[0], r[1]) + tuple(torch.from_numpy(a) for a in r[2:]) for r in res]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
