@@ -135,3 +135,32 @@ def test_seeded_generator_is_a_pure_function_of_name():
     text = si.text_param_shapes()
     n = sum(int(np.prod(s)) for s in shapes.values()) + sum(int(np.prod(s)) for s in text.values()) + 2 * (768 * 256 + 256)
     assert n == 180922112 + 8 * 768                     # == the instantiated reference at 8 frames
+
+
+def test_checkpoint_interop_vs_reference_golden(golden_dir):
+    """Temporal-embedding inflation (all three fill modes, more / fewer / equal frames) and the `module.` prefix fix
+    against outputs of the reference's own functions (tests/golden/make_golden_ckpt.py)."""
+    import os
+    from collections import OrderedDict
+    from OATrans.model.oa_model import FrozenInTime
+    from OATrans.utils.util import state_dict_data_parallel_fix
+    g = torch.load(os.path.join(golden_dir, "ckpt_interop.pt"), map_location="cpu", weights_only=False)
+
+    class Self:
+        def __init__(self, frames, fix, sd):
+            self.video_params = {"model": "SpaceTimeTransformer", "num_frames": frames}
+            self.load_temporal_fix, self._sd = fix, sd
+
+        def state_dict(self):
+            return self._sd
+
+    for c in g["inflate"]:
+        D = c["load"].shape[2]
+        cur = {"video_model.temporal_embed": torch.zeros(1, c["frames"], D), "video_model.pos_embed": torch.zeros(1, 10, D)}
+        out = FrozenInTime._inflate_positional_embeds(Self(c["frames"], c["mode"], cur),
+                                                      {"video_model.temporal_embed": c["load"].clone(),
+                                                       "video_model.pos_embed": torch.zeros(1, 10, D)})
+        assert torch.equal(out["video_model.temporal_embed"], c["out"]), (c["frames"], c["mode"])
+    for c in g["prefix_fix"]:
+        out = state_dict_data_parallel_fix(OrderedDict((k, i) for i, k in enumerate(c["load"])), OrderedDict((k, 0) for k in c["cur"]))
+        assert list(out.items()) == c["out"], c
