@@ -380,9 +380,13 @@ extern "C" void oat_attn_time_set_variant(int v) { g_time_two_pass = v; }
     case 2: hipLaunchKernelGGL(KERNEL<2>, dim3(blocks), dim3(256), 0, s, a); break;                   \
     case 3: hipLaunchKernelGGL(KERNEL<3>, dim3(blocks), dim3(256), 0, s, a); break;                   \
     case 4: hipLaunchKernelGGL(KERNEL<4>, dim3(blocks), dim3(256), 0, s, a); break;                   \
+    case 5: hipLaunchKernelGGL(KERNEL<5>, dim3(blocks), dim3(256), 0, s, a); break;                   \
+    case 6: hipLaunchKernelGGL(KERNEL<6>, dim3(blocks), dim3(256), 0, s, a); break;                   \
+    case 7: hipLaunchKernelGGL(KERNEL<7>, dim3(blocks), dim3(256), 0, s, a); break;                   \
     case 8: hipLaunchKernelGGL(KERNEL<8>, dim3(blocks), dim3(256), 0, s, a); break;                   \
+    case 12: hipLaunchKernelGGL(KERNEL<12>, dim3(blocks), dim3(256), 0, s, a); break;                 \
     case 16: hipLaunchKernelGGL(KERNEL<16>, dim3(blocks), dim3(256), 0, s, a); break;                 \
-    default: set_error("attn_time: supported frame counts are 1,2,3,4,8,16"); return -3;              \
+    default: set_error("attn_time: supported frame counts are 1-8, 12, 16"); return -3;               \
   }
 
 extern "C" int oat_attn_time_fwd(const void* qkv, int ldqkv, void* out, int ldo, float* lse, int B, int T, int N,
@@ -414,8 +418,9 @@ extern "C" int oat_attn_time_bwd(const void* qkv, int ldqkv, const void* out, in
                                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; } \
       hipLaunchKernelGGL(attn_time_bwd_lds_kernel<TT>, dim3(blocks), dim3(256), LDS, s, a); break; }
     switch (T) {
-      OAT_TIME_LDS(1) OAT_TIME_LDS(2) OAT_TIME_LDS(3) OAT_TIME_LDS(4) OAT_TIME_LDS(8)
-      default: set_error("attn_time: supported frame counts are 1,2,3,4,8,16"); return -3;
+      OAT_TIME_LDS(1) OAT_TIME_LDS(2) OAT_TIME_LDS(3) OAT_TIME_LDS(4) OAT_TIME_LDS(5) OAT_TIME_LDS(6) OAT_TIME_LDS(7)
+      OAT_TIME_LDS(8)
+      default: set_error("attn_time: supported frame counts are 1-8, 12, 16"); return -3;
     }
 #undef OAT_TIME_LDS
     return check_launch("attn_time_bwd");

@@ -32,7 +32,7 @@ def test_argument_validation_without_gpu():
     assert rc < 0 and b"empty" in lib.oat_last_error()
     rc = lib.oat_attn_space_fwd(one, 0, one, 0, one, 1, 1, 4, 2, 100, ctypes.c_float(0.125), null)
     assert rc < 0 and b"head_dim" in lib.oat_last_error()
-    rc = lib.oat_attn_time_fwd(one, 0, one, 0, one, 1, 5, 4, 2, 128, ctypes.c_float(0.125), null)
+    rc = lib.oat_attn_time_fwd(one, 0, one, 0, one, 1, 9, 4, 2, 128, ctypes.c_float(0.125), null)
     assert rc < 0 and b"frame counts" in lib.oat_last_error()
 
 

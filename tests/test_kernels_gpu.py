@@ -253,7 +253,8 @@ def ref_attention(qkv_ref, mode, B, T, N, H):
 
 @pytest.mark.parametrize("mode", ["space", "time"])
 @pytest.mark.parametrize("B,T,N,H", [(2, 3, 9, 2), (2, 2, 9, 2), (1, 1, 4, 1), (2, 8, 196, 12), (1, 4, 196, 12),
-                                     (2, 2, 441, 3), (1, 16, 441, 2), (2, 1, 256, 2), (1, 2, 224, 2), (1, 2, 447, 1)])   # 336^2 / 16 = 441
+                                     (2, 2, 441, 3), (1, 16, 441, 2), (2, 1, 256, 2), (1, 2, 224, 2), (1, 2, 447, 1),   # 336^2 / 16 = 441
+                                     (1, 5, 9, 1), (2, 6, 20, 2), (1, 7, 9, 2), (1, 12, 16, 1)])
 def test_attention_fwd_bwd(mode, B, T, N, H):
     hip = _hip()
     D = H * 64
