@@ -28,7 +28,7 @@ import torch.distributed as dist  # noqa: E402
 BF16_DENSE_PEAK_TFLOPS = 2500.0          # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 
 
-def flops_per_pair(T, N=196, D=768, depth=12, Lt=32):
+def flops_per_pair(T, N=196, D=768, depth=12, Lt=32):  # noqa: E302
     """Algorithmic fwd+bwd FLOPs per video-text pair (1 MAC = 2 FLOP, bwd = 2x fwd)."""
     S = 1 + T * N
     video = 2 * T * N * D * D + depth * (32 * S * D * D + 4 * D * (2 * S + N * T * (T + 1) + T * N * (N + 1))) + 2 * D * 256
@@ -46,7 +46,8 @@ def build(args, device):
     model = cls(
         video_params=dict(model="SpaceTimeTransformer", arch_config="base_patch16_224",
                           num_frames=args.frames if args.variant == "frozen" else max(1, args.frames // 2),
-                          pretrained=True, time_init="rand", two_outputs=False),
+                          pretrained=True, time_init="rand", two_outputs=False,
+                          **({"arch_kwargs": {"img_size": args.res}} if args.res != 224 else {})),
         object_params=dict(model="", input_objects=False),
         text_params=dict(model="pretrained/distilbert-base-uncased", pretrained=True, input="text"),
         projection="minimal", load_checkpoint="")
@@ -69,7 +70,7 @@ def build(args, device):
 def synthetic_batch(args, rank, device):
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     B, T, L = args.batch, args.frames, 32
-    video = torch.randn(B, T, 3, 224, 224, generator=g).to(torch.bfloat16).to(device)
+    video = torch.randn(B, T, 3, args.res, args.res, generator=g).to(torch.bfloat16).to(device)
     ids = torch.randint(1000, 30000, (B, L), generator=g)
     ids[:, 0], ids[:, -1] = 101, 102
     batch = {"video": video, "text": {"input_ids": ids.to(device), "attention_mask": torch.ones(B, L, dtype=torch.int64, device=device)}}
@@ -121,7 +122,7 @@ def pmc_traffic(kernel, args):
     (profiles/round1c_pmc_hbm_traffic.md: separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections);
     null when the workload differs from the measured one."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1c_pmc_traffic.json")
-    if not os.path.exists(path) or (args.variant, args.batch, args.frames) != ("frozen", 32, 8):
+    if not os.path.exists(path) or (args.variant, args.batch, args.frames, args.res) != ("frozen", 32, 8, 224):
         return None
     with open(path) as fh:
         rec = json.load(fh)
@@ -167,6 +168,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
     ap.add_argument("--frames", type=int, default=8)
+    ap.add_argument("--res", type=int, default=224, help="frame size (336 -> 441 patches per frame, BASELINE config 5's geometry)")
     ap.add_argument("--lr", type=float, default=2e-5,
                     help="AdamW step size (the reference config uses 2e-4 on PRETRAINED towers; random-init towers on one repeated "
                          "synthetic batch spike at that value, which says nothing about throughput but makes final_loss useless)")
@@ -219,14 +221,14 @@ def main():
     loss_val = float(loss.item())
     pairs = world * args.batch * args.steps
     value = pairs / elapsed
-    gf_pair = flops_per_pair(args.frames) / 1e9
+    gf_pair = flops_per_pair(args.frames, N=(args.res // 16) ** 2) / 1e9
     cls_name = {"frozen": "oa_model", "region_mem": "oa_model_region_mem", "global_local": "oa_model_global_local"}[args.variant]
     out = {
         "metric": "video-text pairs/sec fwd+bwd, 8-frame ViT-B/16, 1/2/4/8 MI355X",
         "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"[{args.variant}] {args.frames}-frame 224^2 ViT-B/16 SpaceTimeTransformer + DistilBERT-base ({cls_name}.FrozenInTime), "
+        "config": {"workload": f"[{args.variant}] {args.frames}-frame {args.res}^2 ViT-B/16 SpaceTimeTransformer + DistilBERT-base ({cls_name}.FrozenInTime), "
                                f"bs {args.batch}/GPU, Lt 32, fwd+bwd+AdamW, InfoNCE over all-gathered embeddings",
                    "per_gpu_batch": args.batch, "global_batch": world * args.batch, "frames": args.frames,
                    "parallelism": f"dp{world}", "gflop_per_pair": round(gf_pair, 1)},
