@@ -51,7 +51,7 @@ OAT_DEV void mfma_agpr(f32x4& c, const bf16x8 a, const bf16x8 b) {
 OAT_DEV int swz(int r, int lc) { return r * 128 + ((lc ^ ((r >> 1) & 7)) << 4); }
 
 // WM x WN waves, each owning TM x TN MFMA tiles of 16x16:  <2,2,4,4> = 128x128 / 4 waves,
-// <2,4,8,4> = 256x256 / 8 waves (one workgroup per CU, 128 KB LDS).
+// <2,4,8,4> = 256x256 / 8 waves (one workgroup per CU, 160 KB LDS).
 //
 // Staging pipeline: B (weights: re-read by every workgroup, L2-resident) is double-buffered; A (activations:
 // streamed once from HBM / Infinity Cache, ~2 us away under load) gets NSA = 3 stages in the 256x256
