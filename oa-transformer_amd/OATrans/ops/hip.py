@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _PKG_ROOT = os.path.dirname(os.path.dirname(_HERE))            # oa-transformer_amd/
-LIB_PATH = os.path.join(_PKG_ROOT, "liboatrans_hip.so")
+LIB_PATH = os.environ.get("OAT_LIB") or os.path.join(_PKG_ROOT, "liboatrans_hip.so")     # OAT_LIB: dev A/B of two builds
 HEADER_PATH = os.path.join(os.path.dirname(_PKG_ROOT), "include", "oatrans_hip.h")
 
 _lib = None

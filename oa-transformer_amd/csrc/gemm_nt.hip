@@ -299,8 +299,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
       prefetched = true;
     }
   }
-  constexpr int EP = 144;                         // scratch row pitch: 128 B payload + 16 B pad
+  // per-wave scratch: 64 rows x 128 B, 16-byte chunk c of row r at ((c ^ (r & 7)) << 4).  The earlier padded layout
+  // (144-B pitch) measured SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS = 0.31: its ds_read_b128 lane groups (rows r..r+3,
+  // chunk halves 0-3 / 4-7) collided; with an unpadded pitch they do not, and the XOR keeps the column-strided writes
+  // at their 2-pass minimum.
+  constexpr int EP = 128;
   char* ep = smem + (PREF ? 2 * A_BYTES : 0) + wave * (64 * EP);
+  auto sc = [](int r, int byte_off) { return r * 128 + ((((byte_off >> 4) ^ (r & 7)) << 4) | (byte_off & 15)); };
+  // 8-byte writes (ds_write_b64: 16-lane groups = 16 rows of one column): rows r and r + 8 share a chunk under `sc`,
+  // so rows with bit 3 set use the OTHER half of the chunk; the reader swaps the halves back (compile-time per pass)
+  auto sc8 = [](int r, int byte_off) {
+    return r * 128 + ((((byte_off >> 4) ^ (r & 7)) << 4) | ((((byte_off >> 3) ^ (r >> 3)) & 1) << 3));
+  };
   const int rrow = lane >> 3, rch = lane & 7;     // read phase: 8 rows x 8 chunks of 16 B
   const int wrow0 = m0 + wm * TM * 16;
   static_assert(TN % 4 == 0, "epilogue works on 64-column groups of the wave tile");
@@ -318,14 +328,20 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
         for (int j = 0; j < 4; ++j) {
           const f32x4 v = acc[rh * 4 + i][cg * 4 + j] + bias_v[cg * 4 + j];
           const bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-          *reinterpret_cast<bf16x4*>(ep + (i * 16 + frow) * EP + (j * 16 + fk * 4) * 2) = o;
+          *reinterpret_cast<bf16x4*>(ep + sc8(i * 16 + frow, (j * 16 + fk * 4) * 2)) = o;
         }
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
         const int lr = it * 8 + rrow;
         const int row = wrow0 + rh * 64 + lr, col = wcol0 + rch * 8;
-        const bf16x8 hv = *reinterpret_cast<const bf16x8*>(ep + lr * EP + rch * 16);
+        bf16x8 hv;
+        {
+          typedef __attribute__((ext_vector_type(2))) unsigned long long u64x2;
+          const u64x2 raw = *reinterpret_cast<const u64x2*>(ep + sc(lr, rch * 16));
+          const u64x2 fixed = (it & 1) ? u64x2{raw[1], raw[0]} : raw;      // rows with bit 3 set: halves swapped (renaming)
+          hv = __builtin_bit_cast(bf16x8, fixed);
+        }
         if (row < g.M && col < g.N) {
           const int orow = (g.dbg & 4) ? (row & 1023) : row;      // ablation: all row panels overwrite the first 1024 rows
           if (!(g.dbg & 8)) *reinterpret_cast<bf16x8*>((bf16*)g.out + (size_t)orow * g.ldc + col) = hv;
@@ -342,22 +358,23 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
       }
       __builtin_amdgcn_wave_barrier();
     } else if constexpr (EPI == EPI_DGELU && BM == 256) {
-      // fp32 scratch, 64 rows x 64 cols (272-B pitch; 8 waves x 17 KB fit the 160 KB ring): a lane then owns 8
+      // fp32 scratch, 64 rows x 64 cols (8 waves x 16 KB fit the 160 KB ring): a lane then owns 8
       // consecutive columns, so the saved pre-activation is read and dH written in full 128-byte lines
-      constexpr int EW = 272;
-      char* ew = smem + wave * (64 * EW);
+      constexpr int EW = 256;                           // unpadded; 16-byte chunk c of row r at (c ^ (r & 7)): conflict-free
+      char* ew = smem + wave * (64 * EW);                // for the b128 writes (8 rows x 1 column) and the b128 reads
+      auto sw = [](int r, int byte_off) { return r * 256 + ((((byte_off >> 4) ^ (r & 7))) << 4); };
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          *reinterpret_cast<f32x4*>(ew + (i * 16 + frow) * EW + (j * 16 + fk * 4) * 4) = acc[rh * 4 + i][cg * 4 + j];
+          *reinterpret_cast<f32x4*>(ew + sw(i * 16 + frow, (j * 16 + fk * 4) * 4)) = acc[rh * 4 + i][cg * 4 + j];
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
         const int lr = it * 8 + rrow;
         const int row = wrow0 + rh * 64 + lr, col = wcol0 + rch * 8;
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(ew + lr * EW + rch * 32);
-        const f32x4 v1 = *reinterpret_cast<const f32x4*>(ew + lr * EW + rch * 32 + 16);
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(ew + sw(lr, rch * 32));
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(ew + sw(lr, rch * 32 + 16));
         if (row < g.M && col < g.N) {
           const bf16x8 h = *reinterpret_cast<const bf16x8*>(g.aux + (size_t)row * g.ldaux + col);
           bf16x8 o;
@@ -378,13 +395,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int jj = 0; jj < 2; ++jj)
-            *reinterpret_cast<f32x4*>(ep + (i * 16 + frow) * EP + (jj * 16 + fk * 4) * 4) = acc[rh * 4 + i][cg * 4 + ch * 2 + jj];
+            *reinterpret_cast<f32x4*>(ep + sc(i * 16 + frow, (jj * 16 + fk * 4) * 4)) = acc[rh * 4 + i][cg * 4 + ch * 2 + jj];
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
           const int lr = it * 8 + rrow;
           const int row = wrow0 + rh * 64 + lr, col = wcol0 + ch * 32 + rch * 4;
-          f32x4 v = *reinterpret_cast<const f32x4*>(ep + lr * EP + rch * 16);
+          f32x4 v = *reinterpret_cast<const f32x4*>(ep + sc(lr, rch * 16));
           if (row < g.M && col < g.N) {
             if (g.bias) v += *reinterpret_cast<const f32x4*>(g.bias + col);
             if constexpr (EPI == EPI_F32 || EPI == EPI_F32_BF16) {
