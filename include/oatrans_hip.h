@@ -36,7 +36,8 @@ int oat_gemm_nt(const void* A, const void* B, int M, int N, int K, int lda, int 
                 int ldr, int resid_mod, const void* aux, int ldaux, void* stream);
 
 /* tuning hook.  bits 0-7: 0 = auto tile choice, 1 = force 128x128 (4 waves), 2 = force 256x256 (8 waves),
- * 3 = 256x256 with 4 hand-pipelined waves; bits 8-15: flags (1 = skip the epilogue [ablation], 64 = split the
+ * 3 = 256x256 with 4 hand-pipelined waves; bits 8-15: flags (ablations: 1 = skip the epilogue, 4 = all row panels write the first 1024
+ * output rows, 8 = no global stores, 16 / 32 = every workgroup stages A / B tile 0; 64 = split the
  * last, mostly empty round of 256x256 tiles into 128x128 tiles [opt-in]);
  * bits 16-31: grid of the persistent 256x256 launch (0 = one workgroup per CU, 0xffff = one per tile) */
 void oat_gemm_set_variant(int v);

@@ -97,13 +97,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
   for (int i = 0; i < GA; ++i) {
     const int r = (wave * GA + i) * 8 + srow;
     const int lc = (lane & 7) ^ ((r >> 1) & 7);            // inverse swizzle on the source side
-    a_src[i] = g.A + (size_t)min(m0 + r, g.M - 1) * g.lda + lc * 8;   // clamp: ragged M reads a valid row
+    a_src[i] = g.A + (size_t)min(((g.dbg & 16) ? 0 : m0) + r, g.M - 1) * g.lda + lc * 8;   // clamp: ragged M reads a valid row
   }
 #pragma unroll
   for (int i = 0; i < GB; ++i) {
     const int r = (wave * GB + i) * 8 + srow;
     const int lc = (lane & 7) ^ ((r >> 1) & 7);
-    b_src[i] = g.B + (size_t)min(n0 + r, g.N - 1) * g.ldb + lc * 8;
+    b_src[i] = g.B + (size_t)min(((g.dbg & 32) ? 0 : n0) + r, g.N - 1) * g.ldb + lc * 8;
   }
   char* const sA0 = smem;
   char* const sB0 = smem + NSA * A_BYTES;
