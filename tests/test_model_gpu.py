@@ -193,3 +193,36 @@ def test_frozen_in_time_vitb_vs_reference_golden(golden_dir):
         if nerr > 5e-2 or perr > 1.0:      # sampled entries, in units of the tensor RMS (bs 2: heavy cancellation)
             bad.append((k, nerr, perr))
     assert not bad, bad[:10]
+
+
+def test_ragged_shapes_take_optimiser_steps():
+    """Edge shapes the reference accepts: a single pair (B = 1: the reference itself trips an in-place-on-view error
+    there), odd batches, one frame, one-token captions, changing shapes between steps."""
+    import argparse
+    from OATrans import model as module_arch
+    from OATrans.optim import AdamW
+    from OATrans.parallel import HipDataParallel
+    from OATrans.trainer.step import hot_step
+    torch.manual_seed(0)
+    m = module_arch.FrozenInTime(
+        video_params=dict(model="SpaceTimeTransformer", arch_config="base_patch16_224", num_frames=3, pretrained=True,
+                          time_init="rand", arch_kwargs=dict(depth=2)),
+        object_params=dict(model="", input_objects=False),
+        text_params=dict(model="pretrained/distilbert-base-uncased", pretrained=True, input="text", config=dict(n_layers=1)),
+        projection="minimal", load_checkpoint="").cuda()
+    m.set_device(torch.device("cuda"))
+    for sub in (m.video_model, m.text_model):
+        sub.flatten_parameters()
+    dp = HipDataParallel(m)
+    opt = AdamW([p for p in m.parameters() if p.requires_grad], lr=1e-5)
+    sa = argparse.Namespace(world_size=1, rank=0, local_rank=0)
+    for B, T, L in ((1, 3, 5), (3, 2, 9), (5, 1, 32), (2, 3, 1)):
+        g = torch.Generator().manual_seed(B)
+        data = {"video": torch.randn(B, T, 3, 224, 224, generator=g).cuda(),
+                "text": {"input_ids": torch.randint(1000, 30000, (B, L), generator=g).cuda(),
+                         "attention_mask": torch.ones(B, L, dtype=torch.int64).cuda()}}
+        losses = [hot_step(dp, module_arch.NormSoftmaxLoss(), opt, data, sa).item() for _ in range(2)]
+        assert all(l == l and abs(l) < 1e3 for l in losses), (B, T, L, losses)
+        if B > 1:
+            assert losses[1] < losses[0], (B, T, L, losses)
+    assert all(torch.isfinite(p).all().item() for p in m.parameters())
