@@ -41,6 +41,9 @@ int oat_gemm_nt(const void* A, const void* B, int M, int N, int K, int lda, int 
  * last, mostly empty round of 256x256 tiles into 128x128 tiles [opt-in]);
  * bits 16-31: grid of the persistent 256x256 launch (0 = one workgroup per CU, 0xffff = one per tile) */
 void oat_gemm_set_variant(int v);
+/* launch policy, not tuning: 1 = split the last, mostly empty round of 256x256 tiles into 128x128 tiles.  Pays when
+ * nothing else shares the GPU (the forward pass), costs when a second stream would have used the idle CUs (backward). */
+void oat_gemm_set_tail_split(int on);
 
 /* out[N1,N2] (fp32, (+)=) sum_m P[m,N1]^T Q[m,N2]  - weight gradients of every nn.Linear.
  * Rows [M, round_up(M,64)) of P and Q must be readable (contents ignored).

@@ -134,6 +134,7 @@ class VideoEngine:
         self.shadow_versions = None
         self._cast = None
         self.lanes = int(os.environ.get("OAT_LANES", "1"))   # half-batches on two streams (1 = off)
+        self.tail_split = os.environ.get("OAT_TAIL_SPLIT", "1") != "0"
         self.min_lane_rows = 8192        # token rows per lane below which splitting only adds launches
         self._streams = None
         self._tn_ws = None
@@ -200,6 +201,9 @@ class VideoEngine:
             lanes.append(pl)
         if two:
             st["lane1"].wait_stream(main)
+        # forward runs alone on the GPU: the third, 31 %-full round of the N = 768 GEMMs (591 tiles on 256 CUs) is
+        # re-tiled as 128x128; in backward the weight-gradient stream fills those CUs instead (see gemm_nt.hip)
+        hip.gemm_set_tail_split(self.tail_split and not two)
         for pl in lanes:
             with torch.cuda.stream(pl.stream):
                 self._embed(pl, params, C, R)
@@ -215,6 +219,7 @@ class VideoEngine:
                 outs.append(self._final_fwd(pl, params, need_patches, region_layer))
         for pl in lanes:
             pl.video = None
+        hip.gemm_set_tail_split(False)
         if two:
             main.wait_stream(st["lane1"])
             return torch.cat([o[0] for o in outs], dim=0), None, run

@@ -88,6 +88,10 @@ def gemm_set_variant(v):
     lib().oat_gemm_set_variant(int(v))
 
 
+def gemm_set_tail_split(on):
+    lib().oat_gemm_set_tail_split(int(bool(on)))
+
+
 def gemm_tn_set_variant(v):
     lib().oat_gemm_tn_set_variant(int(v))
 

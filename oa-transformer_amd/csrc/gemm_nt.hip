@@ -435,7 +435,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
 
 // tuning hook: variant 0 = auto, 1 = force 128x128, 2 = force 256x256, 3 = 4-wave pipelined 256x256;
 // persist 0 = one workgroup per CU, 0xffff = one workgroup per tile, else the grid size
-static int g_variant = 0, g_dbg = 0, g_persist = 0;
+static int g_variant = 0, g_dbg = 0, g_persist = 0, g_tail = 0;
 
 static int cu_count() {
   static int cus = 0;
@@ -483,7 +483,7 @@ static int launch(const GemmArgs& g, hipStream_t s) {
     // Measured: +5...9 % per launch at R = 2 (-1.6 % at R = 9) on an idle GPU, but -1 % for the training step, where
     // the weight-gradient stream already fills that third round and an exact two-round fit has no slack when a few
     // CUs are busy at launch.  Opt-in (ablation bit 64).
-    if ((g_dbg & 64) && R >= 1 && R <= 4 && r > 0 && r * 10 < cus * 7 && panels_main >= 1 && panels_main < ntm) {
+    if (((g_dbg & 64) || g_tail) && R >= 1 && R <= 4 && r > 0 && r * 10 < cus * 7 && panels_main >= 1 && panels_main < ntm) {
       const int M1 = panels_main * 256;
       GemmArgs a = g;
       a.M = M1;
@@ -507,6 +507,7 @@ static int launch(const GemmArgs& g, hipStream_t s) {
 
 }  // namespace oat
 
+extern "C" void oat_gemm_set_tail_split(int on) { oat::g_tail = on; }
 extern "C" void oat_gemm_set_variant(int v) { oat::g_variant = v & 0xff; oat::g_dbg = (v >> 8) & 0xff; oat::g_persist = (v >> 16) & 0xffff; }
 
 extern "C" int oat_gemm_nt(const void* A, const void* B, int M, int N, int K, int lda, int ldb,
