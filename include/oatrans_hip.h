@@ -52,7 +52,9 @@ size_t oat_gemm_tn_workspace_bytes(int M, int N1, int N2);
 int oat_gemm_tn(const void* P, const void* Q, int M, int N1, int N2, int ldp, int ldq, float* out,
                 float* bias_out /* [N1] column sums of P, or NULL */, int accumulate, void* workspace,
                 size_t workspace_bytes, void* stream);
-void oat_gemm_tn_set_variant(int v);   /* tuning hook: 0 auto, 1 force 128x128, 2 force 256x256 */
+void oat_gemm_tn_set_variant(int v);   /* bits 0-7: 0 auto, 1 force 128x128, 2 force 256x256 tiles; bits 8-15: ablations (1 = no
+                                          * global loads after the ring fill, 2 = no slab store); bits 16-31: workgroup budget of the
+                                          * 256x256 launch (0 = 256): the caller's share of the CUs when another stream needs the rest */
 
 /* ---- LayerNorm (video_transformer.py:164,167,174,346; DistilBERT LayerNorms) ------------- */
 int oat_layernorm_fwd(const float* x, int ldx, const float* gamma, const float* beta, void* y_bf16,

@@ -135,6 +135,7 @@ class VideoEngine:
         self._cast = None
         self.lanes = int(os.environ.get("OAT_LANES", "1"))   # half-batches on two streams (1 = off)
         self.tail_split = os.environ.get("OAT_TAIL_SPLIT", "1") != "0"
+        self.wgrad_cus = int(os.environ.get("OAT_WGRAD_CUS", "192"))   # workgroup budget of a weight-gradient GEMM
         self.min_lane_rows = 8192        # token rows per lane below which splitting only adds launches
         self._streams = None
         self._tn_ws = None
@@ -341,6 +342,9 @@ class VideoEngine:
                 self._final_bwd(ln, run, params, grads)
         if run.region_layer is not None:
             ready = None                     # region_norm gradients arrive out of block order: reduce after backward
+        # weight gradients leave a quarter of the CUs to the data-gradient chain (the critical path): a 256-workgroup
+        # gemm_tn holds every CU for its whole duration and the chain's next kernel has to wait for it to retire
+        hip.gemm_tn_set_variant(self.wgrad_cus << 16)
         for i in reversed(range(self.depth)):
             for ln in lanes:
                 with torch.cuda.stream(ln.pl.stream):
@@ -350,6 +354,7 @@ class VideoEngine:
             with torch.cuda.stream(ln.pl.stream):
                 self._embed_bwd(ln, grads, wg)
         self._announce(lanes[-1], wg, ready, ("cls_token", "pos_embed", "temporal_embed", "patch_embed."))
+        hip.gemm_tn_set_variant(0)
         if two:
             main.wait_stream(st["lane1"])
         main.wait_stream(wg)                 # every weight gradient is complete before the caller continues

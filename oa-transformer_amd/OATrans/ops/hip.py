@@ -44,8 +44,10 @@ def lib():
         for name in declared_symbols():
             if not hasattr(_lib, name):
                 raise OatError(f"liboatrans_hip.so lacks symbol {name}")
-        if os.environ.get("OAT_GEMM_VARIANT"):           # tuning hook (see oat_gemm_set_variant)
+        if os.environ.get("OAT_GEMM_VARIANT"):           # tuning hooks (see oat_gemm_set_variant / oat_gemm_tn_set_variant)
             _lib.oat_gemm_set_variant(int(os.environ["OAT_GEMM_VARIANT"], 0))
+        if os.environ.get("OAT_GEMM_TN_VARIANT"):
+            _lib.oat_gemm_tn_set_variant(int(os.environ["OAT_GEMM_TN_VARIANT"], 0))
     return _lib
 
 

@@ -219,7 +219,7 @@ __global__ void tn_reduce_kernel(const float* slabs, float* out, int n4, int spl
   }
 }
 
-static int g_tn_variant = 0, g_tn_dbg = 0;   // 0 auto, 1 force 128^2, 2 force 256^2
+static int g_tn_variant = 0, g_tn_dbg = 0, g_tn_slots = 0;   // 0 auto, 1 force 128^2, 2 force 256^2
 
 template <int WM, int WN, int TM, int TN>
 static int launch_tn(TnArgs g, int splits, float* out, float* bias_out, int accumulate, hipStream_t s) {
@@ -245,7 +245,7 @@ static int launch_tn(TnArgs g, int splits, float* out, float* bias_out, int accu
 
 }  // namespace oat
 
-extern "C" void oat_gemm_tn_set_variant(int v) { oat::g_tn_variant = v & 0xff; oat::g_tn_dbg = v >> 8; }
+extern "C" void oat_gemm_tn_set_variant(int v) { oat::g_tn_variant = v & 0xff; oat::g_tn_dbg = (v >> 8) & 0xff; oat::g_tn_slots = (v >> 16) & 0xffff; }
 
 // tile shape and split count of a launch (shared by the launcher and the workspace query)
 static void tn_plan(int M, int N1, int N2, bool* big_, int* splits_, int* cps_) {
@@ -254,7 +254,7 @@ static void tn_plan(int M, int N1, int N2, bool* big_, int* splits_, int* cps_) 
   const int B = big ? 256 : 128;
   const int tiles = ((N1 + B - 1) / B) * ((N2 + B - 1) / B);
   const int nchunks = (M + TK - 1) / TK;
-  const int slots = big ? 256 : 512;                // one 8-wave workgroup per CU, or two 4-wave ones
+  const int slots = big ? (g_tn_slots > 0 ? g_tn_slots : 256) : 512;   // one 8-wave workgroup per CU, or two 4-wave ones
   int splits = slots / tiles;                       // largest split count that still fits one round
   if (splits < 1) splits = 1;
   if (splits > 32) splits = 32;
