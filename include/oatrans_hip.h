@@ -36,7 +36,7 @@ int oat_gemm_nt(const void* A, const void* B, int M, int N, int K, int lda, int 
                 int ldr, int resid_mod, const void* aux, int ldaux, void* stream);
 
 /* tuning hook.  bits 0-7: 0 = auto tile choice, 1 = force 128x128 (4 waves), 2 = force 256x256 (8 waves),
- * 3 = 256x256 with 4 hand-pipelined waves; bits 8-15: flags (ablations: 1 = skip the epilogue, 4 = all row panels write the first 1024
+ * 3 = 256x256 with 4 hand-pipelined waves; bits 8-15: flags (ablations: 128 = static tile walk even with counters, 1 = skip the epilogue, 4 = all row panels write the first 1024
  * output rows, 8 = no global stores, 16 / 32 = every workgroup stages A / B tile 0; 64 = split the
  * last, mostly empty round of 256x256 tiles into 128x128 tiles [opt-in]);
  * bits 16-31: grid of the persistent 256x256 launch (0 = one workgroup per CU, 0xffff = one per tile) */
@@ -44,6 +44,10 @@ void oat_gemm_set_variant(int v);
 /* launch policy, not tuning: 1 = split the last, mostly empty round of 256x256 tiles into 128x128 tiles.  Pays when
  * nothing else shares the GPU (the forward pass), costs when a second stream would have used the idle CUs (backward). */
 void oat_gemm_set_tail_split(int on);
+/* Optional: 32 KiB of ZEROED device memory that persistent gemm_nt launches use as atomic tile counters (dynamic tile
+ * scheduling: a workgroup whose CU was busy at launch takes fewer tiles).  Caller-owned, must outlive every launch;
+ * NULL returns to the static walk.  The library never allocates. */
+int oat_gemm_set_tile_counters(void* zeroed_device_ints, size_t bytes);
 
 /* out[N1,N2] (fp32, (+)=) sum_m P[m,N1]^T Q[m,N2]  - weight gradients of every nn.Linear.
  * Rows [M, round_up(M,64)) of P and Q must be readable (contents ignored).

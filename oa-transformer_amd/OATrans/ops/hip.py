@@ -75,9 +75,24 @@ def _f(x):
 EPI_BF16, EPI_F32, EPI_GELU_DUAL, EPI_DGELU, EPI_F32_BF16 = 0, 1, 2, 3, 4
 
 
+_tile_counters = {}
+_DYNAMIC_TILES = os.environ.get("OAT_GEMM_DYNAMIC", "0") == "1"     # opt-in: slower on an idle GPU (see gemm_nt.hip)
+
+
+def _ensure_tile_counters(device):
+    """32 KiB of zeroed device ints for the dynamic tile scheduler of persistent gemm_nt launches (caller-owned)."""
+    key = str(device)
+    if key not in _tile_counters:
+        buf = torch.zeros(8192, dtype=torch.int32, device=device)
+        _check(lib().oat_gemm_set_tile_counters(_ptr(buf), ctypes.c_size_t(buf.numel() * 4)), "oat_gemm_set_tile_counters")
+        _tile_counters[key] = buf
+
+
 def gemm_nt(A, B, M, N, K, epi, out, out2=None, bias=None, resid=None, resid_mod=0, aux=None,
             lda=None, ldb=None, ldc=None, ld2=None, ldr=None, ldaux=None):
     """out[M,N] = A[M,K] @ B[N,K]^T (+epilogue).  Tensors may hold more rows than M."""
+    if M >= 4096 and _DYNAMIC_TILES:
+        _ensure_tile_counters(A.device)
     rc = lib().oat_gemm_nt(_ptr(A), _ptr(B), M, N, K, lda or A.stride(0), ldb or B.stride(0), epi,
                            _ptr(out), ldc or out.stride(0), _ptr(out2),
                            (ld2 or (out2.stride(0) if out2 is not None else 0)), _ptr(bias), _ptr(resid),

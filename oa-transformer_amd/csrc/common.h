@@ -71,6 +71,16 @@ OAT_DEV void glds16_asm(const void* gptr, void* lds_wave_base) {
                : "=&s"(keep) : "v"(gptr), "s"(lds) : "memory");
 }
 
+// Same, with the address split into a wave-uniform 64-bit base (SGPR pair) and a per-lane 32-bit byte offset: half the
+// address VGPRs of the flat form and no 64-bit VALU add per piece.
+OAT_DEV void glds16_asm_so(const void* uniform_base, uint32_t lane_byte_off, void* lds_wave_base) {
+  const uint32_t lds = __builtin_amdgcn_readfirstlane(
+      (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)lds_wave_base));
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(lane_byte_off), "s"(uniform_base), "s"(lds) : "memory");
+}
+
 // LDS transpose read: within each 16-lane group, lane s fetches 4 contiguous bf16 at its own
 // address; output lane i, element j = fetched[lane 4*j + (i >> 2)][i & 3].
 OAT_DEV s16x4 lds_tr16(const void* lds_ptr) {

@@ -16,6 +16,7 @@
 // output columns of one row: bias/residual loads are float4 and stores are 8/16 bytes.
 #include "common.h"
 #include <type_traits>
+#include <atomic>
 
 namespace oat {
 
@@ -37,6 +38,8 @@ struct GemmArgs {
   const bf16* aux; int ldaux;
   int dbg;
   int row0;            // first row of this launch inside the caller's problem (tail launches; used by resid_mod)
+  int* ctr;            // persistent launch: 8 per-XCD tile counters of THIS launch (zero on entry), or nullptr = static walk
+  int* ctr_reset;      // counters of a launch far in the future, zeroed by this one
 };
 
 constexpr int BK = 64;
@@ -84,36 +87,76 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
   // workgroup's NEXT tile are already streaming into A slots 0 and 1.
   constexpr bool PREF = !PIPE && NSA == 3 && EPI != EPI_DGELU;
   bool prefetched = false;
-  for (int tile = blockIdx.x; tile < nwg; tile += gridDim.x) {
-  const int bid = remap(tile);
+  // Tile scheduling.  Static: workgroup w walks tiles w, w + gridDim.x, ...  Dynamic (g.ctr): every workgroup pulls
+  // the next tile of ITS XCD's contiguous range from an atomic counter (and steals from the other XCDs when its own
+  // range is exhausted), so a workgroup that starts late - its CU was busy with another stream's kernel or with RCCL -
+  // simply takes fewer tiles instead of stretching the launch.  The index travels through the last word of the ring.
+  constexpr int LDS_TOTAL = (NSA * BM + 2 * BN) * BK * 2;
+  volatile int* const tile_word = reinterpret_cast<volatile int*>(smem + LDS_TOTAL - 16);
+  int static_tile = blockIdx.x;
+  // Thread 0 requests its XCD's counter during the main loop and uses the answer in the epilogue.  (hipcc waits for an
+  // atomic's result right where it is issued - vmcnt(0) inside the K loop - which costs 5-15 % on short-K shapes; an
+  // inline-asm atomic parked in an AGPR hung the GPU in testing.  Dynamic scheduling is therefore OPT-IN.)
+  int pending = 0;
+  auto request = [&]() {
+    if (g.ctr != nullptr && threadIdx.x == 0) pending = atomicAdd(g.ctr + (blockIdx.x & 7), 1);
+  };
+  auto fetch = [&]() -> int {
+    if (g.ctr == nullptr) {
+      const int t = static_tile;
+      static_tile += gridDim.x;
+      return t < nwg ? remap(t) : -1;
+    }
+    if (threadIdx.x == 0) {
+      const int q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
+      int res = -1;
+      if (pending < q + (xcd < r ? 1 : 0)) {
+        res = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pending;
+      } else {
+        for (int d = 1; d < 8 && res < 0; ++d) {         // own range exhausted: steal (end of the launch only)
+          const int x = (xcd + d) & 7;
+          const int idx = atomicAdd(g.ctr + x, 1);
+          if (idx < q + (x < r ? 1 : 0)) res = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
+        }
+      }
+      *tile_word = res;
+    }
+    __syncthreads();
+    const int v = *tile_word;
+    __syncthreads();                       // nobody restages that word before everyone has read it
+    return v;
+  };
+  if (g.ctr_reset != nullptr && blockIdx.x == 0 && threadIdx.x < 8) g.ctr_reset[threadIdx.x] = 0;
+  request();
+  int bid = fetch();
+  while (bid >= 0) {
   const int tm = bid / ntn, tn = bid % ntn;
   const int m0 = tm * BM, n0 = tn * BN;
 
   // ---- staging addresses: wave w stages GA (GB) slabs of 8 rows of A (B), one glds each
   const int srow = lane >> 3;                   // row within an 8-row slab
-  const bf16* a_src[GA];
-  const bf16* b_src[GB];
+  uint32_t a_src[GA], b_src[GB];                // per-lane BYTE offsets into A / B (the K offset rides in the scalar base)
 #pragma unroll
   for (int i = 0; i < GA; ++i) {
     const int r = (wave * GA + i) * 8 + srow;
     const int lc = (lane & 7) ^ ((r >> 1) & 7);            // inverse swizzle on the source side
-    a_src[i] = g.A + (size_t)min(((g.dbg & 16) ? 0 : m0) + r, g.M - 1) * g.lda + lc * 8;   // clamp: ragged M reads a valid row
+    a_src[i] = (uint32_t)(((size_t)min(((g.dbg & 16) ? 0 : m0) + r, g.M - 1) * g.lda + lc * 8) * 2);   // clamp: ragged M reads a valid row
   }
 #pragma unroll
   for (int i = 0; i < GB; ++i) {
     const int r = (wave * GB + i) * 8 + srow;
     const int lc = (lane & 7) ^ ((r >> 1) & 7);
-    b_src[i] = g.B + (size_t)min(((g.dbg & 32) ? 0 : n0) + r, g.N - 1) * g.ldb + lc * 8;
+    b_src[i] = (uint32_t)(((size_t)min(((g.dbg & 32) ? 0 : n0) + r, g.N - 1) * g.ldb + lc * 8) * 2);
   }
   char* const sA0 = smem;
   char* const sB0 = smem + NSA * A_BYTES;
   auto stageA = [&](int buf, int k0) {
 #pragma unroll
-    for (int i = 0; i < GA; ++i) glds16_asm(a_src[i] + k0, sA0 + buf * A_BYTES + (wave * GA + i) * 1024);
+    for (int i = 0; i < GA; ++i) glds16_asm_so(g.A + k0, a_src[i], sA0 + buf * A_BYTES + (wave * GA + i) * 1024);
   };
   auto stageB = [&](int buf, int k0) {
 #pragma unroll
-    for (int i = 0; i < GB; ++i) glds16_asm(b_src[i] + k0, sB0 + buf * B_BYTES + (wave * GB + i) * 1024);
+    for (int i = 0; i < GB; ++i) glds16_asm_so(g.B + k0, b_src[i], sB0 + buf * B_BYTES + (wave * GB + i) * 1024);
   };
 
   f32x4 acc[TM][TN];
@@ -194,15 +237,16 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
         for (int j = 0; j < 4; ++j) mfma_agpr(acc[i][j0 + j], fb[1][j0 + j], fa[1][i]);
         if constexpr (more) ld_item(0, sa1, sb1, 0, gq);
         if (gq < GB) {
-          if constexpr (moreB) glds16_asm(b_src[gq] + (kt + 2) * BK, sB0 + (kt & 1) * B_BYTES + (wave * GB + gq) * 1024);
+          if constexpr (moreB) glds16_asm_so(g.B + (kt + 2) * BK, b_src[gq], sB0 + (kt & 1) * B_BYTES + (wave * GB + gq) * 1024);
         } else {
-          if constexpr (moreA) glds16_asm(a_src[gq - GB] + (kt + 3) * BK, sA0 + abuf * A_BYTES + (wave * GA + gq - GB) * 1024);
+          if constexpr (moreA) glds16_asm_so(g.A + (kt + 3) * BK, a_src[gq - GB], sA0 + abuf * A_BYTES + (wave * GA + gq - GB) * 1024);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
       abuf = abuf1;
     };
     using T_ = std::true_type; using F_ = std::false_type;
+    request();
     int kt = 0;
     for (; kt + 3 < nk; ++kt) kstep(kt, T_{}, T_{}, T_{});
     if (kt + 2 < nk) { kstep(kt, T_{}, T_{}, F_{}); ++kt; }
@@ -229,6 +273,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
       if (moreB) stageB(bbuf_n, (kt + 1) * BK);
       if (moreA) stageA(abuf_n, ka_n);
     }
+    // the NEXT tile's counter request goes out in the second K-step: issued earlier it would be the oldest
+    // outstanding memory operation of wave 0 and every counted wait of this tile would sit on its round trip
+    if (kt == (nk > 1 ? 1 : 0)) request();
     const char* sa = sA0 + abuf * A_BYTES;
     const char* sb = sB0 + (kt & 1) * B_BYTES;
     abuf = abuf + 1 == NSA ? 0 : abuf + 1;
@@ -256,9 +303,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
             const int pc = slot / EVERY;
             __builtin_amdgcn_sched_barrier(0);
             if (pc < GB) {
-              if (moreB) glds16_asm(b_src[pc] + (kt + 1) * BK, sB0 + bbuf_n * B_BYTES + (wave * GB + pc) * 1024);
+              if (moreB) glds16_asm_so(g.B + (kt + 1) * BK, b_src[pc], sB0 + bbuf_n * B_BYTES + (wave * GB + pc) * 1024);
             } else {
-              if (moreA) glds16_asm(a_src[pc - GB] + ka_n, sA0 + abuf_n * A_BYTES + (wave * GA + pc - GB) * 1024);
+              if (moreA) glds16_asm_so(g.A + ka_n, a_src[pc - GB], sA0 + abuf_n * A_BYTES + (wave * GA + pc - GB) * 1024);
             }
             __builtin_amdgcn_sched_barrier(0);
           }
@@ -275,6 +322,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(acc[i][j]));
     __syncthreads();
+    bid = fetch();
     continue;
   }
   // ---- epilogue.  Each lane owns C[row = .. + (lane & 15)][col = .. + (lane >> 4) * 4 + 0..3]
@@ -284,15 +332,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
   // FULL 128-byte lines, 16 B per lane; residual / aux loads use the same coalesced shape.
   __syncthreads();
   prefetched = false;
+  const int bid_next = fetch();            // the LDS staging data is dead here: the broadcast word is safe
   if constexpr (PREF) {
-    const int tile_n = tile + (int)gridDim.x;
-    if (tile_n < nwg && nk > 1 && !(g.dbg & 2)) {
-      const int m0n = (remap(tile_n) / ntn) * BM;
+    if (bid_next >= 0 && nk > 1 && !(g.dbg & 2)) {
+      const int m0n = (bid_next / ntn) * BM;
 #pragma unroll
       for (int i = 0; i < GA; ++i) {
         const int r = (wave * GA + i) * 8 + srow;
         const int lc = (lane & 7) ^ ((r >> 1) & 7);
-        a_src[i] = g.A + (size_t)min(m0n + r, g.M - 1) * g.lda + lc * 8;
+        a_src[i] = (uint32_t)(((size_t)min(m0n + r, g.M - 1) * g.lda + lc * 8) * 2);
       }
       stageA(0, 0);
       stageA(1, BK);
@@ -426,16 +474,20 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
       }
     }
   }
-  if (tile + (int)gridDim.x < nwg) {      // the epilogue scratch lives in the staging ring the next tile refills
+  if (bid_next >= 0) {                     // the epilogue scratch lives in the staging ring the next tile refills
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
+  bid = bid_next;
   }   // tile loop
 }
 
 // tuning hook: variant 0 = auto, 1 = force 128x128, 2 = force 256x256, 3 = 4-wave pipelined 256x256;
 // persist 0 = one workgroup per CU, 0xffff = one workgroup per tile, else the grid size
 static int g_variant = 0, g_dbg = 0, g_persist = 0, g_tail = 0;
+constexpr unsigned CTR_SETS = 1024;           // counter sets in the caller's buffer (8 ints each); set s is zeroed by launch s - 512
+static int* g_ctr = nullptr;
+static std::atomic<unsigned> g_seq{0};
 
 static int cu_count() {
   static int cus = 0;
@@ -460,11 +512,19 @@ static int launch_cfg(const GemmArgs& g, hipStream_t s) {
     attr_set = true;
   }
   int grid = ntm * ntn;
+  GemmArgs a = g;
   if (BM == 256 && g_persist != 0xffff) {        // persistent: one workgroup per CU walks the tiles (+1.8 % per step)
     const int slots = g_persist > 0 ? g_persist : cu_count();
-    if (grid > slots) grid = slots;
+    if (grid > slots) {
+      grid = slots;
+      if (g_ctr != nullptr && !(g_dbg & 128)) {  // dynamic tile scheduling over a ring of counter sets
+        const unsigned seq = g_seq.fetch_add(1);
+        a.ctr = g_ctr + (seq % CTR_SETS) * 8;
+        a.ctr_reset = g_ctr + ((seq + CTR_SETS / 2) % CTR_SETS) * 8;
+      }
+    }
   }
-  hipLaunchKernelGGL((gemm_nt_kernel<EPI, WM, WN, TM, TN, NSA, SPREAD, PIPE>), dim3(grid), dim3(WM * WN * 64), LDS, s, g);
+  hipLaunchKernelGGL((gemm_nt_kernel<EPI, WM, WN, TM, TN, NSA, SPREAD, PIPE>), dim3(grid), dim3(WM * WN * 64), LDS, s, a);
   return check_launch("gemm_nt");
 }
 
@@ -508,6 +568,14 @@ static int launch(const GemmArgs& g, hipStream_t s) {
 }  // namespace oat
 
 extern "C" void oat_gemm_set_tail_split(int on) { oat::g_tail = on; }
+extern "C" int oat_gemm_set_tile_counters(void* zeroed_device_ints, size_t bytes) {
+  if (zeroed_device_ints != nullptr && bytes < oat::CTR_SETS * 8 * sizeof(int)) {
+    oat::set_error("gemm_set_tile_counters: need 32 KiB of zeroed device memory");
+    return -3;
+  }
+  oat::g_ctr = static_cast<int*>(zeroed_device_ints);
+  return 0;
+}
 extern "C" void oat_gemm_set_variant(int v) { oat::g_variant = v & 0xff; oat::g_dbg = (v >> 8) & 0xff; oat::g_persist = (v >> 16) & 0xffff; }
 
 extern "C" int oat_gemm_nt(const void* A, const void* B, int M, int N, int K, int lda, int ldb,
@@ -522,7 +590,7 @@ extern "C" int oat_gemm_nt(const void* A, const void* B, int M, int N, int K, in
   }
   if (!A || !B || !out) { set_error("gemm_nt: null pointer"); return -4; }
   GemmArgs g{(const bf16*)A, (const bf16*)B, M, N, K, lda, ldb, out, ldc, out2, ld2,
-             bias, resid, ldr, resid_mod, (const bf16*)aux, ldaux, g_dbg, 0};
+             bias, resid, ldr, resid_mod, (const bf16*)aux, ldaux, g_dbg, 0, nullptr, nullptr};
   hipStream_t s = (hipStream_t)stream;
   switch (epi) {
     case EPI_BF16: return launch<EPI_BF16>(g, s);
