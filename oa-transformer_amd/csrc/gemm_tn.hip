@@ -96,9 +96,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_tn_kernel(TnArgs g) {
     const bf16* Pm = g.P + (size_t)chunk * TK * g.ldp;
     const bf16* Qm = g.Q + (size_t)chunk * TK * g.ldq;
 #pragma unroll
-    for (int i = 0; i < GP; ++i) glds16_asm(Pm + p_off[i], base + (wave * GP + i) * 1024);
+    for (int i = 0; i < GP; ++i) glds16_asm_so(Pm, (uint32_t)p_off[i] * 2u, base + (wave * GP + i) * 1024);
 #pragma unroll
-    for (int i = 0; i < GQ; ++i) glds16_asm(Qm + q_off[i], base + P_BYTES + (wave * GQ + i) * 1024);
+    for (int i = 0; i < GQ; ++i) glds16_asm_so(Qm, (uint32_t)q_off[i] * 2u, base + P_BYTES + (wave * GQ + i) * 1024);
   };
 
   f32x4 acc[TM][TN], accb[TM];
