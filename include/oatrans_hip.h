@@ -30,7 +30,11 @@ int oat_abi_version(void);
  * (fc1/GELU/fc2), oa_model.py:68-74 (txt_proj/vid_proj), and Conv2d patch-embed :69-75.
  * epi: 0 out(bf16)=acc+bias | 1 out(f32)=acc+bias+resid[row % resid_mod] |
  *      2 out(bf16)=h=acc+bias, out2(bf16)=gelu(h) | 3 out(bf16)=acc*gelu'(aux) |
- *      4 like 1 plus bf16 copy in out2.   bias/resid/out2/aux may be NULL where unused. */
+ *      4 like 1 plus bf16 copy in out2 |
+ *      5 h=acc+bias (fp32): out(bf16)=gelu'(h), out2(bf16)=gelu(h) | 6 out(bf16)=(acc+bias)*aux[row,col]
+ *      (5 + 6 are the MLP pair the engine uses: the derivative is evaluated once, in forward, next to the
+ *      activation it shares its erf / exp with; backward only multiplies).
+ *      bias/resid/out2/aux may be NULL where unused. */
 int oat_gemm_nt(const void* A, const void* B, int M, int N, int K, int lda, int ldb, int epi,
                 void* out, int ldc, void* out2, int ld2, const float* bias, const float* resid,
                 int ldr, int resid_mod, const void* aux, int ldaux, void* stream);

@@ -130,7 +130,7 @@ class TextEngine:
                         resid=x)
             hip.layernorm_fwd(a.s, p("sa_layer_norm.weight"), p("sa_layer_norm.bias"), M, D, 1e-12, y=a.x1_16,
                               y32=a.x1, mean=a.stats[0], rstd=a.stats[1])
-            hip.gemm_nt(a.x1_16, w("ffn.lin1"), M, Hd, D, hip.EPI_GELU_DUAL, a.h, out2=a.g, bias=p("ffn.lin1.bias"))
+            hip.gemm_nt(a.x1_16, w("ffn.lin1"), M, Hd, D, hip.EPI_GELU_GRAD, a.h, out2=a.g, bias=p("ffn.lin1.bias"))
             hip.gemm_nt(a.g, w("ffn.lin2"), M, D, Hd, hip.EPI_F32, a.f, bias=p("ffn.lin2.bias"), resid=a.x1)
             hip.layernorm_fwd(a.f, p("output_layer_norm.weight"), p("output_layer_norm.bias"), M, D, 1e-12,
                               y=a.x2_16, y32=a.x2, mean=a.stats[2], rstd=a.stats[3])
@@ -157,7 +157,7 @@ class TextEngine:
                               dgamma=gr("output_layer_norm.weight"), dbeta=gr("output_layer_norm.bias"),
                               accumulate=acc)                                              # G = dL/df
             hip.gemm_tn(g16, a.g, M, D, Hd, gr("ffn.lin2.weight"), accumulate=acc, bias_out=gr("ffn.lin2.bias"))
-            hip.gemm_nt(g16, wT("ffn.lin2"), M, Hd, D, hip.EPI_DGELU, pl.d_h, aux=a.h)
+            hip.gemm_nt(g16, wT("ffn.lin2"), M, Hd, D, hip.EPI_MUL_AUX, pl.d_h, aux=a.h)
             hip.gemm_tn(pl.d_h, a.x1_16, M, Hd, D, gr("ffn.lin1.weight"), accumulate=acc, bias_out=gr("ffn.lin1.bias"))
             hip.gemm_nt(pl.d_h, wT("ffn.lin1"), M, D, Hd, hip.EPI_F32, G, resid=G)          # G = dL/dx1
             # x1 = LN(s), s = x + out_lin(attn(qkv(x)))

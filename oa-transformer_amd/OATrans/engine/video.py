@@ -265,7 +265,7 @@ class VideoEngine:
         # space residual comes from x, NOT from x + time (video_transformer.py:170)
         hip.add_layernorm_fwd(x, br, a.y, p("norm2.weight"), p("norm2.bias"), M, D, 1e-6, y=a.a2, mean=st[4],
                               rstd=st[5])                                           # y = x + space
-        hip.gemm_nt(a.a2, w("mlp.fc1"), M, Hd, D, hip.EPI_GELU_DUAL, a.h, out2=a.g, bias=p("mlp.fc1.bias"))
+        hip.gemm_nt(a.a2, w("mlp.fc1"), M, Hd, D, hip.EPI_GELU_GRAD, a.h, out2=a.g, bias=p("mlp.fc1.bias"))
         hip.gemm_nt(a.g, w("mlp.fc2"), M, D, Hd, hip.EPI_BF16, br, bias=p("mlp.fc2.bias"))
         return a                                                                    # out = y + br, formed lazily
 
@@ -440,7 +440,7 @@ class VideoEngine:
         d_h, gb, d_qkv_s, gc, d_qkv_t = st8["d_h"], st8["gb"], st8["d_qkv_s"], st8["gc"], st8["d_qkv_t"]
         # ---- MLP: out = y + fc2(gelu(fc1(LN2(y))))
         self._wgrad(ln, wg, ga, a.g, M, D, Hd, gr("mlp.fc2.weight"), gr("mlp.fc2.bias"))
-        hip.gemm_nt(ga, wT("mlp.fc2"), M, Hd, D, hip.EPI_DGELU, d_h, aux=a.h)
+        hip.gemm_nt(ga, wT("mlp.fc2"), M, Hd, D, hip.EPI_MUL_AUX, d_h, aux=a.h)
         self._wgrad(ln, wg, d_h, a.a2, M, Hd, D, gr("mlp.fc1.weight"), gr("mlp.fc1.bias"))
         hip.gemm_nt(d_h, wT("mlp.fc1"), M, D, Hd, hip.EPI_BF16, pl.d_a)
         self._own_grad(ln, lambda acc: hip.layernorm_bwd(

@@ -72,7 +72,7 @@ def _f(x):
     return ctypes.c_float(float(x))
 
 
-EPI_BF16, EPI_F32, EPI_GELU_DUAL, EPI_DGELU, EPI_F32_BF16 = 0, 1, 2, 3, 4
+EPI_BF16, EPI_F32, EPI_GELU_DUAL, EPI_DGELU, EPI_F32_BF16, EPI_GELU_GRAD, EPI_MUL_AUX = 0, 1, 2, 3, 4, 5, 6
 
 
 _tile_counters = {}

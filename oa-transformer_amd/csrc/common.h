@@ -53,6 +53,20 @@ OAT_DEV float dgelu_f(float x) {
   const float cdf = 0.5f * (1.0f + erf_as(x * 0.70710678118f));
   return cdf + x * 0.3989422804f * __expf(-0.5f * x * x);
 }
+// gelu(x) and gelu'(x) from ONE erf / exp evaluation (exp(-x^2/2) is both the A-S tail and the normal density)
+OAT_DEV void gelu_both(float x, float& gl, float& dg) {
+  const float ax = fabsf(x) * 0.70710678118f;
+  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+  float p = 1.061405429f;
+  p = p * t - 1.453152027f;
+  p = p * t + 1.421413741f;
+  p = p * t - 0.284496736f;
+  p = p * t + 0.254829592f;
+  const float e = __expf(-ax * ax);
+  const float cdf = 0.5f + 0.5f * copysignf(1.0f - p * t * e, x);
+  gl = x * cdf;
+  dg = cdf + x * 0.3989422804f * e;
+}
 
 // 16-byte async global -> LDS copy: lane i's 16 B land at lds_base + 16 * i.
 OAT_DEV void glds16(const void* gptr, void* lds_wave_base) {

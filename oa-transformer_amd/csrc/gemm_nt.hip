@@ -26,6 +26,8 @@ enum GemmEpi : int {
   EPI_GELU_DUAL = 2,  // out(bf16) = h = acc + bias ; out2(bf16) = gelu(h)
   EPI_DGELU = 3,      // out(bf16) = acc * gelu'(aux[row, col])   (aux = saved pre-activation h)
   EPI_F32_BF16 = 4,   // EPI_F32 plus a bf16 copy in out2
+  EPI_GELU_GRAD = 5,  // h = acc + bias (fp32) ; out(bf16) = gelu'(h) ; out2(bf16) = gelu(h)
+  EPI_MUL_AUX = 6,    // out(bf16) = (acc + bias) * aux[row, col]      (aux = the gelu'(h) saved by EPI_GELU_GRAD)
 };
 
 struct GemmArgs {
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
   // bias of this lane's output columns, requested before the main loop: fetched in the epilogue it costs one
   // exposed global-load latency per tile (22 of 193 us at N = 2304, K = 768)
   f32x4 bias_v[TN];
-  if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU_DUAL) {
+  if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU_DUAL || EPI == EPI_GELU_GRAD || EPI == EPI_MUL_AUX) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int col = n0 + wn * TN * 16 + j * 16 + fk * 4;
@@ -368,8 +370,59 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
 #pragma unroll
   for (int cg = 0; cg < TN / 4; ++cg) {
     const int wcol0 = wcol00 + cg * 64;
-    if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU_DUAL) {
+    if constexpr (EPI == EPI_GELU_GRAD) {
+      // GELU and its derivative share one erf / exp evaluation on the fp32 pre-activation.  gelu'(h) goes through the
+      // wave's bf16 scratch first; gelu(h) waits, packed, in 32 registers and takes the same route afterwards.
+      bf16x4 glv[4][4];
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            bf16x4 o;
+            if (pass == 0) {
+              const f32x4 v = acc[rh * 4 + i][cg * 4 + j] + bias_v[cg * 4 + j];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                float gl, dg;
+                gelu_both(v[e], gl, dg);
+                o[e] = f2bf(dg);
+                glv[i][j][e] = f2bf(gl);
+              }
+            } else {
+              o = glv[i][j];
+            }
+            *reinterpret_cast<bf16x4*>(ep + sc8(i * 16 + frow, (j * 16 + fk * 4) * 2)) = o;
+            if (pass == 0) __builtin_amdgcn_sched_barrier(0);     // one tile's erf / exp chains at a time: no spills
+          }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int lr = it * 8 + rrow;
+          const int row = wrow0 + rh * 64 + lr, col = wcol0 + rch * 8;
+          typedef __attribute__((ext_vector_type(2))) unsigned long long u64x2;
+          const u64x2 raw = *reinterpret_cast<const u64x2*>(ep + sc(lr, rch * 16));
+          const u64x2 fixed = (it & 1) ? u64x2{raw[1], raw[0]} : raw;      // see the bf16 path below
+          if (row < g.M && col < g.N) {
+            if (pass == 0) *reinterpret_cast<u64x2*>((bf16*)g.out + (size_t)row * g.ldc + col) = fixed;
+            else *reinterpret_cast<u64x2*>((bf16*)g.out2 + (size_t)row * g.ld2 + col) = fixed;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    } else if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU_DUAL || EPI == EPI_MUL_AUX) {
       // bf16 scratch: 64 rows x 64 cols
+      bf16x8 auxv[8];
+      auto aux_load = [&](int it) {
+        const int row = wrow0 + rh * 64 + it * 8 + rrow, col = wcol0 + rch * 8;
+        if (row < g.M && col < g.N) auxv[it] = *reinterpret_cast<const bf16x8*>(g.aux + (size_t)row * g.ldaux + col);
+      };
+      if constexpr (EPI == EPI_MUL_AUX) {         // first half requested before the transpose: its latency hides behind it
+#pragma unroll
+        for (int it = 0; it < 2; ++it) aux_load(it);
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -379,6 +432,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
           *reinterpret_cast<bf16x4*>(ep + sc8(i * 16 + frow, (j * 16 + fk * 4) * 2)) = o;
         }
       __builtin_amdgcn_wave_barrier();
+      if constexpr (EPI == EPI_MUL_AUX) {         // second half: this chunk's accumulators are dead now
+#pragma unroll
+        for (int it = 2; it < 8; ++it) aux_load(it);
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
         const int lr = it * 8 + rrow;
@@ -391,6 +449,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
           hv = __builtin_bit_cast(bf16x8, fixed);
         }
         if (row < g.M && col < g.N) {
+          if constexpr (EPI == EPI_MUL_AUX) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) hv[e] = f2bf(bf2f(hv[e]) * bf2f(auxv[it][e]));
+          }
           const int orow = (g.dbg & 4) ? (row & 1023) : row;      // ablation: all row panels overwrite the first 1024 rows
           if (!(g.dbg & 8)) *reinterpret_cast<bf16x8*>((bf16*)g.out + (size_t)orow * g.ldc + col) = hv;
           else asm volatile("" ::"v"(hv));
@@ -604,6 +666,12 @@ extern "C" int oat_gemm_nt(const void* A, const void* B, int M, int N, int K, in
     case EPI_F32_BF16:
       if (!out2) { set_error("gemm_nt: EPI_F32_BF16 needs out2"); return -4; }
       return launch<EPI_F32_BF16>(g, s);
+    case EPI_GELU_GRAD:
+      if (!out2) { set_error("gemm_nt: EPI_GELU_GRAD needs out2"); return -4; }
+      return launch<EPI_GELU_GRAD>(g, s);
+    case EPI_MUL_AUX:
+      if (!aux) { set_error("gemm_nt: EPI_MUL_AUX needs aux"); return -4; }
+      return launch<EPI_MUL_AUX>(g, s);
     default: set_error("gemm_nt: unknown epilogue"); return -5;
   }
 }

@@ -24,4 +24,8 @@ for rep in range(2):
     print(f"N=3072 K=768 EPI_GELU_DUAL: {2*M*n*k/t/1e12:7.1f} TF/s ({t*1e6:7.1f} us)")
     t = timeit(lambda: hip.gemm_nt(A, B, M, n, k, hip.EPI_DGELU, o1, aux=h))
     print(f"N=3072 K=768 EPI_DGELU    : {2*M*n*k/t/1e12:7.1f} TF/s ({t*1e6:7.1f} us)")
+    t = timeit(lambda: hip.gemm_nt(A, B, M, n, k, hip.EPI_GELU_GRAD, o1, out2=o2, bias=bias))
+    print(f"N=3072 K=768 EPI_GELU_GRAD: {2*M*n*k/t/1e12:7.1f} TF/s ({t*1e6:7.1f} us)")
+    t = timeit(lambda: hip.gemm_nt(A, B, M, n, k, hip.EPI_MUL_AUX, o1, aux=h))
+    print(f"N=3072 K=768 EPI_MUL_AUX  : {2*M*n*k/t/1e12:7.1f} TF/s ({t*1e6:7.1f} us)")
     print("checksum", o1.float().abs().sum().item())

@@ -97,6 +97,32 @@ def test_gemm_nt_gelu_and_dgelu():
     close(out, hf.grad, atol=2e-2, rtol=1.5e-2, what="dgelu")
 
 
+@pytest.mark.parametrize("M,N,K", [(515, 512, 128), (1300, 768, 192)])
+def test_gemm_nt_gelu_grad_and_mul_aux(M, N, K):
+    """The MLP pair the engine uses: forward stores gelu'(h) next to gelu(h) (one erf / exp evaluation on the fp32
+    pre-activation), backward multiplies by it (reference: Mlp.forward, video_transformer.py:45-51, nn.GELU)."""
+    hip = _hip()
+    A = rnd(M, K, dtype=torch.bfloat16, seed=9)
+    B = rnd(N, K, scale=K ** -0.5, dtype=torch.bfloat16, seed=10)
+    bias = rnd(N, seed=11)
+    d = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    g = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    hip.gemm_nt(A, B, M, N, K, hip.EPI_GELU_GRAD, d, out2=g, bias=bias)
+    href = (A.float() @ B.float().t() + bias).requires_grad_(True)
+    gref = torch.nn.functional.gelu(href)
+    gref.sum().backward()
+    close(g, gref.detach(), atol=1e-2, rtol=1e-2, what="gelu(h)")
+    close(d, href.grad, atol=6e-3, rtol=8e-3, what="gelu'(h)")
+    K2 = 256
+    A2 = rnd(M, K2, dtype=torch.bfloat16, seed=12)
+    B2 = rnd(N, K2, scale=K2 ** -0.5, dtype=torch.bfloat16, seed=13)
+    out = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    hip.gemm_nt(A2, B2, M, N, K2, hip.EPI_MUL_AUX, out, aux=d)
+    close(out, (A2.float() @ B2.float().t()) * d.float(), atol=2e-2, rtol=1.5e-2, what="mul_aux")
+    hip.gemm_nt(A2, B2, M, N, K2, hip.EPI_MUL_AUX, out, aux=d, bias=bias)
+    close(out, (A2.float() @ B2.float().t() + bias) * d.float(), atol=2e-2, rtol=1.5e-2, what="mul_aux + bias")
+
+
 # ----------------------------------------------------------------------------- GEMM TN
 @pytest.mark.parametrize("M,N1,N2", [(1000, 256, 384), (64, 128, 128), (5000, 768, 768), (777, 64, 2304), (333, 3072, 128)])
 def test_gemm_tn(M, N1, N2):
