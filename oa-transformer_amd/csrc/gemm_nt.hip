@@ -88,6 +88,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
   // PREF: while a tile's epilogue runs (scratch in the upper 96 KB of the ring), the first two A stages of the
   // workgroup's NEXT tile are already streaming into A slots 0 and 1.
   constexpr bool PREF = !PIPE && NSA == 3 && EPI != EPI_DGELU;
+  // DIRECT: bf16 outputs are stored straight from the accumulators, with no transpose through LDS, no scratch and no
+  // wave barriers.  The MFMA operands are NOT swapped here (lane l holds rows 4*(l>>4)+r, column l&15 of a 16x16 tile)
+  // and the B rows (= output columns) are PERMUTED on their way into LDS: tile j, MFMA column c of a wave's 64-column
+  // group is output column 4*c + j.  A lane then owns 4 consecutive columns of a row across its TN = 4 tiles (one 8-B
+  // store) and the 16 consecutive lanes of a row write one full 128-byte line.
+  constexpr bool DIRECT = !PIPE && TN == 4 && (EPI == EPI_BF16 || EPI == EPI_GELU_GRAD || EPI == EPI_MUL_AUX);
   bool prefetched = false;
   // Tile scheduling.  Static: workgroup w walks tiles w, w + gridDim.x, ...  Dynamic (g.ctr): every workgroup pulls
   // the next tile of ITS XCD's contiguous range from an atomic counter (and steals from the other XCDs when its own
@@ -148,7 +154,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
   for (int i = 0; i < GB; ++i) {
     const int r = (wave * GB + i) * 8 + srow;
     const int lc = (lane & 7) ^ ((r >> 1) & 7);
-    b_src[i] = (uint32_t)(((size_t)min(((g.dbg & 32) ? 0 : n0) + r, g.N - 1) * g.ldb + lc * 8) * 2);
+    const int rg = DIRECT ? ((r & ~63) | ((r & 15) << 2) | ((r >> 4) & 3)) : r;   // LDS row r <- B row rg
+    b_src[i] = (uint32_t)(((size_t)min(((g.dbg & 32) ? 0 : n0) + rg, g.N - 1) * g.ldb + lc * 8) * 2);
   }
   char* const sA0 = smem;
   char* const sB0 = smem + NSA * A_BYTES;
@@ -161,12 +168,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
     for (int i = 0; i < GB; ++i) glds16_asm_so(g.B + k0, b_src[i], sB0 + buf * B_BYTES + (wave * GB + i) * 1024);
   };
 
-  f32x4 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
   const int nk = g.K / BK;
   const int frow = lane & 15, fk = lane >> 4;
   // bias of this lane's output columns, requested before the main loop: fetched in the epilogue it costs one
@@ -175,10 +176,20 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
   if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU_DUAL || EPI == EPI_GELU_GRAD || EPI == EPI_MUL_AUX) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int col = n0 + wn * TN * 16 + j * 16 + fk * 4;
+      const int col = n0 + wn * TN * 16 + (DIRECT ? frow * 4 : j * 16 + fk * 4);     // DIRECT: only bias_v[0] is used
       bias_v[j] = (g.bias && col < g.N) ? *reinterpret_cast<const f32x4*>(g.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   }
+  // DIRECT: the bias is the accumulators' initial value (lane column 4 * frow + j is the same for every row it owns),
+  // so the epilogue is conversions and stores only
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const float b0 = DIRECT ? bias_v[0][j & 3] : 0.f;
+      acc[i][j] = f32x4{b0, b0, b0, b0};
+    }
   if constexpr (PIPE) {
     // One wave per SIMD (4 waves x 128x128): nothing hides a wave's own LDS latency or its barrier, so the
     // loop is software-pipelined by hand.  Fragments are double-buffered in registers (set 0 = k-half 0, set 1 =
@@ -294,7 +305,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
       for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = DIRECT ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0)
+                             : __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
         if constexpr (SPREAD) {
           // one LDS-DMA piece per SLOT MFMA groups: a piece blocks its wave's issue port for 60-180 cycles;
           // spread through the MFMA stream that time is hidden behind matrix work instead of stalling both
@@ -365,6 +377,80 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
   const int wrow0 = m0 + wm * TM * 16;
   static_assert(TN % 4 == 0, "epilogue works on 64-column groups of the wave tile");
   const int wcol00 = n0 + wn * TN * 16;
+  if constexpr (DIRECT) {
+    const int col = wcol00 + frow * 4;
+    auto finish = [&](const f32x4 v, const bf16x4 a, bf16x4& o, bf16x4& o2) {
+      if constexpr (EPI == EPI_GELU_GRAD) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float gl, dg;
+          gelu_both(v[e], gl, dg);
+          o[e] = f2bf(dg);
+          o2[e] = f2bf(gl);
+        }
+      } else if constexpr (EPI == EPI_MUL_AUX) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e] * bf2f(a[e]));
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+      }
+    };
+    if (m0 + BM <= g.M && n0 + BN <= g.N && g.dbg == 0) {
+      // interior tile (all but the last row panel): no bounds checks, and every address is a wave-uniform 64-bit base
+      // (scalar registers, advanced with scalar adds) plus ONE 32-bit lane offset per matrix
+      const size_t t0 = (size_t)wrow0;
+      char* const ob = reinterpret_cast<char*>(g.out) + (t0 * g.ldc + wcol00) * 2;
+      char* const ob2 = EPI == EPI_GELU_GRAD ? reinterpret_cast<char*>(g.out2) + (t0 * g.ld2 + wcol00) * 2 : nullptr;
+      const char* const ab = EPI == EPI_MUL_AUX ? reinterpret_cast<const char*>(g.aux) + (t0 * g.ldaux + wcol00) * 2 : nullptr;
+      const uint32_t lo = (uint32_t)(fk * 4 * g.ldc + frow * 4) * 2;
+      const uint32_t lo2 = EPI == EPI_GELU_GRAD ? (uint32_t)(fk * 4 * g.ld2 + frow * 4) * 2 : 0;
+      const uint32_t la = EPI == EPI_MUL_AUX ? (uint32_t)(fk * 4 * g.ldaux + frow * 4) * 2 : 0;
+      bf16x4 an[4] = {}, ac[4] = {};
+      if constexpr (EPI == EPI_MUL_AUX) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) an[r] = *reinterpret_cast<const bf16x4*>(ab + (size_t)(uint32_t)(r * g.ldaux * 2) + la);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        if constexpr (EPI == EPI_MUL_AUX) {        // the saved derivative of row group i + 1 is requested one group ahead
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ac[r] = an[r];
+          if (i + 1 < TM) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              an[r] = *reinterpret_cast<const bf16x4*>(ab + (size_t)(uint32_t)(((i + 1) * 16 + r) * g.ldaux * 2) + la);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const f32x4 v = f32x4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+          bf16x4 o, o2;
+          finish(v, ac[r], o, o2);
+          const uint32_t rr = (uint32_t)(i * 16 + r);
+          *reinterpret_cast<bf16x4*>(ob + (size_t)(rr * (uint32_t)g.ldc * 2) + lo) = o;
+          if constexpr (EPI == EPI_GELU_GRAD) *reinterpret_cast<bf16x4*>(ob2 + (size_t)(rr * (uint32_t)g.ld2 * 2) + lo2) = o2;
+        }
+      }
+    } else {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = wrow0 + i * 16 + fk * 4 + r;
+        const f32x4 v = f32x4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+        if (row < g.M && col < g.N) {
+          bf16x4 o, o2, a = {};
+          if constexpr (EPI == EPI_MUL_AUX) a = *reinterpret_cast<const bf16x4*>(g.aux + (size_t)row * g.ldaux + col);
+          finish(v, a, o, o2);
+          if constexpr (EPI == EPI_GELU_GRAD) *reinterpret_cast<bf16x4*>((bf16*)g.out2 + (size_t)row * g.ld2 + col) = o2;
+          const int orow = (g.dbg & 4) ? (row & 1023) : row;
+          if (!(g.dbg & 8)) *reinterpret_cast<bf16x4*>((bf16*)g.out + (size_t)orow * g.ldc + col) = o;
+          else asm volatile("" ::"v"(o));
+        }
+      }
+    }
+  } else {
 #pragma unroll
   for (int rh = 0; rh < TM / 4; ++rh)
 #pragma unroll
@@ -536,7 +622,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
       }
     }
   }
-  if (bid_next >= 0) {                     // the epilogue scratch lives in the staging ring the next tile refills
+  }
+  if (!DIRECT && bid_next >= 0) {          // the epilogue scratch lives in the staging ring the next tile refills
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }

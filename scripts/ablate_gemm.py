@@ -19,7 +19,7 @@ for (m, n, k) in [(M, 768, 3072), (M, 2304, 768), (M, 768, 768), (M, 3072, 768),
     bias = torch.randn(n, device="cuda"); out16 = torch.zeros(Mp, n, device="cuda", dtype=torch.bfloat16)
     for rep in range(2):
       for VAR in (2,):
-        for dbg in (128, 0):
+        for dbg in [int(x) for x in os.environ.get("DBGS", "128,0").split(",")]:
             hip.gemm_set_variant(VAR | (dbg << 8))
             t = timeit(lambda: hip.gemm_nt(A, B, m, n, k, hip.EPI_BF16, out16, bias=bias))
             print(f"N={n} K={k} variant={VAR & 0xff} persist={VAR >> 16} dbg={dbg}: {2*m*n*k/t/1e12:7.1f} TF/s ({t*1e6:7.1f} us)")
