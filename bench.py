@@ -63,6 +63,8 @@ def build(args, device):
         m.flatten_parameters()
     dp = HipDataParallel(model)
     opt = AdamW([p for p in model.parameters() if p.requires_grad], lr=args.lr)
+    if os.environ.get("OAT_EAGER_ADAM", "0") == "1":
+        opt.attach(model)          # parameter updates start under backward: measured SLOWER (56.5 -> 57.2 ms), opt-in
     loss_fn = module_arch.NormSoftmaxLoss()
     return dp, opt, loss_fn
 

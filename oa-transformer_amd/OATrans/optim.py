@@ -21,6 +21,52 @@ class AdamW(torch.optim.Optimizer):
         self.hf_style = hf_style
         self.grad_scale = grad_scale
         self._runs = None
+        self._stream = None          # eager mode: side stream the early launches run on
+        self.eager_launches = 0      # launches issued from grad-ready announcements (introspection / tests)
+
+    def attach(self, model):
+        """EAGER mode (opt-in, single rank): the engine modules announce gradient ranges as soon as the kernels that
+        write them are enqueued (`grad_ready_hook`, the same announcements the gradient all-reduce overlaps with);
+        each announced range is updated right away on a side stream, under the rest of backward, instead of in
+        `step()` after it.  `step()` then updates whatever was not announced and joins the side stream.  The result
+        is identical to the plain `backward(); step()` sequence of the reference trainer (trainer_dist.py:163-166);
+        do not attach when gradients are inspected or backward is run without a following `step()`.
+        With more than one rank the announcements belong to the gradient all-reduce and nothing is attached."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return self
+        for m in model.modules():
+            if hasattr(m, "flat_grad") and hasattr(m, "_engine_params") and getattr(m, "grad_ready_hook", None) is None:
+                m.grad_ready_hook = self._on_ready
+        return self
+
+    def _on_ready(self, module, lo, hi):
+        """flat_grad()[lo:hi] of `module` is final once the work enqueued so far on the CURRENT stream is done."""
+        if hi <= lo or self._runs is None or not self._runs_valid():
+            return                               # first step (state not built yet) or buffers moved: step() does it all
+        ptr = module.flat_grad().data_ptr() + 4 * lo
+        n = hi - lo
+        for r in self._runs:
+            if r['g0'] <= ptr and ptr + 4 * n <= r['g0'] + 4 * r['n']:
+                break
+        else:
+            return
+        off = (ptr - r['g0']) // 4
+        if self._stream is None:
+            self._stream = torch.cuda.Stream()
+        ev = torch.cuda.Event()
+        ev.record()
+        self._stream.wait_event(ev)
+        with torch.cuda.stream(self._stream), torch.no_grad():
+            self._launch(r, off, off + n)
+        r['done'].append((off, off + n))
+        self.eager_launches += 1
+
+    def _launch(self, r, a, b):
+        g = self.param_groups[r['group']]
+        step = self.state[r['params'][0]]['step'] + 1
+        hip.adamw(r['flat_p'][a:b], r['flat_g'][a:b], r['m'][a:b], r['v'][a:b], g['lr'], g['betas'][0], g['betas'][1],
+                  g['eps'], g['weight_decay'], step, hf_style=self.hf_style, gscale=self.grad_scale)
 
     def _build_runs(self):
         """Coalesce parameters that are adjacent in memory in BOTH .data and .grad (the engine modules
@@ -55,6 +101,10 @@ class AdamW(torch.optim.Optimizer):
                 st.setdefault('step', 0)
                 off += p.numel()
             r['sig'] = tuple((p.data.data_ptr(), p.grad.data_ptr()) for p in r['params'])
+            p0 = r['params'][0]
+            r['flat_p'] = torch.as_strided(p0.data, (r['n'],), (1,))
+            r['flat_g'] = torch.as_strided(p0.grad, (r['n'],), (1,))
+            r['done'] = []
         self._runs = runs
 
     def _runs_valid(self):
@@ -69,16 +119,19 @@ class AdamW(torch.optim.Optimizer):
         if not self._runs_valid():
             self._build_runs()
         for r in self._runs:
-            g = self.param_groups[r['group']]
-            p0 = r['params'][0]
-            st = self.state[p0]
-            step = st['step'] + 1
-            flat_p = torch.as_strided(p0.data, (r['n'],), (1,))
-            flat_g = torch.as_strided(p0.grad, (r['n'],), (1,))
-            hip.adamw(flat_p, flat_g, r['m'], r['v'], g['lr'], g['betas'][0], g['betas'][1], g['eps'],
-                      g['weight_decay'], step, hf_style=self.hf_style, gscale=self.grad_scale)
+            pos = 0
+            for a, b in sorted(r['done']):       # ranges already updated under backward (eager mode)
+                if a > pos:
+                    self._launch(r, pos, a)
+                pos = max(pos, b)
+            if pos < r['n']:
+                self._launch(r, pos, r['n'])
+            r['done'] = []
+            step = self.state[r['params'][0]]['step'] + 1
             for p in r['params']:
                 self.state[p]['step'] = step
+        if self._stream is not None:
+            torch.cuda.current_stream().wait_stream(self._stream)
         bump_weights_epoch()     # kernels wrote through raw pointers: tell the engines to re-cast shadows
         return loss
 

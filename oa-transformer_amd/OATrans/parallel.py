@@ -88,7 +88,7 @@ class GradSync:
             except ImportError:                      # entry points run from inside OATrans/ import us as a top-level module
                 from ops import hip
             hip.gemm_set_variant(0xffff << 16)
-        if overlap:
+        if overlap and (W > 1 or force):     # a single rank leaves the announcements to the eager optimiser (optim.AdamW.attach)
             for m in model.modules():
                 if hasattr(m, "flat_grad") and hasattr(m, "_engine_params"):
                     m.grad_ready_hook = self.on_ready

@@ -226,3 +226,53 @@ def test_ragged_shapes_take_optimiser_steps():
         if B > 1:
             assert losses[1] < losses[0], (B, T, L, losses)
     assert all(torch.isfinite(p).all().item() for p in m.parameters())
+
+
+def test_eager_adamw_equals_step_after_backward():
+    """AdamW.attach: ranges announced during backward are updated under it on a side stream; the parameters after
+    each step must equal the plain backward(); step() sequence (trainer_dist.py:163-166).  Identical gradients give
+    bit-identical updates (same kernel, same operands), so the only tolerance is the fp32-atomics noise of the
+    CLS-row gradients between two runs of backward."""
+    import argparse
+    import copy
+    from OATrans import model as module_arch
+    from OATrans.optim import AdamW
+    from OATrans.parallel import HipDataParallel
+    from OATrans.trainer.step import hot_step
+    torch.manual_seed(0)
+    base = module_arch.FrozenInTime(
+        video_params=dict(model="SpaceTimeTransformer", arch_config="base_patch16_224", num_frames=2, pretrained=True,
+                          time_init="rand", arch_kwargs=dict(depth=3)),
+        object_params=dict(model="", input_objects=False),
+        text_params=dict(model="pretrained/distilbert-base-uncased", pretrained=True, input="text", config=dict(n_layers=2)),
+        projection="minimal", load_checkpoint="")
+    sa = argparse.Namespace(world_size=1, rank=0, local_rank=0)
+    g = torch.Generator().manual_seed(5)
+    B, T, L = 4, 2, 12
+    data = {"video": torch.randn(B, T, 3, 224, 224, generator=g).cuda(),
+            "text": {"input_ids": torch.randint(1000, 30000, (B, L), generator=g).cuda(),
+                     "attention_mask": torch.ones(B, L, dtype=torch.int64).cuda()}}
+    results = []
+    for eager in (False, True):
+        m = copy.deepcopy(base).cuda()
+        m.set_device(torch.device("cuda"))
+        for sub in (m.video_model, m.text_model):
+            sub.flatten_parameters()
+        dp = HipDataParallel(m)
+        opt = AdamW([p for p in m.parameters() if p.requires_grad], lr=1e-4, weight_decay=0.01)
+        if eager:
+            opt.attach(m)
+        losses = [hot_step(dp, module_arch.NormSoftmaxLoss(), opt, data, sa).item() for _ in range(4)]
+        torch.cuda.synchronize()
+        # the first step builds the optimiser state in step(); from the second on every block and the text tower are eager
+        assert opt.eager_launches == (3 * (3 + 1 + 1) if eager else 0), opt.eager_launches
+        assert all(st['step'] == 4 for st in opt.state.values())
+        results.append((losses, {n: p.detach().clone() for n, p in m.named_parameters()}))
+    (l0, p0), (l1, p1) = results
+    assert max(abs(a - b) for a, b in zip(l0, l1)) < 2e-3, (l0, l1)
+    assert l0[-1] < l0[0]
+    for n in p0:
+        # 4 steps of at most lr each; an element whose gradient sign flips with the atomics noise moves by <= 2 lr per step
+        d = (p0[n] - p1[n]).abs()
+        assert d.max().item() <= 8e-4 + 1e-6, (n, d.max().item())
+        assert d.mean().item() < 2e-5, (n, d.mean().item())
