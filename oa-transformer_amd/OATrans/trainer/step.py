@@ -20,14 +20,14 @@ def hot_step(model_dp, loss_fn, optimizer, data, args):
     text_embeds, video_embeds = model_dp(data, aug=True)
     video_all, text_all = allgather_pair(video_embeds, text_embeds, args)
     loss = loss_fn(sim_matrix(text_all, video_all))
-    loss.backward()
+    model_dp.backward(loss) if hasattr(model_dp, 'backward') else loss.backward()
     model_dp.sync_gradients()
     optimizer.step()
     return loss.detach()
 
 
 def _finish(model_dp, optimizer, loss):
-    loss.backward()
+    model_dp.backward(loss) if hasattr(model_dp, 'backward') else loss.backward()
     model_dp.sync_gradients()
     optimizer.step()
     return loss.detach()

@@ -46,6 +46,16 @@ def _worker(rank, world, port, q):
     sync = GradSync(model)
     assert len(sync.ranges()) == 1 and sync.ranges()[0].numel() == 256
     sync.all_reduce(average=True)
+    # 4. HipDataParallel.backward: 1/W on the loss + SUM all-reduce must give the same mean, bit for bit (W = 2)
+    from OATrans.parallel import HipDataParallel
+    lin = torch.nn.Linear(8, 16, bias=False)
+    with torch.no_grad():
+        lin.weight.copy_(W1)
+    dp = HipDataParallel(lin)
+    v_all2, t_all2 = allgather_pair(xb @ W2.detach().t(), dp(xa), args)
+    dp.backward(orc.norm_softmax_loss(orc.sim_matrix(t_all2, v_all2)))
+    dp.sync_gradients()
+    assert torch.equal(lin.weight.grad, W1.grad), (lin.weight.grad - W1.grad).abs().max()
     # numpy, not torch tensors: torch shares tensor storage by file descriptor, which fails if this process exits
     # before the parent has unpickled the message
     q.put((rank, loss.item(), W1.grad.numpy().copy(), W2.grad.numpy().copy(), xa.numpy().copy(), xb.numpy().copy()))
