@@ -108,6 +108,7 @@ int oat_attn_time_fwd(const void* qkv, int ldqkv, void* out, int ldo, float* lse
 void oat_attn_time_set_variant(int v);   /* tuning hook: 0 auto (single-read LDS kernel for T <= 8), 1 force two-pass */
 int oat_attn_cls_fwd(const void* qkv, int ldqkv, void* out, int ldo, float* lse, int B, int T, int N,
                      int H, int D, float scale, void* stream);
+int oat_attn_space_set_variant(int v);   /* tuning hook for the backward at >= 97 patches: 0 = 16 waves x one 16-row tile each (default), 1 = 8 waves x tile pairs */
 /* cls_side: fp32 [B,H,3,64], zero on entry; finish with oat_attn_cls_finalize. */
 int oat_attn_space_bwd(const void* qkv, int ldqkv, const void* out, int ldo, const float* lse,
                        const void* dout, int lddo, void* dqkv, int lddqkv, float* cls_side, int B, int T,

@@ -165,9 +165,13 @@ __global__ __launch_bounds__(FWD_THREADS) void attn_space_fwd_kernel(SpaceArgs a
 // neither phase needs all four.  Phase A (dQ) streams over K and V and touches Q / dO only as the per-wave row
 // fragments; phase B (dK, dV) is the mirror image.  So LDS holds TWO tiles: K, V during phase A, then - after a
 // barrier - Q, dO for phase B, and the per-wave row fragments come straight from global memory.
-template <int NKT, bool BIG>
-__global__ __launch_bounds__(BWD_THREADS) void attn_space_bwd_kernel(SpaceArgs a) {
+// WIDE: 16 waves (four per SIMD, <= 128 VGPRs) that each own ONE 16-row tile instead of 8 waves with a tile pair: the
+// kernel is bound by its dependent LDS -> MFMA -> exp -> MFMA chains, not by LDS or MFMA throughput, so twice the
+// resident waves hide twice the latency.
+template <int NKT, bool BIG, bool WIDE>
+__global__ __launch_bounds__(WIDE ? 1024 : 512) void attn_space_bwd_kernel(SpaceArgs a) {
   constexpr int NKP = NKT * 16;
+  constexpr int THR = WIDE ? 1024 : BWD_THREADS, STEP = WIDE ? 1 : 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Kt = smem;
   char* Vt = smem + NKP * 128;
@@ -181,10 +185,10 @@ __global__ __launch_bounds__(BWD_THREADS) void attn_space_bwd_kernel(SpaceArgs a
   const int N = a.N;
   const size_t base_row = (size_t)bf * N;
   const size_t cls_row = (size_t)a.B * a.T * N + b;
-  if (!BIG) load_tile<NKT, BWD_THREADS>(Qt, a.qkv, a.ldqkv, h * 64, base_row, cls_row, N);
-  load_tile<NKT, BWD_THREADS>(Kt, a.qkv, a.ldqkv, a.D + h * 64, base_row, cls_row, N);
-  load_tile<NKT, BWD_THREADS>(Vt, a.qkv, a.ldqkv, 2 * a.D + h * 64, base_row, cls_row, N);
-  if (!BIG) load_tile<NKT, BWD_THREADS>(Dt, a.dout, a.lddo, h * 64, base_row, cls_row, N);
+  if (!BIG) load_tile<NKT, THR>(Qt, a.qkv, a.ldqkv, h * 64, base_row, cls_row, N);
+  load_tile<NKT, THR>(Kt, a.qkv, a.ldqkv, a.D + h * 64, base_row, cls_row, N);
+  load_tile<NKT, THR>(Vt, a.qkv, a.ldqkv, 2 * a.D + h * 64, base_row, cls_row, N);
+  if (!BIG) load_tile<NKT, THR>(Dt, a.dout, a.lddo, h * 64, base_row, cls_row, N);
   // row fragment of a token-row matrix straight from global memory (same element order as row_frag on a tile)
   auto grow_frag = [&](const bf16* src, int ld, int col, int r0, int ks, int lane_) {
     const int j = r0 + (lane_ & 15);
@@ -193,11 +197,11 @@ __global__ __launch_bounds__(BWD_THREADS) void attn_space_bwd_kernel(SpaceArgs a
   };
   // delta = rowsum(dO * O) and lse (log2 units), 8 lanes per row; all loads issued before the first use
   {
-    constexpr int ITER = (NKP * 8 + BWD_THREADS - 1) / BWD_THREADS;
+    constexpr int ITER = (NKP * 8 + THR - 1) / THR;
     bf16x8 gv[ITER], ov[ITER];
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
-      const int idx = it * BWD_THREADS + threadIdx.x;
+      const int idx = it * THR + threadIdx.x;
       const int j = min(idx >> 3, N), c = idx & 7;
       const size_t r = j < N ? base_row + j : cls_row;
       gv[it] = *reinterpret_cast<const bf16x8*>(a.dout + r * a.lddo + h * 64 + c * 8);
@@ -205,7 +209,7 @@ __global__ __launch_bounds__(BWD_THREADS) void attn_space_bwd_kernel(SpaceArgs a
     }
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
-      const int idx = it * BWD_THREADS + threadIdx.x;
+      const int idx = it * THR + threadIdx.x;
       const int j = idx >> 3, c = idx & 7;
       float d = 0.f;
 #pragma unroll
@@ -237,9 +241,9 @@ __global__ __launch_bounds__(BWD_THREADS) void attn_space_bwd_kernel(SpaceArgs a
 
   // ------------------------------------------------ phase A: lane = query column, produces dQ
   // streamed over key pairs: dS of keys [32u, 32u+32) is consumed by the dQ MFMAs right away
-  for (int pr = wave; pr * 2 < ntile; pr += BWD_THREADS / 64) {
-    const int qt0 = pr * 2;
-    const bool two = qt0 + 1 < ntile;                   // wave-uniform
+  for (int pr = wave; pr * STEP < ntile; pr += THR / 64) {
+    const int qt0 = pr * STEP;
+    const bool two = !WIDE && qt0 + 1 < ntile;                   // wave-uniform
     const int qiA = qt0 * 16 + (lane & 15), qiB = qiA + 16;
     const float lqA = lse_s[qiA], dlA = del_s[qiA], lqB = lse_s[qiB], dlB = del_s[qiB];
     bf16x8 qfA[2], dfA[2], qfB[2], dfB[2];
@@ -280,8 +284,8 @@ __global__ __launch_bounds__(BWD_THREADS) void attn_space_bwd_kernel(SpaceArgs a
           const bool clsdup = key == N && f != 0;       // CLS->CLS pair is counted once (frame 0)
           const bool okA = key <= N && qiA <= N && !(qiA == N && clsdup);
           const bool okB = key <= N && qiB <= N && !(qiB == N && clsdup);
-          dsA[hf][r] = okA ? exp2f(sA[r] * c2 - lqA) * (pA[r] - dlA) : 0.f;
-          dsB[hf][r] = (two && okB) ? exp2f(sB[r] * c2 - lqB) * (pB[r] - dlB) : 0.f;
+          dsA[hf][r] = okA ? __builtin_amdgcn_exp2f(sA[r] * c2 - lqA) * (pA[r] - dlA) : 0.f;
+          dsB[hf][r] = (two && okB) ? __builtin_amdgcn_exp2f(sB[r] * c2 - lqB) * (pB[r] - dlB) : 0.f;
         }
       }
       const bf16x8 sbA = pack8(dsA[0], dsA[1]), sbB = pack8(dsB[0], dsB[1]);
@@ -315,13 +319,13 @@ __global__ __launch_bounds__(BWD_THREADS) void attn_space_bwd_kernel(SpaceArgs a
   // ------------------------------------------------ phase B: lane = key column, produces dK, dV
   if constexpr (BIG) {
     __syncthreads();                                      // every wave is done with K, V in LDS
-    load_tile<NKT, BWD_THREADS>(Qt, a.qkv, a.ldqkv, h * 64, base_row, cls_row, N);
-    load_tile<NKT, BWD_THREADS>(Dt, a.dout, a.lddo, h * 64, base_row, cls_row, N);
+    load_tile<NKT, THR>(Qt, a.qkv, a.ldqkv, h * 64, base_row, cls_row, N);
+    load_tile<NKT, THR>(Dt, a.dout, a.lddo, h * 64, base_row, cls_row, N);
     __syncthreads();
   }
-  for (int pr = wave; pr * 2 < ntile; pr += BWD_THREADS / 64) {
-    const int kt0 = pr * 2;
-    const bool two = kt0 + 1 < ntile;
+  for (int pr = wave; pr * STEP < ntile; pr += THR / 64) {
+    const int kt0 = pr * STEP;
+    const bool two = !WIDE && kt0 + 1 < ntile;
     const int keyA = kt0 * 16 + (lane & 15), keyB = keyA + 16;
     bf16x8 kfA[2], vfA[2], kfB[2], vfB[2];
 #pragma unroll
@@ -364,8 +368,8 @@ __global__ __launch_bounds__(BWD_THREADS) void attn_space_bwd_kernel(SpaceArgs a
           const bool clsq = qi == N && f != 0;
           const bool okA = keyA <= N && qi <= N && !(clsq && keyA == N);
           const bool okB = two && keyB <= N && qi <= N && !(clsq && keyB == N);
-          const float a_ = okA ? exp2f(sA[r] * c2 - lq) : 0.f;
-          const float b_ = okB ? exp2f(sB[r] * c2 - lq) : 0.f;
+          const float a_ = okA ? __builtin_amdgcn_exp2f(sA[r] * c2 - lq) : 0.f;
+          const float b_ = okB ? __builtin_amdgcn_exp2f(sB[r] * c2 - lq) : 0.f;
           pvA[hf][r] = a_; svA[hf][r] = a_ * (pA[r] - dl);
           pvB[hf][r] = b_; svB[hf][r] = b_ * (pB[r] - dl);
         }
@@ -426,14 +430,15 @@ static int launch_fwd(const SpaceArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(attn_space_fwd_kernel<NKT>, dim3(a.B * a.T * a.H), dim3(FWD_THREADS), lds, s, a);
   return check_launch("attn_space_fwd");
 }
-template <int NKT, bool BIG = false>
+template <int NKT, bool BIG = false, bool WIDE = false>
 static int launch_bwd(const SpaceArgs& a, hipStream_t s) {
   const int lds = (BIG ? 2 : 4) * NKT * 16 * 128 + 2 * NKT * 16 * 4;
   static bool set = false;
-  if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_space_bwd_kernel<NKT, BIG>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
-  hipLaunchKernelGGL((attn_space_bwd_kernel<NKT, BIG>), dim3(a.B * a.T * a.H), dim3(BWD_THREADS), lds, s, a);
+  if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_space_bwd_kernel<NKT, BIG, WIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
+  hipLaunchKernelGGL((attn_space_bwd_kernel<NKT, BIG, WIDE>), dim3(a.B * a.T * a.H), dim3(WIDE ? 1024 : BWD_THREADS), lds, s, a);
   return check_launch("attn_space_bwd");
 }
+static int g_space_variant = 0;      // tuning hook: 0 = 16 waves x one tile for >= 97 patches (default), 1 = 8 waves x tile pairs
 
 static int pick_nkt(int N) {
   const int need = (N + 1 + 31) / 32 * 2;     // even number of 16-key tiles
@@ -477,10 +482,12 @@ extern "C" int oat_attn_space_bwd(const void* qkv, int ldqkv, const void* out, i
     case 2: return launch_bwd<2>(a, s);
     case 4: return launch_bwd<4>(a, s);
     case 8: return launch_bwd<8>(a, s);
-    case 14: return launch_bwd<14>(a, s);
-    default: return launch_bwd<28, true>(a, s);
+    case 14: return g_space_variant == 1 ? launch_bwd<14>(a, s) : launch_bwd<14, false, true>(a, s);
+    default: return g_space_variant == 1 ? launch_bwd<28, true>(a, s) : launch_bwd<28, true, true>(a, s);
   }
 }
+
+extern "C" int oat_attn_space_set_variant(int v) { g_space_variant = v; return 0; }
 
 extern "C" int oat_attn_cls_finalize(const float* cls_side, void* dqkv, int lddqkv, int B, int T, int N, int H, int D,
                                      void* stream) {

@@ -3,7 +3,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "oa-transformer_amd")); sys.path.insert(0, ROOT)
 import torch
 from OATrans.ops import hip
-B, T, N, H = int(os.environ.get("B", 32)), 8, 196, 12
+B, T, N, H = int(os.environ.get("B", 32)), 8, int(os.environ.get("N", 196)), 12
 D = H * 64; M = B * T * N + B; Mp = (M + 255) // 256 * 256
 qkv = torch.zeros(Mp, 3 * D, dtype=torch.bfloat16, device="cuda"); qkv[:M] = torch.randn(M, 3 * D, device="cuda").bfloat16()
 out = torch.zeros(Mp, D, dtype=torch.bfloat16, device="cuda"); lse = torch.zeros(Mp, H, device="cuda")
@@ -31,3 +31,11 @@ for rep in range(2):
         t = timeit(lambda: hip.attn_time_bwd(qkv, out, lse, dout, dqkv, side, B, T, N, H, D, sc))
         print(f"time bwd variant {var} ({'two-pass' if var else 'single-read LDS'}): {t:.1f} us  checksum {dqkv.float().abs().sum().item():.6e}")
 hip.lib().oat_attn_time_set_variant(0)
+hip.attn_space_fwd(qkv, out, lse, B, T, N, H, D, sc)
+for rep in range(2):
+    for var in (1, 0):
+        hip.lib().oat_attn_space_set_variant(var)
+        side.zero_(); dqkv.zero_()
+        t = timeit(lambda: hip.attn_space_bwd(qkv, out, lse, dout, dqkv, side, B, T, N, H, D, sc))
+        print(f"space bwd variant {var}: {t:.1f} us  checksum {dqkv[:M - B].float().abs().sum().item():.6e}")
+hip.lib().oat_attn_space_set_variant(0)

@@ -282,6 +282,21 @@ def ref_attention(qkv_ref, mode, B, T, N, H):
                                      (2, 2, 441, 3), (1, 16, 441, 2), (2, 1, 256, 2), (1, 2, 224, 2), (1, 2, 447, 1),   # 336^2 / 16 = 441
                                      (1, 5, 9, 1), (2, 6, 20, 2), (1, 7, 9, 2), (1, 12, 16, 1)])
 def test_attention_fwd_bwd(mode, B, T, N, H):
+    _attention_case(mode, B, T, N, H)
+
+
+@pytest.mark.parametrize("B,T,N,H", [(2, 8, 196, 12), (2, 2, 441, 3), (1, 2, 224, 2)])
+def test_attention_space_bwd_paired_variant(B, T, N, H):
+    """tuning variant 1 of the space backward (8 waves x tile pairs; the default is 16 waves x one tile)"""
+    hip = _hip()
+    hip.lib().oat_attn_space_set_variant(1)
+    try:
+        _attention_case("space", B, T, N, H)
+    finally:
+        hip.lib().oat_attn_space_set_variant(0)
+
+
+def _attention_case(mode, B, T, N, H):
     hip = _hip()
     D = H * 64
     M = B * T * N + B
