@@ -168,10 +168,12 @@ __global__ __launch_bounds__(FWD_THREADS) void attn_space_fwd_kernel(SpaceArgs a
 // WIDE: 16 waves (four per SIMD, <= 128 VGPRs) that each own ONE 16-row tile instead of 8 waves with a tile pair: the
 // kernel is bound by its dependent LDS -> MFMA -> exp -> MFMA chains, not by LDS or MFMA throughput, so twice the
 // resident waves hide twice the latency.
-template <int NKT, bool BIG, bool WIDE>
-__global__ __launch_bounds__(WIDE ? 1024 : 512) void attn_space_bwd_kernel(SpaceArgs a) {
+// WIDE == 2: single tiles on 8 waves, registers capped at 128: with the two-tile BIG layout (59 KB at 196 patches) TWO
+// workgroups share a CU and one's loads / stores overlap the other's MFMA phases.
+template <int NKT, bool BIG, int WIDE>
+__global__ __launch_bounds__(WIDE == 1 ? 1024 : 512, WIDE == 2 ? 4 : 2) void attn_space_bwd_kernel(SpaceArgs a) {
   constexpr int NKP = NKT * 16;
-  constexpr int THR = WIDE ? 1024 : BWD_THREADS, STEP = WIDE ? 1 : 2;
+  constexpr int THR = WIDE == 1 ? 1024 : BWD_THREADS, STEP = WIDE ? 1 : 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Kt = smem;
   char* Vt = smem + NKP * 128;
@@ -430,15 +432,17 @@ static int launch_fwd(const SpaceArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(attn_space_fwd_kernel<NKT>, dim3(a.B * a.T * a.H), dim3(FWD_THREADS), lds, s, a);
   return check_launch("attn_space_fwd");
 }
-template <int NKT, bool BIG = false, bool WIDE = false>
+template <int NKT, bool BIG = false, int WIDE = 0>
 static int launch_bwd(const SpaceArgs& a, hipStream_t s) {
   const int lds = (BIG ? 2 : 4) * NKT * 16 * 128 + 2 * NKT * 16 * 4;
   static bool set = false;
   if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_space_bwd_kernel<NKT, BIG, WIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
-  hipLaunchKernelGGL((attn_space_bwd_kernel<NKT, BIG, WIDE>), dim3(a.B * a.T * a.H), dim3(WIDE ? 1024 : BWD_THREADS), lds, s, a);
+  hipLaunchKernelGGL((attn_space_bwd_kernel<NKT, BIG, WIDE>), dim3(a.B * a.T * a.H), dim3(WIDE == 1 ? 1024 : BWD_THREADS), lds, s, a);
   return check_launch("attn_space_bwd");
 }
-static int g_space_variant = 0;      // tuning hook: 0 = 16 waves x one tile for >= 97 patches (default), 1 = 8 waves x tile pairs
+// tuning hook.  0 (default): 97..223 patches -> two 8-wave workgroups per CU on the two-tile layout, one tile per wave;
+// 224..447 patches -> 16 waves x one tile.  1 = 8 waves x tile pairs (the earlier kernel).  2 = 16 waves x one tile, four-tile layout.
+static int g_space_variant = 0;
 
 static int pick_nkt(int N) {
   const int need = (N + 1 + 31) / 32 * 2;     // even number of 16-key tiles
@@ -482,8 +486,8 @@ extern "C" int oat_attn_space_bwd(const void* qkv, int ldqkv, const void* out, i
     case 2: return launch_bwd<2>(a, s);
     case 4: return launch_bwd<4>(a, s);
     case 8: return launch_bwd<8>(a, s);
-    case 14: return g_space_variant == 1 ? launch_bwd<14>(a, s) : launch_bwd<14, false, true>(a, s);
-    default: return g_space_variant == 1 ? launch_bwd<28, true>(a, s) : launch_bwd<28, true, true>(a, s);
+    case 14: return g_space_variant == 1 ? launch_bwd<14>(a, s) : g_space_variant == 2 ? launch_bwd<14, false, 1>(a, s) : launch_bwd<14, true, 2>(a, s);
+    default: return g_space_variant == 1 ? launch_bwd<28, true>(a, s) : launch_bwd<28, true, 1>(a, s);
   }
 }
 

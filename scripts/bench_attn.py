@@ -33,7 +33,7 @@ for rep in range(2):
 hip.lib().oat_attn_time_set_variant(0)
 hip.attn_space_fwd(qkv, out, lse, B, T, N, H, D, sc)
 for rep in range(2):
-    for var in (1, 0):
+    for var in (1, 2, 0):
         hip.lib().oat_attn_space_set_variant(var)
         side.zero_(); dqkv.zero_()
         t = timeit(lambda: hip.attn_space_bwd(qkv, out, lse, dout, dqkv, side, B, T, N, H, D, sc))

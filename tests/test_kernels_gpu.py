@@ -285,11 +285,12 @@ def test_attention_fwd_bwd(mode, B, T, N, H):
     _attention_case(mode, B, T, N, H)
 
 
-@pytest.mark.parametrize("B,T,N,H", [(2, 8, 196, 12), (2, 2, 441, 3), (1, 2, 224, 2)])
-def test_attention_space_bwd_paired_variant(B, T, N, H):
-    """tuning variant 1 of the space backward (8 waves x tile pairs; the default is 16 waves x one tile)"""
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("B,T,N,H", [(2, 8, 196, 12), (2, 2, 441, 3), (1, 2, 224, 2), (1, 2, 100, 2)])
+def test_attention_space_bwd_tuning_variants(B, T, N, H, variant):
+    """the non-default schedules of the space backward (oat_attn_space_set_variant) compute the same gradients"""
     hip = _hip()
-    hip.lib().oat_attn_space_set_variant(1)
+    hip.lib().oat_attn_space_set_variant(variant)
     try:
         _attention_case("space", B, T, N, H)
     finally:
