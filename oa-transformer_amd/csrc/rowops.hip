@@ -153,30 +153,33 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* dy_, int lddy, 
   }
 }
 
-// out[c] (+)= sum_p part[p * stride + c]; block = 32 columns x 8 partial-lanes (coalesced 128 B rows)
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* part, int P, size_t stride, float* out,
-                                                              int n, int accumulate) {
-  __shared__ float red[8][33];
+// out[c] (+)= sum_p part[p * stride + c]; block = 32 columns x 32 partial-lanes (coalesced 128 B rows).  Columns
+// >= n1 go to out2[c - n1]: LayerNorm's (dgamma | dbeta) partials are finished by ONE launch.  These launches sit on
+// the backward chain between two LayerNorm kernels, so their latency (few workgroups, little data) is what counts.
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* part, int P, size_t stride, float* out,
+                                                               int n, int accumulate, float* out2, int n1) {
+  __shared__ float red[32][33];
   const int cl = threadIdx.x & 31, pg = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (c < n) {
     int p = pg;
-    for (; p + 24 < P; p += 32) {
+    for (; p + 96 < P; p += 128) {
       s0 += part[(size_t)p * stride + c];
-      s1 += part[(size_t)(p + 8) * stride + c];
-      s2 += part[(size_t)(p + 16) * stride + c];
-      s3 += part[(size_t)(p + 24) * stride + c];
+      s1 += part[(size_t)(p + 32) * stride + c];
+      s2 += part[(size_t)(p + 64) * stride + c];
+      s3 += part[(size_t)(p + 96) * stride + c];
     }
-    for (; p < P; p += 8) s0 += part[(size_t)p * stride + c];
+    for (; p < P; p += 32) s0 += part[(size_t)p * stride + c];
   }
   red[pg][cl] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (pg == 0 && c < n) {
     float s = 0.f;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) s += red[r][cl];
-    out[c] = accumulate ? out[c] + s : s;
+    for (int r = 0; r < 32; ++r) s += red[r][cl];
+    float* o = c < n1 ? out + c : out2 + (c - n1);
+    *o = accumulate ? *o + s : s;
   }
 }
 
@@ -380,10 +383,15 @@ extern "C" int oat_layernorm_bwd(const void* dy, int dy_is_bf16, int lddy, const
                        lddres, dx, lddx, (bf16*)dx16, lddx16, dx16_excl_res, part, M, D);
   int rc = check_launch("layernorm_bwd");
   if (rc || !part) return rc;
-  if (dgamma) hipLaunchKernelGGL(reduce_partials_kernel, dim3((D + 31) / 32), dim3(256), 0, s, part, blocks,
-                                 (size_t)2 * D, dgamma, D, accumulate);
-  if (dbeta) hipLaunchKernelGGL(reduce_partials_kernel, dim3((D + 31) / 32), dim3(256), 0, s, part + D, blocks,
-                                (size_t)2 * D, dbeta, D, accumulate);
+  if (dgamma && dbeta)
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * D + 31) / 32), dim3(1024), 0, s, part, blocks, (size_t)2 * D, dgamma,
+                       2 * D, accumulate, dbeta, D);
+  else if (dgamma)
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((D + 31) / 32), dim3(1024), 0, s, part, blocks, (size_t)2 * D, dgamma, D,
+                       accumulate, (float*)nullptr, D);
+  else if (dbeta)
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((D + 31) / 32), dim3(1024), 0, s, part + D, blocks, (size_t)2 * D, dbeta, D,
+                       accumulate, (float*)nullptr, D);
   return check_launch("layernorm_bwd_finish");
 }
 
@@ -399,8 +407,8 @@ extern "C" int oat_colsum(const void* A, int is_bf16, int lda, int M, int N, flo
   dim3 grid((N + 255) / 256, rows);
   if (is_bf16) hipLaunchKernelGGL(colsum_kernel<true>, grid, dim3(256), 0, s, A, lda, M, N, part);
   else hipLaunchKernelGGL(colsum_kernel<false>, grid, dim3(256), 0, s, A, lda, M, N, part);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 31) / 32), dim3(256), 0, s, part, rows, (size_t)N, out, N,
-                     accumulate);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 31) / 32), dim3(1024), 0, s, part, rows, (size_t)N, out, N,
+                     accumulate, (float*)nullptr, N);
   return check_launch("colsum");
 }
 
