@@ -109,14 +109,15 @@ void oat_attn_time_set_variant(int v);   /* tuning hook: 0 auto (single-read LDS
 int oat_attn_cls_fwd(const void* qkv, int ldqkv, void* out, int ldo, float* lse, int B, int T, int N,
                      int H, int D, float scale, void* stream);
 int oat_attn_space_set_variant(int v);   /* tuning hook for the backward at >= 97 patches: 0 = default (97..223 patches: two 8-wave workgroups per CU, one 16-row tile per wave, K,V then Q,dO in LDS; 224..447: 16 waves), 1 = 8 waves x tile pairs, 2 = 16 waves x one tile with all four tiles in LDS */
-/* cls_side: fp32 [B,H,3,64], zero on entry; finish with oat_attn_cls_finalize. */
+/* cls_side: fp32 [B,H,3,64], zero on entry; finish with oat_attn_cls_finalize, which writes the CLS row of dqkv and
+ * leaves cls_side zero again for the next backward launch. */
 int oat_attn_space_bwd(const void* qkv, int ldqkv, const void* out, int ldo, const float* lse,
                        const void* dout, int lddo, void* dqkv, int lddqkv, float* cls_side, int B, int T,
                        int N, int H, int D, float scale, void* stream);
 int oat_attn_time_bwd(const void* qkv, int ldqkv, const void* out, int ldo, const float* lse,
                       const void* dout, int lddo, void* dqkv, int lddqkv, float* cls_side, int B, int T,
                       int N, int H, int D, float scale, void* stream);
-int oat_attn_cls_finalize(const float* cls_side, void* dqkv, int lddqkv, int B, int T, int N, int H, int D,
+int oat_attn_cls_finalize(float* cls_side, void* dqkv, int lddqkv, int B, int T, int N, int H, int D,
                           void* stream);
 
 /* ---- text encoder (HF DistilBertModel, called at oa_model.py:113; third-party algorithm) ---------

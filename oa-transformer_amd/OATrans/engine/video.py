@@ -339,6 +339,7 @@ class VideoEngine:
             lanes[1].follow = lanes[0].order
         for ln in lanes:
             with torch.cuda.stream(ln.pl.stream):
+                ln.pl.cls_side.zero_()       # once per backward; every attn_cls_finalize leaves it zero for the next one
                 self._final_bwd(ln, run, params, grads)
         if run.region_layer is not None:
             ready = None                     # region_norm gradients arrive out of block order: reduce after backward
@@ -449,7 +450,6 @@ class VideoEngine:
         # ---- space attention: y = x + proj(attn(LN1(xt)))
         self._wgrad(ln, wg, gb, a.o_s, M, D, D, gr("attn.proj.weight"), gr("attn.proj.bias"))
         hip.gemm_nt(gb, wT("attn.proj"), M, D, D, hip.EPI_BF16, pl.d_o)
-        pl.cls_side.zero_()
         hip.attn_space_bwd(a.qkv_s, a.o_s, a.lse_s, pl.d_o, d_qkv_s, pl.cls_side, B, T, N, H, D, self.scale)
         hip.attn_cls_finalize(pl.cls_side, d_qkv_s, B, T, N, H, D)
         self._wgrad(ln, wg, d_qkv_s, a.a1, M, 3 * D, D, gr("attn.qkv.weight"), gr("attn.qkv.bias"))
@@ -461,7 +461,6 @@ class VideoEngine:
         # ---- time attention: xt = x + proj(attn(LN3(x)))
         self._wgrad(ln, wg, gc, a.o_t, M, D, D, gr("timeattn.proj.weight"), gr("timeattn.proj.bias"))
         hip.gemm_nt(gc, wT("timeattn.proj"), M, D, D, hip.EPI_BF16, pl.d_o)
-        pl.cls_side.zero_()
         hip.attn_time_bwd(a.qkv_t, a.o_t, a.lse_t, pl.d_o, d_qkv_t, pl.cls_side, B, T, N, H, D, self.scale)
         hip.attn_cls_finalize(pl.cls_side, d_qkv_t, B, T, N, H, D)
         self._wgrad(ln, wg, d_qkv_t, a.a3, M, 3 * D, D, gr("timeattn.qkv.weight"), gr("timeattn.qkv.bias"))

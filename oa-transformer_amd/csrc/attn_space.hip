@@ -415,12 +415,14 @@ __global__ __launch_bounds__(WIDE == 1 ? 1024 : 512, WIDE == 2 ? 4 : 2) void att
   }
 }
 
-// dqkv[cls row(b)][which*D + h*64 + d] = bf16(side[b][h][which][d])
-__global__ void attn_cls_finalize_kernel(const float* side, bf16* dqkv, int lddqkv, int B, int H, int D, size_t cls_row0) {
+// dqkv[cls row(b)][which*D + h*64 + d] = bf16(side[b][h][which][d]); side is left ZERO again, ready for the next
+// backward launch (saves a memset launch per attention on the backward chain)
+__global__ void attn_cls_finalize_kernel(float* side, bf16* dqkv, int lddqkv, int B, int H, int D, size_t cls_row0) {
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   const int t = threadIdx.x;                       // 192 threads: which = t / 64, d = t % 64
   if (t >= 192) return;
   const float v = side[((size_t)b * H + h) * 192 + t];
+  side[((size_t)b * H + h) * 192 + t] = 0.f;
   dqkv[(cls_row0 + b) * lddqkv + (t >> 6) * D + h * 64 + (t & 63)] = f2bf(v);
 }
 
@@ -472,7 +474,7 @@ extern "C" int oat_attn_space_fwd(const void* qkv, int ldqkv, void* out, int ldo
 }
 
 // cls_side: fp32 [B, H, 3, 64], must be ZERO on entry (caller memsets); it receives the CLS row's
-// dq/dk/dv partial sums.  Call oat_attn_cls_finalize afterwards to write them into dqkv.
+// dq/dk/dv partial sums.  Call oat_attn_cls_finalize afterwards to write them into dqkv (it zeroes cls_side again).
 extern "C" int oat_attn_space_bwd(const void* qkv, int ldqkv, const void* out, int ldo, const float* lse,
                                   const void* dout, int lddo, void* dqkv, int lddqkv, float* cls_side, int B, int T,
                                   int N, int H, int D, float scale, void* stream) {
@@ -493,7 +495,7 @@ extern "C" int oat_attn_space_bwd(const void* qkv, int ldqkv, const void* out, i
 
 extern "C" int oat_attn_space_set_variant(int v) { g_space_variant = v; return 0; }
 
-extern "C" int oat_attn_cls_finalize(const float* cls_side, void* dqkv, int lddqkv, int B, int T, int N, int H, int D,
+extern "C" int oat_attn_cls_finalize(float* cls_side, void* dqkv, int lddqkv, int B, int T, int N, int H, int D,
                                      void* stream) {
   hipLaunchKernelGGL(attn_cls_finalize_kernel, dim3(B * H), dim3(192), 0, (hipStream_t)stream, cls_side, (bf16*)dqkv,
                      lddqkv, B, H, D, (size_t)B * T * N);
