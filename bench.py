@@ -121,9 +121,9 @@ def instrumented_gemm_profile(step_fn):
 def pmc_traffic(kernel, args):
     """HBM-side bytes per launch of the dominant kernel.  PMC counters cannot be sampled from inside this
     process, so this is the committed rocprofv3 measurement of the same command and workload
-    (profiles/round1d_pmc_hbm_traffic.md: separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections);
+    (profiles/round1e_pmc_hbm_traffic.md: separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections);
     null when the workload differs from the measured one."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1d_pmc_traffic.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1e_pmc_traffic.json")
     if not os.path.exists(path) or (args.variant, args.batch, args.frames, args.res) != ("frozen", 32, 8, 224):
         return None
     with open(path) as fh:
@@ -243,7 +243,8 @@ def main():
         by, _ = instrumented_gemm_profile(step)
         names = {0: "gemm_nt_kernel<EPI_BF16,2,4,8,4>", 1: "gemm_nt_kernel<EPI_F32,2,4,8,4>",
                  2: "gemm_nt_kernel<EPI_GELU_DUAL,2,4,8,4>", 3: "gemm_nt_kernel<EPI_DGELU,2,4,8,4>",
-                 4: "gemm_nt_kernel<EPI_F32_BF16,2,4,8,4>"}
+                 4: "gemm_nt_kernel<EPI_F32_BF16,2,4,8,4>", 5: "gemm_nt_kernel<EPI_GELU_GRAD,2,4,8,4>",
+                 6: "gemm_nt_kernel<EPI_MUL_AUX,2,4,8,4>"}
         if by:
             epi, d = max(by.items(), key=lambda kv: kv[1]["ms"])
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
