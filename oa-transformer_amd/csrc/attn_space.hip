@@ -58,7 +58,7 @@ struct SpaceArgs {
 // forward: 4 waves, 56 KB LDS -> two workgroups per CU overlap each other's prologue;
 // backward: 116 KB LDS pins one workgroup per CU, so it runs 8 waves (two per SIMD) to hide the
 // MFMA / LDS / exp latency chains (measured 899 -> 526 us at B=32, T=8).
-constexpr int FWD_THREADS = 256, BWD_THREADS = 512;
+constexpr int FWD_THREADS = 512, BWD_THREADS = 512;
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 
@@ -80,7 +80,7 @@ OAT_DEV void load_tile(char* tile, const bf16* src, int ld, int col, size_t base
 }
 
 template <int NKT>
-__global__ __launch_bounds__(FWD_THREADS) void attn_space_fwd_kernel(SpaceArgs a) {
+__global__ __launch_bounds__(FWD_THREADS, NKT <= 14 ? 4 : 2) void attn_space_fwd_kernel(SpaceArgs a) {
   constexpr int NKP = NKT * 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Kt = smem;
@@ -127,6 +127,7 @@ __global__ __launch_bounds__(FWD_THREADS) void attn_space_fwd_kernel(SpaceArgs a
         m = fmaxf(m, acc[r]);
       }
       st[kt] = acc;
+      if (kt & 1) __builtin_amdgcn_sched_barrier(0);     // keeps the K fragments of at most two tiles live (3 waves/SIMD)
     }
     m = fmaxf(m, __shfl_xor(m, 16, 64));
     m = fmaxf(m, __shfl_xor(m, 32, 64));
@@ -147,6 +148,7 @@ __global__ __launch_bounds__(FWD_THREADS) void attn_space_fwd_kernel(SpaceArgs a
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
         ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Vt, u * 32, dt, lane), pb, ot[dt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (qi < N) {
       const float inv = 1.0f / l;

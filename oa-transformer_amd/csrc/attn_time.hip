@@ -56,7 +56,7 @@ struct TimeArgs {
 
 // grid: B*H*ceil(N/8) waves (4 per block); wave -> (b, h, n0), 8-lane group gq -> n = n0 + gq
 template <int TT>
-__global__ __launch_bounds__(256) void attn_time_fwd_kernel(TimeArgs a) {
+__global__ __launch_bounds__(256, TT <= 8 ? 4 : 2) void attn_time_fwd_kernel(TimeArgs a) {
   const int lane = threadIdx.x & 63;
   const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int ng = (a.N + 7) / 8;
@@ -76,10 +76,16 @@ __global__ __launch_bounds__(256) void attn_time_fwd_kernel(TimeArgs a) {
     v[j] = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + 2 * a.D + col);
   }
   const float c2 = a.scale * T_LOG2E;
-#pragma unroll
+  // rolled frame loop with the next query requested one iteration ahead: K and V (72 registers) stay resident and the
+  // kernel fits 4 waves per SIMD (the unrolled loop hoisted all T query loads and ran at 2)
+  bf16x8 qn = *reinterpret_cast<const bf16x8*>(a.qkv + (((size_t)b * TT) * a.N + nn) * a.ldqkv + col);
+#pragma unroll 1
   for (int f = 0; f < TT; ++f) {
     const size_t r = ((size_t)b * TT + f) * a.N + nn;
-    const bf16x8 q = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + col);
+#pragma unroll
+    for (int j = 0; j <= TT; ++j) { asm volatile("" : "+v"(k[j])); asm volatile("" : "+v"(v[j])); }   // keep K, V packed (no hoisted fp32 copies)
+    const bf16x8 q = qn;
+    if (f + 1 < TT) qn = *reinterpret_cast<const bf16x8*>(a.qkv + (r + a.N) * a.ldqkv + col);
     float s[TT + 1], m = -INFINITY;
 #pragma unroll
     for (int j = 0; j <= TT; ++j) { s[j] = red8(dot8x(q, k[j])) * c2; m = fmaxf(m, s[j]); }
