@@ -38,7 +38,7 @@ OAT_DEV float wave_max(float v) {
 // erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below bf16 resolution).
 OAT_DEV float erf_as(float x) {
   const float ax = fabsf(x);
-  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);      // v_rcp_f32 (1 ulp); __frcp_rn expands to the 12-instruction IEEE division
   float p = 1.061405429f;
   p = p * t - 1.453152027f;
   p = p * t + 1.421413741f;
@@ -56,7 +56,7 @@ OAT_DEV float dgelu_f(float x) {
 // gelu(x) and gelu'(x) from ONE erf / exp evaluation (exp(-x^2/2) is both the A-S tail and the normal density)
 OAT_DEV void gelu_both(float x, float& gl, float& dg) {
   const float ax = fabsf(x) * 0.70710678118f;
-  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);      // v_rcp_f32 (1 ulp); __frcp_rn expands to the 12-instruction IEEE division
   float p = 1.061405429f;
   p = p * t - 1.453152027f;
   p = p * t + 1.421413741f;
