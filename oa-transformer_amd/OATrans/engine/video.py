@@ -136,6 +136,7 @@ class VideoEngine:
         self.lanes = int(os.environ.get("OAT_LANES", "1"))   # half-batches on two streams (1 = off)
         self.tail_split = os.environ.get("OAT_TAIL_SPLIT", "1") != "0"
         self.wgrad_cus = int(os.environ.get("OAT_WGRAD_CUS", "192"))   # workgroup budget of a weight-gradient GEMM
+        self.bwd_nt_grid = int(os.environ.get("OAT_BWD_NT_GRID", "0"), 0)   # gemm_nt grid during backward (0 = as in forward, 0xffff = one workgroup per tile)
         self.min_lane_rows = 8192        # token rows per lane below which splitting only adds launches
         self._streams = None
         self._tn_ws = None
@@ -346,6 +347,9 @@ class VideoEngine:
         # weight gradients leave a quarter of the CUs to the data-gradient chain (the critical path): a 256-workgroup
         # gemm_tn holds every CU for its whole duration and the chain's next kernel has to wait for it to retire
         hip.gemm_tn_set_variant(self.wgrad_cus << 16)
+        nt_prev = hip.gemm_get_variant()
+        if self.bwd_nt_grid and (nt_prev >> 16) == 0:
+            hip.gemm_set_variant((nt_prev & 0xffff) | (self.bwd_nt_grid << 16))
         for i in reversed(range(self.depth)):
             for ln in lanes:
                 with torch.cuda.stream(ln.pl.stream):
@@ -356,6 +360,8 @@ class VideoEngine:
                 self._embed_bwd(ln, grads, wg)
         self._announce(lanes[-1], wg, ready, ("cls_token", "pos_embed", "temporal_embed", "patch_embed."))
         hip.gemm_tn_set_variant(0)
+        if hip.gemm_get_variant() != nt_prev:
+            hip.gemm_set_variant(nt_prev)
         if two:
             main.wait_stream(st["lane1"])
         main.wait_stream(wg)                 # every weight gradient is complete before the caller continues

@@ -46,6 +46,7 @@ def lib():
                 raise OatError(f"liboatrans_hip.so lacks symbol {name}")
         if os.environ.get("OAT_GEMM_VARIANT"):           # tuning hooks (see oat_gemm_set_variant / oat_gemm_tn_set_variant)
             _lib.oat_gemm_set_variant(int(os.environ["OAT_GEMM_VARIANT"], 0))
+            _gemm_variant[0] = int(os.environ["OAT_GEMM_VARIANT"], 0)
         if os.environ.get("OAT_GEMM_TN_VARIANT"):
             _lib.oat_gemm_tn_set_variant(int(os.environ["OAT_GEMM_TN_VARIANT"], 0))
     return _lib
@@ -101,8 +102,17 @@ def gemm_nt(A, B, M, N, K, epi, out, out2=None, bias=None, resid=None, resid_mod
     _check(rc, "oat_gemm_nt")
 
 
+_gemm_variant = [0]
+
+
 def gemm_set_variant(v):
+    _gemm_variant[0] = int(v)
     lib().oat_gemm_set_variant(int(v))
+
+
+def gemm_get_variant():
+    """last value passed to gemm_set_variant (the library keeps no getter)"""
+    return _gemm_variant[0]
 
 
 def gemm_set_tail_split(on):

@@ -339,7 +339,9 @@ static int ln_fwd_launch(const float* x, int ldx, const float* gamma, const floa
                          float* sum32, int ldsum, void* stream) {
   if (M <= 0) return 0;
   if (D % 4 || D > LN_MAXV * 256 || ldx % 4 || (y && ldy % 4)) { set_error("layernorm_fwd: D%4==0, D<=1024 required"); return -3; }
-  int blocks = (M + 3) / 4; if (blocks > 4096) blocks = 4096;
+  static int cap = 0;
+  if (cap == 0) { const char* e = getenv("OAT_LN_FWD_BLOCKS"); cap = e ? atoi(e) : 4096; if (cap < 1) cap = 4096; }
+  int blocks = (M + 3) / 4; if (blocks > cap) blocks = cap;
   hipLaunchKernelGGL(ln_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta,
                      (bf16*)y, ldy, y32, ldy32, mean, rstd, M, D, eps, (const bf16*)add16, ldadd, sum32, ldsum);
   return check_launch("layernorm_fwd");
