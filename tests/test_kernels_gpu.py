@@ -31,7 +31,8 @@ def close(a, b, atol, rtol, what=""):
 
 
 # ----------------------------------------------------------------------------- GEMM NT
-@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (1000, 768, 768), (130, 64, 64), (4, 128, 3072), (2049, 2304, 768)])
+@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (1000, 768, 768), (130, 64, 64), (4, 128, 3072), (2049, 2304, 768),
+                                   (333, 200, 64), (70, 72, 128), (5000, 264, 192), (4500, 1000, 64)])   # N not a multiple of the 64-column wave group
 def test_gemm_nt_bias_bf16(M, N, K):
     hip = _hip()
     A = rnd(M, K, dtype=torch.bfloat16, seed=1)
@@ -97,7 +98,7 @@ def test_gemm_nt_gelu_and_dgelu():
     close(out, hf.grad, atol=2e-2, rtol=1.5e-2, what="dgelu")
 
 
-@pytest.mark.parametrize("M,N,K", [(515, 512, 128), (1300, 768, 192)])
+@pytest.mark.parametrize("M,N,K", [(515, 512, 128), (1300, 768, 192), (4400, 328, 64), (97, 40, 64)])
 def test_gemm_nt_gelu_grad_and_mul_aux(M, N, K):
     """The MLP pair the engine uses: forward stores gelu'(h) next to gelu(h) (one erf / exp evaluation on the fp32
     pre-activation), backward multiplies by it (reference: Mlp.forward, video_transformer.py:45-51, nn.GELU)."""
