@@ -105,7 +105,7 @@ int oat_attn_space_fwd(const void* qkv, int ldqkv, void* out, int ldo, float* ls
                        int H, int D, float scale, void* stream);
 int oat_attn_time_fwd(const void* qkv, int ldqkv, void* out, int ldo, float* lse, int B, int T, int N,
                       int H, int D, float scale, void* stream);
-void oat_attn_time_set_variant(int v);   /* tuning hook: 0 auto (single-read LDS kernel for T <= 8), 1 force two-pass */
+void oat_attn_time_set_variant(int v);   /* tuning hook for the backward: 0 = MFMA kernel on 16-row mini problems (default), 1 = two-pass VALU kernel, 2 = VALU kernels (single-read LDS kernel for T <= 8, two-pass above) */
 int oat_attn_cls_fwd(const void* qkv, int ldqkv, void* out, int ldo, float* lse, int B, int T, int N,
                      int H, int D, float scale, void* stream);
 int oat_attn_space_set_variant(int v);   /* tuning hook for the backward at >= 97 patches: 0 = default (97..223 patches: two 8-wave workgroups per CU, one 16-row tile per wave, K,V then Q,dO in LDS; 224..447: 16 waves), 1 = 8 waves x tile pairs, 2 = 16 waves x one tile with all four tiles in LDS */

@@ -25,19 +25,20 @@ OAT_DEV int sw8(int row) { const int rp = (row >> 1) & 7; return ((rp << 1) + (r
 OAT_DEV int tile_off(int row, int lc) { return row * 128 + ((lc ^ sw8(row)) << 4); }
 
 // row fragment (A/B operand with k = head dim): 16 rows starting at r0, k-step ks (32 dims)
-OAT_DEV bf16x8 row_frag(const char* tile, int r0, int ks, int lane) {
-  const int row = r0 + (lane & 15);
+// rmax: rows beyond it read row rmax instead (TIME mode keeps 17-row tiles: every padding row is the CLS row)
+OAT_DEV bf16x8 row_frag(const char* tile, int r0, int ks, int lane, int rmax = 0x7fffffff) {
+  const int row = min(r0 + (lane & 15), rmax);
   return *reinterpret_cast<const bf16x8*>(tile + tile_off(row, ks * 4 + (lane >> 4)));
 }
 // transposed fragment: A operand [i = dim dt*16 + (lane&15)][k-slot (g,e)] = tile[row(g,e)][dim]
 // rows of slot (g,e): e < 4 -> r0 + g*4 + e ; e >= 4 -> r0 + 16 + g*4 + (e-4)
-OAT_DEV bf16x8 tr_frag(const char* tile, int r0, int dt, int lane) {
+OAT_DEV bf16x8 tr_frag(const char* tile, int r0, int dt, int lane, int rmax = 0x7fffffff) {
   const int s = lane & 15, g = lane >> 4;
   bf16x8 out;
   s16x4* o = reinterpret_cast<s16x4*>(&out);
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
-    const int row = r0 + half * 16 + g * 4 + (s >> 2);
+    const int row = min(r0 + half * 16 + g * 4 + (s >> 2), rmax);
     const int lc = dt * 2 + ((s & 3) >> 1);
     o[half] = lds_tr16(tile + tile_off(row, lc) + ((s & 1) << 3));
   }
@@ -53,6 +54,7 @@ struct SpaceArgs {
   float* cls_side;                 // bwd: [B, H, 3, 64] fp32 (dq, dk, dv of the CLS row)
   int B, T, N, H, D;
   float scale;
+  int gpw;                         // TIME backward: position groups per workgroup (0 = 1)
 };
 
 // forward: 4 waves, 56 KB LDS -> two workgroups per CU overlap each other's prologue;
@@ -66,16 +68,40 @@ constexpr float LN2 = 0.6931471805599453f;
 // alias of the CLS row (padding rows are never used un-masked: their scores are -inf / their P is 0, so they
 // only need to be finite).  All slabs of a tile are in flight at once (the earlier load->wait->ds_write loop
 // serialised ~7 HBM latencies per tile); the bank swizzle is applied on the per-lane SOURCE address.
-template <int NKT, int NTHR>
-OAT_DEV void load_tile(char* tile, const bf16* src, int ld, int col, size_t base_row, size_t cls_row, int N) {
+// Which token row a workgroup-local row j is.  SPACE: the workgroup owns frame (b, f): j < N -> patch j of that frame,
+// j == N -> the sample's CLS row.  TIME (backward only): the workgroup owns G = 16 / T consecutive patch POSITIONS of one
+// sample across all T frames - local row j = (position n0 + j / T, frame j % T), CLS at index N = G * T - and the
+// attention mask is block-diagonal: a patch query sees the keys of its own position plus CLS.  Positions past the end of
+// the frame (ragged last group) read a clamped row and are masked out.
+struct RowMap {
+  size_t base_row, cls_row;
+  int N;                     // CLS index = number of local patch rows
+  int T, Nf, n0;             // TIME: frames, patches per frame, first position of the group
+  template <bool TIME> OAT_DEV size_t row(int j) const {
+    if (j >= N) return cls_row;
+    if (!TIME) return base_row + j;
+    return base_row + (size_t)(j % T) * Nf + min(n0 + j / T, Nf - 1);     // base_row = b * T * Nf
+  }
+  template <bool TIME> OAT_DEV bool live(int j) const { return !TIME || j >= N || n0 + j / T < Nf; }
+  // may query q see key k (both <= N)?
+  template <bool TIME> OAT_DEV bool sees(int q, int k) const {
+    if (!TIME) return true;
+    if (q >= N) return live<TIME>(k);
+    if (k >= N) return live<TIME>(q);
+    return q / T == k / T && live<TIME>(q);
+  }
+};
+
+template <int NKT, int NTHR, bool TIME = false>
+OAT_DEV void load_tile(char* tile, const bf16* src, int ld, int col, const RowMap& rm) {
   constexpr int NSLAB = NKT * 2;                    // 8 rows (1 KB) per wave instruction
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   for (int slab = wave; slab < NSLAB; slab += NTHR / 64) {
     const int j = slab * 8 + (lane >> 3);
     const int lc = (lane & 7) ^ sw8(j);
-    const size_t r = j < N ? base_row + j : cls_row;
-    glds16(src + r * ld + col + lc * 8, tile + slab * 1024);
+    if (TIME && j > 16) continue;                   // 17-row tiles: rows past the CLS slot are never staged (inactive lanes do not write)
+    glds16(src + rm.row<TIME>(j) * ld + col + lc * 8, tile + slab * 1024);
   }
 }
 
@@ -103,8 +129,9 @@ __global__ __launch_bounds__(FWD_THREADS, NKT <= 14 ? 4 : 2) void attn_space_fwd
   };
   bf16x8 qnext[2];
   load_q(min(wave, nqt - 1), qnext);
-  load_tile<NKT, FWD_THREADS>(Kt, a.qkv, a.ldqkv, a.D + h * 64, base_row, cls_row, N);
-  load_tile<NKT, FWD_THREADS>(Vt, a.qkv, a.ldqkv, 2 * a.D + h * 64, base_row, cls_row, N);
+  const RowMap rm{base_row, cls_row, N, 1, N, 0};
+  load_tile<NKT, FWD_THREADS>(Kt, a.qkv, a.ldqkv, a.D + h * 64, rm);
+  load_tile<NKT, FWD_THREADS>(Vt, a.qkv, a.ldqkv, 2 * a.D + h * 64, rm);
   __syncthreads();
 
   const float c2 = a.scale * LOG2E;
@@ -172,27 +199,55 @@ __global__ __launch_bounds__(FWD_THREADS, NKT <= 14 ? 4 : 2) void attn_space_fwd
 // resident waves hide twice the latency.
 // WIDE == 2: single tiles on 8 waves, registers capped at 128: with the two-tile BIG layout (59 KB at 196 patches) TWO
 // workgroups share a CU and one's loads / stores overlap the other's MFMA phases.
-template <int NKT, bool BIG, int WIDE>
-__global__ __launch_bounds__(WIDE == 1 ? 1024 : 512, WIDE == 2 ? 4 : 2) void attn_space_bwd_kernel(SpaceArgs a) {
+// TIME (see RowMap): the same kernel as a ONE-wave workgroup (WIDE == 3) on a 16-row mini problem; the time-attention
+// backward of attn_time.hip evaluates every score twice on the VALU (8-lane dot products), this one spends two dozen
+// mostly-masked MFMAs per problem and is bound by its loads and stores.
+// A TIME workgroup walks `gpw` consecutive position groups of its (sample, head): the CLS row is row N of every one of
+// them, so its three gradients stay in registers across the walk and cost one set of atomics per workgroup (one per
+// group put 7 M contended atomics on 4.6 K addresses).  TT = frame count at compile time (row <-> (position, frame)
+// is a division per row otherwise).
+template <int NKT, bool BIG, int WIDE, bool TIME = false, int TT = 0>
+__global__ __launch_bounds__(WIDE == 1 ? 1024 : WIDE == 3 ? 64 : 512, WIDE == 2 ? 4 : 2) void attn_space_bwd_kernel(SpaceArgs a) {
   constexpr int NKP = NKT * 16;
-  constexpr int THR = WIDE == 1 ? 1024 : BWD_THREADS, STEP = WIDE ? 1 : 2;
+  constexpr int THR = WIDE == 1 ? 1024 : WIDE == 3 ? 64 : BWD_THREADS, STEP = (WIDE == 1 || WIDE == 2) ? 1 : 2;
+  static_assert(!TIME || (!BIG && NKT == 2), "time mode = 16 local rows + CLS");
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  // TIME: rows 0..16 of a tile are real (16 patch rows + CLS), every padding row reads row 16: 17-row tiles, 8.8 KB per workgroup
+  constexpr int TROWS = TIME ? 17 : NKP, RMAX = TIME ? 16 : 0x7fffffff;
   char* Kt = smem;
-  char* Vt = smem + NKP * 128;
-  char* Qt = BIG ? Kt : smem + 2 * NKP * 128;            // BIG: aliases, valid in phase B only
-  char* Dt = BIG ? Vt : smem + 3 * NKP * 128;            // dO tile
-  float* lse_s = reinterpret_cast<float*>(smem + (BIG ? 2 : 4) * NKP * 128);
+  char* Vt = smem + TROWS * 128;
+  char* Qt = BIG ? Kt : smem + 2 * TROWS * 128;          // BIG: aliases, valid in phase B only
+  char* Dt = BIG ? Vt : smem + 3 * TROWS * 128;          // dO tile
+  float* lse_s = reinterpret_cast<float*>(smem + (BIG ? 2 : 4) * TROWS * 128);
   float* del_s = lse_s + NKP;
   const int h = blockIdx.x % a.H;
   const int bf = blockIdx.x / a.H;
-  const int b = bf / a.T, f = bf % a.T;
-  const int N = a.N;
-  const size_t base_row = (size_t)bf * N;
-  const size_t cls_row = (size_t)a.B * a.T * N + b;
-  if (!BIG) load_tile<NKT, THR>(Qt, a.qkv, a.ldqkv, h * 64, base_row, cls_row, N);
-  load_tile<NKT, THR>(Kt, a.qkv, a.ldqkv, a.D + h * 64, base_row, cls_row, N);
-  load_tile<NKT, THR>(Vt, a.qkv, a.ldqkv, 2 * a.D + h * 64, base_row, cls_row, N);
-  if (!BIG) load_tile<NKT, THR>(Dt, a.dout, a.lddo, h * 64, base_row, cls_row, N);
+  const int Tc = TT > 0 ? TT : a.T;
+  const int G = TIME ? 16 / Tc : 1, ngrp = TIME ? (a.N + G - 1) / G : a.T;
+  const int gpw = TIME ? max(a.gpw, 1) : 1, nchunk = (ngrp + gpw - 1) / gpw;      // bf = b * nchunk + chunk
+  const int b = bf / nchunk, f_lo = (bf % nchunk) * gpw, f_hi = min(f_lo + gpw, ngrp);
+  const int N = TIME ? G * Tc : a.N;
+  const size_t cls_row = (size_t)a.B * a.T * a.N + b;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4;
+  const float c2 = a.scale * LOG2E;
+  float* side = a.cls_side + ((size_t)b * a.H + h) * 3 * 64;
+  f32x4 cls_dq[4], cls_dk[4], cls_dv[4];                // TIME: the CLS row's gradients, summed over the walk
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) { cls_dq[dt] = f32x4{0, 0, 0, 0}; cls_dk[dt] = f32x4{0, 0, 0, 0}; cls_dv[dt] = f32x4{0, 0, 0, 0}; }
+  for (int f = f_lo; f < f_hi; ++f) {                   // f: frame (SPACE, one pass) / position group (TIME); 0 owns the CLS->CLS pair
+  const RowMap rm{TIME ? (size_t)b * Tc * a.N : (size_t)bf * a.N, cls_row, N, Tc, a.N, f * G};
+  const size_t base_row = rm.base_row;
+  if (TIME && f != f_lo) {
+    // the previous group's LDS reads are done before the DMA overwrites the tiles.  NOT __syncthreads(): that also waits
+    // for the acknowledgements of the stores just issued; they drain under this group's load latency instead
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (THR > 64) __builtin_amdgcn_s_barrier();
+  }
+  if (!BIG) load_tile<NKT, THR, TIME>(Qt, a.qkv, a.ldqkv, h * 64, rm);
+  load_tile<NKT, THR, TIME>(Kt, a.qkv, a.ldqkv, a.D + h * 64, rm);
+  load_tile<NKT, THR, TIME>(Vt, a.qkv, a.ldqkv, 2 * a.D + h * 64, rm);
+  if (!BIG) load_tile<NKT, THR, TIME>(Dt, a.dout, a.lddo, h * 64, rm);
   // row fragment of a token-row matrix straight from global memory (same element order as row_frag on a tile)
   auto grow_frag = [&](const bf16* src, int ld, int col, int r0, int ks, int lane_) {
     const int j = r0 + (lane_ & 15);
@@ -207,7 +262,7 @@ __global__ __launch_bounds__(WIDE == 1 ? 1024 : 512, WIDE == 2 ? 4 : 2) void att
     for (int it = 0; it < ITER; ++it) {
       const int idx = it * THR + threadIdx.x;
       const int j = min(idx >> 3, N), c = idx & 7;
-      const size_t r = j < N ? base_row + j : cls_row;
+      const size_t r = rm.row<TIME>(j);
       gv[it] = *reinterpret_cast<const bf16x8*>(a.dout + r * a.lddo + h * 64 + c * 8);
       ov[it] = *reinterpret_cast<const bf16x8*>(a.out + r * a.ldo + h * 64 + c * 8);
     }
@@ -222,7 +277,7 @@ __global__ __launch_bounds__(WIDE == 1 ? 1024 : 512, WIDE == 2 ? 4 : 2) void att
       d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x4E, 0xF, 0xF, true));
       d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x141, 0xF, 0xF, true));
       if (c == 0 && j < NKP) {
-        const size_t r = j < N ? base_row + j : cls_row;
+        const size_t r = rm.row<TIME>(min(j, N));
         del_s[j] = j <= N ? d : 0.f;
         lse_s[j] = j <= N ? a.lse[r * a.H + h] * LOG2E : 0.f;
       }
@@ -230,10 +285,6 @@ __global__ __launch_bounds__(WIDE == 1 ? 1024 : 512, WIDE == 2 ? 4 : 2) void att
   }
   __syncthreads();
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int g = lane >> 4;
-  const float c2 = a.scale * LOG2E;
-  float* side = a.cls_side + ((size_t)b * a.H + h) * 3 * 64;
 
   // Both phases process TWO 16-wide tiles per wave so that every LDS fragment (row fragments and
   // transpose-read fragments) feeds two MFMA chains: half the LDS traffic per MFMA and two independent
@@ -247,7 +298,7 @@ __global__ __launch_bounds__(WIDE == 1 ? 1024 : 512, WIDE == 2 ? 4 : 2) void att
   // streamed over key pairs: dS of keys [32u, 32u+32) is consumed by the dQ MFMAs right away
   for (int pr = wave; pr * STEP < ntile; pr += THR / 64) {
     const int qt0 = pr * STEP;
-    const bool two = !WIDE && qt0 + 1 < ntile;                   // wave-uniform
+    const bool two = STEP == 2 && qt0 + 1 < ntile;                   // wave-uniform
     const int qiA = qt0 * 16 + (lane & 15), qiB = qiA + 16;
     const float lqA = lse_s[qiA], dlA = del_s[qiA], lqB = lse_s[qiB], dlB = del_s[qiB];
     bf16x8 qfA[2], dfA[2], qfB[2], dfB[2];
@@ -257,8 +308,8 @@ __global__ __launch_bounds__(WIDE == 1 ? 1024 : 512, WIDE == 2 ? 4 : 2) void att
         qfA[ks] = grow_frag(a.qkv, a.ldqkv, h * 64, qt0 * 16, ks, lane); dfA[ks] = grow_frag(a.dout, a.lddo, h * 64, qt0 * 16, ks, lane);
         qfB[ks] = grow_frag(a.qkv, a.ldqkv, h * 64, qt0 * 16 + 16, ks, lane); dfB[ks] = grow_frag(a.dout, a.lddo, h * 64, qt0 * 16 + 16, ks, lane);
       } else {
-        qfA[ks] = row_frag(Qt, qt0 * 16, ks, lane); dfA[ks] = row_frag(Dt, qt0 * 16, ks, lane);
-        qfB[ks] = row_frag(Qt, qt0 * 16 + 16, ks, lane); dfB[ks] = row_frag(Dt, qt0 * 16 + 16, ks, lane);
+        qfA[ks] = row_frag(Qt, qt0 * 16, ks, lane, RMAX); dfA[ks] = row_frag(Dt, qt0 * 16, ks, lane, RMAX);
+        qfB[ks] = row_frag(Qt, qt0 * 16 + 16, ks, lane, RMAX); dfB[ks] = row_frag(Dt, qt0 * 16 + 16, ks, lane, RMAX);
       }
     }
     f32x4 dqA[4], dqB[4];
@@ -274,7 +325,7 @@ __global__ __launch_bounds__(WIDE == 1 ? 1024 : 512, WIDE == 2 ? 4 : 2) void att
         f32x4 sA = {0, 0, 0, 0}, pA = {0, 0, 0, 0}, sB = {0, 0, 0, 0}, pB = {0, 0, 0, 0};
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-          const bf16x8 kf = row_frag(Kt, kt * 16, ks, lane), vf = row_frag(Vt, kt * 16, ks, lane);
+          const bf16x8 kf = row_frag(Kt, kt * 16, ks, lane, RMAX), vf = row_frag(Vt, kt * 16, ks, lane, RMAX);
           sA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qfA[ks], sA, 0, 0, 0);
           pA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dfA[ks], pA, 0, 0, 0);
           if (two) {
@@ -286,8 +337,8 @@ __global__ __launch_bounds__(WIDE == 1 ? 1024 : 512, WIDE == 2 ? 4 : 2) void att
         for (int r = 0; r < 4; ++r) {
           const int key = kt * 16 + g * 4 + r;
           const bool clsdup = key == N && f != 0;       // CLS->CLS pair is counted once (frame 0)
-          const bool okA = key <= N && qiA <= N && !(qiA == N && clsdup);
-          const bool okB = key <= N && qiB <= N && !(qiB == N && clsdup);
+          const bool okA = key <= N && qiA <= N && !(qiA == N && clsdup) && rm.sees<TIME>(qiA, key);
+          const bool okB = key <= N && qiB <= N && !(qiB == N && clsdup) && rm.sees<TIME>(qiB, key);
           dsA[hf][r] = okA ? __builtin_amdgcn_exp2f(sA[r] * c2 - lqA) * (pA[r] - dlA) : 0.f;
           dsB[hf][r] = (two && okB) ? __builtin_amdgcn_exp2f(sB[r] * c2 - lqB) * (pB[r] - dlB) : 0.f;
         }
@@ -295,14 +346,15 @@ __global__ __launch_bounds__(WIDE == 1 ? 1024 : 512, WIDE == 2 ? 4 : 2) void att
       const bf16x8 sbA = pack8(dsA[0], dsA[1]), sbB = pack8(dsB[0], dsB[1]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        const bf16x8 tf = tr_frag(Kt, u * 32, dt, lane);
+        const bf16x8 tf = tr_frag(Kt, u * 32, dt, lane, RMAX);
         dqA[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tf, sbA, dqA[dt], 0, 0, 0);
         if (two) dqB[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tf, sbB, dqB[dt], 0, 0, 0);
       }
     }
     auto put_q = [&](int qi, const f32x4 (&dq)[4]) {
       if (qi < N) {
-        bf16* drow = a.dqkv + (base_row + qi) * a.lddqkv + h * 64 + g * 4;
+        if (!rm.live<TIME>(qi)) return;
+        bf16* drow = a.dqkv + rm.row<TIME>(qi) * a.lddqkv + h * 64 + g * 4;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
           const bf16x4 o = {f2bf(dq[dt][0] * a.scale), f2bf(dq[dt][1] * a.scale), f2bf(dq[dt][2] * a.scale),
@@ -310,10 +362,15 @@ __global__ __launch_bounds__(WIDE == 1 ? 1024 : 512, WIDE == 2 ? 4 : 2) void att
           *reinterpret_cast<bf16x4*>(drow + dt * 16) = o;
         }
       } else if (qi == N) {
+        if constexpr (TIME) {
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
+          for (int dt = 0; dt < 4; ++dt) cls_dq[dt] += dq[dt];
+        } else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) atomicAdd(side + dt * 16 + g * 4 + r, dq[dt][r] * a.scale);
+          for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(side + dt * 16 + g * 4 + r, dq[dt][r] * a.scale);
+        }
       }
     };
     put_q(qiA, dqA);
@@ -323,13 +380,13 @@ __global__ __launch_bounds__(WIDE == 1 ? 1024 : 512, WIDE == 2 ? 4 : 2) void att
   // ------------------------------------------------ phase B: lane = key column, produces dK, dV
   if constexpr (BIG) {
     __syncthreads();                                      // every wave is done with K, V in LDS
-    load_tile<NKT, THR>(Qt, a.qkv, a.ldqkv, h * 64, base_row, cls_row, N);
-    load_tile<NKT, THR>(Dt, a.dout, a.lddo, h * 64, base_row, cls_row, N);
+    load_tile<NKT, THR, TIME>(Qt, a.qkv, a.ldqkv, h * 64, rm);
+    load_tile<NKT, THR, TIME>(Dt, a.dout, a.lddo, h * 64, rm);
     __syncthreads();
   }
   for (int pr = wave; pr * STEP < ntile; pr += THR / 64) {
     const int kt0 = pr * STEP;
-    const bool two = !WIDE && kt0 + 1 < ntile;
+    const bool two = STEP == 2 && kt0 + 1 < ntile;
     const int keyA = kt0 * 16 + (lane & 15), keyB = keyA + 16;
     bf16x8 kfA[2], vfA[2], kfB[2], vfB[2];
 #pragma unroll
@@ -338,8 +395,8 @@ __global__ __launch_bounds__(WIDE == 1 ? 1024 : 512, WIDE == 2 ? 4 : 2) void att
         kfA[ks] = grow_frag(a.qkv, a.ldqkv, a.D + h * 64, kt0 * 16, ks, lane); vfA[ks] = grow_frag(a.qkv, a.ldqkv, 2 * a.D + h * 64, kt0 * 16, ks, lane);
         kfB[ks] = grow_frag(a.qkv, a.ldqkv, a.D + h * 64, kt0 * 16 + 16, ks, lane); vfB[ks] = grow_frag(a.qkv, a.ldqkv, 2 * a.D + h * 64, kt0 * 16 + 16, ks, lane);
       } else {
-        kfA[ks] = row_frag(Kt, kt0 * 16, ks, lane); vfA[ks] = row_frag(Vt, kt0 * 16, ks, lane);
-        kfB[ks] = row_frag(Kt, kt0 * 16 + 16, ks, lane); vfB[ks] = row_frag(Vt, kt0 * 16 + 16, ks, lane);
+        kfA[ks] = row_frag(Kt, kt0 * 16, ks, lane, RMAX); vfA[ks] = row_frag(Vt, kt0 * 16, ks, lane, RMAX);
+        kfB[ks] = row_frag(Kt, kt0 * 16 + 16, ks, lane, RMAX); vfB[ks] = row_frag(Vt, kt0 * 16 + 16, ks, lane, RMAX);
       }
     }
     f32x4 dkA[4], dvA[4], dkB[4], dvB[4];
@@ -357,7 +414,7 @@ __global__ __launch_bounds__(WIDE == 1 ? 1024 : 512, WIDE == 2 ? 4 : 2) void att
         f32x4 sA = {0, 0, 0, 0}, pA = {0, 0, 0, 0}, sB = {0, 0, 0, 0}, pB = {0, 0, 0, 0};
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-          const bf16x8 qf = row_frag(Qt, q0, ks, lane), df = row_frag(Dt, q0, ks, lane);
+          const bf16x8 qf = row_frag(Qt, q0, ks, lane, RMAX), df = row_frag(Dt, q0, ks, lane, RMAX);
           sA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kfA[ks], sA, 0, 0, 0);
           pA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, vfA[ks], pA, 0, 0, 0);
           if (two) {
@@ -370,8 +427,8 @@ __global__ __launch_bounds__(WIDE == 1 ? 1024 : 512, WIDE == 2 ? 4 : 2) void att
           const int qi = q0 + g * 4 + r;
           const float lq = lse_s[qi], dl = del_s[qi];
           const bool clsq = qi == N && f != 0;
-          const bool okA = keyA <= N && qi <= N && !(clsq && keyA == N);
-          const bool okB = two && keyB <= N && qi <= N && !(clsq && keyB == N);
+          const bool okA = keyA <= N && qi <= N && !(clsq && keyA == N) && rm.sees<TIME>(qi, keyA);
+          const bool okB = two && keyB <= N && qi <= N && !(clsq && keyB == N) && rm.sees<TIME>(qi, keyB);
           const float a_ = okA ? __builtin_amdgcn_exp2f(sA[r] * c2 - lq) : 0.f;
           const float b_ = okB ? __builtin_amdgcn_exp2f(sB[r] * c2 - lq) : 0.f;
           pvA[hf][r] = a_; svA[hf][r] = a_ * (pA[r] - dl);
@@ -382,7 +439,7 @@ __global__ __launch_bounds__(WIDE == 1 ? 1024 : 512, WIDE == 2 ? 4 : 2) void att
       const bf16x8 pbB = pack8(pvB[0], pvB[1]), sbB = pack8(svB[0], svB[1]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        const bf16x8 td = tr_frag(Dt, u * 32, dt, lane), tq = tr_frag(Qt, u * 32, dt, lane);
+        const bf16x8 td = tr_frag(Dt, u * 32, dt, lane, RMAX), tq = tr_frag(Qt, u * 32, dt, lane, RMAX);
         dvA[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(td, pbA, dvA[dt], 0, 0, 0);
         dkA[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tq, sbA, dkA[dt], 0, 0, 0);
         if (two) {
@@ -393,7 +450,8 @@ __global__ __launch_bounds__(WIDE == 1 ? 1024 : 512, WIDE == 2 ? 4 : 2) void att
     }
     auto put_kv = [&](int key, const f32x4 (&dk)[4], const f32x4 (&dv)[4]) {
       if (key < N) {
-        bf16* drow = a.dqkv + (base_row + key) * a.lddqkv + h * 64 + g * 4;
+        if (!rm.live<TIME>(key)) return;
+        bf16* drow = a.dqkv + rm.row<TIME>(key) * a.lddqkv + h * 64 + g * 4;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
           const bf16x4 ok_ = {f2bf(dk[dt][0] * a.scale), f2bf(dk[dt][1] * a.scale), f2bf(dk[dt][2] * a.scale),
@@ -403,17 +461,35 @@ __global__ __launch_bounds__(WIDE == 1 ? 1024 : 512, WIDE == 2 ? 4 : 2) void att
           *reinterpret_cast<bf16x4*>(drow + 2 * a.D + dt * 16) = ov;
         }
       } else if (key == N) {
+        if constexpr (TIME) {
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
+          for (int dt = 0; dt < 4; ++dt) { cls_dk[dt] += dk[dt]; cls_dv[dt] += dv[dt]; }
+        } else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            atomicAdd(side + 64 + dt * 16 + g * 4 + r, dk[dt][r] * a.scale);
-            atomicAdd(side + 128 + dt * 16 + g * 4 + r, dv[dt][r]);
-          }
+          for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              atomicAdd(side + 64 + dt * 16 + g * 4 + r, dk[dt][r] * a.scale);
+              atomicAdd(side + 128 + dt * 16 + g * 4 + r, dv[dt][r]);
+            }
+        }
       }
     };
     put_kv(keyA, dkA, dvA);
     if (two) put_kv(keyB, dkB, dvB);
+  }
+  }   // group walk
+  if constexpr (TIME) {
+    if ((lane & 15) == (N & 15)) {                       // the lanes that own row N of its tile
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          atomicAdd(side + dt * 16 + g * 4 + r, cls_dq[dt][r] * a.scale);
+          atomicAdd(side + 64 + dt * 16 + g * 4 + r, cls_dk[dt][r] * a.scale);
+          atomicAdd(side + 128 + dt * 16 + g * 4 + r, cls_dv[dt][r]);
+        }
+    }
   }
 }
 
@@ -447,6 +523,29 @@ static int launch_bwd(const SpaceArgs& a, hipStream_t s) {
 // tuning hook.  0 (default): 97..223 patches -> two 8-wave workgroups per CU on the two-tile layout, one tile per wave;
 // 224..447 patches -> 16 waves x one tile.  1 = 8 waves x tile pairs (the earlier kernel).  2 = 16 waves x one tile, four-tile layout.
 static int g_space_variant = 0;
+
+// time-attention backward through the MFMA kernel: one single-wave workgroup per (sample, group of 16 / T positions, head)
+template <int TT>
+static int launch_time_bwd(const SpaceArgs& a, int blocks, int lds, hipStream_t s) {
+  hipLaunchKernelGGL((attn_space_bwd_kernel<2, false, 3, true, TT>), dim3(blocks), dim3(64), lds, s, a);
+  return check_launch("attn_time_bwd_mfma");
+}
+int g_time_gpw = 4;        // position groups per workgroup (tuning: oat_attn_time_set_variant bits 8-15)
+int attn_time_bwd_mfma(const void* qkv, int ldqkv, const void* out, int ldo, const float* lse, const void* dout, int lddo,
+                       void* dqkv, int lddqkv, float* cls_side, int B, int T, int N, int H, int D, float scale, hipStream_t s) {
+  SpaceArgs a{(const bf16*)qkv, ldqkv, (bf16*)out, ldo, (float*)lse, (const bf16*)dout, lddo, (bf16*)dqkv, lddqkv,
+              cls_side, B, T, N, H, D, scale, g_time_gpw > 0 ? g_time_gpw : 4};
+  const int G = 16 / T, ngrp = (N + G - 1) / G, nchunk = (ngrp + a.gpw - 1) / a.gpw;
+  const int lds = 4 * 17 * 128 + 2 * 32 * 4, blocks = B * nchunk * H;
+  switch (T) {
+    case 1: return launch_time_bwd<1>(a, blocks, lds, s);
+    case 2: return launch_time_bwd<2>(a, blocks, lds, s);
+    case 4: return launch_time_bwd<4>(a, blocks, lds, s);
+    case 8: return launch_time_bwd<8>(a, blocks, lds, s);
+    case 16: return launch_time_bwd<16>(a, blocks, lds, s);
+    default: return launch_time_bwd<0>(a, blocks, lds, s);      // any other T <= 16: runtime row arithmetic
+  }
+}
 
 static int pick_nkt(int N) {
   const int need = (N + 1 + 31) / 32 * 2;     // even number of 16-key tiles

@@ -54,6 +54,10 @@ struct TimeArgs {
   float scale;
 };
 
+// defined in attn_space.hip (the space backward kernel in its block-diagonal TIME mode)
+int attn_time_bwd_mfma(const void* qkv, int ldqkv, const void* out, int ldo, const float* lse, const void* dout, int lddo,
+                       void* dqkv, int lddqkv, float* cls_side, int B, int T, int N, int H, int D, float scale, hipStream_t s);
+
 // grid: B*H*ceil(N/8) waves (4 per block); wave -> (b, h, n0), 8-lane group gq -> n = n0 + gq
 template <int TT>
 __global__ __launch_bounds__(256, TT <= 8 ? 4 : 2) void attn_time_fwd_kernel(TimeArgs a) {
@@ -378,7 +382,9 @@ __global__ __launch_bounds__(256) void attn_cls_fwd_kernel(TimeArgs a) {
 using namespace oat;
 
 static int g_time_two_pass = 0;   // tuning hook: 1 = force the two-pass backward for every T
-extern "C" void oat_attn_time_set_variant(int v) { g_time_two_pass = v; }
+// 0 = MFMA kernel (default, T <= 16), 1 = two-pass VALU kernel, 2 = VALU kernels as before (single-read LDS kernel for T <= 8)
+namespace oat { extern int g_time_gpw; }     // attn_space.hip: position groups per workgroup of the MFMA kernel (bits 8-15, 0 = keep)
+extern "C" void oat_attn_time_set_variant(int v) { g_time_two_pass = v & 0xff; if ((v >> 8) & 0xff) oat::g_time_gpw = (v >> 8) & 0xff; }
 
 #define OAT_TIME_DISPATCH(KERNEL)                                                                     \
   switch (T) {                                                                                        \
@@ -413,9 +419,11 @@ extern "C" int oat_attn_time_bwd(const void* qkv, int ldqkv, const void* out, in
   TimeArgs a{(const bf16*)qkv, ldqkv, (bf16*)out, ldo, (float*)lse, (const bf16*)dout, lddo, (bf16*)dqkv, lddqkv,
              cls_side, B, T, N, H, D, scale};
   hipStream_t s = (hipStream_t)stream;
+  if (g_time_two_pass == 0 && T <= 16)        // default: the MFMA kernel of attn_space.hip on 16-row mini problems
+    return attn_time_bwd_mfma(qkv, ldqkv, out, ldo, lse, dout, lddo, dqkv, lddqkv, cls_side, B, T, N, H, D, scale, s);
   const int waves = B * H * ((N + 7) / 8);
   const int blocks = (waves + 3) / 4;
-  if (T <= 8 && !g_time_two_pass) {
+  if (T <= 8 && g_time_two_pass != 1) {
 #define OAT_TIME_LDS(TT) \
     case TT: { \
       constexpr int LDS = 4 * ((TT + 1) * 64 * 32 + 8 * (TT + 1) * 8); \

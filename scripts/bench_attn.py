@@ -27,11 +27,11 @@ print("time  fwd us", timeit(lambda: hip.attn_time_fwd(qkv, out, lse, B, T, N, H
 print("time  bwd us", timeit(lambda: hip.attn_time_bwd(qkv, out, lse, dout, dqkv, side, B, T, N, H, D, sc)))
 hip.attn_cls_fwd(qkv, out, lse, B, T, N, H, D, sc); hip.attn_time_fwd(qkv, out, lse, B, T, N, H, D, sc)
 for rep in range(2):
-    for var in (1, 0):
+    for var in (1, 2, 0):
         hip.lib().oat_attn_time_set_variant(var)
         side.zero_()
         t = timeit(lambda: hip.attn_time_bwd(qkv, out, lse, dout, dqkv, side, B, T, N, H, D, sc))
-        print(f"time bwd variant {var} ({'two-pass' if var else 'single-read LDS'}): {t:.1f} us  checksum {dqkv.float().abs().sum().item():.6e}")
+        print(f"time bwd variant {var} ({['mfma', 'two-pass', 'single-read LDS'][var]}): {t:.1f} us  checksum {dqkv.float().abs().sum().item():.6e}")
 hip.lib().oat_attn_time_set_variant(0)
 hip.attn_space_fwd(qkv, out, lse, B, T, N, H, D, sc)
 for rep in range(2):
@@ -41,3 +41,9 @@ for rep in range(2):
         t = timeit(lambda: hip.attn_space_bwd(qkv, out, lse, dout, dqkv, side, B, T, N, H, D, sc))
         print(f"space bwd variant {var}: {t:.1f} us  checksum {dqkv[:M - B].float().abs().sum().item():.6e}")
 hip.lib().oat_attn_space_set_variant(0)
+for gpw in (1, 2, 4, 7, 14, 25):
+    hip.lib().oat_attn_time_set_variant(gpw << 8)
+    side.zero_()
+    t = timeit(lambda: hip.attn_time_bwd(qkv, out, lse, dout, dqkv, side, B, T, N, H, D, sc))
+    print(f"time bwd mfma gpw={gpw}: {t:.1f} us")
+hip.lib().oat_attn_time_set_variant(4 << 8)

@@ -298,6 +298,18 @@ def test_attention_space_bwd_tuning_variants(B, T, N, H, variant):
         hip.lib().oat_attn_space_set_variant(0)
 
 
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("B,T,N,H", [(2, 8, 196, 12), (2, 3, 9, 2), (1, 16, 441, 2), (1, 12, 16, 1)])
+def test_attention_time_bwd_tuning_variants(B, T, N, H, variant):
+    """the VALU kernels of the time backward (the default is the MFMA kernel on 16-row mini problems)"""
+    hip = _hip()
+    hip.lib().oat_attn_time_set_variant(variant)
+    try:
+        _attention_case("time", B, T, N, H)
+    finally:
+        hip.lib().oat_attn_time_set_variant(0)
+
+
 def _attention_case(mode, B, T, N, H):
     hip = _hip()
     D = H * 64
