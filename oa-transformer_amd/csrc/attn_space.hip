@@ -92,7 +92,9 @@ struct RowMap {
   }
 };
 
-template <int NKT, int NTHR, bool TIME = false>
+// ASM: the LDS-DMA is issued from inline asm, invisible to hipcc's wait-count pass (which drains every DMA it knows of
+// with vmcnt(0) before the next LDS read): the caller waits itself - used to stage the NEXT problem under the current one.
+template <int NKT, int NTHR, bool TIME = false, bool ASM = false>
 OAT_DEV void load_tile(char* tile, const bf16* src, int ld, int col, const RowMap& rm) {
   constexpr int NSLAB = NKT * 2;                    // 8 rows (1 KB) per wave instruction
   const int lane = threadIdx.x & 63;
@@ -101,7 +103,8 @@ OAT_DEV void load_tile(char* tile, const bf16* src, int ld, int col, const RowMa
     const int j = slab * 8 + (lane >> 3);
     const int lc = (lane & 7) ^ sw8(j);
     if (TIME && j > 16) continue;                   // 17-row tiles: rows past the CLS slot are never staged (inactive lanes do not write)
-    glds16(src + rm.row<TIME>(j) * ld + col + lc * 8, tile + slab * 1024);
+    if (ASM) glds16_asm(src + rm.row<TIME>(j) * ld + col + lc * 8, tile + slab * 1024);
+    else glds16(src + rm.row<TIME>(j) * ld + col + lc * 8, tile + slab * 1024);
   }
 }
 
@@ -214,12 +217,7 @@ __global__ __launch_bounds__(WIDE == 1 ? 1024 : WIDE == 3 ? 64 : 512, WIDE == 2 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // TIME: rows 0..16 of a tile are real (16 patch rows + CLS), every padding row reads row 16: 17-row tiles, 8.8 KB per workgroup
   constexpr int TROWS = TIME ? 17 : NKP, RMAX = TIME ? 16 : 0x7fffffff;
-  char* Kt = smem;
-  char* Vt = smem + TROWS * 128;
-  char* Qt = BIG ? Kt : smem + 2 * TROWS * 128;          // BIG: aliases, valid in phase B only
-  char* Dt = BIG ? Vt : smem + 3 * TROWS * 128;          // dO tile
-  float* lse_s = reinterpret_cast<float*>(smem + (BIG ? 2 : 4) * TROWS * 128);
-  float* del_s = lse_s + NKP;
+  constexpr int BUF = (BIG ? 2 : 4) * TROWS * 128 + 2 * NKP * 4;     // one problem's tiles + (lse, delta); TIME keeps two
   const int h = blockIdx.x % a.H;
   const int bf = blockIdx.x / a.H;
   const int Tc = TT > 0 ? TT : a.T;
@@ -235,56 +233,79 @@ __global__ __launch_bounds__(WIDE == 1 ? 1024 : WIDE == 3 ? 64 : 512, WIDE == 2 
   f32x4 cls_dq[4], cls_dk[4], cls_dv[4];                // TIME: the CLS row's gradients, summed over the walk
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) { cls_dq[dt] = f32x4{0, 0, 0, 0}; cls_dk[dt] = f32x4{0, 0, 0, 0}; cls_dv[dt] = f32x4{0, 0, 0, 0}; }
-  for (int f = f_lo; f < f_hi; ++f) {                   // f: frame (SPACE, one pass) / position group (TIME); 0 owns the CLS->CLS pair
-  const RowMap rm{TIME ? (size_t)b * Tc * a.N : (size_t)bf * a.N, cls_row, N, Tc, a.N, f * G};
-  const size_t base_row = rm.base_row;
-  if (TIME && f != f_lo) {
-    // the previous group's LDS reads are done before the DMA overwrites the tiles.  NOT __syncthreads(): that also waits
-    // for the acknowledgements of the stores just issued; they drain under this group's load latency instead
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (THR > 64) __builtin_amdgcn_s_barrier();
+  // delta = rowsum(dO * O) and lse (log2 units), 8 lanes per row: request (registers) and finish (LDS) are separate so
+  // that TIME can request the NEXT group's rows before the current group's phases
+  constexpr int ITER = (NKP * 8 + THR - 1) / THR;
+  bf16x8 gv[ITER], ov[ITER];
+  float lv[ITER];
+  auto delta_request = [&](const RowMap& rq) {
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int idx = it * THR + threadIdx.x;
+      const int j = min(idx >> 3, N), c = idx & 7;
+      const size_t r = rq.row<TIME>(j);
+      gv[it] = *reinterpret_cast<const bf16x8*>(a.dout + r * a.lddo + h * 64 + c * 8);
+      ov[it] = *reinterpret_cast<const bf16x8*>(a.out + r * a.ldo + h * 64 + c * 8);
+      lv[it] = a.lse[r * a.H + h];
+    }
+  };
+  auto stage = [&](const RowMap& rq, char* base) {      // K, V, Q, dO tiles of one problem
+    if (!BIG) load_tile<NKT, THR, TIME, TIME>(base + 2 * TROWS * 128, a.qkv, a.ldqkv, h * 64, rq);
+    load_tile<NKT, THR, TIME, TIME>(base, a.qkv, a.ldqkv, a.D + h * 64, rq);
+    load_tile<NKT, THR, TIME, TIME>(base + TROWS * 128, a.qkv, a.ldqkv, 2 * a.D + h * 64, rq);
+    if (!BIG) load_tile<NKT, THR, TIME, TIME>(base + 3 * TROWS * 128, a.dout, a.lddo, h * 64, rq);
+  };
+  auto group_map = [&](int f) { return RowMap{TIME ? (size_t)b * Tc * a.N : (size_t)bf * a.N, cls_row, N, Tc, a.N, f * G}; };
+  if constexpr (TIME) {                                  // pipeline prologue: the first group's tiles and delta rows
+    const RowMap r0 = group_map(f_lo);
+    stage(r0, smem);
+    delta_request(r0);
   }
-  if (!BIG) load_tile<NKT, THR, TIME>(Qt, a.qkv, a.ldqkv, h * 64, rm);
-  load_tile<NKT, THR, TIME>(Kt, a.qkv, a.ldqkv, a.D + h * 64, rm);
-  load_tile<NKT, THR, TIME>(Vt, a.qkv, a.ldqkv, 2 * a.D + h * 64, rm);
-  if (!BIG) load_tile<NKT, THR, TIME>(Dt, a.dout, a.lddo, h * 64, rm);
+  for (int f = f_lo; f < f_hi; ++f) {                   // f: frame (SPACE, one pass) / position group (TIME); 0 owns the CLS->CLS pair
+  const RowMap rm = group_map(f);
+  const size_t base_row = rm.base_row;
+  char* const buf = smem + (TIME ? ((f - f_lo) & 1) * BUF : 0);
+  char* Kt = buf;
+  char* Vt = buf + TROWS * 128;
+  char* Qt = BIG ? Kt : buf + 2 * TROWS * 128;           // BIG: aliases, valid in phase B only
+  char* Dt = BIG ? Vt : buf + 3 * TROWS * 128;           // dO tile
+  float* lse_s = reinterpret_cast<float*>(buf + (BIG ? 2 : 4) * TROWS * 128);
+  float* del_s = lse_s + NKP;
+  if constexpr (TIME) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this group's tiles (staged one group ago) have landed
+  } else {
+    stage(rm, buf);
+    delta_request(rm);
+  }
   // row fragment of a token-row matrix straight from global memory (same element order as row_frag on a tile)
   auto grow_frag = [&](const bf16* src, int ld, int col, int r0, int ks, int lane_) {
     const int j = r0 + (lane_ & 15);
     const size_t r = j < N ? base_row + j : cls_row;
     return *reinterpret_cast<const bf16x8*>(src + r * ld + col + (ks * 4 + (lane_ >> 4)) * 8);
   };
-  // delta = rowsum(dO * O) and lse (log2 units), 8 lanes per row; all loads issued before the first use
-  {
-    constexpr int ITER = (NKP * 8 + THR - 1) / THR;
-    bf16x8 gv[ITER], ov[ITER];
 #pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-      const int idx = it * THR + threadIdx.x;
-      const int j = min(idx >> 3, N), c = idx & 7;
-      const size_t r = rm.row<TIME>(j);
-      gv[it] = *reinterpret_cast<const bf16x8*>(a.dout + r * a.lddo + h * 64 + c * 8);
-      ov[it] = *reinterpret_cast<const bf16x8*>(a.out + r * a.ldo + h * 64 + c * 8);
-    }
+  for (int it = 0; it < ITER; ++it) {
+    const int idx = it * THR + threadIdx.x;
+    const int j = idx >> 3, c = idx & 7;
+    float d = 0.f;
 #pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-      const int idx = it * THR + threadIdx.x;
-      const int j = idx >> 3, c = idx & 7;
-      float d = 0.f;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) d += bf2f(gv[it][e]) * bf2f(ov[it][e]);
-      d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0xB1, 0xF, 0xF, true));
-      d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x4E, 0xF, 0xF, true));
-      d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x141, 0xF, 0xF, true));
-      if (c == 0 && j < NKP) {
-        const size_t r = rm.row<TIME>(min(j, N));
-        del_s[j] = j <= N ? d : 0.f;
-        lse_s[j] = j <= N ? a.lse[r * a.H + h] * LOG2E : 0.f;
-      }
+    for (int e = 0; e < 8; ++e) d += bf2f(gv[it][e]) * bf2f(ov[it][e]);
+    d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0xB1, 0xF, 0xF, true));
+    d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x4E, 0xF, 0xF, true));
+    d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x141, 0xF, 0xF, true));
+    if (c == 0 && j < NKP) {
+      del_s[j] = j <= N ? d : 0.f;
+      lse_s[j] = j <= N ? lv[it] * LOG2E : 0.f;
     }
   }
   __syncthreads();
-
+  if constexpr (TIME) {
+    if (f + 1 < f_hi) {                                  // the next group's tiles and delta rows fly under this group's phases
+      const RowMap rn = group_map(f + 1);
+      stage(rn, smem + (((f + 1 - f_lo) & 1) * BUF));
+      delta_request(rn);
+    }
+  }
 
   // Both phases process TWO 16-wide tiles per wave so that every LDS fragment (row fragments and
   // transpose-read fragments) feeds two MFMA chains: half the LDS traffic per MFMA and two independent
@@ -536,7 +557,7 @@ int attn_time_bwd_mfma(const void* qkv, int ldqkv, const void* out, int ldo, con
   SpaceArgs a{(const bf16*)qkv, ldqkv, (bf16*)out, ldo, (float*)lse, (const bf16*)dout, lddo, (bf16*)dqkv, lddqkv,
               cls_side, B, T, N, H, D, scale, g_time_gpw > 0 ? g_time_gpw : 4};
   const int G = 16 / T, ngrp = (N + G - 1) / G, nchunk = (ngrp + a.gpw - 1) / a.gpw;
-  const int lds = 4 * 17 * 128 + 2 * 32 * 4, blocks = B * nchunk * H;
+  const int lds = 2 * (4 * 17 * 128 + 2 * 32 * 4), blocks = B * nchunk * H;      // two problem buffers
   switch (T) {
     case 1: return launch_time_bwd<1>(a, blocks, lds, s);
     case 2: return launch_time_bwd<2>(a, blocks, lds, s);
