@@ -12,8 +12,12 @@
 // staged with 16-byte global_load_lds (no VGPR round trip) into an LDS ring (see the kernel comment); the
 // LDS image is lane-linear, so the bank-conflict swizzle (chunk ^= (row >> 1) & 7 inside a
 // 128-byte row) is applied to the per-lane GLOBAL source address and again on the read.
-// MFMA operands are swapped (acc = mfma(Bfrag, Afrag)) so each lane owns 4 CONSECUTIVE
-// output columns of one row: bias/residual loads are float4 and stores are 8/16 bytes.
+// Epilogues.  fp32 outputs (residual / row-modulo table / bf16 copy) and the two legacy GELU forms: MFMA operands
+// swapped (acc = mfma(Bfrag, Afrag)) so a lane owns 4 consecutive output columns of one row, then a transpose through
+// per-wave LDS scratch to full 128-byte lines.  bf16 outputs (EPI_BF16 / EPI_GELU_GRAD / EPI_MUL_AUX, 98 % of the
+// launches of a training step): DIRECT - operands not swapped, B rows permuted on their way into LDS so that a lane's
+// four tiles hold 4 consecutive columns and 16 consecutive lanes store one 128-byte line straight from the
+// accumulators (see DIRECT in the kernel).
 #include "common.h"
 #include <type_traits>
 #include <atomic>
@@ -339,11 +343,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
     bid = fetch();
     continue;
   }
-  // ---- epilogue.  Each lane owns C[row = .. + (lane & 15)][col = .. + (lane >> 4) * 4 + 0..3]
+  // ---- epilogue.  Non-DIRECT forms: each lane owns C[row = .. + (lane & 15)][col = .. + (lane >> 4) * 4 + 0..3]
   // (4 columns = 8..16 B): storing that directly gives 32-64 B fragments per row and an
   // issue-bound store tail (measured: 40 % of a K=768 GEMM).  Instead every wave transposes
   // 64-row chunks through its own LDS scratch (the staging buffers are free now) and writes
   // FULL 128-byte lines, 16 B per lane; residual / aux loads use the same coalesced shape.
+  // DIRECT forms need none of that (their lane layout already is line-shaped) and use no LDS here.
   __syncthreads();
   prefetched = false;
   const int bid_next = fetch();            // the LDS staging data is dead here: the broadcast word is safe
