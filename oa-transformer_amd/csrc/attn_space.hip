@@ -340,6 +340,7 @@ __global__ __launch_bounds__(WIDE == 1 ? 1024 : WIDE == 3 ? 64 : 512, WIDE == 2 
     for (int u = 0; u < NKT / 2; ++u) {
       if (u * 32 > N) break;
       f32x4 dsA[2], dsB[2];
+      const bool plain = !TIME && (qt0 + (two ? 2 : 1)) * 16 <= N && u * 32 + 32 <= N;      // wave-uniform
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         const int kt = 2 * u + hf;
@@ -354,14 +355,22 @@ __global__ __launch_bounds__(WIDE == 1 ? 1024 : WIDE == 3 ? 64 : 512, WIDE == 2 
             pB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dfB[ks], pB, 0, 0, 0);
           }
         }
+        if (plain) {          // every query and key of this pass is an ordinary patch row: no masks (the kernel is issue-bound)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = kt * 16 + g * 4 + r;
-          const bool clsdup = key == N && f != 0;       // CLS->CLS pair is counted once (frame 0)
-          const bool okA = key <= N && qiA <= N && !(qiA == N && clsdup) && rm.sees<TIME>(qiA, key);
-          const bool okB = key <= N && qiB <= N && !(qiB == N && clsdup) && rm.sees<TIME>(qiB, key);
-          dsA[hf][r] = okA ? __builtin_amdgcn_exp2f(sA[r] * c2 - lqA) * (pA[r] - dlA) : 0.f;
-          dsB[hf][r] = (two && okB) ? __builtin_amdgcn_exp2f(sB[r] * c2 - lqB) * (pB[r] - dlB) : 0.f;
+          for (int r = 0; r < 4; ++r) {
+            dsA[hf][r] = __builtin_amdgcn_exp2f(sA[r] * c2 - lqA) * (pA[r] - dlA);
+            dsB[hf][r] = two ? __builtin_amdgcn_exp2f(sB[r] * c2 - lqB) * (pB[r] - dlB) : 0.f;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = kt * 16 + g * 4 + r;
+            const bool clsdup = key == N && f != 0;       // CLS->CLS pair is counted once (frame 0)
+            const bool okA = key <= N && qiA <= N && !(qiA == N && clsdup) && rm.sees<TIME>(qiA, key);
+            const bool okB = key <= N && qiB <= N && !(qiB == N && clsdup) && rm.sees<TIME>(qiB, key);
+            dsA[hf][r] = okA ? __builtin_amdgcn_exp2f(sA[r] * c2 - lqA) * (pA[r] - dlA) : 0.f;
+            dsB[hf][r] = (two && okB) ? __builtin_amdgcn_exp2f(sB[r] * c2 - lqB) * (pB[r] - dlB) : 0.f;
+          }
         }
       }
       const bf16x8 sbA = pack8(dsA[0], dsA[1]), sbB = pack8(dsB[0], dsB[1]);
@@ -429,6 +438,7 @@ __global__ __launch_bounds__(WIDE == 1 ? 1024 : WIDE == 3 ? 64 : 512, WIDE == 2 
     for (int u = 0; u < NKT / 2; ++u) {
       if (u * 32 > N) break;
       f32x4 pvA[2], svA[2], pvB[2], svB[2];
+      const bool plain = !TIME && (kt0 + (two ? 2 : 1)) * 16 <= N && u * 32 + 32 <= N;      // wave-uniform
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         const int q0 = u * 32 + hf * 16;
@@ -443,17 +453,29 @@ __global__ __launch_bounds__(WIDE == 1 ? 1024 : WIDE == 3 ? 64 : 512, WIDE == 2 
             pB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, vfB[ks], pB, 0, 0, 0);
           }
         }
+        if (plain) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int qi = q0 + g * 4 + r;
-          const float lq = lse_s[qi], dl = del_s[qi];
-          const bool clsq = qi == N && f != 0;
-          const bool okA = keyA <= N && qi <= N && !(clsq && keyA == N) && rm.sees<TIME>(qi, keyA);
-          const bool okB = two && keyB <= N && qi <= N && !(clsq && keyB == N) && rm.sees<TIME>(qi, keyB);
-          const float a_ = okA ? __builtin_amdgcn_exp2f(sA[r] * c2 - lq) : 0.f;
-          const float b_ = okB ? __builtin_amdgcn_exp2f(sB[r] * c2 - lq) : 0.f;
-          pvA[hf][r] = a_; svA[hf][r] = a_ * (pA[r] - dl);
-          pvB[hf][r] = b_; svB[hf][r] = b_ * (pB[r] - dl);
+          for (int r = 0; r < 4; ++r) {
+            const int qi = q0 + g * 4 + r;
+            const float lq = lse_s[qi], dl = del_s[qi];
+            const float a_ = __builtin_amdgcn_exp2f(sA[r] * c2 - lq);
+            const float b_ = two ? __builtin_amdgcn_exp2f(sB[r] * c2 - lq) : 0.f;
+            pvA[hf][r] = a_; svA[hf][r] = a_ * (pA[r] - dl);
+            pvB[hf][r] = b_; svB[hf][r] = b_ * (pB[r] - dl);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int qi = q0 + g * 4 + r;
+            const float lq = lse_s[qi], dl = del_s[qi];
+            const bool clsq = qi == N && f != 0;
+            const bool okA = keyA <= N && qi <= N && !(clsq && keyA == N) && rm.sees<TIME>(qi, keyA);
+            const bool okB = two && keyB <= N && qi <= N && !(clsq && keyB == N) && rm.sees<TIME>(qi, keyB);
+            const float a_ = okA ? __builtin_amdgcn_exp2f(sA[r] * c2 - lq) : 0.f;
+            const float b_ = okB ? __builtin_amdgcn_exp2f(sB[r] * c2 - lq) : 0.f;
+            pvA[hf][r] = a_; svA[hf][r] = a_ * (pA[r] - dl);
+            pvB[hf][r] = b_; svB[hf][r] = b_ * (pB[r] - dl);
+          }
         }
       }
       const bf16x8 pbA = pack8(pvA[0], pvA[1]), sbA = pack8(svA[0], svA[1]);
