@@ -121,9 +121,9 @@ def instrumented_gemm_profile(step_fn):
 def pmc_traffic(kernel, args):
     """HBM-side bytes per launch of the dominant kernel.  PMC counters cannot be sampled from inside this
     process, so this is the committed rocprofv3 measurement of the same command and workload
-    (profiles/round1g_pmc_hbm_traffic.md: separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections);
+    (profiles/round1h_pmc_hbm_traffic.md: separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections);
     null when the workload differs from the measured one."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1g_pmc_traffic.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1h_pmc_traffic.json")
     if not os.path.exists(path) or (args.variant, args.batch, args.frames, args.res) != ("frozen", 32, 8, 224):
         return None
     with open(path) as fh:
