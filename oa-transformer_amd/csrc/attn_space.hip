@@ -453,11 +453,12 @@ __global__ __launch_bounds__(WIDE == 1 ? 1024 : WIDE == 3 ? 64 : 512, WIDE == 2 
             pB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, vfB[ks], pB, 0, 0, 0);
           }
         }
+        // this lane's four query rows q0 + 4g .. + 3 are contiguous: one 16-byte read each for lse and delta
+        const f32x4 lq4 = *reinterpret_cast<const f32x4*>(lse_s + q0 + g * 4), dl4 = *reinterpret_cast<const f32x4*>(del_s + q0 + g * 4);
         if (plain) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int qi = q0 + g * 4 + r;
-            const float lq = lse_s[qi], dl = del_s[qi];
+            const float lq = lq4[r], dl = dl4[r];
             const float a_ = __builtin_amdgcn_exp2f(sA[r] * c2 - lq);
             const float b_ = two ? __builtin_amdgcn_exp2f(sB[r] * c2 - lq) : 0.f;
             pvA[hf][r] = a_; svA[hf][r] = a_ * (pA[r] - dl);
@@ -467,7 +468,7 @@ __global__ __launch_bounds__(WIDE == 1 ? 1024 : WIDE == 3 ? 64 : 512, WIDE == 2 
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int qi = q0 + g * 4 + r;
-            const float lq = lse_s[qi], dl = del_s[qi];
+            const float lq = lq4[r], dl = dl4[r];
             const bool clsq = qi == N && f != 0;
             const bool okA = keyA <= N && qi <= N && !(clsq && keyA == N) && rm.sees<TIME>(qi, keyA);
             const bool okB = two && keyB <= N && qi <= N && !(clsq && keyB == N) && rm.sees<TIME>(qi, keyB);
