@@ -189,10 +189,12 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path for the product)")
+    if os.environ.get("OAT_BENCH_ONE_DEVICE") == "1":      # dry run of the N > 1 path on a one-GPU box (with OAT_BENCH_BACKEND=gloo)
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device(f"cuda:{local}")
     if world > 1:
-        dist.init_process_group(backend="nccl", init_method="tcp://{}:{}".format(
+        dist.init_process_group(backend=os.environ.get("OAT_BENCH_BACKEND", "nccl"), init_method="tcp://{}:{}".format(
             os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ.get("MASTER_PORT", "29500")), rank=rank, world_size=world)
     from OATrans.trainer.step import global_local_step, hot_step, region_mem_step
     step_impl = {"frozen": hot_step, "region_mem": region_mem_step, "global_local": global_local_step}[args.variant]
@@ -239,8 +241,10 @@ def main():
         "final_loss": round(loss_val, 4),
         "host_enqueue_ms_per_step": round(host_elapsed / args.steps * 1e3, 2),
     }
+    # one more, instrumented, step for the roofline figure.  EVERY rank runs it (its collectives need all of them);
+    # rank 0 reports
+    by, _ = instrumented_gemm_profile(step)
     if rank == 0:
-        by, _ = instrumented_gemm_profile(step)
         names = {0: "gemm_nt_kernel<EPI_BF16,2,4,8,4>", 1: "gemm_nt_kernel<EPI_F32,2,4,8,4>",
                  2: "gemm_nt_kernel<EPI_GELU_DUAL,2,4,8,4>", 3: "gemm_nt_kernel<EPI_DGELU,2,4,8,4>",
                  4: "gemm_nt_kernel<EPI_F32_BF16,2,4,8,4>", 5: "gemm_nt_kernel<EPI_GELU_GRAD,2,4,8,4>",
