@@ -50,8 +50,10 @@ def run(config, args):
     logger = config.get_logger('train')
     os.environ['TOKENIZERS_PARALLELISM'] = "false"
     os.environ['TRANSFORMERS_OFFLINE'] = "1"
+    if os.environ.get('OAT_ONE_DEVICE') == '1':      # dry run of the multi-rank path on a one-GPU box (with OAT_DIST_BACKEND=gloo)
+        args.local_rank = 0
     torch.cuda.set_device(args.local_rank)
-    torch.distributed.init_process_group(backend='nccl', init_method='tcp://{}:{}'.format(args.master_address, args.master_port),
+    torch.distributed.init_process_group(backend=os.environ.get('OAT_DIST_BACKEND', 'nccl'), init_method='tcp://{}:{}'.format(args.master_address, args.master_port),
                                          rank=args.rank, world_size=args.world_size)
     if args.rank == 0:
         print('world_size', args.world_size, 'local_rank', args.local_rank, flush=True)

@@ -52,3 +52,28 @@ def test_entry_point_trains_checkpoints_and_resumes(tmp_path):
     assert all(torch.isfinite(v).all() for v in ck["state_dict"].values() if v.is_floating_point())
     out = _run(["-r", ckpts[0]], str(tmp_path))
     assert "Checkpoint loaded. Resume training from epoch 2" in out, out[-2000:]
+
+
+def test_entry_point_two_ranks_on_one_gpu(tmp_path):
+    """The same entry point at world size 2 (two processes share the GPU over gloo; RCCL refuses two ranks on one device):
+    DistributedSampler shards, the packed gather, the overlapped gradient all-reduce, validation with the raw all_gather
+    and rank-0-only logging / checkpointing (base_trainer.py:95,118,142) all run."""
+    cfg = json.load(open(os.path.join(PKG, "configs/pt/synthetic/frozen_1f_bs2.json")))
+    cfg["arch"]["args"]["video_params"]["arch_kwargs"] = {"depth": 2}
+    cfg["arch"]["args"]["text_params"]["config"] = {"n_layers": 1}
+    cfg["trainer"].update(epochs=1, max_samples_per_epoch=8, save_dir=str(tmp_path / "exps"), save_period=1)
+    path = tmp_path / "cfg.json"
+    path.write_text(json.dumps(cfg))
+    port = str(_free_port())
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank),
+                   OAT_ONE_DEVICE="1", OAT_DIST_BACKEND="gloo")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(PKG, "train_dist_multi.py"), "-c", str(path)], cwd=str(tmp_path),
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs[0][-3000:] + outs[1][-3000:]
+    assert "val_loss_0" in outs[0] and "Saving checkpoint" in outs[0], outs[0][-2000:]
+    assert "Saving checkpoint" not in outs[1], outs[1][-2000:]                      # rank 0 only
+    ckpts = [os.path.join(d, f) for d, _, fs in os.walk(tmp_path / "exps") for f in fs if f == "checkpoint-epoch1.pth"]
+    assert len(ckpts) == 1, ckpts
