@@ -20,6 +20,7 @@ def timeit(fn, n=10):
 sc = 0.125
 for _r in range(3): print("space fwd us", timeit(lambda: hip.attn_space_fwd(qkv, out, lse, B, T, N, H, D, sc)))
 print("space fwd us", timeit(lambda: hip.attn_space_fwd(qkv, out, lse, B, T, N, H, D, sc)))
+for _r in range(2): print("cls   fwd us", timeit(lambda: hip.attn_cls_fwd(qkv, out, lse, B, T, N, H, D, sc)))
 print("cls   fwd us", timeit(lambda: hip.attn_cls_fwd(qkv, out, lse, B, T, N, H, D, sc)))
 print("space bwd us", timeit(lambda: hip.attn_space_bwd(qkv, out, lse, dout, dqkv, side, B, T, N, H, D, sc)))
 for _r in range(3): print("time  fwd us", timeit(lambda: hip.attn_time_fwd(qkv, out, lse, B, T, N, H, D, sc)))
