@@ -109,9 +109,9 @@ def instrumented_gemm_profile(step_fn):
         hip.gemm_nt = orig
     by = {}
     for epi, M, N, K, s, e in records:
-        if M < 4096:                      # the 256x256 kernel serves the big-M launches; small ones are a different kernel
-            continue
-        d = by.setdefault(epi, dict(flops=0.0, ms=0.0, n=0))
+        # the 256x256 / 8-wave kernel serves the big-M launches, the 128x128 / 4-wave one the small ones: two kernel classes
+        key = (epi, "2,4,8,4" if (M >= 4096 and N % 256 == 0) else "2,2,4,4")
+        d = by.setdefault(key, dict(flops=0.0, ms=0.0, n=0))
         d["flops"] += 2.0 * M * N * K
         d["ms"] += s.elapsed_time(e)
         d["n"] += 1
@@ -245,16 +245,14 @@ def main():
     # rank 0 reports
     by, _ = instrumented_gemm_profile(step)
     if rank == 0:
-        names = {0: "gemm_nt_kernel<EPI_BF16,2,4,8,4>", 1: "gemm_nt_kernel<EPI_F32,2,4,8,4>",
-                 2: "gemm_nt_kernel<EPI_GELU_DUAL,2,4,8,4>", 3: "gemm_nt_kernel<EPI_DGELU,2,4,8,4>",
-                 4: "gemm_nt_kernel<EPI_F32_BF16,2,4,8,4>", 5: "gemm_nt_kernel<EPI_GELU_GRAD,2,4,8,4>",
-                 6: "gemm_nt_kernel<EPI_MUL_AUX,2,4,8,4>"}
+        epis = {0: "EPI_BF16", 1: "EPI_F32", 2: "EPI_GELU_DUAL", 3: "EPI_DGELU", 4: "EPI_F32_BF16", 5: "EPI_GELU_GRAD", 6: "EPI_MUL_AUX"}
         if by:
-            epi, d = max(by.items(), key=lambda kv: kv[1]["ms"])
+            (epi, shape), d = max(by.items(), key=lambda kv: kv[1]["ms"])
+            kname = f"gemm_nt_kernel<{epis.get(epi, epi)},{shape}>"
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": names.get(epi, str(epi)), "achieved": round(ach, 1),
+            out["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 1),
                                "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / BF16_DENSE_PEAK_TFLOPS, 4),
-                               "traffic": pmc_traffic(names.get(epi, str(epi)), args), "launches_per_step": d["n"],
+                               "traffic": pmc_traffic(kname, args), "launches_per_step": d["n"],
                                "avg_launch_us": round(d["ms"] / d["n"] * 1e3, 1),
                                "gflop_per_launch": round(d["flops"] / d["n"] / 1e9, 1)}
         if world == 1 and not args.no_cpu_baseline and args.variant == "frozen":

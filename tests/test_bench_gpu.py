@@ -1,0 +1,60 @@
+"""bench.py's contract: one JSON line on rank 0 with the fields the driver reads, at one rank and at two ranks.
+The two-rank run is the dry-run form (two processes on the one GPU over gloo, OAT_BENCH_ONE_DEVICE / OAT_BENCH_BACKEND):
+it exercises every `world > 1` branch of bench.py - barriers, max-over-ranks time, the instrumented step that EVERY rank
+has to run because it contains collectives - so that a hang there is caught before the multi-GPU scaling run."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roofline"]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _line(out):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-3000:]                       # exactly one JSON line (rank 0 only)
+    return json.loads(lines[0])
+
+
+def _check(rec, n):
+    for k in REQUIRED:
+        assert k in rec, k
+    assert rec["n_gpus"] == n and rec["unit"] == "pairs/s" and rec["higher_is_better"] is True and rec["scaling"] == "weak"
+    assert rec["vs_baseline"] is None and rec["dtype"] == "bf16" and rec["data"] == "synthetic" and "workload" in rec["config"]
+    assert rec["value"] > 0 and abs(rec["value"] - n * rec["config"]["per_gpu_batch"] / (rec["ms_per_step"] * 1e-3)) < 0.01 * rec["value"]
+    r = rec["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+
+
+def test_bench_single_rank_line():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "4", "--frames", "2"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    rec = _line(r.stdout)
+    _check(rec, 1)
+    cb = rec["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "pairs/s" and cb["sample"]
+
+
+def test_bench_two_rank_dry_run_terminates():
+    env = dict(os.environ, OAT_BENCH_ONE_DEVICE="1", OAT_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "4", "--frames", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    _check(_line(r.stdout), 2)
