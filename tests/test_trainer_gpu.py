@@ -77,3 +77,28 @@ def test_entry_point_two_ranks_on_one_gpu(tmp_path):
     assert "Saving checkpoint" not in outs[1], outs[1][-2000:]                      # rank 0 only
     ckpts = [os.path.join(d, f) for d, _, fs in os.walk(tmp_path / "exps") for f in fs if f == "checkpoint-epoch1.pth"]
     assert len(ckpts) == 1, ckpts
+
+
+@pytest.mark.parametrize("entry,config", [("train_dist_region_mem.py", "region_mem_2f.json"),
+                                           ("train_dist_multi_global_local.py", "global_local_2f.json")])
+@pytest.mark.parametrize("world", [1, 2])
+def test_oa_entry_points_train_an_epoch(tmp_path, entry, config, world):
+    """The object-aware entry points through their trainers: one epoch on the synthetic loader, at one
+    rank and at two ranks sharing the GPU over gloo (4 and 6 tensors in ONE packed all-gather per step)."""
+    cfg = json.load(open(os.path.join(PKG, "configs/pt/synthetic", config)))
+    depth = 6 if "region" in config else 2                   # the region variant taps block 6
+    cfg["arch"]["args"]["video_params"]["arch_kwargs"] = {"depth": depth}
+    cfg["arch"]["args"]["text_params"]["config"] = {"n_layers": 1}
+    cfg["trainer"].update(epochs=1, max_samples_per_epoch=16, save_dir=str(tmp_path / "exps"), save_period=1)
+    path = tmp_path / "cfg.json"
+    path.write_text(json.dumps(cfg))
+    port = str(_free_port())
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                   OAT_ONE_DEVICE="1", OAT_DIST_BACKEND="gloo" if world > 1 else "nccl")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(PKG, entry), "-c", str(path)], cwd=str(tmp_path), env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n=====\n".join(o[-3000:] for o in outs)
+    assert "Saving checkpoint" in outs[0], outs[0][-2000:]
