@@ -124,6 +124,50 @@ def test_gemm_nt_gelu_grad_and_mul_aux(M, N, K):
     close(out, (A2.float() @ B2.float().t() + bias) * d.float(), atol=2e-2, rtol=1.5e-2, what="mul_aux + bias")
 
 
+def test_gemm_nt_tail_split_and_random_shapes():
+    """(1) The forward pass runs its GEMMs with the tail split on (rows of the last, partly filled round of 256x256 tiles go
+    to the 128x128 kernel): every epilogue family must give the same result with it.  (2) A seeded sweep of shapes around the
+    tile, wave-group and bounds-check edges of both kernel configurations."""
+    hip = _hip()
+    M, N, K = 256 * 100 + 40, 768, 64                       # 303 tiles: one full round of 256 + a 47-tile tail
+    A = rnd(M, K, dtype=torch.bfloat16, seed=40)
+    B = rnd(N, K, scale=K ** -0.5, dtype=torch.bfloat16, seed=41)
+    bias = rnd(N, seed=42)
+    ref = A.float() @ B.float().t() + bias
+    table = rnd(97, N, seed=43)
+    aux = rnd(M, N, dtype=torch.bfloat16, seed=44)
+    hip.gemm_set_tail_split(True)
+    try:
+        o16 = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+        hip.gemm_nt(A, B, M, N, K, hip.EPI_BF16, o16, bias=bias)
+        close(o16, ref, atol=2e-2, rtol=1e-2, what="tail split bf16")
+        o32 = torch.zeros(M, N, device=DEV)
+        c16 = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+        hip.gemm_nt(A, B, M, N, K, hip.EPI_F32_BF16, o32, out2=c16, bias=bias, resid=table, resid_mod=97)
+        want = ref + table[torch.arange(M, device=DEV) % 97]
+        close(o32, want, atol=2e-4, rtol=1e-4, what="tail split f32 + row-modulo table")
+        close(c16, want, atol=2e-2, rtol=1e-2, what="tail split bf16 copy")
+        d = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+        g = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+        hip.gemm_nt(A, B, M, N, K, hip.EPI_GELU_GRAD, d, out2=g, bias=bias)
+        close(g, torch.nn.functional.gelu(ref), atol=1e-2, rtol=1e-2, what="tail split gelu")
+        hip.gemm_nt(A, B, M, N, K, hip.EPI_MUL_AUX, o16, aux=aux, bias=bias)
+        close(o16, ref * aux.float(), atol=3e-2, rtol=1.5e-2, what="tail split mul_aux")
+    finally:
+        hip.gemm_set_tail_split(False)
+    gen = torch.Generator().manual_seed(7)
+    for _ in range(12):
+        M = int(torch.randint(1, 9000, (1,), generator=gen))
+        N = int(torch.randint(1, 130, (1,), generator=gen)) * 8
+        K = int(torch.randint(1, 6, (1,), generator=gen)) * 64
+        A = rnd(M, K, dtype=torch.bfloat16, seed=M)
+        B = rnd(N, K, scale=K ** -0.5, dtype=torch.bfloat16, seed=N)
+        bias = rnd(N, seed=K)
+        out = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+        hip.gemm_nt(A, B, M, N, K, hip.EPI_BF16, out, bias=bias)
+        close(out, A.float() @ B.float().t() + bias, atol=2e-2, rtol=1e-2, what=f"random shape {(M, N, K)}")
+
+
 # ----------------------------------------------------------------------------- GEMM TN
 @pytest.mark.parametrize("M,N1,N2", [(1000, 256, 384), (64, 128, 128), (5000, 768, 768), (777, 64, 2304), (333, 3072, 128)])
 def test_gemm_tn(M, N1, N2):
