@@ -155,6 +155,18 @@ def test_gemm_nt_tail_split_and_random_shapes():
         close(o16, ref * aux.float(), atol=3e-2, rtol=1.5e-2, what="tail split mul_aux")
     finally:
         hip.gemm_set_tail_split(False)
+    # the grid forms of the 256x256 kernel: one workgroup per tile (what multi-GPU runs use), a short persistent grid
+    M, N, K = 256 * 37 + 13, 1024, 128
+    A = rnd(M, K, dtype=torch.bfloat16, seed=45)
+    B = rnd(N, K, scale=K ** -0.5, dtype=torch.bfloat16, seed=46)
+    bias = rnd(N, seed=47)
+    ref = A.float() @ B.float().t() + bias
+    for persist in (0xffff, 24, 0):
+        hip.gemm_set_variant(persist << 16)
+        out = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+        hip.gemm_nt(A, B, M, N, K, hip.EPI_BF16, out, bias=bias)
+        close(out, ref, atol=2e-2, rtol=1e-2, what=f"grid form {persist:#x}")
+    hip.gemm_set_variant(0)
     gen = torch.Generator().manual_seed(7)
     for _ in range(12):
         M = int(torch.randint(1, 9000, (1,), generator=gen))
