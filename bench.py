@@ -93,8 +93,33 @@ def instrumented_gemm_profile(step_fn):
     records = []
     orig = hip.gemm_nt
 
+    # raw HIP events created with hipEventDisableSystemFence ("for events that only measure timing"): torch's timing
+    # events carry a system-scope release fence per record, which adds ~30 us around every launch of the instrumented step
+    import ctypes
+    rt = ctypes.CDLL("libamdhip64.so")
+    rt.hipEventCreateWithFlags.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint]
+    rt.hipEventRecord.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    rt.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
+    rt.hipEventDestroy.argtypes = [ctypes.c_void_p]
+
+    class Ev:
+        def __init__(self):
+            self.h = ctypes.c_void_p()
+            if rt.hipEventCreateWithFlags(ctypes.byref(self.h), 0x20000000) != 0:
+                raise RuntimeError("hipEventCreateWithFlags failed")
+
+        def record(self):
+            if rt.hipEventRecord(self.h, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) != 0:
+                raise RuntimeError("hipEventRecord failed")
+
+        def elapsed_time(self, other):
+            ms = ctypes.c_float()
+            if rt.hipEventElapsedTime(ctypes.byref(ms), self.h, other.h) != 0:
+                raise RuntimeError("hipEventElapsedTime failed")
+            return ms.value
+
     def timed(A, B, M, N, K, epi, out, **kw):
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s, e = Ev(), Ev()
         s.record()
         orig(A, B, M, N, K, epi, out, **kw)
         e.record()
@@ -115,6 +140,9 @@ def instrumented_gemm_profile(step_fn):
         d["flops"] += 2.0 * M * N * K
         d["ms"] += s.elapsed_time(e)
         d["n"] += 1
+    for _, _, _, _, s, e in records:
+        rt.hipEventDestroy(s.h)
+        rt.hipEventDestroy(e.h)
     return by, len(mods)
 
 
@@ -129,6 +157,23 @@ def pmc_traffic(kernel, args):
     with open(path) as fh:
         rec = json.load(fh)
     return rec["bytes_per_launch"] if rec.get("kernel") == kernel else None
+
+
+def rocprof_avg_us(kernel, args):
+    """Average duration of the dominant kernel in the committed rocprofv3 --kernel-trace --stats run of this command
+    (profiles/round1h_bench_kernel_stats.csv).  The live figure above brackets each launch with HIP events on its stream,
+    so it also contains the dispatch gap after the stream's previous kernel and the two event packets; rocprofv3 times the
+    kernel alone.  null when the workload differs from the profiled one."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1h_bench_kernel_stats.csv")
+    if not os.path.exists(path) or kernel != "gemm_nt_kernel<EPI_BF16,2,4,8,4>" or \
+            (args.variant, args.batch, args.frames, args.res) != ("frozen", 32, 8, 224):
+        return None
+    import csv
+    with open(path) as fh:
+        for row in csv.DictReader(fh):
+            if row["Name"].startswith("void oat::gemm_nt_kernel<0, 2, 4, 8, 4, 3, true, false>"):
+                return round(float(row["AverageNs"]) / 1e3, 1)
+    return None
 
 
 def cpu_baseline(frames, threads):
@@ -254,6 +299,7 @@ def main():
                                "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / BF16_DENSE_PEAK_TFLOPS, 4),
                                "traffic": pmc_traffic(kname, args), "launches_per_step": d["n"],
                                "avg_launch_us": round(d["ms"] / d["n"] * 1e3, 1),
+                               "rocprof_avg_launch_us": rocprof_avg_us(kname, args),
                                "gflop_per_launch": round(d["flops"] / d["n"] / 1e9, 1)}
         if world == 1 and not args.no_cpu_baseline and args.variant == "frozen":
             # torch CPU kernels collapse when all 256 SMT threads of the GPU box are used (measured 325 s /
