@@ -93,10 +93,12 @@ int oat_pos_table(const float* pos, const float* temporal, const float* cls_toke
 int oat_broadcast_rows(const float* src, float* dst, int ld, int R, int D, void* stream);
 int oat_cast_bf16(const float* src, void* dst_bf16, void* dstT_bf16, int R, int C, void* stream);
 /* All weight shadows of a module in one launch.  desc: device array of n_matrices records of eight int64
- * {src f32*, dst bf16* | 0, dstT bf16* | 0, R, C, ldd, ldT, first_tile}; matrix m owns the 32x32 tiles
+ * {src f32*, dst bf16* | 0, dstT bf16* | 0, R, C, ldd, ldT, first_tile}; matrix m owns the T x T tiles (T = oat_cast_bf16_tile())
  * [first_tile[m], first_tile[m+1]) of the grid, total_tiles blocks in all (the per-weight `.to(bfloat16)` /
  * `.t().contiguous()` / `torch.cat` ATen work a mixed-precision port of video_transformer.py:102,133,46-50 performs). */
-int oat_cast_bf16_multi(const void* desc, int n_matrices, int total_tiles, void* stream);
+int oat_cast_bf16_tile(void);   /* edge of the square tiles oat_cast_bf16_multi counts in (first_tile, total_tiles) */
+int oat_cast_bf16_multi(const void* desc, int n_matrices, int total_tiles, const int* tile_matrix /* device int32[total_tiles]: matrix of each tile, or NULL (binary search per block) */,
+                        void* stream);
 
 /* ---- divided space-time attention (video_transformer.py:99-135, :28-32) ------------------
  * qkv: bf16 [M, 3*D] (q | k | v, heads contiguous); out: bf16 [M, D]; lse: fp32 [M, H].

@@ -239,19 +239,22 @@ class CastTable:
     column slices of larger shadows (ldd / ldT = their leading dimensions)."""
 
     def __init__(self, entries):
-        rows, tiles = [], 0
+        rows, tiles, T, owner = [], 0, lib().oat_cast_bf16_tile(), []
         for src, dst, dstT, ldd, ldT in entries:
             R, C = src.shape
             rows.append([src.data_ptr(), dst.data_ptr() if dst is not None else 0,
                          dstT.data_ptr() if dstT is not None else 0, R, C, ldd, ldT, tiles])
-            tiles += ((R + 31) // 32) * ((C + 31) // 32)
+            nt = ((R + T - 1) // T) * ((C + T - 1) // T)
+            owner.append(torch.full((nt,), len(rows) - 1, dtype=torch.int32))
+            tiles += nt
+        self.owner = torch.cat(owner).to(entries[0][0].device)     # tile -> matrix (spares the kernel a binary search)
         self.n, self.tiles = len(rows), tiles
         self.key = tuple(r[0] for r in rows)
         self.table = torch.tensor(rows, dtype=torch.int64).to(entries[0][0].device)
         self.keep = entries                      # the table holds raw pointers: keep the tensors alive
 
     def run(self):
-        _check(lib().oat_cast_bf16_multi(_ptr(self.table), self.n, self.tiles, _stream()), "oat_cast_bf16_multi")
+        _check(lib().oat_cast_bf16_multi(_ptr(self.table), self.n, self.tiles, _ptr(self.owner), _stream()), "oat_cast_bf16_multi")
 
 
 def _attn_fwd(fn, name, qkv, out, lse, B, T, N, H, D, scale):

@@ -300,33 +300,67 @@ __global__ void cast_bf16_kernel(const float* src, bf16* dst, bf16* dstT, int R,
   }
 }
 
-// Every weight shadow of a module in ONE launch.  desc[m] = {src, dst, dstT, R, C, ldd, ldT, first_tile}: 32x32
-// tiles of matrix m start at block first_tile; dst / dstT may carry their own leading dimension, so the casts can
-// also assemble concatenated shadows (DistilBERT's q|k|v weights) without a separate copy.
+// Every weight shadow of a module in ONE launch.  desc[m] = {src, dst, dstT, R, C, ldd, ldT, first_tile}: the
+// CAST_TILE x CAST_TILE tiles of matrix m start at block first_tile; dst / dstT may carry their own leading dimension,
+// so the casts can also assemble concatenated shadows (DistilBERT's q|k|v weights) without a separate copy.
+// 64x64 tiles, 16-byte loads, 8-byte stores for both copies (the transposed one through a bf16 LDS tile): the first
+// version moved one element per thread through 32x32 tiles and ran at 2 TB/s.
+constexpr int CAST_TILE = 64;
 struct CastDesc { const float* src; bf16* dst; bf16* dstT; long long R, C, ldd, ldT, first_tile; };
-__global__ void cast_bf16_multi_kernel(const CastDesc* desc, int n) {
-  __shared__ float tile[32][33];
+__global__ __launch_bounds__(256) void cast_bf16_multi_kernel(const CastDesc* desc, int n, const int* tile_matrix) {
+  __shared__ __attribute__((aligned(8))) bf16 tile[CAST_TILE][CAST_TILE + 4];     // 136-byte pitch: rows stay 8-byte aligned
   int lo = 0, hi = n - 1;                               // last matrix whose first_tile <= blockIdx.x
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (desc[mid].first_tile <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+  if (tile_matrix) {
+    lo = tile_matrix[blockIdx.x];                       // caller-built map: a binary search here is ~8 dependent global loads
+  } else {
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (desc[mid].first_tile <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
   }
   const CastDesc d = desc[lo];
   const int R = (int)d.R, C = (int)d.C;
-  const int t = blockIdx.x - (int)d.first_tile, tpr = (C + 31) / 32;
-  const int c0 = (t % tpr) * 32, r0 = (t / tpr) * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  for (int i = ty; i < 32; i += 8) {
-    const int r = r0 + i, c = c0 + tx;
-    float v = 0.f;
-    if (r < R && c < C) { v = d.src[(size_t)r * C + c]; if (d.dst) d.dst[(size_t)r * d.ldd + c] = f2bf(v); }
-    tile[i][tx] = v;
-  }
-  if (!d.dstT) return;
-  __syncthreads();
-  for (int i = ty; i < 32; i += 8) {
-    const int c = c0 + i, r = r0 + tx;
-    if (r < R && c < C) d.dstT[(size_t)c * d.ldT + r] = f2bf(tile[tx][i]);
+  const int t = blockIdx.x - (int)d.first_tile, tpr = (C + CAST_TILE - 1) / CAST_TILE;
+  const int c0 = (t % tpr) * CAST_TILE, r0 = (t / tpr) * CAST_TILE;
+  const bool vec = C % 4 == 0 && R % 4 == 0 && d.ldd % 4 == 0 && d.ldT % 4 == 0 &&
+                   (reinterpret_cast<uintptr_t>(d.src) & 15) == 0 && (reinterpret_cast<uintptr_t>(d.dst) & 7) == 0 &&
+                   (reinterpret_cast<uintptr_t>(d.dstT) & 7) == 0;
+  const int q = threadIdx.x >> 4, e4 = (threadIdx.x & 15) * 4;       // 16 rows x 16 groups of 4 elements per pass
+  if (vec) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int r = r0 + p * 16 + q, c = c0 + e4;
+      bf16x4 o = {f2bf(0.f), f2bf(0.f), f2bf(0.f), f2bf(0.f)};
+      if (r < R && c < C) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(d.src + (size_t)r * C + c);
+        o = bf16x4{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+        if (d.dst) *reinterpret_cast<bf16x4*>(d.dst + (size_t)r * d.ldd + c) = o;
+      }
+      *reinterpret_cast<bf16x4*>(&tile[p * 16 + q][e4]) = o;
+    }
+    if (!d.dstT) return;
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int cc = p * 16 + q, rr = e4;                 // output row c0 + cc, four consecutive source rows
+      if (c0 + cc < C && r0 + rr < R) {
+        const bf16x4 o = {tile[rr][cc], tile[rr + 1][cc], tile[rr + 2][cc], tile[rr + 3][cc]};
+        *reinterpret_cast<bf16x4*>(d.dstT + (size_t)(c0 + cc) * d.ldT + r0 + rr) = o;
+      }
+    }
+  } else {                                                // odd shapes / alignments: one element at a time
+    for (int i = threadIdx.x; i < CAST_TILE * CAST_TILE; i += 256) {
+      const int lr = i / CAST_TILE, lc = i % CAST_TILE, r = r0 + lr, c = c0 + lc;
+      bf16 o = f2bf(0.f);
+      if (r < R && c < C) { o = f2bf(d.src[(size_t)r * C + c]); if (d.dst) d.dst[(size_t)r * d.ldd + c] = o; }
+      tile[lr][lc] = o;
+    }
+    if (!d.dstT) return;
+    __syncthreads();
+    for (int i = threadIdx.x; i < CAST_TILE * CAST_TILE; i += 256) {
+      const int lc = i / CAST_TILE, lr = i % CAST_TILE, r = r0 + lr, c = c0 + lc;
+      if (r < R && c < C) d.dstT[(size_t)c * d.ldT + r] = tile[lr][lc];
+    }
   }
 }
 
@@ -448,11 +482,12 @@ extern "C" int oat_broadcast_rows(const float* src, float* dst, int ld, int R, i
   hipLaunchKernelGGL(broadcast_rows_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, src, dst, ld, R, D);
   return check_launch("broadcast_rows");
 }
-extern "C" int oat_cast_bf16_multi(const void* desc, int n_matrices, int total_tiles, void* stream) {
+extern "C" int oat_cast_bf16_tile(void) { return CAST_TILE; }
+extern "C" int oat_cast_bf16_multi(const void* desc, int n_matrices, int total_tiles, const int* tile_matrix, void* stream) {
   if (n_matrices <= 0 || total_tiles <= 0) return 0;
   if (!desc) { set_error("cast_bf16_multi: null descriptor table"); return -4; }
   hipLaunchKernelGGL(cast_bf16_multi_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream,
-                     (const CastDesc*)desc, n_matrices);
+                     (const CastDesc*)desc, n_matrices, tile_matrix);
   return check_launch("cast_bf16_multi");
 }
 extern "C" int oat_cast_bf16(const float* src, void* dst, void* dstT, int R, int C, void* stream) {
