@@ -149,9 +149,9 @@ def instrumented_gemm_profile(step_fn):
 def pmc_traffic(kernel, args):
     """HBM-side bytes per launch of the dominant kernel.  PMC counters cannot be sampled from inside this
     process, so this is the committed rocprofv3 measurement of the same command and workload
-    (profiles/round1i_pmc_hbm_traffic.md: separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections);
+    (profiles/round1j_pmc_hbm_traffic.md: separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections);
     null when the workload differs from the measured one."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1i_pmc_traffic.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1j_pmc_traffic.json")
     if not os.path.exists(path) or (args.variant, args.batch, args.frames, args.res) != ("frozen", 32, 8, 224):
         return None
     with open(path) as fh:
@@ -161,10 +161,10 @@ def pmc_traffic(kernel, args):
 
 def rocprof_avg_us(kernel, args):
     """Average duration of the dominant kernel in the committed rocprofv3 --kernel-trace --stats run of this command
-    (profiles/round1i_bench_kernel_stats.csv).  The live figure above brackets each launch with HIP events on its stream,
+    (profiles/round1j_bench_kernel_stats.csv).  The live figure above brackets each launch with HIP events on its stream,
     so it also contains the dispatch gap after the stream's previous kernel and the two event packets; rocprofv3 times the
     kernel alone.  null when the workload differs from the profiled one."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1i_bench_kernel_stats.csv")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1j_bench_kernel_stats.csv")
     if not os.path.exists(path) or kernel != "gemm_nt_kernel<EPI_BF16,2,4,8,4>" or \
             (args.variant, args.batch, args.frames, args.res) != ("frozen", 32, 8, 224):
         return None
