@@ -95,6 +95,13 @@ OAT_DEV void glds16_asm_so(const void* uniform_base, uint32_t lane_byte_off, voi
                : "=&s"(keep) : "v"(lane_byte_off), "s"(uniform_base), "s"(lds) : "memory");
 }
 
+// Same, destination given as a wave-uniform 32-bit LDS byte address (no generic-pointer cast, no null check).
+OAT_DEV void glds16_asm_lds(const void* uniform_base, uint32_t lane_byte_off, uint32_t lds_addr) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(lane_byte_off), "s"(uniform_base), "s"(lds_addr) : "memory");
+}
+
 // LDS transpose read: within each 16-lane group, lane s fetches 4 contiguous bf16 at its own
 // address; output lane i, element j = fetched[lane 4*j + (i >> 2)][i & 3].
 OAT_DEV s16x4 lds_tr16(const void* lds_ptr) {

@@ -1,0 +1,38 @@
+// Shared declarations of the "NT" GEMM family (gemm_nt.hip: lockstep 256x256 / 128x128 kernels and the dispatcher;
+// gemm_nt_pp.hip: the two-wave-group "ping-pong" 256x256 kernel).
+#pragma once
+#include "common.h"
+
+namespace oat {
+
+enum GemmEpi : int {
+  EPI_BF16 = 0,       // out(bf16) = acc (+bias)
+  EPI_F32 = 1,        // out(f32)  = acc (+bias) (+resid[row % resid_mod])
+  EPI_GELU_DUAL = 2,  // out(bf16) = h = acc + bias ; out2(bf16) = gelu(h)
+  EPI_DGELU = 3,      // out(bf16) = acc * gelu'(aux[row, col])   (aux = saved pre-activation h)
+  EPI_F32_BF16 = 4,   // EPI_F32 plus a bf16 copy in out2
+  EPI_GELU_GRAD = 5,  // h = acc + bias (fp32) ; out(bf16) = gelu'(h) ; out2(bf16) = gelu(h)
+  EPI_MUL_AUX = 6,    // out(bf16) = (acc + bias) * aux[row, col]      (aux = the gelu'(h) saved by EPI_GELU_GRAD)
+};
+
+struct GemmArgs {
+  const bf16* A; const bf16* B;
+  int M, N, K, lda, ldb;
+  void* out; int ldc;
+  void* out2; int ld2;
+  const float* bias;
+  const float* resid; int ldr; int resid_mod;
+  const bf16* aux; int ldaux;
+  int dbg;
+  int row0;            // first row of this launch inside the caller's problem (tail launches; used by resid_mod)
+  int* ctr;            // persistent launch: 8 per-XCD tile counters of THIS launch (zero on entry), or nullptr = static walk
+  int* ctr_reset;      // counters of a launch far in the future, zeroed by this one
+};
+
+constexpr int BK = 64;
+
+// gemm_nt_pp.hip.  pp_supported: does the ping-pong kernel cover this launch (epilogue, shape)?
+bool pp_supported(int epi, const GemmArgs& g);
+int launch_pp(int epi, const GemmArgs& g, int grid_slots, int flags, hipStream_t s);
+
+}  // namespace oat

@@ -18,37 +18,12 @@
 // launches of a training step): DIRECT - operands not swapped, B rows permuted on their way into LDS so that a lane's
 // four tiles hold 4 consecutive columns and 16 consecutive lanes store one 128-byte line straight from the
 // accumulators (see DIRECT in the kernel).
-#include "common.h"
+#include "gemm.h"
 #include <type_traits>
 #include <atomic>
 
 namespace oat {
 
-enum GemmEpi : int {
-  EPI_BF16 = 0,       // out(bf16) = acc (+bias)
-  EPI_F32 = 1,        // out(f32)  = acc (+bias) (+resid[row % resid_mod])
-  EPI_GELU_DUAL = 2,  // out(bf16) = h = acc + bias ; out2(bf16) = gelu(h)
-  EPI_DGELU = 3,      // out(bf16) = acc * gelu'(aux[row, col])   (aux = saved pre-activation h)
-  EPI_F32_BF16 = 4,   // EPI_F32 plus a bf16 copy in out2
-  EPI_GELU_GRAD = 5,  // h = acc + bias (fp32) ; out(bf16) = gelu'(h) ; out2(bf16) = gelu(h)
-  EPI_MUL_AUX = 6,    // out(bf16) = (acc + bias) * aux[row, col]      (aux = the gelu'(h) saved by EPI_GELU_GRAD)
-};
-
-struct GemmArgs {
-  const bf16* A; const bf16* B;
-  int M, N, K, lda, ldb;
-  void* out; int ldc;
-  void* out2; int ld2;
-  const float* bias;
-  const float* resid; int ldr; int resid_mod;
-  const bf16* aux; int ldaux;
-  int dbg;
-  int row0;            // first row of this launch inside the caller's problem (tail launches; used by resid_mod)
-  int* ctr;            // persistent launch: 8 per-XCD tile counters of THIS launch (zero on entry), or nullptr = static walk
-  int* ctr_reset;      // counters of a launch far in the future, zeroed by this one
-};
-
-constexpr int BK = 64;
 
 // MFMA with the accumulator pinned to AGPRs.  With 256 accumulator registers per lane (128x128 wave tile) hipcc
 // otherwise selects the VGPR form and shuttles every result through v_accvgpr_write / _read.
@@ -636,7 +611,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
   }   // tile loop
 }
 
-// tuning hook: variant 0 = auto, 1 = force 128x128, 2 = force 256x256, 3 = 4-wave pipelined 256x256;
+// tuning hook: variant 0 = auto, 1 = force 128x128, 2 = force the lockstep 256x256, 3 = 4-wave pipelined 256x256,
+// 4 = force the ping-pong 256x256 where supported (flag bits then toggle its PPF_* options);
 // persist 0 = one workgroup per CU, 0xffff = one workgroup per tile, else the grid size
 static int g_variant = 0, g_dbg = 0, g_persist = 0, g_tail = 0;
 constexpr unsigned CTR_SETS = 1024;           // counter sets in the caller's buffer (8 ints each); set s is zeroed by launch s - 512
@@ -682,9 +658,15 @@ static int launch_cfg(const GemmArgs& g, hipStream_t s) {
   return check_launch("gemm_nt");
 }
 
+static int g_pp_default = 1;     // auto tile choice prefers the ping-pong kernel (gemm_nt_pp.hip) where it applies
+
 template <int EPI>
 static int launch(const GemmArgs& g, hipStream_t s) {
   const bool big = g_variant >= 2 || (g_variant == 0 && g.M >= 4096 && g.N % 256 == 0);
+  if (big && (g_variant == 4 || (g_variant == 0 && g_pp_default)) && pp_supported(EPI, g)) {
+    const int slots = g_persist == 0xffff ? 0x7fffffff : g_persist > 0 ? g_persist : cu_count();
+    return launch_pp(EPI, g, slots, g_variant == 4 ? g_dbg : 0, s);
+  }
   if (big && g_variant == 3) return launch_cfg<EPI, 2, 2, 8, 8, 3, false, true>(g, s);   // 4 waves x 128x128, hand-pipelined
   if (big) {
     // Tail split.  256x256 tiles leave the last round of workgroups mostly empty when tiles % CUs is small (N = 768 at

@@ -1,0 +1,364 @@
+// bf16 MFMA GEMM, "NT" form, two-wave-group ("ping-pong") 256x256x64 kernel:  C[M,N] = A[M,K] * B[N,K]^T (+ epilogue)
+//
+// Same contract and same arithmetic as gemm_nt_kernel<EPI,2,4,8,4,...> (gemm_nt.hip) for the three bf16-output
+// epilogues that make up 98 % of the GEMM launches of a training step (EPI_BF16, EPI_GELU_GRAD, EPI_MUL_AUX;
+// replaces the nn.Linear calls at /root/reference/OATrans/model/video_transformer.py:46-50,102,133 and their
+// data gradients).  What differs is the K loop.
+//
+// The lockstep kernel runs all 8 waves of a workgroup through "barrier - 24 ds_read_b128 - 64 MFMA" together, so the
+// two waves that share a SIMD want the matrix pipe at the same time and wait for the LDS at the same time (PMC: MFMA
+// pipe busy 58 % of the K loop).  Here the 8 waves form two groups (waves 0-3 / 4-7: wave w and w + 4 share a SIMD)
+// that run the SAME instruction stream ONE barrier interval apart:
+//
+//     interval      t        t+1       t+2       t+3    ...
+//     group 0      L1        M1        L2        M2            L = LDS -> register fragments of the next quadrant
+//     group 1      M4'       L1        M1        L2                + 2 LDS-DMA pieces of a later K-tile + counted vmcnt
+//                                                              M = 16 MFMAs (one 64x32 quadrant x K = 64), s_setprio 1
+//
+// so on every SIMD one wave feeds the matrix pipe while the other one talks to the LDS and the memory pipeline.
+// A K-tile (64 k) is 4 quadrants = 8 intervals per wave; quadrant order (a0,b0) (a1,b0) (a1,b1) (a0,b1) keeps both A
+// half-fragments (2 x 32 VGPRs) and two B half-fragments (2 x 16 VGPRs) live and reads 8 / 8 / 4 / 4 ds_read_b128 in
+// L1..L4 (L4 pre-reads b0 of the NEXT K-tile).
+//
+// LDS: two K-tile buffers of A (2 x 32 KB) and B (2 x 32 KB) + the bias vector = 144 KB.  A buffer is not recycled as a
+// whole: the 64-row / 32-row region a quadrant read last is dead one interval later (the trailing group has read it
+// too), so the region b0 | a0 | a1 | b1 of K-tile s is refilled with K-tile s + 2 in L1 | L2 | L3 | L4 of K-tile s
+// itself.  Every piece is therefore issued ~1.75 K-tiles (14 intervals) before its first read, and after the prologue
+// every wait is the same `s_waitcnt vmcnt(12)`: the 12 youngest LDS-DMA pieces may still fly (derivation at `endL`).
+// The stream of K-tiles is continuous across the tiles a persistent workgroup walks, so the first two K-tiles of the
+// next tile are already in flight or landed when the epilogue of a tile stores its accumulators, and those stores
+// drain under the next tile's K loop (vmcnt retires loads and stores in issue order on gfx950; the first six waits
+// after an interior epilogue allow its NST stores on top of the 12 pieces).
+#include "gemm.h"
+#include <type_traits>
+
+namespace oat {
+
+namespace {
+
+constexpr int PP_A1 = 32768, PP_B0 = 65536, PP_BIAS = 131072;
+constexpr int PP_MAXN = 4096;                       // bias vector kept in LDS
+constexpr int PP_LDS = PP_BIAS + PP_MAXN * 4;
+
+enum : int { PPF_PRIO = 1, PPF_NOSTAGGER = 2, PPF_LGKM = 4, PPF_BONUS = 8, PPF_NOEPI = 16 };
+
+template <int EPI, int FL>
+__global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs g) {
+  constexpr bool PRIO = FL & PPF_PRIO, STAGGER = !(FL & PPF_NOSTAGGER), LGKM = FL & PPF_LGKM, BONUS = FL & PPF_BONUS;
+  constexpr bool NOEPI = FL & PPF_NOEPI;
+  constexpr int NST = EPI == EPI_GELU_GRAD ? 64 : 32;           // stores per lane of an interior epilogue
+  constexpr int WB = 12 + NST > 63 ? 63 : 12 + NST;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;                      // wave tile: rows wm*128.., columns wn*64..
+  const int ntn = g.N >> 8, ntm = (g.M + 255) >> 8, nwg = ntm * ntn;
+  const int nk = g.K >> 6;
+  const int ntl = (nwg - 1 - (int)blockIdx.x) / (int)gridDim.x + 1;     // tiles this workgroup walks
+  const int S = ntl * nk;                                               // its stream of K-tiles
+  struct Tile { int m0, n0; };
+  auto tile_of = [&](int t) __attribute__((always_inline)) {
+    const int w = blockIdx.x + t * gridDim.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = w & 7, idx = w >> 3;
+    const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;   // XCD-contiguous, bijective
+    const int tm = bid / ntn;
+    return Tile{tm << 8, (bid - tm * ntn) << 8};
+  };
+
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  float* const sbias = reinterpret_cast<float*>(smem + PP_BIAS);
+  for (int i = tid; i < g.N; i += 512) sbias[i] = g.bias ? g.bias[i] : 0.f;
+
+  // ---- staging.  One LDS-DMA piece = 8 tile rows x 128 B.  Per K-tile a wave stages two pieces of each class:
+  //   a0 = A rows {0..63, 128..191} (first halves of the two wave rows), a1 = the other A rows,
+  //   b0 = B rows with (row >> 5) even (first halves of the four wave columns), b1 = the others.
+  const int srow = lane >> 3;
+  const uint32_t c16_0 = (uint32_t)(((lane & 7) ^ (srow >> 1)) << 4);          // 16-byte chunk, source-side swizzle
+  const uint32_t lda2 = (uint32_t)g.lda * 2u, ldb2 = (uint32_t)g.ldb * 2u;
+  int pa[2], pb[2];                                                             // piece index of (class 0, e)
+  uint32_t boff[2][2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int idx = wave * 2 + e;
+    pa[e] = idx < 8 ? idx : idx + 8;
+    pb[e] = ((idx >> 2) << 3) | (idx & 3);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int r = (pb[e] + c * 4) * 8 + srow;                                 // LDS row <- B row rg (DIRECT epilogue)
+      const int rg = (r & ~63) | ((r & 15) << 2) | ((r >> 4) & 3);
+      boff[c][e] = (uint32_t)rg * ldb2 + (c16_0 ^ (e << 6));
+    }
+  }
+  // staging cursor: K-tile cs = s + 2 of the stream
+  int ckt = 0, ctl = 0, crmax;
+  const bf16 *ca, *cb;
+  uint32_t lda2c = lda2, bmask = ~0u;          // zeroed once the stream is exhausted (see `advance`)
+  {
+    const Tile t = tile_of(0);
+    ca = g.A + (size_t)t.m0 * g.lda;
+    cb = g.B + (size_t)t.n0 * g.ldb;
+    crmax = g.M - 1 - t.m0;
+  }
+  // Past the last K-tile of the stream the cursor stays where it is and the pieces degenerate to re-reads of ONE
+  // 128-byte line per operand into regions nobody reads any more: the op stream - and with it every vmcnt count -
+  // stays uniform to the end, for 2 K-tiles of dummy pieces per workgroup and launch.
+  auto advance = [&]() __attribute__((always_inline)) {
+    ++ckt;
+    ca += 64;
+    cb += 64;
+    if (ckt == nk) {                            // selects, not branches: every path assigns every cursor variable
+      const bool more = ctl + 1 < ntl;
+      ctl += more ? 1 : 0;
+      const Tile t = tile_of(ctl);
+      ckt = more ? 0 : nk - 1;
+      ca = more ? g.A + (size_t)t.m0 * g.lda : ca - 64;
+      cb = more ? g.B + (size_t)t.n0 * g.ldb : cb - 64;
+      crmax = g.M - 1 - t.m0;
+      lda2c = more ? lda2c : 0u;
+      bmask = more ? bmask : 0x7fu;
+    }
+  };
+  auto stageA = [&](int cls, int buf) __attribute__((always_inline)) {        // cls 0 = a0, 1 = a1
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int p = pa[e] + cls * 8;
+      const uint32_t r = (uint32_t)min(p * 8 + srow, crmax);                    // ragged M: re-read a valid row
+      const uint32_t off = __umul24(r, lda2c) + (c16_0 ^ (e << 6));
+      glds16_asm_lds(ca, off, lds0 + buf * PP_A1 + p * 1024);
+    }
+  };
+  auto stageB = [&](int cls, int buf) __attribute__((always_inline)) {        // cls 0 = b0, 1 = b1
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+      glds16_asm_lds(cb, boff[cls][e] & bmask, lds0 + PP_B0 + buf * PP_A1 + (pb[e] + cls * 4) * 1024);
+  };
+
+  // ---- fragment addresses: [rows][64 k] bf16 tiles, 16-byte chunk c of row r at (c ^ ((r >> 1) & 7))
+  const int frow = lane & 15, fk = lane >> 4;
+  const int sw = (frow >> 1) & 7;
+  typedef const __attribute__((address_space(3))) bf16x8* lds_frag;          // 32-bit LDS addresses, immediates fold
+  uint32_t pA[2], pB[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    const int ch = ((kk * 4 + fk) ^ sw) << 4;
+    pA[kk] = lds0 + (wm * 128 + frow) * 128 + ch;
+    pB[kk] = lds0 + PP_B0 + (wn * 64 + frow) * 128 + ch;
+  }
+  bf16x8 fbx[2][2];                          // b0 of the current K-tile (pre-read in L4 of the previous one)
+  f32x4 acc[8][4];
+  auto readA = [&](bf16x8 (&f)[2][4], int half, int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        f[kk][i] = *(lds_frag)(uintptr_t)(pA[kk] + buf * PP_A1 + (half * 64 + i * 16) * 128);
+  };
+  auto readB = [&](bf16x8 (&f)[2][2], int half, int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        f[kk][j] = *(lds_frag)(uintptr_t)(pB[kk] + buf * PP_A1 + (half * 32 + j * 16) * 128);
+  };
+  // end of an L interval.  Counted wait: the LDS-DMA stream of a wave is  ... b0(s+2) a0(s+2) a1(s+2) b1(s+2) b0(s+3) ...
+  // (2 pieces each, issued in L1..L4 of K-tile s); the region read NEXT was issued six groups before the group this
+  // interval just issued, so 12 younger pieces may stay in flight.  Each wave waits for ITS pieces, the barrier
+  // publishes them; the first reader comes one interval (other group) or two (same group) later.
+  // `bonus` (head pair of a tile only): the NST stores of the previous, INTERIOR tile's epilogue are younger too.
+  auto endL = [&](bool bonus) __attribute__((always_inline)) {
+    if constexpr (LGKM) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (bonus) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WB) : "memory");
+    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto mma = [&](const bf16x8 (&fa)[2][4], const bf16x8 (&fb)[2][2], int ah, int bh) __attribute__((always_inline)) {
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[ah * 4 + i][bh * 2 + j] =
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kk][i], fb[kk][j], acc[ah * 4 + i][bh * 2 + j], 0, 0, 0);
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---- prologue: K-tiles 0 and 1 in canonical issue order, then b0(0) into registers
+  stageB(0, 0); stageA(0, 0); stageA(1, 0); stageB(1, 0);
+  advance();
+  stageB(0, 1); stageA(0, 1); stageA(1, 1); stageB(1, 1);
+  advance();
+  asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // b0(0), a0(0) landed (K-tile 0's a1, b1 and K-tile 1 may fly)
+  __syncthreads();                                       // ... for every wave; also publishes the bias vector
+  readB(fbx, 0, 0);
+  if (STAGGER && wm == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one interval behind from here on
+  __builtin_amdgcn_sched_barrier(0);
+
+  // Two K-tiles (LDS buffers 0 and 1).  HEAD = first pair of a tile: when the previous tile's epilogue was an interior
+  // one (`bon`), its NST stores are younger than the awaited pieces in all four waits of the first K-tile and in L1 / L2
+  // of the second (the later targets were issued after the stores).
+  auto pair = [&](auto head, const bool bon) __attribute__((always_inline)) {
+    constexpr bool HEAD = decltype(head)::value;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      // buffer u holds K-tile s; its dead regions are refilled with K-tile s + 2 (the cursor)
+      bf16x8 fa0[2][4], fa1[2][4], fby[2][2];
+      const bool bh = HEAD && bon, bf = HEAD && bon && u == 0;
+      readA(fa0, 0, u); stageB(0, u); endL(bh);
+      mma(fa0, fbx, 0, 0);
+      readA(fa1, 1, u); stageA(0, u); endL(bh);
+      mma(fa1, fbx, 1, 0);
+      readB(fby, 1, u); stageA(1, u); endL(bf);
+      mma(fa1, fby, 1, 1);
+      readB(fbx, 0, u ^ 1); stageB(1, u); endL(bf);
+      mma(fa0, fby, 0, 1);
+      advance();
+    }
+  };
+
+  bool prev_interior = false;
+  for (int tl = 0; tl < ntl; ++tl) {
+    const Tile tile = tile_of(tl);
+    const int m0 = tile.m0, n0 = tile.n0;
+    {
+      const f32x4 b = *reinterpret_cast<const f32x4*>(sbias + n0 + wn * 64 + frow * 4);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{b[j], b[j], b[j], b[j]};
+    }
+    pair(std::true_type{}, BONUS && prev_interior);
+    for (int kt = 2; kt < nk; kt += 2) pair(std::false_type{}, false);
+    // ---- epilogue (no LDS, no barriers): lane (fk, frow) owns rows 16 i + 4 fk + r and the 4 consecutive columns
+    // 4 frow + j of its wave tile, so 16 consecutive lanes store one 128-byte line per row
+    if constexpr (NOEPI) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+      prev_interior = false;
+      continue;
+    }
+    const int wrow0 = m0 + wm * 128, wcol00 = n0 + wn * 64;
+    auto finish = [&](const f32x4 v, const bf16x4 a, bf16x4& o, bf16x4& o2) {
+      if constexpr (EPI == EPI_GELU_GRAD) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float gl, dg;
+          gelu_both(v[e], gl, dg);
+          o[e] = f2bf(dg);
+          o2[e] = f2bf(gl);
+        }
+      } else if constexpr (EPI == EPI_MUL_AUX) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e] * bf2f(a[e]));
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+      }
+    };
+    prev_interior = m0 + 256 <= g.M;
+    if (prev_interior) {
+      const size_t t0 = (size_t)wrow0;
+      char* const ob = reinterpret_cast<char*>(g.out) + (t0 * g.ldc + wcol00) * 2;
+      char* const ob2 = EPI == EPI_GELU_GRAD ? reinterpret_cast<char*>(g.out2) + (t0 * g.ld2 + wcol00) * 2 : nullptr;
+      const char* const ab = EPI == EPI_MUL_AUX ? reinterpret_cast<const char*>(g.aux) + (t0 * g.ldaux + wcol00) * 2 : nullptr;
+      const uint32_t lo = (uint32_t)(fk * 4 * g.ldc + frow * 4) * 2;
+      const uint32_t lo2 = EPI == EPI_GELU_GRAD ? (uint32_t)(fk * 4 * g.ld2 + frow * 4) * 2 : 0;
+      const uint32_t la = EPI == EPI_MUL_AUX ? (uint32_t)(fk * 4 * g.ldaux + frow * 4) * 2 : 0;
+      bf16x4 an[4] = {}, ac[4] = {};
+      if constexpr (EPI == EPI_MUL_AUX) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) an[r] = *reinterpret_cast<const bf16x4*>(ab + (size_t)(uint32_t)(r * g.ldaux * 2) + la);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if constexpr (EPI == EPI_MUL_AUX) {        // the saved derivative of row group i + 1 is requested one group ahead
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ac[r] = an[r];
+          if (i + 1 < 8) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              an[r] = *reinterpret_cast<const bf16x4*>(ab + (size_t)(uint32_t)(((i + 1) * 16 + r) * g.ldaux * 2) + la);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const f32x4 v = f32x4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+          bf16x4 o, o2;
+          finish(v, ac[r], o, o2);
+          const uint32_t rr = (uint32_t)(i * 16 + r);
+          *reinterpret_cast<bf16x4*>(ob + (size_t)(rr * (uint32_t)g.ldc * 2) + lo) = o;
+          if constexpr (EPI == EPI_GELU_GRAD) *reinterpret_cast<bf16x4*>(ob2 + (size_t)(rr * (uint32_t)g.ld2 * 2) + lo2) = o2;
+        }
+      }
+    } else {
+      const int col = wcol00 + frow * 4;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = wrow0 + i * 16 + fk * 4 + r;
+          const f32x4 v = f32x4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+          if (row < g.M) {
+            bf16x4 o, o2, a = {};
+            if constexpr (EPI == EPI_MUL_AUX) a = *reinterpret_cast<const bf16x4*>(g.aux + (size_t)row * g.ldaux + col);
+            finish(v, a, o, o2);
+            if constexpr (EPI == EPI_GELU_GRAD) *reinterpret_cast<bf16x4*>((bf16*)g.out2 + (size_t)row * g.ld2 + col) = o2;
+            *reinterpret_cast<bf16x4*>((bf16*)g.out + (size_t)row * g.ldc + col) = o;
+          }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (STAGGER && wm == 0) __builtin_amdgcn_s_barrier();  // pairs with group 1's extra barrier
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no LDS-DMA may outlive the workgroup's LDS allocation
+}
+
+template <int EPI, int FL>
+int launch_pp_cfg(const GemmArgs& g, int grid_slots, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_pp_kernel<EPI, FL>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+    attr_set = true;
+  }
+  const int nwg = ((g.M + 255) / 256) * (g.N / 256);
+  const int grid = nwg < grid_slots ? nwg : grid_slots;
+  hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, FL>), dim3(grid), dim3(512), PP_LDS, s, g);
+  return check_launch("gemm_nt_pp");
+}
+
+}  // namespace
+
+bool pp_supported(int epi, const GemmArgs& g) {
+  if (epi != EPI_BF16 && epi != EPI_GELU_GRAD && epi != EPI_MUL_AUX) return false;
+  const int nk = g.K / 64;
+  return g.N % 256 == 0 && g.N <= PP_MAXN && nk >= 2 && nk % 2 == 0 && g.M >= 256 && g.lda < (1 << 22) &&
+         g.ldb < (1 << 22);
+}
+
+// flags: tuning / ablation bits (PPF_*); 0 = the shipped configuration
+int launch_pp(int epi, const GemmArgs& g, int grid_slots, int flags, hipStream_t s) {
+  constexpr int DEF = PPF_PRIO | PPF_BONUS | PPF_LGKM;   // LGKM: measured free, and it makes the WAR spacing strict
+  const int fl = DEF ^ flags;                    // a set bit toggles the default
+  if (epi == EPI_GELU_GRAD) return launch_pp_cfg<EPI_GELU_GRAD, DEF>(g, grid_slots, s);
+  if (epi == EPI_MUL_AUX) return launch_pp_cfg<EPI_MUL_AUX, DEF>(g, grid_slots, s);
+  switch (fl) {
+    case DEF: return launch_pp_cfg<EPI_BF16, DEF>(g, grid_slots, s);
+    case DEF ^ PPF_PRIO: return launch_pp_cfg<EPI_BF16, DEF ^ PPF_PRIO>(g, grid_slots, s);
+    case DEF | PPF_NOSTAGGER: return launch_pp_cfg<EPI_BF16, DEF | PPF_NOSTAGGER>(g, grid_slots, s);
+    case DEF ^ PPF_LGKM: return launch_pp_cfg<EPI_BF16, DEF ^ PPF_LGKM>(g, grid_slots, s);
+    case DEF ^ PPF_BONUS: return launch_pp_cfg<EPI_BF16, DEF ^ PPF_BONUS>(g, grid_slots, s);
+    case DEF | PPF_NOEPI: return launch_pp_cfg<EPI_BF16, DEF | PPF_NOEPI>(g, grid_slots, s);
+    default: set_error("gemm_nt_pp: flag combination not built"); return -7;
+  }
+}
+
+}  // namespace oat

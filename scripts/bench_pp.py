@@ -1,0 +1,132 @@
+"""Dev: ping-pong gemm_nt (variant 4) vs the lockstep 256x256 kernel (variant 2): bit-exactness on the hot shapes
+(incl. the ragged last row panel of M = 50208), a repeat-run race screen, and interleaved timing of the PPF_* toggles."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oa-transformer_amd")); sys.path.insert(0, ROOT)
+import torch
+from OATrans.ops import hip
+
+M = int(os.environ.get("M", 50208))
+Mp = (M + 255) // 256 * 256
+SHAPES = [(M, 2304, 768), (M, 768, 768), (M, 3072, 768), (M, 768, 3072), (M, 768, 2304)]
+PRIO, NOSTAG, LGKM, BONUS, NOEPI = 1, 2, 4, 8, 16
+VARIANTS = [("lockstep", 2), ("pp", 4), ("pp-noprio", 4 | (PRIO << 8)), ("pp-nostagger", 4 | (NOSTAG << 8)),
+            ("pp-lgkm", 4 | (LGKM << 8)), ("pp-nobonus", 4 | (BONUS << 8)), ("pp-noepi", 4 | (NOEPI << 8)),
+            ("lock-noepi", 2 | (1 << 8))]
+ROUNDS = int(os.environ.get("ROUNDS", 4))
+
+
+def timeit(fn, n=10):
+    st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    st.record()
+    for _ in range(n):
+        fn()
+    en.record()
+    torch.cuda.synchronize()
+    return st.elapsed_time(en) / n * 1e-3
+
+
+def check():
+    torch.manual_seed(0)
+    ok = True
+    for (m, n, k) in SHAPES + [(1000, 768, 128), (256, 256, 128), (4096 + 17, 512, 256)]:
+        mp = (m + 255) // 256 * 256
+        A = torch.randn(mp, k, device="cuda").bfloat16()
+        B = (torch.randn(n, k, device="cuda") * k ** -0.5).bfloat16()
+        bias = torch.randn(n, device="cuda")
+        aux = torch.randn(mp, n, device="cuda").bfloat16()
+        for epi, name in ((hip.EPI_BF16, "bf16"), (hip.EPI_GELU_GRAD, "gelu_grad"), (hip.EPI_MUL_AUX, "mul_aux")):
+            outs = []
+            for v in (2, 4):
+                hip.gemm_set_variant(v)
+                o = torch.full((mp, n), 7.0, device="cuda", dtype=torch.bfloat16)
+                o2 = torch.full((mp, n), 7.0, device="cuda", dtype=torch.bfloat16)
+                hip.gemm_nt(A, B, m, n, k, epi, o, out2=o2 if epi == hip.EPI_GELU_GRAD else None, bias=bias,
+                            aux=aux if epi == hip.EPI_MUL_AUX else None)
+                outs.append((o, o2))
+            same = torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+            untouched = bool((outs[1][0][m:] == 7.0).all())
+            ref = (A[:m].float() @ B.float().t() + bias)
+            if epi == hip.EPI_BF16:
+                err = (outs[1][0][:m].float() - ref).abs().max().item()
+            else:
+                err = float("nan")
+            print(f"check M={m} N={n} K={k} {name}: identical={same} rows>=M untouched={untouched} maxerr_vs_fp32={err:.4f}")
+            ok &= same and untouched
+        # no-bias path
+        hip.gemm_set_variant(4)
+        o = torch.empty(mp, n, device="cuda", dtype=torch.bfloat16)
+        hip.gemm_nt(A, B, m, n, k, hip.EPI_BF16, o)
+        hip.gemm_set_variant(2)
+        o_ = torch.empty(mp, n, device="cuda", dtype=torch.bfloat16)
+        hip.gemm_nt(A, B, m, n, k, hip.EPI_BF16, o_)
+        ok &= torch.equal(o[:m], o_[:m])
+    # race screen: the same launch 30 times, under a competing stream, all bit-identical
+    m, n, k = SHAPES[0]
+    A = torch.randn(Mp, k, device="cuda").bfloat16(); B = (torch.randn(n, k, device="cuda") * k ** -0.5).bfloat16()
+    bias = torch.randn(n, device="cuda")
+    hip.gemm_set_variant(4)
+    ref = torch.empty(Mp, n, device="cuda", dtype=torch.bfloat16)
+    hip.gemm_nt(A, B, m, n, k, hip.EPI_BF16, ref, bias=bias)
+    side = torch.cuda.Stream()
+    junk = torch.randn(64 << 20, device="cuda")
+    bad = 0
+    for it in range(30):
+        with torch.cuda.stream(side):
+            junk.mul_(1.0001)
+        o = torch.empty(Mp, n, device="cuda", dtype=torch.bfloat16)
+        hip.gemm_nt(A, B, m, n, k, hip.EPI_BF16, o, bias=bias)
+        bad += int(not torch.equal(o[:m], ref[:m]))
+    torch.cuda.synchronize()
+    print(f"race screen: {bad} of 30 launches differ")
+    ok &= bad == 0
+    # persistent grid sizes (192 / 128 workgroups, one per tile)
+    for grid in (192, 128, 0xffff, 7):
+        hip.gemm_set_variant(4 | (grid << 16))
+        o = torch.empty(Mp, n, device="cuda", dtype=torch.bfloat16)
+        hip.gemm_nt(A, B, m, n, k, hip.EPI_BF16, o, bias=bias)
+        same = torch.equal(o[:m], ref[:m])
+        print(f"grid {grid}: identical={same}")
+        ok &= same
+    hip.gemm_set_variant(0)
+    print("CHECK", "PASSED" if ok else "FAILED")
+    return ok
+
+
+def bench():
+    res = {}
+    for (m, n, k) in SHAPES:
+        A = torch.randn(Mp, k, device="cuda").bfloat16(); B = (torch.randn(n, k, device="cuda") * k ** -0.5).bfloat16()
+        bias = torch.randn(n, device="cuda"); out = torch.zeros(Mp, n, device="cuda", dtype=torch.bfloat16)
+        for name, v in VARIANTS:                       # warm-up (hipFuncSetAttribute, code load)
+            hip.gemm_set_variant(v)
+            hip.gemm_nt(A, B, m, n, k, hip.EPI_BF16, out, bias=bias)
+        for r in range(ROUNDS):
+            for name, v in VARIANTS:
+                hip.gemm_set_variant(v)
+                t = timeit(lambda: hip.gemm_nt(A, B, m, n, k, hip.EPI_BF16, out, bias=bias))
+                res.setdefault((n, k, name), []).append(t)
+        for name, v in VARIANTS:
+            ts = sorted(res[(n, k, name)])
+            med = ts[len(ts) // 2]
+            print(f"N={n:5d} K={k:5d} {name:14s}: median {2*m*n*k/med/1e12:7.1f} TF/s ({med*1e6:7.1f} us)  best {2*m*n*k/ts[0]/1e12:7.1f}")
+        # the MLP pair epilogues
+    for (m, n, k, epi, nm) in [(M, 3072, 768, hip.EPI_GELU_GRAD, "gelu_grad"), (M, 3072, 768, hip.EPI_MUL_AUX, "mul_aux")]:
+        A = torch.randn(Mp, k, device="cuda").bfloat16(); B = (torch.randn(n, k, device="cuda") * k ** -0.5).bfloat16()
+        bias = torch.randn(n, device="cuda"); out = torch.zeros(Mp, n, device="cuda", dtype=torch.bfloat16)
+        out2 = torch.zeros(Mp, n, device="cuda", dtype=torch.bfloat16); aux = torch.randn(Mp, n, device="cuda").bfloat16()
+        for r in range(ROUNDS):
+            for name, v in (("lockstep", 2), ("pp", 4)):
+                hip.gemm_set_variant(v)
+                t = timeit(lambda: hip.gemm_nt(A, B, m, n, k, epi, out, out2=out2, bias=bias, aux=aux))
+                res.setdefault((nm, name), []).append(t)
+        for name in ("lockstep", "pp"):
+            ts = sorted(res[(nm, name)]); med = ts[len(ts) // 2]
+            print(f"{nm:10s} N={n} K={k} {name:10s}: median {2*m*n*k/med/1e12:7.1f} TF/s ({med*1e6:7.1f} us)")
+    hip.gemm_set_variant(0)
+
+
+if __name__ == "__main__":
+    ok = check()
+    if ok or os.environ.get("FORCE_BENCH"):
+        bench()
