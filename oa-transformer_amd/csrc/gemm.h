@@ -31,6 +31,20 @@ struct GemmArgs {
 
 constexpr int BK = 64;
 
+struct TnArgs {
+  const bf16* P; const bf16* Q;
+  int M, N1, N2, ldp, ldq;
+  float* slabs;            // [splits][N1][N2]
+  float* bias_slabs;       // [splits][N1] or nullptr
+  int chunks_per_split;    // in units of TK rows
+  int splits;
+  int dbg;                 // ablation bits: 1 = no global loads after the first stages, 2 = no slab store
+};
+
+// gemm_tn_pp.hip: ping-pong 256x256 weight-gradient kernel.  Writes the same fp32 slabs as gemm_tn_kernel (the caller
+// runs tn_reduce afterwards); g.chunks_per_split is in units of 64 rows there.
+int launch_tn_pp(const TnArgs& g, int flags, hipStream_t s);
+
 // gemm_nt_pp.hip.  pp_supported: does the ping-pong kernel cover this launch (epilogue, shape)?
 bool pp_supported(int epi, const GemmArgs& g);
 int launch_pp(int epi, const GemmArgs& g, int grid_slots, int flags, hipStream_t s);

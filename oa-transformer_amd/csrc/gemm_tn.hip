@@ -17,7 +17,7 @@
 // (n1-tile, k-step) against an all-ones operand in the workgroups of the first N2 tile.
 // Contract: rows [M, round_up(M,64)) of P and Q must be READABLE (inside the allocation); their
 // contents are ignored (the ragged tail of the last chunk is zeroed in LDS).
-#include "common.h"
+#include "gemm.h"
 
 namespace oat {
 
@@ -25,16 +25,6 @@ constexpr int TK = 32;             // m rows per stage (one MFMA k-step)
 constexpr int NS = 4;              // LDS ring depth: loads run NS-1 stages ahead of the math
 
 OAT_DEV int tn_f(int m) { return ((m & 3) << 1) | (((m >> 3) & 1) << 3); }
-
-struct TnArgs {
-  const bf16* P; const bf16* Q;
-  int M, N1, N2, ldp, ldq;
-  float* slabs;            // [splits][N1][N2]
-  float* bias_slabs;       // [splits][N1] or nullptr
-  int chunks_per_split;    // in units of TK rows
-  int splits;
-  int dbg;                 // ablation bits: 1 = no global loads after the first stages, 2 = no slab store
-};
 
 template <int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_tn_kernel(TnArgs g) {
@@ -219,7 +209,17 @@ __global__ void tn_reduce_kernel(const float* slabs, float* out, int n4, int spl
   }
 }
 
-static int g_tn_variant = 0, g_tn_dbg = 0, g_tn_slots = 0;   // 0 auto, 1 force 128^2, 2 force 256^2
+static int g_tn_variant = 0, g_tn_dbg = 0, g_tn_slots = 0;   // 0 auto, 1 force 128^2, 2 force the lockstep 256^2, 4 force ping-pong
+static int g_tn_pp_default = 1;   // auto prefers the ping-pong kernel (gemm_tn_pp.hip) for 256^2 launches
+
+static int reduce_slabs(const TnArgs& g, int splits, float* out, float* bias_out, int accumulate, hipStream_t s) {
+  const int n4 = g.N1 * g.N2 / 4, nb4 = bias_out ? g.N1 / 4 : 0;
+  int blocks = (n4 + nb4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(tn_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)g.slabs, out, n4, splits,
+                     (size_t)g.N1 * g.N2 / 4, (const float*)g.bias_slabs, bias_out, nb4, accumulate);
+  return check_launch("gemm_tn_reduce");
+}
 
 template <int WM, int WN, int TM, int TN>
 static int launch_tn(TnArgs g, int splits, float* out, float* bias_out, int accumulate, hipStream_t s) {
@@ -235,12 +235,7 @@ static int launch_tn(TnArgs g, int splits, float* out, float* bias_out, int accu
   hipLaunchKernelGGL((gemm_tn_kernel<WM, WN, TM, TN>), dim3(tiles * splits), dim3(WM * WN * 64), LDS, s, g);
   int rc = check_launch("gemm_tn");
   if (rc) return rc;
-  const int n4 = g.N1 * g.N2 / 4, nb4 = bias_out ? g.N1 / 4 : 0;
-  int blocks = (n4 + nb4 + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(tn_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)g.slabs, out, n4, splits,
-                     (size_t)g.N1 * g.N2 / 4, (const float*)g.bias_slabs, bias_out, nb4, accumulate);
-  return check_launch("gemm_tn_reduce");
+  return reduce_slabs(g, splits, out, bias_out, accumulate, s);
 }
 
 }  // namespace oat
@@ -248,20 +243,25 @@ static int launch_tn(TnArgs g, int splits, float* out, float* bias_out, int accu
 extern "C" void oat_gemm_tn_set_variant(int v) { oat::g_tn_variant = v & 0xff; oat::g_tn_dbg = (v >> 8) & 0xff; oat::g_tn_slots = (v >> 16) & 0xffff; }
 
 // tile shape and split count of a launch (shared by the launcher and the workspace query)
-static void tn_plan(int M, int N1, int N2, bool* big_, int* splits_, int* cps_) {
+static void tn_plan(int M, int N1, int N2, bool* big_, int* splits_, int* cps_, bool* pp_ = nullptr) {
   using namespace oat;
-  const bool big = g_tn_variant == 2 || (g_tn_variant == 0 && M >= 4096 && N1 % 256 == 0 && N2 % 256 == 0);
+  const bool fits = N1 % 256 == 0 && N2 % 256 == 0;
+  const bool big = g_tn_variant == 2 || (g_tn_variant == 4 && fits) || (g_tn_variant == 0 && M >= 4096 && fits);
+  const bool pp = big && fits && (g_tn_variant == 4 || (g_tn_variant == 0 && g_tn_pp_default));
   const int B = big ? 256 : 128;
   const int tiles = ((N1 + B - 1) / B) * ((N2 + B - 1) / B);
-  const int nchunks = (M + TK - 1) / TK;
+  const int unit = pp ? 64 : TK;                    // rows per chunk (ping-pong: K-tiles of 64 rows, an even number per split)
+  const int nchunks = (M + unit - 1) / unit;
   const int slots = big ? (g_tn_slots > 0 ? g_tn_slots : 256) : 512;   // one 8-wave workgroup per CU, or two 4-wave ones
   int splits = slots / tiles;                       // largest split count that still fits one round
   if (splits < 1) splits = 1;
   if (splits > 32) splits = 32;
   if (splits > nchunks) splits = nchunks;
-  const int cps = (nchunks + splits - 1) / splits;
+  int cps = (nchunks + splits - 1) / splits;
+  if (pp) cps += cps & 1;
   splits = (nchunks + cps - 1) / cps;
   *big_ = big; *splits_ = splits; *cps_ = cps;
+  if (pp_) *pp_ = pp;
 }
 
 // M > 0: exact need of that launch; M <= 0: worst case over every M (32 splits)
@@ -280,14 +280,19 @@ extern "C" int oat_gemm_tn(const void* P, const void* Q, int M, int N1, int N2, 
   if (M <= 0 || N1 <= 0 || N2 <= 0) { set_error("gemm_tn: empty problem"); return -1; }
   if (N1 % 8 || N2 % 8 || ldp % 8 || ldq % 8) { set_error("gemm_tn: N1,N2,ldp,ldq must be multiples of 8"); return -3; }
   if (!P || !Q || !out || !workspace) { set_error("gemm_tn: null pointer"); return -4; }
-  bool big; int splits, cps;
-  tn_plan(M, N1, N2, &big, &splits, &cps);
+  bool big, pp; int splits, cps;
+  tn_plan(M, N1, N2, &big, &splits, &cps, &pp);
   const size_t need = (size_t)splits * ((size_t)N1 * N2 + N1) * sizeof(float);
   if (need > workspace_bytes) { set_error("gemm_tn: workspace too small"); return -6; }
   float* slabs = (float*)workspace;
   TnArgs g{(const bf16*)P, (const bf16*)Q, M, N1, N2, ldp, ldq, slabs,
            bias_out ? slabs + (size_t)splits * N1 * N2 : nullptr, cps, splits, g_tn_dbg};
   hipStream_t s = (hipStream_t)stream;
+  if (pp) {
+    int rc = launch_tn_pp(g, g_tn_variant == 4 ? g_tn_dbg : 0, s);
+    if (rc) return rc;
+    return reduce_slabs(g, splits, out, bias_out, accumulate, s);
+  }
   if (big) return launch_tn<2, 4, 8, 4>(g, splits, out, bias_out, accumulate, s);
   return launch_tn<2, 2, 4, 4>(g, splits, out, bias_out, accumulate, s);
 }
