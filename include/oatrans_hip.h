@@ -23,6 +23,11 @@ extern "C" {
 
 const char* oat_last_error(void);
 int oat_abi_version(void);
+/* Stream-ordered delay of ~`nanoseconds` (one sleeping wave).  Scheduling aid, no reference counterpart: the engine
+ * puts it in front of an HBM-bound kernel on a side stream so that the CU-filling GEMM launched beside it on the main
+ * stream gets its workgroups placed first (two kernels that become runnable together are otherwise dispatched
+ * interleaved, and the small blocks of the streaming kernel keep the GEMM's 128-KB-LDS workgroups off every CU). */
+int oat_delay(int nanoseconds, void* stream);
 
 /* ---- GEMM -------------------------------------------------------------------------------
  * C[M,N] = A[M,K] * B[N,K]^T (+epilogue), bf16 in, fp32 accumulate.  K % 64 == 0.

@@ -17,14 +17,12 @@ HBM layout
                 W [out,in] (forward "NT" operand) and W^T [in,out] (data-gradient operand)
 
 Concurrency (HIP streams and events, no graph compiler)
-  * LANES: a large batch is split into two half-batches that walk the network on two streams, interleaved
-    block by block.  The HBM- or latency-bound kernels of one lane (LayerNorm, attention, GEMM epilogues)
-    overlap the MFMA-bound GEMM main loops of the other.  Lane 1 is chained behind lane 0 wherever both
-    write the same gradient buffer (lane 0 overwrites, lane 1 accumulates: a fixed order, so results are
-    deterministic), which also keeps the two lanes out of phase.
-  * weight gradients (gemm_tn + fused bias sums) go to a third stream as soon as their dY exists: the
-    data-gradient chain never depends on them.
-  * the CLS-query attention (independent of the patch attention) runs beside it on a side stream.
+  * Every kernel of the video tower runs in order on the caller's stream and owns the whole GPU.  Measured on MI355X:
+    two MFMA-bound kernels side by side only split the machine, and the HBM-bound kernels (LayerNorm, attention) are
+    limited by per-CU load throughput, so confined to the CUs a GEMM leaves free they slow down by as much as the
+    overlap would gain (the `bwd_side` option keeps that "slot" schedule for experiments).
+  * forward: the CLS-query attention (independent of the patch attention) runs beside it on a side stream; the text
+    tower (0.7 % of the FLOPs, latency-bound) runs on its own stream beside the video tower.
 """
 import os
 
@@ -53,7 +51,7 @@ class _BlockActs:
 
 
 class _Plan:
-    """Buffers of one lane (one half-batch, or the whole batch when lanes are off)."""
+    """Activation and gradient buffers of one (B, T, N) shape, allocated once and reused every step."""
 
     def __init__(self, B, T, N, D, Hd, H, depth, Kp, dev):
         self.B, self.T, self.N = B, T, N
@@ -81,35 +79,23 @@ class _Plan:
         self.d_o = z16(D)
         self.cls_side = torch.zeros(B, H, 3, 64, dtype=torch.float32, device=dev)
         self.Gp = torch.zeros(T * N, D, dtype=torch.float32, device=dev)
-        self.stream = self.side = self.video = self.x_final = None      # set per call
+        self.side = self.video = self.x_final = None      # set per call
 
 
 class _Run:
-    """What a forward leaves for its backward: the lane plans (1 or 2) and the output flags."""
+    """What a forward leaves for its backward: the plan and the output flags."""
 
-    def __init__(self, lanes, need_patches, region_layer):
-        self.lanes, self.need_patches, self.region_layer = lanes, need_patches, region_layer
-        self.B = sum(pl.B for pl in lanes)
-        self.G = lanes[0].G
+    def __init__(self, pl, need_patches, region_layer):
+        self.pl, self.need_patches, self.region_layer = pl, need_patches, region_layer
+        self.B, self.G = pl.B, pl.G
 
     @property
     def region(self):
-        return self.lanes[0].region
+        return self.pl.region
 
     @property
     def blocks(self):
-        return self.lanes[0].blocks
-
-
-class _Lane:
-    """Backward-pass state of one lane."""
-
-    def __init__(self, pl, index, d_cls, d_patches, d_region):
-        self.pl, self.index = pl, index
-        self.d_cls, self.d_patches, self.d_region = d_cls, d_patches, d_region
-        self.done = {}            # block index -> event: its weight gradients finished on the wgrad stream
-        self.order = []           # lane 0: events recorded after each gradient its own stream writes
-        self.follow = None        # lane 1: lane 0's `order`
+        return self.pl.blocks
 
 
 class VideoEngine:
@@ -133,11 +119,15 @@ class VideoEngine:
         self.shadow = {}
         self.shadow_versions = None
         self._cast = None
-        self.lanes = int(os.environ.get("OAT_LANES", "1"))   # half-batches on two streams (1 = off)
         self.tail_split = os.environ.get("OAT_TAIL_SPLIT", "1") != "0"
-        self.wgrad_cus = int(os.environ.get("OAT_WGRAD_CUS", "192"))   # workgroup budget of a weight-gradient GEMM
+        self.wgrad_cus = int(os.environ.get("OAT_WGRAD_CUS", "192"))   # workgroup budget of a weight-gradient GEMM that shares its slot
         self.bwd_nt_grid = int(os.environ.get("OAT_BWD_NT_GRID", "0"), 0)   # gemm_nt grid during backward (0 = as in forward, 0xffff = one workgroup per tile)
-        self.min_lane_rows = 8192        # token rows per lane below which splitting only adds launches
+        self.slot_delay_ns = int(os.environ.get("OAT_SLOT_DELAY_NS", "4000"))
+        # 1: LayerNorm / attention backward on a side stream beside the weight-gradient GEMMs ("slots").  Measured equal to
+        # the plain in-order schedule (48.9-49.4 vs 49.2 ms): the streaming kernels are bound by per-CU load throughput
+        # (~27 GB/s per CU), so on the quarter of the CUs a GEMM leaves them they take 2-2.5x as long - what the overlap
+        # gains, the partition loses.  Default: every kernel alone on the GPU, in order, on the caller's stream.
+        self.bwd_side = os.environ.get("OAT_BWD_SIDE", "0") != "0"
         self._streams = None
         self._tn_ws = None
 
@@ -161,8 +151,8 @@ class VideoEngine:
         self._cast.run()                                          # all 73 W / W^T shadows in one launch
         self.shadow_versions = sig
 
-    def plan(self, B, T, N, dev, slot=0):
-        key = (B, T, N, str(dev), slot)
+    def plan(self, B, T, N, dev):
+        key = (B, T, N, str(dev))
         if key not in self.plans:
             self.plans[key] = _Plan(B, T, N, self.D, self.Hd, self.H, self.depth, self.Kp, dev)
         return self.plans[key]
@@ -171,9 +161,7 @@ class VideoEngine:
         """Streams are created only when used: HIP multiplexes streams onto a few hardware queues
         (GPU_MAX_HW_QUEUES, default 4) and two streams that share a queue run in enqueue order."""
         if self._streams is None:
-            two = self.lanes == 2
-            self._streams = dict(lane1=torch.cuda.Stream() if two else None, wgrad=torch.cuda.Stream(),
-                                 side=[torch.cuda.Stream(), torch.cuda.Stream() if two else None])
+            self._streams = dict(side=torch.cuda.Stream(), hbm=torch.cuda.Stream())
         return self._streams
 
     # ------------------------------------------------------------------ forward
@@ -189,43 +177,21 @@ class VideoEngine:
         self.refresh_shadows(params, sig)
         dev = video.device
         st = self._get_streams(dev)
-        main = torch.cuda.current_stream()
-        two = (self.lanes == 2 and not need_patches and region_layer is None and B % 2 == 0
-               and (B // 2) * (T * N + 1) >= self.min_lane_rows)
-        video = video.contiguous()
-        lanes = []
-        for h in range(2 if two else 1):
-            Bh = B // 2 if two else B
-            pl = self.plan(Bh, T, N, dev, slot=h)
-            pl.stream = main if h == 0 else st["lane1"]
-            pl.side = st["side"][h]
-            pl.video = video[h * Bh:(h + 1) * Bh]
-            lanes.append(pl)
-        if two:
-            st["lane1"].wait_stream(main)
+        pl = self.plan(B, T, N, dev)
+        pl.side = st["side"]
+        pl.video = video.contiguous()
         # forward runs alone on the GPU: the third, 31 %-full round of the N = 768 GEMMs (591 tiles on 256 CUs) is
-        # re-tiled as 128x128; in backward the weight-gradient stream fills those CUs instead (see gemm_nt.hip)
-        hip.gemm_set_tail_split(self.tail_split and not two)
-        for pl in lanes:
-            with torch.cuda.stream(pl.stream):
-                self._embed(pl, params, C, R)
-        pend = [None] * len(lanes)
+        # re-tiled as 128x128 where the lockstep kernel serves a launch (see gemm_nt.hip)
+        hip.gemm_set_tail_split(self.tail_split)
+        self._embed(pl, params, C, R)
+        pend = None
         for i in range(self.depth):
-            for h, pl in enumerate(lanes):
-                with torch.cuda.stream(pl.stream):
-                    pend[h] = self._block_fwd(pl, i, params, pend[h], region_layer)
-        run = _Run(lanes, need_patches, region_layer)
-        outs = []
-        for pl in lanes:
-            with torch.cuda.stream(pl.stream):
-                outs.append(self._final_fwd(pl, params, need_patches, region_layer))
-        for pl in lanes:
-            pl.video = None
+            pend = self._block_fwd(pl, i, params, pend, region_layer)
+        run = _Run(pl, need_patches, region_layer)
+        out = self._final_fwd(pl, params, need_patches, region_layer)
+        pl.video = None
         hip.gemm_set_tail_split(False)
-        if two:
-            main.wait_stream(st["lane1"])
-            return torch.cat([o[0] for o in outs], dim=0), None, run
-        return outs[0][0], outs[0][1], run
+        return out[0], out[1], run
 
     def _embed(self, pl, params, C, R):
         B, T, N, D = pl.B, pl.T, pl.N, self.D
@@ -316,127 +282,102 @@ class VideoEngine:
         None (contract class oa_model.FrozenInTime discards patch outputs); d_region fp32 [B*T*N, D] =
         gradient of run.region (enters the residual stream below block `region_layer`).
 
-        Streams: each lane's data-gradient chain (dgrad GEMMs, LayerNorm / attention backward) runs on the
-        lane's stream; every weight gradient goes to the shared wgrad stream as soon as its dY exists (lane 0
-        overwrites, lane 1 accumulates - one stream, so the order is fixed).  The chain never depends on a
-        weight gradient, so the MFMA-bound wgrad GEMMs fill the HBM-bound stretches of the chains.  Gradients
-        the chains write themselves (LayerNorm gains, positional tables) are ordered lane 0 -> lane 1 by events.
+        Schedule (see the module docstring): GEMMs in order on the caller's stream; LayerNorm / attention backward on
+        the `hbm` side stream inside the slot after the GEMM that feeds them, beside weight-gradient GEMMs.
 
-        `ready(prefixes)` (optional) is called - with the wgrad stream current and ordered after everything
-        that writes them - as soon as all gradients of the parameters named by `prefixes` are enqueued: one call
-        per block, top to bottom, so the gradient all-reduce can start while backward is still running."""
+        `ready(prefixes)` (optional) is called - on the caller's stream, after everything that writes them - as soon
+        as all gradients of the parameters named by `prefixes` are enqueued: one call per block, top to bottom, so
+        the gradient all-reduce can start while backward is still running."""
         st = self._get_streams(run.G.device)
-        main, wg = torch.cuda.current_stream(), st["wgrad"]
-        two = len(run.lanes) == 2
-        if two:
-            st["lane1"].wait_stream(main)    # d_cls was produced on the caller's stream
-        wg.wait_stream(main)                 # no weight gradient before this step's forward is done
-        d_cls = d_cls.contiguous()
-        lanes, off = [], 0
-        for h, pl in enumerate(run.lanes):
-            lanes.append(_Lane(pl, h, d_cls[off:off + pl.B], d_patches, d_region))
-            off += pl.B
-        if two:
-            lanes[1].follow = lanes[0].order
-        for ln in lanes:
-            with torch.cuda.stream(ln.pl.stream):
-                ln.pl.cls_side.zero_()       # once per backward; every attn_cls_finalize leaves it zero for the next one
-                self._final_bwd(ln, run, params, grads)
+        pl = run.pl
+        pl.hbm = st["hbm"] if self.bwd_side else None
+        pl.cls_side.zero_()          # once per backward; every attn_cls_finalize leaves it zero for the next one
+        self._final_bwd(pl, run, params, grads, d_cls.contiguous(), d_patches, d_region)
         if run.region_layer is not None:
             ready = None                     # region_norm gradients arrive out of block order: reduce after backward
-        # weight gradients leave a quarter of the CUs to the data-gradient chain (the critical path): a 256-workgroup
-        # gemm_tn holds every CU for its whole duration and the chain's next kernel has to wait for it to retire
-        hip.gemm_tn_set_variant(self.wgrad_cus << 16)
+        hip.gemm_tn_set_variant((self.wgrad_cus << 16) if self.bwd_side else 0)
         nt_prev = hip.gemm_get_variant()
         if self.bwd_nt_grid and (nt_prev >> 16) == 0:
             hip.gemm_set_variant((nt_prev & 0xffff) | (self.bwd_nt_grid << 16))
         for i in reversed(range(self.depth)):
-            for ln in lanes:
-                with torch.cuda.stream(ln.pl.stream):
-                    self._block_bwd(ln, i, run, params, grads, wg)
-            self._announce(lanes[-1], wg, ready, (f"blocks.{i}.", "norm.") if i == self.depth - 1 else (f"blocks.{i}.",))
-        for ln in lanes:
-            with torch.cuda.stream(ln.pl.stream):
-                self._embed_bwd(ln, grads, wg)
-        self._announce(lanes[-1], wg, ready, ("cls_token", "pos_embed", "temporal_embed", "patch_embed."))
+            self._block_bwd(pl, i, run, params, grads, d_region)
+            if ready is not None:
+                ready((f"blocks.{i}.", "norm.") if i == self.depth - 1 else (f"blocks.{i}.",))
+        self._embed_bwd(pl, grads)
+        if ready is not None:
+            ready(("cls_token", "pos_embed", "temporal_embed", "patch_embed."))
         hip.gemm_tn_set_variant(0)
         if hip.gemm_get_variant() != nt_prev:
             hip.gemm_set_variant(nt_prev)
-        if two:
-            main.wait_stream(st["lane1"])
-        main.wait_stream(wg)                 # every weight gradient is complete before the caller continues
+
+    def _slot(self, pl, fn, wgrads=()):
+        """One slot of backward: the weight-gradient GEMMs `wgrads` (callables) on the caller's stream and, beside
+        them, the HBM-bound kernel(s) `fn` on the side stream; both ordered after everything enqueued so far on the
+        caller's stream.  The GEMM is enqueued first and the side stream starts `slot_delay_ns` late, so the GEMM's
+        workgroups are placed before the streaming kernel takes what is left (the other way round its small blocks
+        land on every CU and the GEMM waits for them to drain).  Returns the event the consumer of `fn`'s outputs
+        waits for (None: everything ran in stream order)."""
+        if pl.hbm is None:
+            fn()
+            for w in wgrads:
+                w()
+            return None
+        cur = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        for w in wgrads:
+            w()
+        pl.hbm.wait_event(ev)
+        with torch.cuda.stream(pl.hbm):
+            if wgrads and self.slot_delay_ns:
+                hip.delay(self.slot_delay_ns)
+            fn()
+            done = torch.cuda.Event()
+            done.record(pl.hbm)
+        return done
 
     @staticmethod
-    def _announce(last_lane, wg, ready, prefixes):
-        if ready is None:
-            return
-        ev = torch.cuda.Event()
-        ev.record(last_lane.pl.stream)       # LayerNorm / table gradients of the last lane are enqueued
-        wg.wait_event(ev)
-        with torch.cuda.stream(wg):
-            ready(prefixes)
+    def _join(done):
+        if done is not None:
+            torch.cuda.current_stream().wait_event(done)
 
-    def _own_grad(self, ln, fn):
-        """Run `fn(accumulate)` - kernels that write parameter gradients from the lane's own stream - so that
-        lane 0 overwrites first and lane 1 accumulates after it."""
-        cur = torch.cuda.current_stream()
-        if ln.index == 0:
-            fn(False)
-            ev = torch.cuda.Event()
-            ev.record(cur)
-            ln.order.append(ev)
-        else:
-            cur.wait_event(ln.follow.pop(0))     # recorded already: lane 0 is always enqueued first
-            fn(True)
-
-    def _wgrad(self, ln, wg, P, Q, rows, n1, n2, w, b):
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream())   # P was produced by everything enqueued on this lane so far
-        wg.wait_event(ev)
+    def _wgrad(self, P, Q, rows, n1, n2, w, b):
         need = hip.lib().oat_gemm_tn_workspace_bytes(rows, n1, n2) // 4     # exact for this (rows, shape)
         if self._tn_ws is None or self._tn_ws.numel() < need:
-            with torch.cuda.stream(wg):                 # one slab workspace for the (serial) wgrad stream, grown on demand
-                self._tn_ws = torch.empty(need, dtype=torch.float32, device=P.device)
-        with torch.cuda.stream(wg):
-            hip.gemm_tn(P, Q, rows, n1, n2, w, bias_out=b, ws=self._tn_ws, accumulate=(ln.index == 1))
+            self._tn_ws = torch.empty(need, dtype=torch.float32, device=P.device)   # one slab workspace, grown on demand
+        hip.gemm_tn(P, Q, rows, n1, n2, w, bias_out=b, ws=self._tn_ws)
 
-    def _final_bwd(self, ln, run, params, grads):
-        pl, D = ln.pl, self.D
+    def _final_bwd(self, pl, run, params, grads, d_cls, d_patches, d_region):
+        D = self.D
         B, M = pl.B, pl.M
         BTN = M - B
         G = pl.G
         g16 = pl.ga[(self.depth - 1) % 3]
-        if run.need_patches and ln.d_patches is not None:
-            dn = torch.cat([ln.d_patches, ln.d_cls], dim=0).contiguous()
-            self._own_grad(ln, lambda acc: hip.layernorm_bwd(
-                dn, pl.x_final, pl.fstats[0], pl.fstats[1], params["norm.weight"], M, D, dx=G, dx16=g16,
-                dgamma=grads["norm.weight"], dbeta=grads["norm.bias"], accumulate=acc))
+        if run.need_patches and d_patches is not None:
+            dn = torch.cat([d_patches, d_cls], dim=0).contiguous()
+            hip.layernorm_bwd(dn, pl.x_final, pl.fstats[0], pl.fstats[1], params["norm.weight"], M, D, dx=G, dx16=g16,
+                              dgamma=grads["norm.weight"], dbeta=grads["norm.bias"])
         else:
             G[:BTN].zero_()
             g16[:BTN].zero_()
-            self._own_grad(ln, lambda acc: hip.layernorm_bwd(
-                ln.d_cls, pl.x_final[BTN:], pl.fstats[0][BTN:], pl.fstats[1][BTN:], params["norm.weight"], B, D,
-                dx=G[BTN:], dx16=g16[BTN:], dgamma=grads["norm.weight"], dbeta=grads["norm.bias"], accumulate=acc))
-        if run.region_layer is not None and ln.d_region is None:
+            hip.layernorm_bwd(d_cls, pl.x_final[BTN:], pl.fstats[0][BTN:], pl.fstats[1][BTN:], params["norm.weight"], B, D,
+                              dx=G[BTN:], dx16=g16[BTN:], dgamma=grads["norm.weight"], dbeta=grads["norm.bias"])
+        if run.region_layer is not None and d_region is None:
             for k in ("region_norm.weight", "region_norm.bias"):
                 grads[k].zero_()
 
-    def _block_bwd(self, ln, i, run, params, grads, wg):
-        pl = ln.pl
+    def _block_bwd(self, pl, i, run, params, grads, d_region):
         B, T, N, M = pl.B, pl.T, pl.N, pl.M
         D, Hd, H = self.D, self.Hd, self.H
         BTN = M - B
         G = pl.G
-        cur = torch.cuda.current_stream()
         a = pl.blocks[i]
         st8 = pl.sets[i % 2]
         ga, ga_next = pl.ga[i % 3], pl.ga[(i - 1) % 3]     # dL/d(block output) bf16 ; written by this block's LN3 bwd
-        if i + 2 in ln.done:
-            cur.wait_event(ln.done[i + 2])                 # ring slot i%2 (and ga[(i-1)%3]) is free again
         rl = run.region_layer
-        if rl is not None and ln.d_region is not None and i + 1 == rl:
+        if rl is not None and d_region is not None and i + 1 == rl:
             # region tokens branch off the output of block rl-1: add their gradient to the stream
-            hip.layernorm_bwd(ln.d_region.contiguous(), a.out, pl.rstats[0], pl.rstats[1], params["region_norm.weight"],
+            hip.layernorm_bwd(d_region.contiguous(), a.out, pl.rstats[0], pl.rstats[1], params["region_norm.weight"],
                               BTN, D, dx=G, dx16=ga, dres=G, dgamma=grads["region_norm.weight"],
                               dbeta=grads["region_norm.bias"])
         x = pl.blocks[i - 1].out if i > 0 else pl.x0
@@ -446,59 +387,61 @@ class VideoEngine:
         st = a.stats
         d_h, gb, d_qkv_s, gc, d_qkv_t = st8["d_h"], st8["gb"], st8["d_qkv_s"], st8["gc"], st8["d_qkv_t"]
         # ---- MLP: out = y + fc2(gelu(fc1(LN2(y))))
-        self._wgrad(ln, wg, ga, a.g, M, D, Hd, gr("mlp.fc2.weight"), gr("mlp.fc2.bias"))
         hip.gemm_nt(ga, wT("mlp.fc2"), M, Hd, D, hip.EPI_MUL_AUX, d_h, aux=a.h)
-        self._wgrad(ln, wg, d_h, a.a2, M, Hd, D, gr("mlp.fc1.weight"), gr("mlp.fc1.bias"))
         hip.gemm_nt(d_h, wT("mlp.fc1"), M, D, Hd, hip.EPI_BF16, pl.d_a)
-        self._own_grad(ln, lambda acc: hip.layernorm_bwd(
+        s1 = self._slot(pl, lambda: hip.layernorm_bwd(
             pl.d_a, a.y, st[4], st[5], p("norm2.weight"), M, D, dx=G, dx16=gb, dres=G,
-            dgamma=gr("norm2.weight"), dbeta=gr("norm2.bias"), accumulate=acc))              # G = dL/dy
+            dgamma=gr("norm2.weight"), dbeta=gr("norm2.bias")),                               # G = dL/dy
+            [lambda: self._wgrad(ga, a.g, M, D, Hd, gr("mlp.fc2.weight"), gr("mlp.fc2.bias"))])
+        self._join(s1)
         # ---- space attention: y = x + proj(attn(LN1(xt)))
-        self._wgrad(ln, wg, gb, a.o_s, M, D, D, gr("attn.proj.weight"), gr("attn.proj.bias"))
         hip.gemm_nt(gb, wT("attn.proj"), M, D, D, hip.EPI_BF16, pl.d_o)
-        hip.attn_space_bwd(a.qkv_s, a.o_s, a.lse_s, pl.d_o, d_qkv_s, pl.cls_side, B, T, N, H, D, self.scale)
-        hip.attn_cls_finalize(pl.cls_side, d_qkv_s, B, T, N, H, D)
-        self._wgrad(ln, wg, d_qkv_s, a.a1, M, 3 * D, D, gr("attn.qkv.weight"), gr("attn.qkv.bias"))
+
+        def space_bwd():
+            hip.attn_space_bwd(a.qkv_s, a.o_s, a.lse_s, pl.d_o, d_qkv_s, pl.cls_side, B, T, N, H, D, self.scale)
+            hip.attn_cls_finalize(pl.cls_side, d_qkv_s, B, T, N, H, D)
+        s2 = self._slot(pl, space_bwd,
+                        [lambda: self._wgrad(d_h, a.a2, M, Hd, D, gr("mlp.fc1.weight"), gr("mlp.fc1.bias"))])
+        self._join(s2)
         hip.gemm_nt(d_qkv_s, wT("attn.qkv"), M, D, 3 * D, hip.EPI_BF16, pl.d_a)
         # G <- dL/dy + dL/dxt (both reach x directly); gc <- dL/dxt alone (feeds the time branch)
-        self._own_grad(ln, lambda acc: hip.layernorm_bwd(
+        s3 = self._slot(pl, lambda: hip.layernorm_bwd(
             pl.d_a, a.xt, st[2], st[3], p("norm1.weight"), M, D, dx=G, dx16=gc, dres=G, dx16_excl_res=True,
-            dgamma=gr("norm1.weight"), dbeta=gr("norm1.bias"), accumulate=acc))
+            dgamma=gr("norm1.weight"), dbeta=gr("norm1.bias")),
+            [lambda: self._wgrad(d_qkv_s, a.a1, M, 3 * D, D, gr("attn.qkv.weight"), gr("attn.qkv.bias"))])
+        self._join(s3)
         # ---- time attention: xt = x + proj(attn(LN3(x)))
-        self._wgrad(ln, wg, gc, a.o_t, M, D, D, gr("timeattn.proj.weight"), gr("timeattn.proj.bias"))
         hip.gemm_nt(gc, wT("timeattn.proj"), M, D, D, hip.EPI_BF16, pl.d_o)
-        hip.attn_time_bwd(a.qkv_t, a.o_t, a.lse_t, pl.d_o, d_qkv_t, pl.cls_side, B, T, N, H, D, self.scale)
-        hip.attn_cls_finalize(pl.cls_side, d_qkv_t, B, T, N, H, D)
-        self._wgrad(ln, wg, d_qkv_t, a.a3, M, 3 * D, D, gr("timeattn.qkv.weight"), gr("timeattn.qkv.bias"))
-        hip.gemm_nt(d_qkv_t, wT("timeattn.qkv"), M, D, 3 * D, hip.EPI_BF16, pl.d_a)
-        self._own_grad(ln, lambda acc: hip.layernorm_bwd(
-            pl.d_a, x, st[0], st[1], p("norm3.weight"), M, D, dx=G, dx16=ga_next, dres=G,
-            dgamma=gr("norm3.weight"), dbeta=gr("norm3.bias"), accumulate=acc))              # G = dL/dx
-        ev = torch.cuda.Event()
-        with torch.cuda.stream(wg):
-            ev.record(wg)
-        ln.done[i] = ev
 
-    def _embed_bwd(self, ln, grads, wg):
+        def time_bwd():
+            hip.attn_time_bwd(a.qkv_t, a.o_t, a.lse_t, pl.d_o, d_qkv_t, pl.cls_side, B, T, N, H, D, self.scale)
+            hip.attn_cls_finalize(pl.cls_side, d_qkv_t, B, T, N, H, D)
+        s4 = self._slot(pl, time_bwd,
+                        [lambda: self._wgrad(gb, a.o_s, M, D, D, gr("attn.proj.weight"), gr("attn.proj.bias")),
+                         lambda: self._wgrad(gc, a.o_t, M, D, D, gr("timeattn.proj.weight"), gr("timeattn.proj.bias"))])
+        self._join(s4)
+        hip.gemm_nt(d_qkv_t, wT("timeattn.qkv"), M, D, 3 * D, hip.EPI_BF16, pl.d_a)
+        s5 = self._slot(pl, lambda: hip.layernorm_bwd(
+            pl.d_a, x, st[0], st[1], p("norm3.weight"), M, D, dx=G, dx16=ga_next, dres=G,
+            dgamma=gr("norm3.weight"), dbeta=gr("norm3.bias")),                               # G = dL/dx
+            [lambda: self._wgrad(d_qkv_t, a.a3, M, 3 * D, D, gr("timeattn.qkv.weight"), gr("timeattn.qkv.bias"))])
+        self._join(s5)
+
+    def _embed_bwd(self, pl, grads):
         """x0[patch] = cols @ Wp^T + b + pos[1+n] + temporal[f] ; x0[cls] = cls + pos[0]"""
-        pl, D = ln.pl, self.D
+        D = self.D
         B, T, N, M = pl.B, pl.T, pl.N, pl.M
         BTN = M - B
         G = pl.G
         gw = grads["patch_embed.proj.weight"]
-        self._wgrad(ln, wg, pl.ga[(-1) % 3], pl.cols, BTN, D, self.Kp, gw.view(D, self.Kp),
-                    grads["patch_embed.proj.bias"])
+        self._wgrad(pl.ga[(-1) % 3], pl.cols, BTN, D, self.Kp, gw.view(D, self.Kp), grads["patch_embed.proj.bias"])
         hip.periodic_rowsum(G, B, T * N, D, pl.Gp)
         gpos = grads["pos_embed"].view(N + 1, D)
         gt = grads["temporal_embed"].view(-1, D)
         gcls = grads["cls_token"].view(1, D)
-
-        def tables(acc):
-            hip.periodic_rowsum(pl.Gp, T, N, D, gpos[1:], accumulate=acc)
-            if T < gt.shape[0] and not acc:
-                gt[T:].zero_()
-            hip.grouped_rowsum(pl.Gp, T, N, D, gt[:T], accumulate=acc)
-            hip.grouped_rowsum(G[BTN:], 1, B, D, gcls, accumulate=acc)
-            gpos[:1].copy_(gcls)             # pos_embed[0] only ever meets the CLS token
-
-        self._own_grad(ln, tables)
+        hip.periodic_rowsum(pl.Gp, T, N, D, gpos[1:])
+        if T < gt.shape[0]:
+            gt[T:].zero_()
+        hip.grouped_rowsum(pl.Gp, T, N, D, gt[:T])
+        hip.grouped_rowsum(G[BTN:], 1, B, D, gcls)
+        gpos[:1].copy_(gcls)             # pos_embed[0] only ever meets the CLS token

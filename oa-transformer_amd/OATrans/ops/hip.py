@@ -76,6 +76,10 @@ def _f(x):
 EPI_BF16, EPI_F32, EPI_GELU_DUAL, EPI_DGELU, EPI_F32_BF16, EPI_GELU_GRAD, EPI_MUL_AUX = 0, 1, 2, 3, 4, 5, 6
 
 
+def delay(nanoseconds):
+    _check(lib().oat_delay(int(nanoseconds), _stream()), "oat_delay")
+
+
 _tile_counters = {}
 _DYNAMIC_TILES = os.environ.get("OAT_GEMM_DYNAMIC", "0") == "1"     # opt-in: slower on an idle GPU (see gemm_nt.hip)
 

@@ -40,7 +40,134 @@ constexpr int PP_A1 = 32768, PP_B0 = 65536, PP_BIAS = 131072;
 constexpr int PP_MAXN = 4096;                       // bias vector kept in LDS
 constexpr int PP_LDS = PP_BIAS + PP_MAXN * 4;
 
-enum : int { PPF_PRIO = 1, PPF_NOSTAGGER = 2, PPF_LGKM = 4, PPF_BONUS = 8, PPF_NOEPI = 16 };
+enum : int { PPF_PRIO = 1, PPF_NOSTAGGER = 2, PPF_LGKM = 4, PPF_BONUS = 8, PPF_NOEPI = 16, PPF_PH2 = 32, PPF_WIDE = 64 };
+
+// In-place MFMA (D = C register block).  hipcc otherwise gives the second k-half's MFMAs fresh destination registers
+// (it renames around the dependent pair), which costs up to 32 VGPRs in a 32-MFMA interval and spills at the 256 limit.
+// Operands come from ds_read (the compiler still places the lgkmcnt wait in front of this statement); the first
+// non-MFMA reader of an accumulator is the epilogue, an `s_nop` block and a barrier later.
+OAT_DEV void mfma_inplace(f32x4& c, const bf16x8 a, const bf16x8 b) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+
+// Epilogue of one 256x256 tile (no LDS, no barriers): lane (fk, frow) owns rows 16 i + 4 fk + r and the 4 consecutive
+// columns 4 frow + j of its wave tile, so 16 consecutive lanes store one 128-byte line per row.  Returns whether the
+// tile was an interior one (then exactly NST = 32 (64 for EPI_GELU_GRAD) store instructions were issued per lane).
+template <int EPI, bool WIDE = false>
+OAT_DEV bool pp_epilogue(const GemmArgs& g, const f32x4 (&acc)[8][4], int m0, int n0, int wm, int wn, int lane) {
+  // lane-constant store offsets are derived from an opaque copy of the lane id: hoisted out of the tile loop they would
+  // sit in VGPRs through the K loop, which has none to spare
+  asm volatile("" : "+v"(lane));
+  const int frow = lane & 15, fk = lane >> 4;
+  const int wrow0 = m0 + wm * 128, wcol00 = n0 + wn * 64;
+  auto finish = [&](const f32x4 v, const bf16x4 a, bf16x4& o, bf16x4& o2) {
+    if constexpr (EPI == EPI_GELU_GRAD) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float gl, dg;
+        gelu_both(v[e], gl, dg);
+        o[e] = f2bf(dg);
+        o2[e] = f2bf(gl);
+      }
+    } else if constexpr (EPI == EPI_MUL_AUX) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e] * bf2f(a[e]));
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+    }
+  };
+  const bool interior = m0 + 256 <= g.M;
+  if constexpr (WIDE && EPI == EPI_BF16) {
+    if (interior) {
+      // 16-byte stores: neighbouring lanes (columns 4 frow .. and 4 (frow ^ 1) ..) trade two of their four rows by DPP,
+      // so the even lane ends up with rows r = 0, 1 and the odd lane with rows r = 2, 3 of 8 consecutive columns:
+      // half as many store instructions, still one full 128-byte line per 8 lanes
+      const bool odd = frow & 1;
+      char* const ob = reinterpret_cast<char*>(g.out) + ((size_t)wrow0 * g.ldc + wcol00) * 2;
+      const uint32_t lo = (uint32_t)((fk * 4 + (odd ? 2 : 0)) * g.ldc + (frow >> 1) * 8) * 2;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        uint32_t w[4][2];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bf16x4 o = {f2bf(acc[i][0][r]), f2bf(acc[i][1][r]), f2bf(acc[i][2][r]), f2bf(acc[i][3][r])};
+          const uint2 u = __builtin_bit_cast(uint2, o);
+          w[r][0] = u.x;
+          w[r][1] = u.y;
+        }
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {           // row pair (pr, pr + 2)
+          uint32_t rc[2];
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {
+            const uint32_t send = odd ? w[pr][d] : w[pr + 2][d];
+            rc[d] = (uint32_t)__builtin_amdgcn_mov_dpp((int)send, 0xB1, 0xf, 0xf, true);     // quad_perm [1,0,3,2]
+          }
+          uint4 v;
+          v.x = odd ? rc[0] : w[pr][0];
+          v.y = odd ? rc[1] : w[pr][1];
+          v.z = odd ? w[pr + 2][0] : rc[0];
+          v.w = odd ? w[pr + 2][1] : rc[1];
+          *reinterpret_cast<uint4*>(ob + (size_t)((uint32_t)(i * 16 + pr) * (uint32_t)g.ldc * 2) + lo) = v;
+        }
+      }
+      return true;
+    }
+  }
+  if (interior) {
+    const size_t t0 = (size_t)wrow0;
+    char* const ob = reinterpret_cast<char*>(g.out) + (t0 * g.ldc + wcol00) * 2;
+    char* const ob2 = EPI == EPI_GELU_GRAD ? reinterpret_cast<char*>(g.out2) + (t0 * g.ld2 + wcol00) * 2 : nullptr;
+    const char* const ab = EPI == EPI_MUL_AUX ? reinterpret_cast<const char*>(g.aux) + (t0 * g.ldaux + wcol00) * 2 : nullptr;
+    const uint32_t lo = (uint32_t)(fk * 4 * g.ldc + frow * 4) * 2;
+    const uint32_t lo2 = EPI == EPI_GELU_GRAD ? (uint32_t)(fk * 4 * g.ld2 + frow * 4) * 2 : 0;
+    const uint32_t la = EPI == EPI_MUL_AUX ? (uint32_t)(fk * 4 * g.ldaux + frow * 4) * 2 : 0;
+    bf16x4 an[4] = {}, ac[4] = {};
+    if constexpr (EPI == EPI_MUL_AUX) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) an[r] = *reinterpret_cast<const bf16x4*>(ab + (size_t)(uint32_t)(r * g.ldaux * 2) + la);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if constexpr (EPI == EPI_MUL_AUX) {        // the saved derivative of row group i + 1 is requested one group ahead
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ac[r] = an[r];
+        if (i + 1 < 8) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            an[r] = *reinterpret_cast<const bf16x4*>(ab + (size_t)(uint32_t)(((i + 1) * 16 + r) * g.ldaux * 2) + la);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const f32x4 v = f32x4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+        bf16x4 o, o2;
+        finish(v, ac[r], o, o2);
+        const uint32_t rr = (uint32_t)(i * 16 + r);
+        *reinterpret_cast<bf16x4*>(ob + (size_t)(rr * (uint32_t)g.ldc * 2) + lo) = o;
+        if constexpr (EPI == EPI_GELU_GRAD) *reinterpret_cast<bf16x4*>(ob2 + (size_t)(rr * (uint32_t)g.ld2 * 2) + lo2) = o2;
+      }
+    }
+  } else {
+    const int col = wcol00 + frow * 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = wrow0 + i * 16 + fk * 4 + r;
+        const f32x4 v = f32x4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+        if (row < g.M) {
+          bf16x4 o, o2, a = {};
+          if constexpr (EPI == EPI_MUL_AUX) a = *reinterpret_cast<const bf16x4*>(g.aux + (size_t)row * g.ldaux + col);
+          finish(v, a, o, o2);
+          if constexpr (EPI == EPI_GELU_GRAD) *reinterpret_cast<bf16x4*>((bf16*)g.out2 + (size_t)row * g.ld2 + col) = o2;
+          *reinterpret_cast<bf16x4*>((bf16*)g.out + (size_t)row * g.ldc + col) = o;
+        }
+      }
+  }
+  return interior;
+}
 
 template <int EPI, int FL>
 __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs g) {
@@ -245,79 +372,210 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs g) {
       prev_interior = false;
       continue;
     }
-    const int wrow0 = m0 + wm * 128, wcol00 = n0 + wn * 64;
-    auto finish = [&](const f32x4 v, const bf16x4 a, bf16x4& o, bf16x4& o2) {
-      if constexpr (EPI == EPI_GELU_GRAD) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float gl, dg;
-          gelu_both(v[e], gl, dg);
-          o[e] = f2bf(dg);
-          o2[e] = f2bf(gl);
-        }
-      } else if constexpr (EPI == EPI_MUL_AUX) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e] * bf2f(a[e]));
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
-      }
-    };
-    prev_interior = m0 + 256 <= g.M;
-    if (prev_interior) {
-      const size_t t0 = (size_t)wrow0;
-      char* const ob = reinterpret_cast<char*>(g.out) + (t0 * g.ldc + wcol00) * 2;
-      char* const ob2 = EPI == EPI_GELU_GRAD ? reinterpret_cast<char*>(g.out2) + (t0 * g.ld2 + wcol00) * 2 : nullptr;
-      const char* const ab = EPI == EPI_MUL_AUX ? reinterpret_cast<const char*>(g.aux) + (t0 * g.ldaux + wcol00) * 2 : nullptr;
-      const uint32_t lo = (uint32_t)(fk * 4 * g.ldc + frow * 4) * 2;
-      const uint32_t lo2 = EPI == EPI_GELU_GRAD ? (uint32_t)(fk * 4 * g.ld2 + frow * 4) * 2 : 0;
-      const uint32_t la = EPI == EPI_MUL_AUX ? (uint32_t)(fk * 4 * g.ldaux + frow * 4) * 2 : 0;
-      bf16x4 an[4] = {}, ac[4] = {};
-      if constexpr (EPI == EPI_MUL_AUX) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) an[r] = *reinterpret_cast<const bf16x4*>(ab + (size_t)(uint32_t)(r * g.ldaux * 2) + la);
-      }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        if constexpr (EPI == EPI_MUL_AUX) {        // the saved derivative of row group i + 1 is requested one group ahead
-#pragma unroll
-          for (int r = 0; r < 4; ++r) ac[r] = an[r];
-          if (i + 1 < 8) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              an[r] = *reinterpret_cast<const bf16x4*>(ab + (size_t)(uint32_t)(((i + 1) * 16 + r) * g.ldaux * 2) + la);
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const f32x4 v = f32x4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
-          bf16x4 o, o2;
-          finish(v, ac[r], o, o2);
-          const uint32_t rr = (uint32_t)(i * 16 + r);
-          *reinterpret_cast<bf16x4*>(ob + (size_t)(rr * (uint32_t)g.ldc * 2) + lo) = o;
-          if constexpr (EPI == EPI_GELU_GRAD) *reinterpret_cast<bf16x4*>(ob2 + (size_t)(rr * (uint32_t)g.ld2 * 2) + lo2) = o2;
-        }
-      }
-    } else {
-      const int col = wcol00 + frow * 4;
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = wrow0 + i * 16 + fk * 4 + r;
-          const f32x4 v = f32x4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
-          if (row < g.M) {
-            bf16x4 o, o2, a = {};
-            if constexpr (EPI == EPI_MUL_AUX) a = *reinterpret_cast<const bf16x4*>(g.aux + (size_t)row * g.ldaux + col);
-            finish(v, a, o, o2);
-            if constexpr (EPI == EPI_GELU_GRAD) *reinterpret_cast<bf16x4*>((bf16*)g.out2 + (size_t)row * g.ld2 + col) = o2;
-            *reinterpret_cast<bf16x4*>((bf16*)g.out + (size_t)row * g.ldc + col) = o;
-          }
-        }
-    }
+    prev_interior = pp_epilogue<EPI>(g, acc, m0, n0, wm, wn, lane);
     __builtin_amdgcn_sched_barrier(0);
   }
   if (STAGGER && wm == 0) __builtin_amdgcn_s_barrier();  // pairs with group 1's extra barrier
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no LDS-DMA may outlive the workgroup's LDS allocation
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Two phases per K-tile (half the barriers, 32 MFMAs per interval) and no pre-read:
+//     L1: all of A (16 ds_read_b128) + b0 (4)   M1: A x b0      L2: b1 (4, into the b0 registers)   M2: A x b1
+// 80 fragment VGPRs instead of 96.  Regions: A(s) and b0(s) are dead after L1(s), b1(s) after L2(s), so the op stream
+// of a wave is   L1(s): b1(s+1) [2 pieces]    L2(s): A(s+2), b0(s+2) [4 + 2 pieces]
+// every piece is issued 6 intervals (~3 k cycles) before its first read and every wait allows the 8 youngest pieces.
+template <int EPI, int FL>
+__global__ __launch_bounds__(512) void gemm_nt_pp2_kernel(GemmArgs g) {
+  constexpr bool PRIO = FL & PPF_PRIO, STAGGER = !(FL & PPF_NOSTAGGER), LGKM = FL & PPF_LGKM, BONUS = FL & PPF_BONUS;
+  constexpr bool NOEPI = FL & PPF_NOEPI;
+  constexpr bool WIDE = (FL & PPF_WIDE) && EPI == EPI_BF16;
+  constexpr int NST = EPI == EPI_GELU_GRAD ? 64 : WIDE ? 16 : 32;
+  constexpr int WB = 8 + NST > 63 ? 63 : 8 + NST;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int ntn = g.N >> 8, ntm = (g.M + 255) >> 8, nwg = ntm * ntn;
+  const int nk = g.K >> 6;
+  const int ntl = (nwg - 1 - (int)blockIdx.x) / (int)gridDim.x + 1;
+  struct Tile { int m0, n0; };
+  auto tile_of = [&](int t) __attribute__((always_inline)) {
+    const int w = blockIdx.x + t * gridDim.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = w & 7, idx = w >> 3;
+    const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int tm = bid / ntn;
+    return Tile{tm << 8, (bid - tm * ntn) << 8};
+  };
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  float* const sbias = reinterpret_cast<float*>(smem + PP_BIAS);
+  for (int i = tid; i < g.N; i += 512) sbias[i] = g.bias ? g.bias[i] : 0.f;
+
+  // ---- staging (pieces, classes and swizzle as in gemm_nt_pp_kernel)
+  const int srow = lane >> 3;
+  const uint32_t c16_0 = (uint32_t)(((lane & 7) ^ (srow >> 1)) << 4);
+  const uint32_t lda2 = (uint32_t)g.lda * 2u, ldb2 = (uint32_t)g.ldb * 2u;
+  int pa[2], pb[2];
+  uint32_t boff[2][2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int idx = wave * 2 + e;
+    pa[e] = idx < 8 ? idx : idx + 8;
+    pb[e] = ((idx >> 2) << 3) | (idx & 3);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int r = (pb[e] + c * 4) * 8 + srow;
+      const int rg = (r & ~63) | ((r & 15) << 2) | ((r >> 4) & 3);
+      boff[c][e] = (uint32_t)rg * ldb2 + (c16_0 ^ (e << 6));
+    }
+  }
+  int ckt = 0, ctl = 0, crmax;
+  const bf16 *ca, *cb, *cb1 = nullptr;         // cursor (K-tile s + 2); cb1 = B panel of K-tile s + 1
+  uint32_t lda2c = lda2, bmask = ~0u, bmask1 = ~0u;
+  {
+    const Tile t = tile_of(0);
+    ca = g.A + (size_t)t.m0 * g.lda;
+    cb = g.B + (size_t)t.n0 * g.ldb;
+    crmax = g.M - 1 - t.m0;
+  }
+  auto advance = [&]() __attribute__((always_inline)) {
+    cb1 = cb;
+    bmask1 = bmask;
+    ++ckt;
+    ca += 64;
+    cb += 64;
+    if (ckt == nk) {
+      const bool more = ctl + 1 < ntl;
+      ctl += more ? 1 : 0;
+      const Tile t = tile_of(ctl);
+      ckt = more ? 0 : nk - 1;
+      ca = more ? g.A + (size_t)t.m0 * g.lda : ca - 64;
+      cb = more ? g.B + (size_t)t.n0 * g.ldb : cb - 64;
+      crmax = g.M - 1 - t.m0;
+      lda2c = more ? lda2c : 0u;
+      bmask = more ? bmask : 0x7fu;
+    }
+  };
+  auto stageA = [&](int cls, int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int p = pa[e] + cls * 8;
+      const uint32_t r = (uint32_t)min(p * 8 + srow, crmax);
+      const uint32_t off = __umul24(r, lda2c) + (c16_0 ^ (e << 6));
+      glds16_asm_lds(ca, off, lds0 + buf * PP_A1 + p * 1024);
+    }
+  };
+  auto stageB0 = [&](int buf) __attribute__((always_inline)) {      // b0 of the cursor's K-tile
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+      glds16_asm_lds(cb, boff[0][e] & bmask, lds0 + PP_B0 + buf * PP_A1 + pb[e] * 1024);
+  };
+  auto stageB1 = [&](const bf16* base, uint32_t mask, int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+      glds16_asm_lds(base, boff[1][e] & mask, lds0 + PP_B0 + buf * PP_A1 + (pb[e] + 4) * 1024);
+  };
+
+  const int frow = lane & 15, fk = lane >> 4;
+  const int sw = (frow >> 1) & 7;
+  typedef const __attribute__((address_space(3))) bf16x8* lds_frag;
+  uint32_t pA[2], pB[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    const int ch = ((kk * 4 + fk) ^ sw) << 4;
+    pA[kk] = lds0 + (wm * 128 + frow) * 128 + ch;
+    pB[kk] = lds0 + PP_B0 + (wn * 64 + frow) * 128 + ch;
+  }
+  f32x4 acc[8][4];
+  auto readA = [&](bf16x8 (&f)[2][8], int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) f[kk][i] = *(lds_frag)(uintptr_t)(pA[kk] + buf * PP_A1 + i * 16 * 128);
+  };
+  auto readB = [&](bf16x8 (&f)[2][2], int half, int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        f[kk][j] = *(lds_frag)(uintptr_t)(pB[kk] + buf * PP_A1 + (half * 32 + j * 16) * 128);
+  };
+  auto endL = [&](bool bonus) __attribute__((always_inline)) {
+    if constexpr (LGKM) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (bonus) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WB) : "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto mma = [&](const bf16x8 (&fa)[2][8], const bf16x8 (&fb)[2][2], int bh) __attribute__((always_inline)) {
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          mfma_inplace(acc[i][bh * 2 + j], fa[kk][i], fb[kk][j]);
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---- prologue, canonical issue order: A(0) b0(0) | b1(0) | A(1) b0(1)      (b1(1) follows in L1 of K-tile 0)
+  stageA(0, 0); stageA(1, 0); stageB0(0);
+  stageB1(cb, bmask, 0);
+  advance();
+  stageA(0, 1); stageA(1, 1); stageB0(1);
+  advance();
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // A(0), b0(0) landed
+  __syncthreads();                                       // ... for every wave; also publishes the bias vector
+  if (STAGGER && wm == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one interval behind from here on
+  __builtin_amdgcn_sched_barrier(0);
+
+  // HEAD = first pair of a tile: after an INTERIOR epilogue (`bon`) its NST stores are younger than both targets of the
+  // first K-tile's waits (issued in the previous tile); the second K-tile's targets were issued after them.
+  auto pair = [&](auto head, const bool bon) __attribute__((always_inline)) {
+    constexpr bool HEAD = decltype(head)::value;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      bf16x8 fa[2][8], fb[2][2];
+      const bool b0 = HEAD && bon && u == 0;
+      readA(fa, u); readB(fb, 0, u); stageB1(cb1, bmask1, u ^ 1); endL(b0);
+      mma(fa, fb, 0);
+      readB(fb, 1, u); stageA(0, u); stageA(1, u); stageB0(u); endL(b0);
+      mma(fa, fb, 1);
+      advance();
+    }
+  };
+
+  bool prev_interior = false;
+  for (int tl = 0; tl < ntl; ++tl) {
+    const Tile tile = tile_of(tl);
+    const int m0 = tile.m0, n0 = tile.n0;
+    {
+      const f32x4 b = *reinterpret_cast<const f32x4*>(sbias + n0 + wn * 64 + frow * 4);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{b[j], b[j], b[j], b[j]};
+    }
+    pair(std::true_type{}, BONUS && prev_interior);
+    for (int kt = 2; kt < nk; kt += 2) pair(std::false_type{}, false);
+    if constexpr (NOEPI) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+      prev_interior = false;
+      continue;
+    }
+    asm volatile("s_nop 15" ::: "memory");               // asm MFMA -> VALU read of its result: wait states are ours
+    prev_interior = pp_epilogue<EPI, WIDE>(g, acc, m0, n0, wm, wn, lane);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (STAGGER && wm == 0) __builtin_amdgcn_s_barrier();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no LDS-DMA may outlive the workgroup's LDS allocation
 }
 
@@ -325,13 +583,18 @@ template <int EPI, int FL>
 int launch_pp_cfg(const GemmArgs& g, int grid_slots, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_pp_kernel<EPI, FL>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+    if constexpr (FL & PPF_PH2)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_pp2_kernel<EPI, FL>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+    else
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_pp_kernel<EPI, FL>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
     attr_set = true;
   }
   const int nwg = ((g.M + 255) / 256) * (g.N / 256);
   const int grid = nwg < grid_slots ? nwg : grid_slots;
-  hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, FL>), dim3(grid), dim3(512), PP_LDS, s, g);
+  if constexpr (FL & PPF_PH2) hipLaunchKernelGGL((gemm_nt_pp2_kernel<EPI, FL>), dim3(grid), dim3(512), PP_LDS, s, g);
+  else hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, FL>), dim3(grid), dim3(512), PP_LDS, s, g);
   return check_launch("gemm_nt_pp");
 }
 
@@ -357,6 +620,10 @@ int launch_pp(int epi, const GemmArgs& g, int grid_slots, int flags, hipStream_t
     case DEF ^ PPF_LGKM: return launch_pp_cfg<EPI_BF16, DEF ^ PPF_LGKM>(g, grid_slots, s);
     case DEF ^ PPF_BONUS: return launch_pp_cfg<EPI_BF16, DEF ^ PPF_BONUS>(g, grid_slots, s);
     case DEF | PPF_NOEPI: return launch_pp_cfg<EPI_BF16, DEF | PPF_NOEPI>(g, grid_slots, s);
+    case DEF | PPF_PH2: return launch_pp_cfg<EPI_BF16, DEF | PPF_PH2>(g, grid_slots, s);
+    case (DEF | PPF_PH2) ^ PPF_BONUS: return launch_pp_cfg<EPI_BF16, (DEF | PPF_PH2) ^ PPF_BONUS>(g, grid_slots, s);
+    case DEF | PPF_PH2 | PPF_NOEPI: return launch_pp_cfg<EPI_BF16, DEF | PPF_PH2 | PPF_NOEPI>(g, grid_slots, s);
+    case DEF | PPF_PH2 | PPF_WIDE: return launch_pp_cfg<EPI_BF16, DEF | PPF_PH2 | PPF_WIDE>(g, grid_slots, s);
     default: set_error("gemm_nt_pp: flag combination not built"); return -7;
   }
 }

@@ -9,10 +9,10 @@ from OATrans.ops import hip
 M = int(os.environ.get("M", 50208))
 Mp = (M + 255) // 256 * 256
 SHAPES = [(M, 2304, 768), (M, 768, 768), (M, 3072, 768), (M, 768, 3072), (M, 768, 2304)]
-PRIO, NOSTAG, LGKM, BONUS, NOEPI = 1, 2, 4, 8, 16
-VARIANTS = [("lockstep", 2), ("pp", 4), ("pp-noprio", 4 | (PRIO << 8)), ("pp-nostagger", 4 | (NOSTAG << 8)),
-            ("pp-lgkm", 4 | (LGKM << 8)), ("pp-nobonus", 4 | (BONUS << 8)), ("pp-noepi", 4 | (NOEPI << 8)),
-            ("lock-noepi", 2 | (1 << 8))]
+PRIO, NOSTAG, LGKM, BONUS, NOEPI, PH2, WIDE = 1, 2, 4, 8, 16, 32, 64
+VARIANTS = [("pp", 4), ("pp-noepi", 4 | (NOEPI << 8)),
+            ("pp2", 4 | (PH2 << 8)), ("pp2-wide", 4 | ((PH2 | WIDE) << 8)), ("pp2-noepi", 4 | ((PH2 | NOEPI) << 8))]
+PPV = int(os.environ.get("PPV", str(4 | (PH2 << 8))), 0)       # the ping-pong variant under test in check()
 ROUNDS = int(os.environ.get("ROUNDS", 4))
 
 
@@ -37,7 +37,7 @@ def check():
         aux = torch.randn(mp, n, device="cuda").bfloat16()
         for epi, name in ((hip.EPI_BF16, "bf16"), (hip.EPI_GELU_GRAD, "gelu_grad"), (hip.EPI_MUL_AUX, "mul_aux")):
             outs = []
-            for v in (2, 4):
+            for v in (2, PPV if epi == hip.EPI_BF16 else 4):
                 hip.gemm_set_variant(v)
                 o = torch.full((mp, n), 7.0, device="cuda", dtype=torch.bfloat16)
                 o2 = torch.full((mp, n), 7.0, device="cuda", dtype=torch.bfloat16)
@@ -54,7 +54,7 @@ def check():
             print(f"check M={m} N={n} K={k} {name}: identical={same} rows>=M untouched={untouched} maxerr_vs_fp32={err:.4f}")
             ok &= same and untouched
         # no-bias path
-        hip.gemm_set_variant(4)
+        hip.gemm_set_variant(PPV)
         o = torch.empty(mp, n, device="cuda", dtype=torch.bfloat16)
         hip.gemm_nt(A, B, m, n, k, hip.EPI_BF16, o)
         hip.gemm_set_variant(2)
@@ -65,7 +65,7 @@ def check():
     m, n, k = SHAPES[0]
     A = torch.randn(Mp, k, device="cuda").bfloat16(); B = (torch.randn(n, k, device="cuda") * k ** -0.5).bfloat16()
     bias = torch.randn(n, device="cuda")
-    hip.gemm_set_variant(4)
+    hip.gemm_set_variant(2)
     ref = torch.empty(Mp, n, device="cuda", dtype=torch.bfloat16)
     hip.gemm_nt(A, B, m, n, k, hip.EPI_BF16, ref, bias=bias)
     side = torch.cuda.Stream()
@@ -75,6 +75,7 @@ def check():
         with torch.cuda.stream(side):
             junk.mul_(1.0001)
         o = torch.empty(Mp, n, device="cuda", dtype=torch.bfloat16)
+        hip.gemm_set_variant(PPV)
         hip.gemm_nt(A, B, m, n, k, hip.EPI_BF16, o, bias=bias)
         bad += int(not torch.equal(o[:m], ref[:m]))
     torch.cuda.synchronize()
@@ -82,7 +83,7 @@ def check():
     ok &= bad == 0
     # persistent grid sizes (192 / 128 workgroups, one per tile)
     for grid in (192, 128, 0xffff, 7):
-        hip.gemm_set_variant(4 | (grid << 16))
+        hip.gemm_set_variant(PPV | (grid << 16))
         o = torch.empty(Mp, n, device="cuda", dtype=torch.bfloat16)
         hip.gemm_nt(A, B, m, n, k, hip.EPI_BF16, o, bias=bias)
         same = torch.equal(o[:m], ref[:m])

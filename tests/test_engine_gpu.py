@@ -118,26 +118,25 @@ def test_vitb_geometry_vs_reference_golden(golden_dir):
     assert sim_err <= 1e-3
 
 
-def test_two_lanes_match_single_lane():
-    """Splitting the batch into two half-batch lanes on two HIP streams (engine/video.py) changes only the
-    fp32 summation order of the parameter gradients: outputs identical, gradients within 1e-4."""
+def test_slot_schedule_matches_serial_schedule():
+    """Backward with the HBM-bound kernels on the side stream (the slots of engine/video.py) runs the same kernels
+    on the same data as the all-on-one-stream schedule: outputs and every parameter gradient bit-identical, also on
+    the second step (plans, streams and gradient buffers reused)."""
     video = si.seeded_tensor(SEED, "in.video.lanes", (4, 3, 3, 48, 48)).cuda()
     gc = si.seeded_tensor(SEED, "g.cls.lanes", (4, 128)).cuda()
     res = []
-    for lanes in (1, 2):
+    for side in (True, False):
         m = small_model()
         m.need_patch_tokens = False
-        m._engine.lanes, m._engine.min_lane_rows = lanes, 0
-        for _ in range(2):                      # second step reuses plans / streams / grad buffers
+        m._engine.bwd_side = side
+        for _ in range(2):
             cls, _ = m(video)
             (cls * gc).sum().backward()
         torch.cuda.synchronize()
-        assert len(m._engine.plans) == lanes
         res.append((cls.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters()}))
     assert torch.equal(res[0][0], res[1][0])
     for k, g1 in res[0][1].items():
-        e = rel(res[1][1][k], g1)
-        assert e < 1e-4, (k, e)
+        assert torch.equal(res[1][1][k], g1), k
 
 
 def test_336_geometry_vs_oracle():
