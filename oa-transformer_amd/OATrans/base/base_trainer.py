@@ -50,6 +50,50 @@ class _TrainerCore:
     def _valid_epoch(self, epoch):
         return {}
 
+    def _run_validation(self, epoch, val_batch):
+        """Shared body of the trainers' _valid_epoch (trainer_dist.py:201-281, trainer.py:117-190 of the reference):
+        `val_batch(data) -> (text embeddings, video embeddings, loss)` for every batch of every validation loader, then -
+        over the WHOLE set - one sim_matrix and every configured metric (t2v_metrics / v2t_metrics), returned as
+        `nested_val_metrics` (train() flattens it to val_{loader}_{metric}_{R1...} for the monitor).  Embeddings stay on
+        the device until a loader is exhausted: one host transfer per loader instead of one per batch."""
+        try:
+            from OATrans.model.layers import sim_matrix
+        except ImportError:
+            from model.layers import sim_matrix
+        self.model.eval()
+        loaders = self.valid_data_loader
+        n_dl = len(loaders)
+        total = [torch.zeros((), device=self.device) for _ in range(n_dl)]
+        nested_metrics = {x: {} for x in range(n_dl)}
+        res_dict = {}
+        with torch.no_grad():
+            for dl_idx, dl in enumerate(loaders):
+                text_arr, vid_arr = [], []
+                for data in dl:
+                    text_all, vid_all, loss = val_batch(data)
+                    text_arr.append(text_all)
+                    vid_arr.append(vid_all)
+                    total[dl_idx] += loss
+                res_dict[f'val_loss_{dl_idx}'] = total[dl_idx].item() / max(1, len(dl))
+                if self.writer is not None:
+                    self.writer.log_scalar(f'loss_val_{dl_idx}', res_dict[f'val_loss_{dl_idx}'])
+                if not text_arr:
+                    continue
+                sims = sim_matrix(torch.cat(text_arr), torch.cat(vid_arr)).detach().cpu().numpy()
+                for metric in (self.metrics or []):
+                    res = metric(sims)
+                    nested_metrics[dl_idx][metric.__name__] = res
+                    if self.is_main:
+                        name = getattr(dl, 'dataset_name', str(dl_idx))
+                        self.logger.info('[{}] {} epoch {}: R@1 {:.1f} R@5 {:.1f} R@10 {:.1f} R@50 {:.1f} MedR {:g} MeanR {:.1f}'.format(
+                            metric.__name__, name, epoch, res['R1'], res['R5'], res['R10'], res['R50'], res['MedR'], res['MeanR']))
+                    if self.writer is not None:
+                        for key, val in res.items():
+                            self.writer.log_scalar(f'{metric.__name__}_{key}_{dl_idx}', val)
+        res_dict['nested_val_metrics'] = nested_metrics
+        self.model.train()
+        return res_dict
+
     def train(self):
         not_improved = 0
         if self.init_val:
@@ -122,6 +166,8 @@ class _TrainerCore:
                 self.optimizer.load_state_dict(checkpoint['optimizer'])
             except (ValueError, KeyError) as e:
                 self.logger.warning(f"optimizer state not resumed: {e}")
+        if hasattr(self.model, 'broadcast_parameters'):
+            self.model.broadcast_parameters()
         self.logger.info("Checkpoint loaded. Resume training from epoch {}".format(self.start_epoch))
 
 

@@ -99,5 +99,6 @@ class EngineModule(nn.Module):
             off += p.numel()
             if p.requires_grad and (p.grad is None or p.grad.data_ptr() != v.data_ptr()):
                 p.grad = v
+            p._oat_engine_grad = True        # written in place by the kernels, overwritten by every backward (optim.zero_grad)
             views[n] = v
         return views

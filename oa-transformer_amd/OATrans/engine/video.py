@@ -180,8 +180,8 @@ class VideoEngine:
         pl = self.plan(B, T, N, dev)
         pl.side = st["side"]
         pl.video = video.contiguous()
-        # forward runs alone on the GPU: the third, 31 %-full round of the N = 768 GEMMs (591 tiles on 256 CUs) is
-        # re-tiled as 128x128 where the lockstep kernel serves a launch (see gemm_nt.hip)
+        # every GEMM has the GPU to itself: the third, 31 %-full round of the N = 768 GEMMs (591 tiles on 256 CUs) is
+        # re-tiled as 128x128 (see gemm_nt.hip)
         hip.gemm_set_tail_split(self.tail_split)
         self._embed(pl, params, C, R)
         pend = None
@@ -295,6 +295,7 @@ class VideoEngine:
         self._final_bwd(pl, run, params, grads, d_cls.contiguous(), d_patches, d_region)
         if run.region_layer is not None:
             ready = None                     # region_norm gradients arrive out of block order: reduce after backward
+        hip.gemm_set_tail_split(self.tail_split and not self.bwd_side)
         hip.gemm_tn_set_variant((self.wgrad_cus << 16) if self.bwd_side else 0)
         nt_prev = hip.gemm_get_variant()
         if self.bwd_nt_grid and (nt_prev >> 16) == 0:
@@ -307,6 +308,7 @@ class VideoEngine:
         if ready is not None:
             ready(("cls_token", "pos_embed", "temporal_embed", "patch_embed."))
         hip.gemm_tn_set_variant(0)
+        hip.gemm_set_tail_split(False)
         if hip.gemm_get_variant() != nt_prev:
             hip.gemm_set_variant(nt_prev)
 

@@ -96,10 +96,17 @@ class AdamW(torch.optim.Optimizer):
             off = 0
             for p in r['params']:
                 st = self.state[p]
-                st['exp_avg'] = r['m'][off:off + p.numel()].view_as(p)
-                st['exp_avg_sq'] = r['v'][off:off + p.numel()].view_as(p)
-                st.setdefault('step', 0)
-                off += p.numel()
+                n = p.numel()
+                m_view, v_view = r['m'][off:off + n].view_as(p), r['v'][off:off + n].view_as(p)
+                # moments that already exist - a resumed checkpoint (load_state_dict), or runs rebuilt because a
+                # buffer moved - are carried over into the flat buffers, not reset
+                if torch.is_tensor(st.get('exp_avg')) and st['exp_avg'].shape == p.shape:
+                    m_view.copy_(st['exp_avg'])
+                if torch.is_tensor(st.get('exp_avg_sq')) and st['exp_avg_sq'].shape == p.shape:
+                    v_view.copy_(st['exp_avg_sq'])
+                st['exp_avg'], st['exp_avg_sq'] = m_view, v_view
+                st['step'] = int(st.get('step', 0))
+                off += n
             r['sig'] = tuple((p.data.data_ptr(), p.grad.data_ptr()) for p in r['params'])
             p0 = r['params'][0]
             r['flat_p'] = torch.as_strided(p0.data, (r['n'],), (1,))
@@ -135,6 +142,19 @@ class AdamW(torch.optim.Optimizer):
         bump_weights_epoch()     # kernels wrote through raw pointers: tell the engines to re-cast shadows
         return loss
 
+    def load_state_dict(self, state_dict):
+        """Resume: the loaded per-parameter moments are copied into the flat buffers when the runs are next built."""
+        super().load_state_dict(state_dict)
+        self._runs = None
+
     def zero_grad(self, set_to_none=False):
-        """Gradients are persistent buffers that every backward OVERWRITES; nothing to clear."""
+        """Engine parameters keep their gradients in persistent flat buffers that every backward OVERWRITES (marked
+        `_oat_engine_grad` by EngineModule._grad_views) - nothing to clear there.  Every other parameter (the
+        projection heads and the loose parameters of the object-aware variants) is an ordinary autograd leaf whose
+        AccumulateGrad ADDS: those gradients are zeroed in place, which keeps the pointers the fused launches were
+        built on (the reference calls zero_grad every step, trainer_dist.py:156)."""
+        for group in self.param_groups:
+            for p in group['params']:
+                if p.grad is not None and not getattr(p, '_oat_engine_grad', False):
+                    p.grad.zero_()
         return None

@@ -165,6 +165,30 @@ class HipDataParallel(nn.Module):
         super().__init__()
         self.module = module
         self.sync = GradSync(module)
+        self.broadcast_parameters()
+
+    def broadcast_parameters(self, src=0):
+        """Every rank starts from rank `src`'s parameters and buffers, as DistributedDataParallel does at construction
+        (base_trainer.py:20-23 of the reference): randomly initialised projections / temporal embeddings - or whole
+        towers when no pretrained files exist - would otherwise differ per rank and gradient averaging would never
+        bring the replicas together.  Also called after a resume.  Flat engine buffers go out as one message each."""
+        W, _ = world()
+        if W == 1:
+            return
+        done = set()
+        for m in self.module.modules():
+            flat = getattr(m, "_flat_param", None)
+            if flat is not None:
+                dist.broadcast(flat, src)
+                done.update(id(p) for _, p in m._engine_params())
+        for t in list(self.module.parameters()) + list(self.module.buffers()):
+            if id(t) not in done:
+                dist.broadcast(t.data, src)
+        try:
+            from .engine.module import bump_weights_epoch
+        except ImportError:
+            from engine.module import bump_weights_epoch
+        bump_weights_epoch()             # parameters changed through .data: the engines re-cast their bf16 shadows
 
     def forward(self, *a, **kw):
         return self.module(*a, **kw)

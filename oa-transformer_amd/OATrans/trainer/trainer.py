@@ -63,12 +63,8 @@ class Trainer(BaseTrainer):
         return log
 
     def _valid_epoch(self, epoch):
-        self.model.eval()
-        totals = [0.0] * len(self.valid_data_loader)
-        with torch.no_grad():
-            for dl_idx, dl in enumerate(self.valid_data_loader):
-                for data in dl:
-                    data = self._to_device(data)
-                    t, v = self.model(data, return_embeds=True)
-                    totals[dl_idx] += self.loss(sim_matrix(t, v)).item()
-        return {f'val_loss_{i}': totals[i] / max(1, len(self.valid_data_loader[i])) for i in range(len(self.valid_data_loader))}
+        """trainer.py:117-190 of the reference: per-batch loss, retrieval metrics over the whole validation set."""
+        def val_batch(data):
+            t, v = self.model(self._to_device(data), return_embeds=True)
+            return t, v, self.loss(sim_matrix(t, v))
+        return self._run_validation(epoch, val_batch)

@@ -94,7 +94,7 @@ class Multi_Trainer_dist(Multi_BaseTrainer_dist):
             n_iter += 1
             if batch_idx == self.len_epoch:
                 break
-        log = {f'loss_{i}': (total_loss[i].item() / max(1, n_iter)) for i in range(len(self.data_loader))}
+        log = {f'loss_{i}': (total_loss[i].item() / max(1, self.len_epoch)) for i in range(len(self.data_loader))}   # reference :187-189
         if self.do_validation:
             val_log = self._valid_epoch(epoch)
             if self.args.rank == 0:
@@ -102,26 +102,24 @@ class Multi_Trainer_dist(Multi_BaseTrainer_dist):
         self._adjust_learning_rate(self.optimizer, epoch, self.args)
         return log
 
+    def _gather_embeds(self, t):
+        """Raw (no-grad) all_gather in rank order, as trainer_dist.py:230-237 of the reference."""
+        if self.n_gpu <= 1:
+            return t
+        out = torch.empty((self.n_gpu * t.shape[0], t.shape[1]), dtype=t.dtype, device=t.device)
+        torch.distributed.all_gather_into_tensor(out, t.contiguous())
+        return out
+
+    def _val_batch(self, data):
+        """(gathered text, gathered video, loss) of one validation batch (trainer_dist.py:226-246); the object-aware
+        trainers override this with their own forward and loss terms."""
+        text_embed, vid_embed = self.model.module(data, return_embeds=True)
+        text_all, vid_all = self._gather_embeds(text_embed), self._gather_embeds(vid_embed)
+        return text_all, vid_all, self.loss(sim_matrix(text_all, vid_all))
+
     def _valid_epoch(self, epoch):
-        """Eval-mode forward, raw all_gather of the embeddings, loss per batch
-        (trainer_dist.py:201-281; the retrieval-metric table is SURVEY.md 8f 'next')."""
-        self.model.eval()
-        totals = [0.0] * len(self.valid_data_loader)
-        with torch.no_grad():
-            for dl_idx, dl in enumerate(self.valid_data_loader):
-                for data in dl:
-                    data = self._to_device(data)
-                    text_embed, vid_embed = self.model.module(data, return_embeds=True)
-                    if self.n_gpu > 1:
-                        gathered = []
-                        for t in (text_embed, vid_embed):
-                            out = torch.empty((self.n_gpu * t.shape[0], t.shape[1]), dtype=t.dtype, device=t.device)
-                            torch.distributed.all_gather_into_tensor(out, t.contiguous())
-                            gathered.append(out)
-                        text_embed, vid_embed = gathered
-                    totals[dl_idx] += self.loss(sim_matrix(text_embed, vid_embed)).item()
-        return {f'val_loss_{i}': totals[i] / max(1, len(self.valid_data_loader[i]))
-                for i in range(len(self.valid_data_loader))}
+        """trainer_dist.py:201-281 of the reference (see _TrainerCore._run_validation)."""
+        return self._run_validation(epoch, lambda data: self._val_batch(self._to_device(data)))
 
     def _progress(self, batch_idx, dl_idx):
         dl = self.data_loader[dl_idx]

@@ -2,9 +2,11 @@
 six gathered tensors (one packed collective here).  The reference leaves torch.autograd.set_detect_anomaly
 on at import (:16) - a debugging leftover that is not reproduced."""
 try:
+    from OATrans.model.layers import sim_matrix
     from OATrans.trainer.step import global_local_step
     from OATrans.trainer.trainer_dist import Multi_Trainer_dist as _Base
 except ImportError:
+    from model.layers import sim_matrix
     from trainer.step import global_local_step
     from trainer.trainer_dist import Multi_Trainer_dist as _Base
 
@@ -22,5 +24,10 @@ class Multi_Trainer_dist(_Base):
     def train_step(self, data):
         return global_local_step(self.model, self.loss, self.optimizer, data, self.args)
 
-    def _valid_epoch(self, epoch):
-        return {}
+    def _val_batch(self, data):
+        """trainer_global_local.py:296-362 of the reference: short-text and tag-padded-text losses against the video
+        embedding; the retrieval metrics of the epoch are computed on (short text, video)."""
+        text, pad_text, video, _pad_video, _extra = self.model.module(data, return_embeds=True)
+        text_all, pad_all, vid_all = (self._gather_embeds(t) for t in (text, pad_text, video))
+        loss = self.loss(sim_matrix(text_all, vid_all)) + self.loss(sim_matrix(pad_all, vid_all))
+        return text_all, vid_all, loss

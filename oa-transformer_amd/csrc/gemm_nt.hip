@@ -660,13 +660,19 @@ static int launch_cfg(const GemmArgs& g, hipStream_t s) {
 
 static int g_pp_default = 1;     // auto tile choice prefers the ping-pong kernel (gemm_nt_pp.hip) where it applies
 
+// the 256x256 configuration of a launch: ping-pong kernel where it applies, else the lockstep kernel
 template <int EPI>
-static int launch(const GemmArgs& g, hipStream_t s) {
-  const bool big = g_variant >= 2 || (g_variant == 0 && g.M >= 4096 && g.N % 256 == 0);
-  if (big && (g_variant == 4 || (g_variant == 0 && g_pp_default)) && pp_supported(EPI, g)) {
+static int launch_big(const GemmArgs& g, hipStream_t s) {
+  if ((g_variant == 4 || (g_variant == 0 && g_pp_default)) && pp_supported(EPI, g)) {
     const int slots = g_persist == 0xffff ? 0x7fffffff : g_persist > 0 ? g_persist : cu_count();
     return launch_pp(EPI, g, slots, g_variant == 4 ? g_dbg : 0, s);
   }
+  return launch_cfg<EPI, 2, 4, 8, 4, 3, true>(g, s);
+}
+
+template <int EPI>
+static int launch(const GemmArgs& g, hipStream_t s) {
+  const bool big = g_variant >= 2 || (g_variant == 0 && g.M >= 4096 && g.N % 256 == 0);
   if (big && g_variant == 3) return launch_cfg<EPI, 2, 2, 8, 8, 3, false, true>(g, s);   // 4 waves x 128x128, hand-pipelined
   if (big) {
     // Tail split.  256x256 tiles leave the last round of workgroups mostly empty when tiles % CUs is small (N = 768 at
@@ -676,14 +682,13 @@ static int launch(const GemmArgs& g, hipStream_t s) {
     const int ntm = (g.M + 255) / 256, ntn = (g.N + 255) / 256, cus = cu_count();
     const int T = ntm * ntn, R = T / cus, r = T - R * cus;
     const int panels_main = R * cus / ntn;
-    // Measured: +5...9 % per launch at R = 2 (-1.6 % at R = 9) on an idle GPU, but -1 % for the training step, where
-    // the weight-gradient stream already fills that third round and an exact two-round fit has no slack when a few
-    // CUs are busy at launch.  Opt-in (ablation bit 64).
+    // Measured with the lockstep kernel: +5...9 % per launch at R = 2 (-1.6 % at R = 9).  A launch policy of the caller
+    // (oat_gemm_set_tail_split): it pays whenever the GEMM has the GPU to itself.
     if (((g_dbg & 64) || g_tail) && R >= 1 && R <= 4 && r > 0 && r * 10 < cus * 7 && panels_main >= 1 && panels_main < ntm) {
       const int M1 = panels_main * 256;
       GemmArgs a = g;
       a.M = M1;
-      int rc = launch_cfg<EPI, 2, 4, 8, 4, 3, true>(a, s);
+      int rc = launch_big<EPI>(a, s);
       if (rc) return rc;
       GemmArgs b = g;
       const size_t osz = (EPI == EPI_F32 || EPI == EPI_F32_BF16) ? 4 : 2;
@@ -696,7 +701,7 @@ static int launch(const GemmArgs& g, hipStream_t s) {
       if (g.resid && g.resid_mod <= 0) b.resid = g.resid + (size_t)M1 * g.ldr;
       return launch_cfg<EPI, 2, 2, 4, 4, 2, false>(b, s);
     }
-    return launch_cfg<EPI, 2, 4, 8, 4, 3, true>(g, s);
+    return launch_big<EPI>(g, s);
   }
   return launch_cfg<EPI, 2, 2, 4, 4, 2, false>(g, s);
 }

@@ -164,3 +164,43 @@ def test_checkpoint_interop_vs_reference_golden(golden_dir):
     for c in g["prefix_fix"]:
         out = state_dict_data_parallel_fix(OrderedDict((k, i) for i, k in enumerate(c["load"])), OrderedDict((k, 0) for k in c["cur"]))
         assert list(out.items()) == c["out"], c
+
+
+REF_CONFIGS = "/root/reference/OATrans/configs"
+
+
+@pytest.mark.skipif(not __import__("os").path.isdir(REF_CONFIGS), reason="reference checkout not present (GPU box)")
+@pytest.mark.parametrize("rel", ["pt/cc3m_webvid/norm.json", "pt/cc3m_webvid/local-region-loss.json",
+                                 "ft/msrvtt/zsl/normal.json", "ft/msrvtt/fine_tune/normal_1_cl.json"])
+def test_reference_shipped_configs_parse_and_build(tmp_path, monkeypatch, rel):
+    """The four JSON configs the reference ships (read in place, not copied) go through ConfigParser unchanged: the
+    schema, the `-c` path, the arch / loss / optimizer / data_loader factories with `args` injection, and the loader
+    kwargs of data_loader/data_loader.py:165-227 (incl. `cut`) are all the reference's."""
+    import os
+    from OATrans import model as module_arch
+    from OATrans import optim as module_optim
+    from OATrans.data_loader import data_loader as module_data
+    from OATrans.parse_config import ConfigParser
+    cfg = json.load(open(os.path.join(REF_CONFIGS, rel)))
+    cfg["trainer"]["save_dir"] = str(tmp_path)
+    local = tmp_path / "cfg.json"
+    local.write_text(json.dumps(cfg))
+    monkeypatch.setattr(sys, "argv", ["x", "-c", str(local)])
+    config = ConfigParser(_parser())
+    assert config["arch"]["type"] == "FrozenInTime" and config["loss"]["type"] == "NormSoftmaxLoss"
+    loss = config.initialize("loss", module_arch)
+    assert type(loss).__name__ == "NormSoftmaxLoss"
+    metrics = [getattr(__import__("OATrans.model.metric", fromlist=["x"]), m) for m in config["metrics"]]
+    assert all(callable(m) for m in metrics)
+    w = torch.nn.Parameter(torch.zeros(3))
+    opt = config.initialize("optimizer", module_optim, [w])
+    assert opt.param_groups[0]["lr"] == cfg["optimizer"]["args"]["lr"]
+    n = len(config["data_loader"]) if isinstance(config["data_loader"], list) else 1
+    for i in range(n):
+        node = config["data_loader"][i] if isinstance(config["data_loader"], list) else config["data_loader"]
+        assert node["type"] in ("MultiDistTextObjectVideoDataLoader", "TextObjectVideoDataLoader"), node["type"]
+        sig = __import__("inspect").signature(getattr(module_data, node["type"]).__init__)
+        unknown = [k for k in node["args"] if k not in sig.parameters]
+        assert not unknown, (rel, unknown)                      # every kwarg the reference passes is accepted
+    vp = config["arch"]["args"]["video_params"]
+    assert vp["model"] == "SpaceTimeTransformer" and vp["arch_config"] == "base_patch16_224"

@@ -276,3 +276,104 @@ def test_eager_adamw_equals_step_after_backward():
         d = (p0[n] - p1[n]).abs()
         assert d.max().item() <= 8e-4 + 1e-6, (n, d.max().item())
         assert d.mean().item() < 2e-5, (n, d.mean().item())
+
+
+def _small_frozen(seed=0, frames=2, depth=2, n_layers=1):
+    from OATrans import model as module_arch
+    torch.manual_seed(seed)
+    m = module_arch.FrozenInTime(
+        video_params=dict(model="SpaceTimeTransformer", arch_config="base_patch16_224", num_frames=frames, pretrained=True,
+                          time_init="rand", arch_kwargs=dict(depth=depth)),
+        object_params=dict(model="", input_objects=False),
+        text_params=dict(model="pretrained/distilbert-base-uncased", pretrained=True, input="text", config=dict(n_layers=n_layers)),
+        projection="minimal", load_checkpoint="").cuda()
+    m.set_device(torch.device("cuda"))
+    for sub in (m.video_model, m.text_model):
+        sub.flatten_parameters()
+    return m
+
+
+def _batch(B=4, T=2, L=12, seed=5):
+    g = torch.Generator().manual_seed(seed)
+    return {"video": torch.randn(B, T, 3, 224, 224, generator=g).cuda(),
+            "text": {"input_ids": torch.randint(1000, 30000, (B, L), generator=g).cuda(),
+                     "attention_mask": torch.ones(B, L, dtype=torch.int64).cuda()}}
+
+
+def test_projection_heads_follow_torch_adamw_over_several_steps():
+    """txt_proj / vid_proj are ordinary autograd leaves (their gradients ACCUMULATE unless zero_grad clears them, unlike
+    the engine parameters whose flat gradient buffers every backward overwrites).  Three training steps: the
+    projection weights must follow a torch.optim.AdamW (transformers-4.6 formula == torch's at weight_decay 0 up to
+    eps placement) fed with the per-step gradients - not the running sum of all past gradients."""
+    import argparse
+    from OATrans import model as module_arch
+    from OATrans.optim import AdamW
+    from OATrans.parallel import HipDataParallel
+    from OATrans.trainer.step import hot_step
+    m = _small_frozen()
+    loose = {n: p for n, p in m.named_parameters() if n.startswith(("txt_proj", "vid_proj"))}
+    assert len(loose) == 4
+    ref = {n: p.detach().double().clone() for n, p in loose.items()}
+    mom = {n: (torch.zeros_like(r), torch.zeros_like(r)) for n, r in ref.items()}
+    dp = HipDataParallel(m)
+    lr, b1, b2, eps = 1e-4, 0.9, 0.999, 1e-6
+    opt = AdamW([p for p in m.parameters() if p.requires_grad], lr=lr)
+    sa = argparse.Namespace(world_size=1, rank=0, local_rank=0)
+    data = _batch()
+    grads_seen = []
+    for step in range(1, 4):
+        hot_step(dp, module_arch.NormSoftmaxLoss(), opt, data, sa)
+        torch.cuda.synchronize()
+        grads_seen.append({n: p.grad.detach().double().clone() for n, p in loose.items()})
+        for n in ref:                                        # transformers.AdamW: eps outside the bias correction
+            g = grads_seen[-1][n]
+            mm, vv = mom[n]
+            mm.mul_(b1).add_(g, alpha=1 - b1)
+            vv.mul_(b2).addcmul_(g, g, value=1 - b2)
+            ref[n] -= lr * (1 - b2 ** step) ** 0.5 / (1 - b1 ** step) * mm / (vv.sqrt() + eps)
+    for n, p in loose.items():
+        assert torch.allclose(p.detach().double(), ref[n], atol=5e-7, rtol=1e-5), (n, (p.detach().double() - ref[n]).abs().max())
+    # and the gradients of consecutive steps are per-step gradients: a running sum would grow ~linearly
+    n0 = "vid_proj.0.weight"
+    norms = [g[n0].norm().item() for g in grads_seen]
+    assert norms[2] < 1.6 * norms[0], norms
+
+
+def test_optimizer_resume_continues_the_trajectory():
+    """save -> load -> step must equal uninterrupted stepping: AdamW.load_state_dict carries the loaded moments into
+    the flat buffers of the fused launches (they used to be rebuilt as zeros with a large step count)."""
+    import argparse
+    import copy
+    from OATrans import model as module_arch
+    from OATrans.optim import AdamW
+    from OATrans.parallel import HipDataParallel
+    from OATrans.trainer.step import hot_step
+    sa = argparse.Namespace(world_size=1, rank=0, local_rank=0)
+    data = _batch()
+    loss_fn = module_arch.NormSoftmaxLoss()
+
+    def fresh():
+        m = _small_frozen(seed=1)
+        return m, HipDataParallel(m), AdamW([p for p in m.parameters() if p.requires_grad], lr=2e-4)
+
+    m1, dp1, opt1 = fresh()
+    for _ in range(2):
+        hot_step(dp1, loss_fn, opt1, data, sa)
+    torch.cuda.synchronize()
+    sd_model = copy.deepcopy(m1.state_dict())
+    sd_opt = copy.deepcopy(opt1.state_dict())
+    hot_step(dp1, loss_fn, opt1, data, sa)                   # third step, uninterrupted
+    m2, dp2, opt2 = fresh()
+    m2.load_state_dict(sd_model)
+    opt2.load_state_dict(sd_opt)
+    hot_step(dp2, loss_fn, opt2, data, sa)                   # third step after a resume
+    torch.cuda.synchronize()
+    assert all(st["step"] == 3 for st in opt2.state.values())
+    for (n, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        # same weights, same moments, same data: only the fp32-atomics noise of the CLS-row gradients differs
+        d = (p1 - p2).abs().max().item()
+        assert d <= 4e-4, (n, d)
+        assert (p1 - p2).abs().mean().item() < 1e-5, n
+    # a zero-moment restart at step 3 would move every weight by ~lr * sign(g): far outside the bound above
+    exp_avg = next(iter(opt2.state.values()))["exp_avg"]
+    assert exp_avg.abs().max().item() > 0

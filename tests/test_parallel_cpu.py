@@ -162,3 +162,41 @@ def test_two_rank_overlapped_gradient_sync():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert got == [0, 1]
+
+
+def _broadcast_worker(rank, world, port, q):
+    from OATrans.parallel import HipDataParallel
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    torch.manual_seed(1000 + rank)                         # every rank initialises DIFFERENTLY (no seed in the entry points)
+    toy = _FlatToy()
+    toy.flatten_parameters()
+    model = torch.nn.ModuleDict({"toy": toy, "head": torch.nn.Linear(4, 3)})
+    model.register_buffer("stat", torch.randn(5))
+    before = torch.cat([p.detach().flatten() for p in model.parameters()] + [model.stat.flatten()]).clone()
+    dp = HipDataParallel(model)                            # DDP broadcasts rank 0's parameters at construction; so does this
+    after = torch.cat([p.detach().flatten() for p in model.parameters()] + [model.stat.flatten()])
+    flat_ok = all(p.data_ptr() >= toy._flat_param.data_ptr() and
+                  p.data_ptr() < toy._flat_param.data_ptr() + 4 * toy._flat_param.numel() for _, p in toy._engine_params())
+    q.put((rank, before.numpy().copy(), after.numpy().copy(), flat_ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_wrapper_broadcasts_rank0_parameters():
+    """base_trainer.py:20-23 of the reference wraps the model in DistributedDataParallel, which broadcasts rank 0's
+    parameters and buffers at construction.  HipDataParallel must do the same: the entry points set no seed, so the
+    randomly initialised projections / temporal embeddings would otherwise differ per rank for the whole run."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_broadcast_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, b0, a0, ok0), (_, b1, a1, ok1) = res
+    assert ok0 and ok1                                      # parameters still live in the flat engine buffer
+    assert not (b0 == b1).all()                             # the ranks really started apart
+    assert (a0 == b0).all() and (a1 == b0).all()            # ... and both now hold rank 0's values

@@ -102,3 +102,69 @@ def test_oa_entry_points_train_an_epoch(tmp_path, entry, config, world):
     outs = [p.communicate(timeout=900)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n=====\n".join(o[-3000:] for o in outs)
     assert "Saving checkpoint" in outs[0], outs[0][-2000:]
+
+
+def test_validation_epoch_reports_retrieval_metrics(tmp_path):
+    """trainer_dist.py:201-281 of the reference: _valid_epoch gathers the embeddings of the whole validation set, runs
+    config['metrics'] on ONE sim matrix and returns `nested_val_metrics`; train() flattens them to
+    val_{loader}_{metric}_{name} so that a monitor such as 'max val_0_t2v_metrics_R1' finds its key.  The numbers must
+    equal model/metric.py applied to the embeddings of the HIP path."""
+    import argparse
+    import sys as _sys
+    _sys.path.insert(0, os.path.join(ROOT, "oa-transformer_amd"))
+    from OATrans import model as module_arch
+    from OATrans.model import metric as module_metric
+    from OATrans.optim import AdamW
+    from OATrans.parse_config import ConfigParser
+    from OATrans.trainer.trainer_dist import Multi_Trainer_dist
+
+    cfg = json.load(open(os.path.join(PKG, "configs/pt/synthetic/frozen_1f_bs2.json")))
+    cfg["arch"]["args"]["video_params"]["arch_kwargs"] = {"depth": 2}
+    cfg["arch"]["args"]["text_params"]["config"] = {"n_layers": 1}
+    cfg["trainer"].update(epochs=1, max_samples_per_epoch=8, save_dir=str(tmp_path / "exps"), save_period=1,
+                          monitor="max val_0_t2v_metrics_R1")
+    cfg["metrics"] = ["t2v_metrics", "v2t_metrics"]
+    config = ConfigParser(cfg)
+    args = argparse.Namespace(world_size=1, rank=0, local_rank=0, learning_rate1=1e-5, schedule=[60, 80])
+    torch.manual_seed(0)
+    model = config.initialize("arch", module_arch)
+
+    class Loader(list):
+        batch_size, n_samples, dataset_name = 2, 6, "SyntheticVal"
+
+        class _S:
+            @staticmethod
+            def set_epoch(e):
+                pass
+        train_sampler = _S()
+
+    def make(seed, n):
+        g = torch.Generator().manual_seed(seed)
+        return Loader({"video": torch.randn(2, 1, 3, 224, 224, generator=g),
+                       "text": {"input_ids": torch.randint(1000, 30000, (2, 9), generator=g),
+                                "attention_mask": torch.ones(2, 9, dtype=torch.int64)}} for _ in range(n))
+
+    train_dl, val_dl = make(1, 2), make(2, 3)
+    loss = module_arch.NormSoftmaxLoss()
+    metrics = [getattr(module_metric, m) for m in cfg["metrics"]]
+    opt = AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-5)
+    trainer = Multi_Trainer_dist(args, model, loss, metrics, opt, config=config, data_loader=[train_dl],
+                                 valid_data_loader=[val_dl], tokenizer=None, max_samples_per_epoch=8)
+    res = trainer._valid_epoch(0)
+    assert set(res) == {"val_loss_0", "nested_val_metrics"}
+    nested = res["nested_val_metrics"][0]
+    assert set(nested) == {"t2v_metrics", "v2t_metrics"}
+    # the same numbers from the embeddings of the HIP path, batch by batch, through metric.py
+    trainer.model.eval()
+    with torch.no_grad():
+        ts, vs = zip(*[trainer.model.module(trainer._to_device(dict(d, text=dict(d["text"]))), return_embeds=True) for d in val_dl])
+    sims = module_arch.sim_matrix(torch.cat(ts), torch.cat(vs)).cpu().numpy()
+    assert sims.shape == (6, 6)
+    for name, fn in (("t2v_metrics", module_metric.t2v_metrics), ("v2t_metrics", module_metric.v2t_metrics)):
+        want = fn(sims)
+        for k, v in want.items():
+            assert abs(nested[name][k] - v) < 1e-9, (name, k, nested[name][k], v)
+    # and train() exposes them under the monitor's key
+    trainer.init_val = False
+    trainer.train()
+    assert trainer.mnt_best != -float("inf"), "monitor 'max val_0_t2v_metrics_R1' never saw its key"
