@@ -8,9 +8,11 @@ ViT-B/16 + DistilBERT-base, per-GPU batch 32, N GPUs of one node (weak scaling).
 
 Prints ONE JSON line on rank 0 (contract in the task statement).  Synthetic inputs are resident in
 HBM before the timed region; weights are random-init of the named architecture.  The `roofline`
-object is measured live with HIP events around every launch of the dominant kernel class (the bf16
-MFMA GEMM) during one extra instrumented step; `cpu_baseline` times the CPU oracle (oracle/, a port
-of the reference's arithmetic) on this box's host cores on a bounded sample (rank 0, N=1 only).
+object is measured live: one extra step with a HIP event pair around EVERY GEMM launch (forward /
+data-gradient GEMMs and weight gradients), grouped by the kernel that serves the launch; the kernel
+with the largest summed time is reported, the others follow in `other_gemm_kernels`.  Nothing is read
+from files.  `cpu_baseline` times the CPU oracle (oracle/, a port of the reference's arithmetic) on
+this box's host cores on a bounded sample (rank 0, N=1 only).
 """
 import argparse
 import json
@@ -87,11 +89,25 @@ def synthetic_batch(args, rank, device):
     return batch
 
 
+def _gemm_class(kind, epi, M, N, K):
+    """Name of the kernel that serves a launch (the dispatch rules of csrc/gemm_nt.hip / gemm_tn.hip), used to group
+    the instrumented launches exactly as rocprofv3 --stats groups them."""
+    epis = {0: "EPI_BF16", 1: "EPI_F32", 2: "EPI_GELU_DUAL", 3: "EPI_DGELU", 4: "EPI_F32_BF16", 5: "EPI_GELU_GRAD", 6: "EPI_MUL_AUX"}
+    if kind == "tn":
+        big = M >= 4096 and N % 256 == 0 and K % 256 == 0          # (N, K) = (N1, N2) here
+        return "gemm_tn_pp_kernel (+ tn_reduce)" if big else "gemm_tn_kernel<2,2,4,4> (+ tn_reduce)"
+    big = M >= 4096 and N % 256 == 0
+    nk = K // 64
+    if big and epi in (0, 5, 6) and N <= 4096 and nk >= 2 and nk % 2 == 0:
+        return f"gemm_nt_pp_kernel<{epis[epi]}>"
+    return f"gemm_nt_kernel<{epis.get(epi, epi)},{'2,4,8,4' if big else '2,2,4,4'}>"
+
+
 def instrumented_gemm_profile(step_fn):
-    """Run one step with a HIP event pair around every gemm_nt launch (same stream as the launch)."""
+    """Run one step with a HIP event pair around every GEMM launch - data / forward GEMMs (oat_gemm_nt) AND weight
+    gradients (oat_gemm_tn) - recorded on the stream the launch goes to.  Returns {kernel class: flops, ms, launches}."""
     from OATrans.ops import hip
     records = []
-    orig = hip.gemm_nt
 
     # raw HIP events created with hipEventDisableSystemFence ("for events that only measure timing"): torch's timing
     # events carry a system-scope release fence per record, which adds ~30 us around every launch of the instrumented step
@@ -118,66 +134,42 @@ def instrumented_gemm_profile(step_fn):
                 raise RuntimeError("hipEventElapsedTime failed")
             return ms.value
 
-    def timed(A, B, M, N, K, epi, out, **kw):
+    orig_nt, orig_tn = hip.gemm_nt, hip.gemm_tn
+
+    def timed_nt(A, B, M, N, K, epi, out, **kw):
         s, e = Ev(), Ev()
         s.record()
-        orig(A, B, M, N, K, epi, out, **kw)
+        orig_nt(A, B, M, N, K, epi, out, **kw)
         e.record()
-        records.append((epi, M, N, K, s, e))
+        records.append((_gemm_class("nt", epi, M, N, K), 2.0 * M * N * K, s, e))
 
-    hip.gemm_nt = timed
-    mods = [m for m in sys.modules.values() if getattr(m, "hip", None) is hip]
+    def timed_tn(P, Q, M, N1, N2, out, **kw):
+        s, e = Ev(), Ev()
+        s.record()
+        orig_tn(P, Q, M, N1, N2, out, **kw)
+        e.record()
+        records.append((_gemm_class("tn", 0, M, N1, N2), 2.0 * M * N1 * N2, s, e))
+
+    hip.gemm_nt, hip.gemm_tn = timed_nt, timed_tn
     try:
         step_fn()
         torch.cuda.synchronize()
     finally:
-        hip.gemm_nt = orig
+        hip.gemm_nt, hip.gemm_tn = orig_nt, orig_tn
     by = {}
-    for epi, M, N, K, s, e in records:
-        # the 256x256 / 8-wave kernel serves the big-M launches, the 128x128 / 4-wave one the small ones: two kernel classes
-        key = (epi, "2,4,8,4" if (M >= 4096 and N % 256 == 0) else "2,2,4,4")
-        d = by.setdefault(key, dict(flops=0.0, ms=0.0, n=0))
-        d["flops"] += 2.0 * M * N * K
+    for name, fl, s, e in records:
+        d = by.setdefault(name, dict(flops=0.0, ms=0.0, n=0))
+        d["flops"] += fl
         d["ms"] += s.elapsed_time(e)
         d["n"] += 1
-    for _, _, _, _, s, e in records:
+    for _, _, s, e in records:
         rt.hipEventDestroy(s.h)
         rt.hipEventDestroy(e.h)
-    return by, len(mods)
+    return by
 
 
-def pmc_traffic(kernel, args):
-    """HBM-side bytes per launch of the dominant kernel.  PMC counters cannot be sampled from inside this
-    process, so this is the committed rocprofv3 measurement of the same command and workload
-    (profiles/round1j_pmc_hbm_traffic.md: separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections);
-    null when the workload differs from the measured one."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1j_pmc_traffic.json")
-    if not os.path.exists(path) or (args.variant, args.batch, args.frames, args.res) != ("frozen", 32, 8, 224):
-        return None
-    with open(path) as fh:
-        rec = json.load(fh)
-    return rec["bytes_per_launch"] if rec.get("kernel") == kernel else None
-
-
-def rocprof_avg_us(kernel, args):
-    """Average duration of the dominant kernel in the committed rocprofv3 --kernel-trace --stats run of this command
-    (profiles/round1j_bench_kernel_stats.csv).  The live figure above brackets each launch with HIP events on its stream,
-    so it also contains the dispatch gap after the stream's previous kernel and the two event packets; rocprofv3 times the
-    kernel alone.  null when the workload differs from the profiled one."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1j_bench_kernel_stats.csv")
-    if not os.path.exists(path) or kernel != "gemm_nt_kernel<EPI_BF16,2,4,8,4>" or \
-            (args.variant, args.batch, args.frames, args.res) != ("frozen", 32, 8, 224):
-        return None
-    import csv
-    with open(path) as fh:
-        for row in csv.DictReader(fh):
-            if row["Name"].startswith("void oat::gemm_nt_kernel<0, 2, 4, 8, 4, 3, true, false>"):
-                return round(float(row["AverageNs"]) / 1e3, 1)
-    return None
-
-
-def cpu_baseline(frames, threads):
-    """fp32 CPU oracle (port of the reference arithmetic) on a bounded sample: bs 2, fwd+bwd."""
+def _cpu_sample(frames, threads, budget, max_iters):
+    """fp32 CPU oracle (port of the reference arithmetic): bs 2, fwd+bwd, `frames` frames; seconds per iteration."""
     from OATrans.utils import seeded_init as si
     from oracle import oatrans_oracle as orc
     torch.set_num_threads(threads)
@@ -198,14 +190,34 @@ def cpu_baseline(frames, threads):
     warm = time.time() - tw
     t0 = time.time()
     n = 0
-    budget = 20.0                         # seconds of timed CPU work (bounded: the default run stays within minutes)
-    while n < 1 or (n < 4 and (time.time() - t0) + warm < budget):
+    while n < 1 or (n < max_iters and (time.time() - t0) + warm < budget):
         one()
         n += 1
-    dt = (time.time() - t0) / n
-    return dict(value=round(B / dt, 4), unit="pairs/s", cores=threads, kind="port",
-                sample=f"oracle fwd+bwd, bs 2, {frames} frames 224^2, Lt 32, {n} timed iterations after 1 warm-up "
-                       f"({dt:.2f} s/iter); reference itself measured 0.236 pairs/s on 8 threads (BASELINE.md)")
+    return (time.time() - t0) / n, n
+
+
+def cpu_baseline(frames):
+    """The CPU oracle on this box's host cores, on a bounded sample (about 25 s of CPU work in total): the headline
+    shape at 8 threads (the count BASELINE.md quotes for the real reference) plus, as `extra`, config 1's shape (1 frame)
+    and the headline shape on more cores.  torch's CPU kernels collapse when every SMT thread of the GPU box is used
+    (measured 325 s / iteration on 256 threads vs ~3 s on 8), so the wide run uses a quarter of the logical CPUs."""
+    ncpu = os.cpu_count() or 1
+    t8 = min(8, ncpu)
+    dt, n = _cpu_sample(frames, t8, 14.0, 4)
+    out = dict(value=round(2 / dt, 4), unit="pairs/s", cores=t8, kind="port",
+               sample=f"oracle fwd+bwd, bs 2, {frames} frames 224^2, Lt 32, {n} timed iterations after 1 warm-up "
+                      f"({dt:.2f} s/iter); reference itself measured 0.236 pairs/s on 8 threads (BASELINE.md)")
+    extra = []
+    dt1, n1 = _cpu_sample(1, t8, 4.0, 3)
+    extra.append(dict(workload="config 1: 1 frame 224^2, bs 2", cores=t8, value=round(2 / dt1, 4), unit="pairs/s",
+                      sample=f"{n1} iterations, {dt1:.2f} s/iter"))
+    wide = max(t8, min(64, ncpu // 4))
+    if wide > t8:
+        dtw, nw = _cpu_sample(frames, wide, 6.0, 2)
+        extra.append(dict(workload=f"{frames} frames 224^2, bs 2", cores=wide, value=round(2 / dtw, 4), unit="pairs/s",
+                          sample=f"{nw} iterations, {dtw:.2f} s/iter ({ncpu} logical CPUs on this host)"))
+    out["extra"] = extra
+    return out
 
 
 def main():
@@ -288,24 +300,26 @@ def main():
     }
     # one more, instrumented, step for the roofline figure.  EVERY rank runs it (its collectives need all of them);
     # rank 0 reports
-    by, _ = instrumented_gemm_profile(step)
+    by = instrumented_gemm_profile(step)
     if rank == 0:
-        epis = {0: "EPI_BF16", 1: "EPI_F32", 2: "EPI_GELU_DUAL", 3: "EPI_DGELU", 4: "EPI_F32_BF16", 5: "EPI_GELU_GRAD", 6: "EPI_MUL_AUX"}
         if by:
-            (epi, shape), d = max(by.items(), key=lambda kv: kv[1]["ms"])
-            kname = f"gemm_nt_kernel<{epis.get(epi, epi)},{shape}>"
-            ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 1),
-                               "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / BF16_DENSE_PEAK_TFLOPS, 4),
-                               "traffic": pmc_traffic(kname, args), "launches_per_step": d["n"],
-                               "avg_launch_us": round(d["ms"] / d["n"] * 1e3, 1),
-                               "rocprof_avg_launch_us": rocprof_avg_us(kname, args),
-                               "gflop_per_launch": round(d["flops"] / d["n"] / 1e9, 1)}
+            def entry(name, d):
+                ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+                return {"kernel": name, "achieved": round(ach, 1), "frac": round(ach / BF16_DENSE_PEAK_TFLOPS, 4),
+                        "launches_per_step": d["n"], "avg_launch_us": round(d["ms"] / d["n"] * 1e3, 1),
+                        "ms_per_step": round(d["ms"], 2), "gflop_per_launch": round(d["flops"] / d["n"] / 1e9, 1)}
+            ranked = sorted(by.items(), key=lambda kv: -kv[1]["ms"])
+            top = entry(*ranked[0])
+            # `traffic` (HBM bytes per launch) needs the PMC counters, which cannot be sampled from inside this process:
+            # null here; the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command are committed under profiles/
+            out["roofline"] = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["achieved"],
+                               "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": top["frac"], "traffic": None,
+                               "launches_per_step": top["launches_per_step"], "avg_launch_us": top["avg_launch_us"],
+                               "ms_per_step": top["ms_per_step"], "gflop_per_launch": top["gflop_per_launch"],
+                               "traffic_profile": "profiles/ (rocprofv3 --pmc passes of this command, per round)",
+                               "other_gemm_kernels": [entry(n, d) for n, d in ranked[1:] if d["ms"] > 0.2]}
         if world == 1 and not args.no_cpu_baseline and args.variant == "frozen":
-            # torch CPU kernels collapse when all 256 SMT threads of the GPU box are used (measured 325 s /
-            # iteration vs ~9 s on 8 threads), so the baseline uses 8 threads, the count BASELINE.md quotes
-            threads = min(8, os.cpu_count() or 1)
-            out["cpu_baseline"] = cpu_baseline(args.frames, threads)
+            out["cpu_baseline"] = cpu_baseline(args.frames)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -77,6 +77,10 @@ int oat_layernorm_fwd(const float* x, int ldx, const float* gamma, const float* 
 int oat_add_layernorm_fwd(const float* x, int ldx, const void* add16, int ldadd, float* sum32, int ldsum,
                           const float* gamma, const float* beta, void* y_bf16, int ldy, float* y_f32, int ldy32,
                           float* mean, float* rstd, int M, int D, float eps, void* stream);
+/* the same with an fp32 addend: s = x + add32 (the precise CLS lane of the video tower) */
+int oat_add32_layernorm_fwd(const float* x, int ldx, const float* add32, int ldadd, float* sum32, int ldsum,
+                            const float* gamma, const float* beta, void* y, int ldy, float* y32, int ldy32,
+                            float* mean, float* rstd, int M, int D, float eps, void* stream);
 int oat_ln_bwd_blocks(int M);   /* partial workspace = blocks * 2 * D floats */
 int oat_layernorm_bwd(const void* dy, int dy_is_bf16, int lddy, const float* x, int ldx,
                       const float* mean, const float* rstd, const float* gamma, const float* dres,
@@ -115,6 +119,10 @@ int oat_attn_time_fwd(const void* qkv, int ldqkv, void* out, int ldo, float* lse
 void oat_attn_time_set_variant(int v);   /* tuning hook for the backward: 0 = MFMA kernel on 16-row mini problems (default), 1 = two-pass VALU kernel, 2 = VALU kernels (single-read LDS kernel for T <= 8, two-pass above) */
 int oat_attn_cls_fwd(const void* qkv, int ldqkv, void* out, int ldo, float* lse, int B, int T, int N,
                      int H, int D, float scale, void* stream);
+/* CLS query attention with a second, PRECISE query: q32 fp32 [B, D] attends the same bf16 keys / values, context written
+ * in fp32 to o32 [B, D].  out / lse of the CLS row (the bf16 path backward uses) as oat_attn_cls_fwd. */
+int oat_attn_cls_fwd_dual(const void* qkv, int ldqkv, void* out, int ldo, float* lse, const float* q32, int ldq32,
+                          float* o32, int ldo32, int B, int T, int N, int H, int D, float scale, void* stream);
 int oat_attn_space_set_variant(int v);   /* tuning hook for the backward at >= 97 patches: 0 = default (97..223 patches: two 8-wave workgroups per CU, one 16-row tile per wave, K,V then Q,dO in LDS; 224..447: 16 waves), 1 = 8 waves x tile pairs, 2 = 16 waves x one tile with all four tiles in LDS */
 /* cls_side: fp32 [B,H,3,64], zero on entry; finish with oat_attn_cls_finalize, which writes the CLS row of dqkv and
  * leaves cls_side zero again for the next backward launch. */
@@ -127,6 +135,16 @@ int oat_attn_time_bwd(const void* qkv, int ldqkv, const void* out, int ldo, cons
 int oat_attn_cls_finalize(float* cls_side, void* dqkv, int lddqkv, int B, int T, int N, int H, int D,
                           void* stream);
 
+/* ---- fp32 linear layer for small row counts (exact-f32 MFMA 16x16x4; fp32 master weights, no bf16 shadow) ---------
+ * out = act(in(A)[M,K] * W[N,K]^T + bias) (+ resid).  Carries the two places where bf16 operand rounding would break
+ * the 1e-3 sim-matrix bound at negligible FLOPs: the text tower and the CLS row of the video tower (oa_model.py:106-133,
+ * video_transformer.py:46-50,102,133 for those rows).  act 0: out32 = out16 = y; 1 (GELU): out32 = out16 = gelu(y),
+ * out16b = gelu'(y); 2: ReLU on A while loading (txt_proj, oa_model.py:68-70).  out32 / out16 / out16b / bias / resid may
+ * be NULL where unused (at least one of out32, out16).  K % 16 == 0, lda % 4 == 0, ldw % 4 == 0. */
+int oat_linear_f32(const float* A, int lda, const float* W, int ldw, const float* bias, int M, int N, int K,
+                   float* out32, int ldo, void* out16, int ld16, void* out16b, int ld16b, const float* resid, int ldr,
+                   int act, void* stream);
+
 /* ---- text encoder (HF DistilBertModel, called at oa_model.py:113; third-party algorithm) ---------
  * ids / mask are int64.  Attention: qkv bf16 [B*L, 3*D]; masked keys are skipped. */
 int oat_embed_fwd(const void* ids, const float* word, const float* pos, float* out, int ld, int M, int L,
@@ -134,6 +152,11 @@ int oat_embed_fwd(const void* ids, const float* word, const float* pos, float* o
 int oat_embed_bwd(const void* ids, const float* g, int ld, float* dword_zeroed, int M, int D, void* stream);
 int oat_attn_text_fwd(const void* qkv, int ldqkv, const void* mask, void* out, int ldo, float* lse, int B,
                       int L, int H, int D, float scale, void* stream);
+/* The same, plus the precise forward value: identical masked attention on the fp32 q|k|v in qkv32 (whose bf16 roundings
+ * are `qkv`), written to out32.  out / lse remain the bf16-path results that oat_attn_text_bwd recomputes from. */
+int oat_attn_text_fwd_dual(const void* qkv, int ldqkv, const float* qkv32, int ldqkv32, const void* mask, void* out,
+                           int ldo, float* out32, int ldo32, float* lse, int B, int L, int H, int D, float scale,
+                           void* stream);
 int oat_attn_text_bwd(const void* qkv, int ldqkv, const void* mask, const void* out, int ldo,
                       const float* lse, float* delta_scratch, const void* dout, int lddo, void* dqkv,
                       int lddqkv, int B, int L, int H, int D, float scale, void* stream);

@@ -18,7 +18,7 @@ def smoke_step():
     seed = 31337
     vshape = dict(embed_dim=128, depth=2, mlp_ratio=4, num_frames=2, patches_per_frame=4, patch=16)
     tshape = dict(dim=128, n_layers=2, hidden_dim=512, vocab=500, max_pos=32)
-    sd = si.frozen_state_dict(seed, vshape, tshape, proj_dim=64)
+    sd = si.frozen_state_dict(seed, vshape, tshape, proj_dim=256)
     dev = torch.device("cuda:0")
     txt = DistilBertHIP(dict(vocab_size=500, max_position_embeddings=32, n_layers=2, n_heads=2, dim=128, hidden_dim=512))
     txt.load_state_dict({k[11:]: v for k, v in sd.items() if k.startswith("text_model.")})
@@ -26,7 +26,7 @@ def smoke_step():
     vid.head = torch.nn.Identity()
     vid.load_state_dict({k[12:]: v for k, v in sd.items() if k.startswith("video_model.")}, strict=False)
     vid.need_patch_tokens = False
-    tp, vp = ReLULinear(128, 64), HipLinear(128, 64)
+    tp, vp = ReLULinear(128, 256), HipLinear(128, 256)      # 256-d projection as in the shipped configs
     tp[1].load_state_dict({"weight": sd["txt_proj.1.weight"], "bias": sd["txt_proj.1.bias"]})
     vp.load_state_dict({"weight": sd["vid_proj.0.weight"], "bias": sd["vid_proj.0.bias"]})
     txt, vid, tp, vp = txt.to(dev), vid.to(dev), tp.to(dev), vp.to(dev)
@@ -46,7 +46,7 @@ def smoke_step():
     torch.cuda.synchronize()
     oloss, osim, _, _ = orc.train_step_loss(sd, video, ids, mask, num_heads=2, text_heads=2)
     err = (sim.detach().cpu() - osim).abs().max().item()
-    assert err <= 4e-3, f"smoke: sim-matrix error {err} vs CPU oracle"
+    assert err <= 1e-3, f"smoke: sim-matrix error {err} vs CPU oracle (stated bound 1e-3)"
     assert abs(loss.item() - oloss.item()) <= 5e-2 * max(1.0, abs(oloss.item())), (loss.item(), oloss.item())
     assert all(torch.isfinite(p).all() for p in params)
     print(f"smoke ok: loss {loss.item():.4f} (oracle {oloss.item():.4f}), sim max-abs err {err:.2e}")

@@ -7,8 +7,11 @@ is executed here with the same GEMM / LayerNorm kernels as the video encoder plu
 attention and embedding kernels of csrc/text.hip.  Dropout is the identity (the parity
 configuration is eval mode; SURVEY.md 'parity traps').
 
-Rows are (b, l) -> b * L + l; fp32 residual stream, bf16 GEMM operands (same conventions as
-engine/video.py).
+Rows are (b, l) -> b * L + l.  FORWARD runs in fp32 end to end (oat_linear_f32 on the fp32 master weights, the precise
+path of oat_attn_text_fwd_dual): the tower is 0.7 % of the step's FLOPs, runs on its own stream beside the video
+tower, and with bf16 operands its ~6e-3 embedding error alone would use up the 1e-3 sim-matrix bound.  Every layer
+also leaves the bf16 copies (LayerNorm outputs, q|k|v, context, GELU and its derivative) that BACKWARD - bf16 MFMA
+GEMMs as in engine/video.py - reads, so backward differentiates one self-consistent bf16 function.
 """
 import torch
 
@@ -24,6 +27,7 @@ class _LayerActs:
         z16 = lambda c: torch.zeros(Mp, c, dtype=torch.bfloat16, device=dev)
         z32 = lambda c: torch.zeros(Mp, c, dtype=torch.float32, device=dev)
         self.qkv, self.ctx = z16(3 * D), z16(D)
+        self.qkv32, self.ctx32, self.g32 = z32(3 * D), z32(D), z32(Hd)      # precise forward chain
         self.lse = z32(H)
         self.s, self.x1, self.f, self.x2 = z32(D), z32(D), z32(D), z32(D)
         self.x1_16, self.x2_16 = z16(D), z16(D)
@@ -119,22 +123,24 @@ class TextEngine:
                       params["embeddings.position_embeddings.weight"], pl.emb, M, L, D)
         hip.layernorm_fwd(pl.emb, params["embeddings.LayerNorm.weight"], params["embeddings.LayerNorm.bias"], M, D,
                           1e-12, y=pl.x0_16, y32=pl.x0, mean=pl.estats[0], rstd=pl.estats[1])
-        x, x16 = pl.x0, pl.x0_16
+        x = pl.x0
         for i, a in enumerate(pl.layers):
             b = f"transformer.layer.{i}."
             p = lambda s: params[b + s]
-            w = lambda s: self.shadow[b + s][0]
-            hip.gemm_nt(x16, w("qkv"), M, 3 * D, D, hip.EPI_BF16, a.qkv, bias=self.shadow[b + "qkv.bias"])
-            hip.attn_text_fwd(a.qkv, pl.mask, a.ctx, a.lse, B, L, H, D, self.scale)
-            hip.gemm_nt(a.ctx, w("attention.out_lin"), M, D, D, hip.EPI_F32, a.s, bias=p("attention.out_lin.bias"),
-                        resid=x)
+            for j, l in enumerate(("q_lin", "k_lin", "v_lin")):
+                hip.linear_f32(x, p(f"attention.{l}.weight"), M, D, D, bias=p(f"attention.{l}.bias"),
+                               out32=a.qkv32[:, j * D:(j + 1) * D], out16=a.qkv[:, j * D:(j + 1) * D])
+            hip.attn_text_fwd_dual(a.qkv, a.qkv32, pl.mask, a.ctx, a.ctx32, a.lse, B, L, H, D, self.scale)
+            hip.linear_f32(a.ctx32, p("attention.out_lin.weight"), M, D, D, bias=p("attention.out_lin.bias"),
+                           out32=a.s, resid=x)
             hip.layernorm_fwd(a.s, p("sa_layer_norm.weight"), p("sa_layer_norm.bias"), M, D, 1e-12, y=a.x1_16,
                               y32=a.x1, mean=a.stats[0], rstd=a.stats[1])
-            hip.gemm_nt(a.x1_16, w("ffn.lin1"), M, Hd, D, hip.EPI_GELU_GRAD, a.h, out2=a.g, bias=p("ffn.lin1.bias"))
-            hip.gemm_nt(a.g, w("ffn.lin2"), M, D, Hd, hip.EPI_F32, a.f, bias=p("ffn.lin2.bias"), resid=a.x1)
+            hip.linear_f32(a.x1, p("ffn.lin1.weight"), M, Hd, D, bias=p("ffn.lin1.bias"), out32=a.g32, out16=a.g,
+                           out16b=a.h, act=hip.LIN_GELU)                 # a.g = gelu(h), a.h = gelu'(h) for backward
+            hip.linear_f32(a.g32, p("ffn.lin2.weight"), M, D, Hd, bias=p("ffn.lin2.bias"), out32=a.f, resid=a.x1)
             hip.layernorm_fwd(a.f, p("output_layer_norm.weight"), p("output_layer_norm.bias"), M, D, 1e-12,
                               y=a.x2_16, y32=a.x2, mean=a.stats[2], rstd=a.stats[3])
-            x, x16 = a.x2, a.x2_16
+            x = a.x2
         return x[:M].view(B, L, D), pl
 
     def backward(self, pl, params, grads, d_hidden, accumulate=False):

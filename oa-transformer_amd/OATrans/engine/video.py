@@ -80,6 +80,7 @@ class _Plan:
         self.cls_side = torch.zeros(B, H, 3, 64, dtype=torch.float32, device=dev)
         self.Gp = torch.zeros(T * N, D, dtype=torch.float32, device=dev)
         self.side = self.video = self.x_final = None      # set per call
+        self.lane = None                                  # fp32 buffers of the precise CLS lane (VideoEngine.forward)
 
 
 class _Run:
@@ -123,6 +124,7 @@ class VideoEngine:
         self.wgrad_cus = int(os.environ.get("OAT_WGRAD_CUS", "192"))   # workgroup budget of a weight-gradient GEMM that shares its slot
         self.bwd_nt_grid = int(os.environ.get("OAT_BWD_NT_GRID", "0"), 0)   # gemm_nt grid during backward (0 = as in forward, 0xffff = one workgroup per tile)
         self.slot_delay_ns = int(os.environ.get("OAT_SLOT_DELAY_NS", "4000"))
+        self.cls_lane = os.environ.get("OAT_CLS_LANE", "1") != "0"      # fp32 lane for the CLS rows (see _lane_ln)
         # 1: LayerNorm / attention backward on a side stream beside the weight-gradient GEMMs ("slots").  Measured equal to
         # the plain in-order schedule (48.9-49.4 vs 49.2 ms): the streaming kernels are bound by per-CU load throughput
         # (~27 GB/s per CU), so on the quarter of the CUs a GEMM leaves them they take 2-2.5x as long - what the overlap
@@ -180,6 +182,12 @@ class VideoEngine:
         pl = self.plan(B, T, N, dev)
         pl.side = st["side"]
         pl.video = video.contiguous()
+        if self.cls_lane and pl.lane is None:
+            z = lambda c: torch.zeros(B, c, dtype=torch.float32, device=dev)
+            pl.lane = dict(x=z(self.D), xt=z(self.D), y=z(self.D), out=z(self.D), a32=z(self.D), q32=z(self.D), o32=z(self.D),
+                           br32=z(self.D), g32=z(self.Hd))
+        elif not self.cls_lane:
+            pl.lane = None
         # every GEMM has the GPU to itself: the third, 31 %-full round of the N = 768 GEMMs (591 tiles on 256 CUs) is
         # re-tiled as 128x128 (see gemm_nt.hip)
         hip.gemm_set_tail_split(self.tail_split)
@@ -202,36 +210,84 @@ class VideoEngine:
                     bias=params["patch_embed.proj.bias"], resid=pl.table, resid_mod=T * N)
         hip.broadcast_rows(pl.cls0, pl.x0[BTN:], B, D)
 
+    # ---- the precise CLS lane ------------------------------------------------------------------------------------
+    # The cosine-similarity matrix must match the fp32 reference within 1e-3.  Only the CLS row of a clip reaches the
+    # embedding, and its OWN rounding errors (bf16 operands of its q / proj / fc1 / fc2 products, bf16 branch outputs)
+    # do not average out - those of the ~1.5 k patch keys it attends do.  So the B CLS rows are computed a second time
+    # by an fp32 lane on the side stream: its own fp32 residual rows -> LayerNorm -> q = oat_linear_f32(master weights)
+    # -> the precise query of oat_attn_cls_fwd_dual against the main path's bf16 keys / values -> proj / fc1 / GELU /
+    # fc2 in fp32.  The lane only CONSUMES the main path (q|k|v buffers) and delivers the final CLS embedding; the
+    # bf16 main path - which backward differentiates - neither waits for it nor reads it, so the lane may lag behind.
+    # ~10 launches of a few us per block; video embedding error 6.7e-3 -> 1-3e-3, sim-matrix error 0.7-1.7e-3 ->
+    # 1-3e-4 (tests/test_model_gpu.py; rounding emulation in the CPU oracle: scripts/dev/rounding_study2.py).
+    def _lane_ln(self, pl, x, add32, sum32, gamma, beta, y32):
+        """side stream: [sum32 = x + add32 ;] y32 = LayerNorm(.)  on the lane's B fp32 rows"""
+        with torch.cuda.stream(pl.side):
+            if add32 is None:
+                hip.layernorm_fwd(x, gamma, beta, pl.B, self.D, 1e-6, y32=y32)
+            else:
+                hip.add32_layernorm_fwd(x, add32, sum32, gamma, beta, pl.B, self.D, 1e-6, y32=y32)
+
+    def _lane_linear(self, pl, A, W, bias, N, K, out32, act=0):
+        with torch.cuda.stream(pl.side):
+            hip.linear_f32(A, W, pl.B, N, K, bias=bias, out32=out32, act=act)
+
     def _block_fwd(self, pl, i, params, pend, region_layer):
         """Residual adds are fused into the NEXT LayerNorm (oat_add_layernorm_fwd): the projection / fc2 GEMMs
         write their branch output as bf16 and the streaming LN kernel forms x + branch, stores the new fp32
         stream and the normalised bf16 operand in one pass.  `pend` = the previous block, whose
         out = y + branch is still to be formed."""
-        M, D, Hd = pl.M, self.D, self.Hd
+        M, D, Hd, B = pl.M, self.D, self.Hd, pl.B
+        BTN = M - B
         a, br = pl.blocks[i], pl.branch16
         p = lambda s: params[f"blocks.{i}.{s}"]
         w = lambda s: self.shadow[f"blocks.{i}.{s}.weight"][0]
         st = a.stats
+        lane = pl.lane
         if pend is None:
             x = pl.x0
             hip.layernorm_fwd(x, p("norm3.weight"), p("norm3.bias"), M, D, 1e-6, y=a.a3, mean=st[0], rstd=st[1])
+            if lane is not None:                         # the lane starts from the embedding's CLS rows
+                e0 = torch.cuda.Event()
+                e0.record(torch.cuda.current_stream())
+                pl.side.wait_event(e0)
+                with torch.cuda.stream(pl.side):
+                    lane["x"].copy_(x[BTN:M])
+                self._lane_ln(pl, lane["x"], None, None, p("norm3.weight"), p("norm3.bias"), lane["a32"])
         else:
             hip.add_layernorm_fwd(pend.y, br, pend.out, p("norm3.weight"), p("norm3.bias"), M, D, 1e-6, y=a.a3,
                                   mean=st[0], rstd=st[1])
             x = pend.out
+            if lane is not None:                         # x = y + mlp of the previous block
+                self._lane_ln(pl, lane["y"], lane["br32"], lane["x"], p("norm3.weight"), p("norm3.bias"), lane["a32"])
             if region_layer is not None and i == region_layer:
                 self._region_tap(pl, params, x)
+        # ---- time attention
+        if lane is not None:
+            self._lane_linear(pl, lane["a32"], p("timeattn.qkv.weight")[:D], p("timeattn.qkv.bias")[:D], D, D, lane["q32"])
         hip.gemm_nt(a.a3, w("timeattn.qkv"), M, 3 * D, D, hip.EPI_BF16, a.qkv_t, bias=p("timeattn.qkv.bias"))
         self._attention(pl, hip.attn_time_fwd, a.qkv_t, a.o_t, a.lse_t)
+        if lane is not None:
+            self._lane_linear(pl, lane["o32"], p("timeattn.proj.weight"), p("timeattn.proj.bias"), D, D, lane["br32"])
+            self._lane_ln(pl, lane["x"], lane["br32"], lane["xt"], p("norm1.weight"), p("norm1.bias"), lane["a32"])
+            self._lane_linear(pl, lane["a32"], p("attn.qkv.weight")[:D], p("attn.qkv.bias")[:D], D, D, lane["q32"])
         hip.gemm_nt(a.o_t, w("timeattn.proj"), M, D, D, hip.EPI_BF16, br, bias=p("timeattn.proj.bias"))
         hip.add_layernorm_fwd(x, br, a.xt, p("norm1.weight"), p("norm1.bias"), M, D, 1e-6, y=a.a1, mean=st[2],
                               rstd=st[3])                                           # xt = x + time
+        # ---- space attention
         hip.gemm_nt(a.a1, w("attn.qkv"), M, 3 * D, D, hip.EPI_BF16, a.qkv_s, bias=p("attn.qkv.bias"))
         self._attention(pl, hip.attn_space_fwd, a.qkv_s, a.o_s, a.lse_s)
+        if lane is not None:
+            self._lane_linear(pl, lane["o32"], p("attn.proj.weight"), p("attn.proj.bias"), D, D, lane["br32"])
+            # space residual comes from x, NOT from x + time (video_transformer.py:170)
+            self._lane_ln(pl, lane["x"], lane["br32"], lane["y"], p("norm2.weight"), p("norm2.bias"), lane["a32"])
+            self._lane_linear(pl, lane["a32"], p("mlp.fc1.weight"), p("mlp.fc1.bias"), Hd, D, lane["g32"], act=hip.LIN_GELU)
+            self._lane_linear(pl, lane["g32"], p("mlp.fc2.weight"), p("mlp.fc2.bias"), D, Hd, lane["br32"])
         hip.gemm_nt(a.o_s, w("attn.proj"), M, D, D, hip.EPI_BF16, br, bias=p("attn.proj.bias"))
         # space residual comes from x, NOT from x + time (video_transformer.py:170)
         hip.add_layernorm_fwd(x, br, a.y, p("norm2.weight"), p("norm2.bias"), M, D, 1e-6, y=a.a2, mean=st[4],
                               rstd=st[5])                                           # y = x + space
+        # ---- MLP
         hip.gemm_nt(a.a2, w("mlp.fc1"), M, Hd, D, hip.EPI_GELU_GRAD, a.h, out2=a.g, bias=p("mlp.fc1.bias"))
         hip.gemm_nt(a.g, w("mlp.fc2"), M, D, Hd, hip.EPI_BF16, br, bias=p("mlp.fc2.bias"))
         return a                                                                    # out = y + br, formed lazily
@@ -241,27 +297,39 @@ class VideoEngine:
         BTN = M - B
         last, br = pl.blocks[-1], pl.branch16
         pl.x_final = last.out
+        lane = pl.lane
+        g, bt = params["norm.weight"], params["norm.bias"]
         tap_last = region_layer is not None and region_layer == self.depth
         if need_patches or tap_last:
-            hip.add_layernorm_fwd(last.y, br, last.out, params["norm.weight"], params["norm.bias"], M, D, 1e-6,
-                                  y32=pl.normed, mean=pl.fstats[0], rstd=pl.fstats[1])
+            hip.add_layernorm_fwd(last.y, br, last.out, g, bt, M, D, 1e-6, y32=pl.normed, mean=pl.fstats[0], rstd=pl.fstats[1])
             if tap_last:
                 self._region_tap(pl, params, last.out)
-            return pl.normed[BTN:M], (pl.normed[:BTN] if need_patches else None)
-        # contract class: only the CLS rows of the last block's output are ever consumed
-        hip.add_layernorm_fwd(last.y[BTN:], br[BTN:], last.out[BTN:], params["norm.weight"], params["norm.bias"], B, D,
-                              1e-6, y32=pl.normed[BTN:], mean=pl.fstats[0][BTN:], rstd=pl.fstats[1][BTN:])
-        return pl.normed[BTN:M], None
+        else:
+            # contract class: only the CLS rows of the last block's output are ever consumed
+            hip.add_layernorm_fwd(last.y[BTN:], br[BTN:], last.out[BTN:], g, bt, B, D, 1e-6, y32=pl.normed[BTN:],
+                                  mean=pl.fstats[0][BTN:], rstd=pl.fstats[1][BTN:])
+        cls_out = pl.normed[BTN:M]
+        if lane is not None:                              # the CLS embedding comes from the lane's fp32 rows
+            self._lane_ln(pl, lane["y"], lane["br32"], lane["x"], g, bt, lane["out"])
+            ev = torch.cuda.Event()
+            with torch.cuda.stream(pl.side):
+                ev.record(pl.side)
+            torch.cuda.current_stream().wait_event(ev)
+            cls_out = lane["out"]
+        return cls_out, (pl.normed[:BTN] if need_patches else None)
 
     def _attention(self, pl, patch_kernel, qkv, out, lse):
-        """Patch attention on the lane's stream, the independent CLS-query attention (it only writes the
-        CLS rows of out / lse) concurrently on the lane's side stream."""
+        """Patch attention on the caller's stream, the independent CLS-query attention (it only writes the
+        CLS rows of out / lse, and the lane's precise context) concurrently on the side stream."""
         cur = torch.cuda.current_stream()
         ev = torch.cuda.Event()
         ev.record(cur)                                   # qkv is complete
         pl.side.wait_event(ev)
         with torch.cuda.stream(pl.side):
-            hip.attn_cls_fwd(qkv, out, lse, pl.B, pl.T, pl.N, self.H, self.D, self.scale)
+            if pl.lane is not None:
+                hip.attn_cls_fwd_dual(qkv, out, lse, pl.lane["q32"], pl.lane["o32"], pl.B, pl.T, pl.N, self.H, self.D, self.scale)
+            else:
+                hip.attn_cls_fwd(qkv, out, lse, pl.B, pl.T, pl.N, self.H, self.D, self.scale)
             done = torch.cuda.Event()
             done.record(pl.side)
         patch_kernel(qkv, out, lse, pl.B, pl.T, pl.N, self.H, self.D, self.scale)

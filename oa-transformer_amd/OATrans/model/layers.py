@@ -11,7 +11,9 @@ def _round_up(x, m):
 
 
 class _LinearFn(torch.autograd.Function):
-    """y = (relu(x) if pre_relu else x) @ W^T + b   on the bf16 MFMA GEMM, fp32 in/out."""
+    """y = (relu(x) if pre_relu else x) @ W^T + b, fp32 in/out.  Forward: exact-f32 MFMA on the master weight
+    (oat_linear_f32; these are the 768 -> 256 projections on B rows, where bf16 operand rounding would eat a third of the
+    1e-3 sim-matrix bound); backward: the bf16 MFMA GEMMs."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, pre_relu):
@@ -23,11 +25,16 @@ class _LinearFn(torch.autograd.Function):
             hip.relu_bf16(x, a16, M, K)
         else:
             hip.cast_bf16(x, a16[:M])
-        w16 = torch.empty(N, K, dtype=torch.bfloat16, device=x.device)
         wT16 = torch.empty(K, N, dtype=torch.bfloat16, device=x.device)
-        hip.cast_bf16(weight.detach().contiguous(), w16, wT16)
+        hip.cast_bf16(weight.detach().contiguous(), None, wT16)
         y = torch.empty(M, N, dtype=torch.float32, device=x.device)
-        hip.gemm_nt(a16, w16, M, N, K, hip.EPI_F32, y, bias=bias.detach() if bias is not None else None)
+        if K % 16 == 0:
+            hip.linear_f32(x, weight.detach(), M, N, K, bias=bias.detach() if bias is not None else None, out32=y,
+                           act=hip.LIN_RELU_IN if pre_relu else hip.LIN_NONE)
+        else:
+            w16 = torch.empty(N, K, dtype=torch.bfloat16, device=x.device)
+            hip.cast_bf16(weight.detach().contiguous(), w16, None)
+            hip.gemm_nt(a16, w16, M, N, K, hip.EPI_F32, y, bias=bias.detach() if bias is not None else None)
         ctx.save_for_backward(x, a16, wT16)
         ctx.pre_relu, ctx.has_bias = pre_relu, bias is not None
         return y

@@ -174,6 +174,16 @@ def add_layernorm_fwd(x, add16, sum32, gamma, beta, M, D, eps, y=None, y32=None,
     _check(rc, "oat_add_layernorm_fwd")
 
 
+def add32_layernorm_fwd(x, add32, sum32, gamma, beta, M, D, eps, y=None, y32=None, mean=None, rstd=None):
+    """sum32 = x + add32 (fp32) ; y / y32 = LN(sum32)."""
+    rc = lib().oat_add32_layernorm_fwd(_ptr(x), x.stride(0), _ptr(add32), add32.stride(0), _ptr(sum32),
+                                       sum32.stride(0) if sum32 is not None else 0, _ptr(gamma), _ptr(beta), _ptr(y),
+                                       y.stride(0) if y is not None else 0, _ptr(y32),
+                                       y32.stride(0) if y32 is not None else 0, _ptr(mean), _ptr(rstd), M, D, _f(eps),
+                                       _stream())
+    _check(rc, "oat_add32_layernorm_fwd")
+
+
 _part_ws = {}
 
 
@@ -278,6 +288,12 @@ def attn_cls_fwd(qkv, out, lse, B, T, N, H, D, scale):
     _attn_fwd(lib().oat_attn_cls_fwd, "oat_attn_cls_fwd", qkv, out, lse, B, T, N, H, D, scale)
 
 
+def attn_cls_fwd_dual(qkv, out, lse, q32, o32, B, T, N, H, D, scale):
+    _check(lib().oat_attn_cls_fwd_dual(_ptr(qkv), qkv.stride(0), _ptr(out), out.stride(0), _ptr(lse), _ptr(q32),
+                                       q32.stride(0), _ptr(o32), o32.stride(0), B, T, N, H, D, _f(scale), _stream()),
+           "oat_attn_cls_fwd_dual")
+
+
 def _attn_bwd(fn, name, qkv, out, lse, dout, dqkv, cls_side, B, T, N, H, D, scale):
     _check(fn(_ptr(qkv), qkv.stride(0), _ptr(out), out.stride(0), _ptr(lse), _ptr(dout), dout.stride(0),
               _ptr(dqkv), dqkv.stride(0), _ptr(cls_side), B, T, N, H, D, _f(scale), _stream()), name)
@@ -311,6 +327,23 @@ def embed_bwd(ids, g, dword, M, D):
 def attn_text_fwd(qkv, mask, out, lse, B, L, H, D, scale):
     _check(lib().oat_attn_text_fwd(_ptr(qkv), qkv.stride(0), _ptr(mask), _ptr(out), out.stride(0), _ptr(lse), B, L,
                                    H, D, _f(scale), _stream()), "oat_attn_text_fwd")
+
+
+def attn_text_fwd_dual(qkv, qkv32, mask, out, out32, lse, B, L, H, D, scale):
+    _check(lib().oat_attn_text_fwd_dual(_ptr(qkv), qkv.stride(0), _ptr(qkv32), qkv32.stride(0), _ptr(mask), _ptr(out),
+                                        out.stride(0), _ptr(out32), out32.stride(0), _ptr(lse), B, L, H, D, _f(scale),
+                                        _stream()), "oat_attn_text_fwd_dual")
+
+
+LIN_NONE, LIN_GELU, LIN_RELU_IN = 0, 1, 2
+
+
+def linear_f32(A, W, M, N, K, bias=None, out32=None, out16=None, out16b=None, resid=None, act=LIN_NONE, lda=None, ldw=None):
+    """out = act(in(A)[M,K] @ W[N,K]^T + bias) (+ resid): fp32 operands on the exact-f32 MFMA (small M only)."""
+    s0 = lambda t: t.stride(0) if t is not None else 0
+    _check(lib().oat_linear_f32(_ptr(A), lda or A.stride(0), _ptr(W), ldw or W.stride(0), _ptr(bias), M, N, K, _ptr(out32),
+                                s0(out32), _ptr(out16), s0(out16), _ptr(out16b), s0(out16b), _ptr(resid), s0(resid),
+                                int(act), _stream()), "oat_linear_f32")
 
 
 def attn_text_bwd(qkv, mask, out, lse, delta, dout, dqkv, B, L, H, D, scale):

@@ -377,6 +377,77 @@ __global__ __launch_bounds__(256) void attn_cls_fwd_kernel(TimeArgs a) {
   }
 }
 
+// The same kernel with a second, PRECISE query: q32 (fp32, row b of [B, D]; e.g. the CLS query computed by
+// oat_linear_f32 from the fp32 residual stream) attends the same bf16 keys / values and its context is written in fp32 to
+// o32[b].  The bf16-path outputs (out / lse of the CLS row: what backward reads and recomputes from) are unchanged.
+__global__ __launch_bounds__(256) void attn_cls_fwd_dual_kernel(TimeArgs a, const float* q32, int ldq32, float* o32, int ldo32) {
+  __shared__ float sm[2][32], sl[2][32], so[2][32][64];
+  const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+  const int grp = threadIdx.x >> 3, pl = threadIdx.x & 7;
+  const int S1 = a.T * a.N;
+  const size_t cls_row = (size_t)a.B * S1 + b;
+  const size_t row0 = (size_t)b * S1;
+  const int col = h * 64 + pl * 8;
+  const bf16x8 q = *reinterpret_cast<const bf16x8*>(a.qkv + cls_row * a.ldqkv + col);
+  const float* qp = q32 + (size_t)b * ldq32 + col;
+  const f32x4 qa = *reinterpret_cast<const f32x4*>(qp), qb = *reinterpret_cast<const f32x4*>(qp + 4);
+  const float c2 = a.scale * T_LOG2E;
+  float m = -INFINITY, l = 0.f, o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  float m2 = -INFINITY, l2 = 0.f, o2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int j = grp; j <= S1; j += 32) {
+    const size_t r = j < S1 ? row0 + j : cls_row;
+    const bf16x8 kk = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + a.D + col);
+    const bf16x8 vv = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + 2 * a.D + col);
+    float kf[8], vf[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { kf[e] = bf2f(kk[e]); vf[e] = bf2f(vv[e]); }
+    {
+      const float s = red8(dot8x(q, kk)) * c2;
+      const float mn = fmaxf(m, s);
+      const float alpha = exp2f(m - mn), p = exp2f(s - mn);
+      l = l * alpha + p;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = o[e] * alpha + p * vf[e];
+      m = mn;
+    }
+    {
+      float d = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d += qa[e] * kf[e];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d += qb[e] * kf[4 + e];
+      const float s = red8(d) * c2;
+      const float mn = fmaxf(m2, s);
+      const float alpha = exp2f(m2 - mn), p = exp2f(s - mn);
+      l2 = l2 * alpha + p;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o2[e] = o2[e] * alpha + p * vf[e];
+      m2 = mn;
+    }
+  }
+  if (pl == 0) { sm[0][grp] = m; sl[0][grp] = l; sm[1][grp] = m2; sl[1][grp] = l2; }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { so[0][grp][pl * 8 + e] = o[e]; so[1][grp][pl * 8 + e] = o2[e]; }
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int w = threadIdx.x >> 6, c = threadIdx.x & 63;
+    float mm = -INFINITY;
+    for (int gq = 0; gq < 32; ++gq) mm = fmaxf(mm, sm[w][gq]);
+    float ll = 0.f, acc = 0.f;
+    for (int gq = 0; gq < 32; ++gq) {
+      const float wt = exp2f(sm[w][gq] - mm);
+      ll += sl[w][gq] * wt;
+      acc += so[w][gq][c] * wt;
+    }
+    if (w == 0) {
+      a.out[cls_row * a.ldo + h * 64 + c] = f2bf(acc / ll);
+      if (c == 0) a.lse[cls_row * a.H + h] = (mm + log2f(ll)) * T_LN2;
+    } else {
+      o32[(size_t)b * ldo32 + h * 64 + c] = acc / ll;
+    }
+  }
+}
+
 }  // namespace oat
 
 using namespace oat;
@@ -449,4 +520,14 @@ extern "C" int oat_attn_cls_fwd(const void* qkv, int ldqkv, void* out, int ldo, 
   TimeArgs a{(const bf16*)qkv, ldqkv, (bf16*)out, ldo, lse, nullptr, 0, nullptr, 0, nullptr, B, T, N, H, D, scale};
   hipLaunchKernelGGL(attn_cls_fwd_kernel, dim3(B * H), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("attn_cls_fwd");
+}
+
+/* CLS query with a second, precise query / output (see attn_cls_fwd_dual_kernel). */
+extern "C" int oat_attn_cls_fwd_dual(const void* qkv, int ldqkv, void* out, int ldo, float* lse, const float* q32, int ldq32,
+                                     float* o32, int ldo32, int B, int T, int N, int H, int D, float scale, void* stream) {
+  if (D != H * 64) { set_error("attn_cls: head_dim must be 64"); return -3; }
+  if (!q32 || !o32) { set_error("attn_cls_fwd_dual: null pointer"); return -4; }
+  TimeArgs a{(const bf16*)qkv, ldqkv, (bf16*)out, ldo, lse, nullptr, 0, nullptr, 0, nullptr, B, T, N, H, D, scale};
+  hipLaunchKernelGGL(attn_cls_fwd_dual_kernel, dim3(B * H), dim3(256), 0, (hipStream_t)stream, a, q32, ldq32, o32, ldo32);
+  return check_launch("attn_cls_fwd_dual");
 }

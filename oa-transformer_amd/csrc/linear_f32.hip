@@ -1,0 +1,157 @@
+// fp32 linear layer for SMALL row counts on the exact-f32 matrix instruction (v_mfma_f32_16x16x4_f32):
+//     out[M,N] = act( in(A)[M,K] * W[N,K]^T + bias ) (+ resid)
+// A, W, bias, resid, out32 are fp32; W is the MASTER weight (no bf16 shadow involved).
+//
+// Why it exists.  The cosine-similarity matrix has to match the fp32 reference within 1e-3 (north_star), and a
+// pipeline whose GEMM operands are all bf16 lands at 0.7-1.7e-3 (embedding error ~6e-3 per tower; measured on the
+// reference golden vectors and reproduced by rounding emulation in the CPU oracle).  Two places carry that error and
+// both are tiny in FLOPs: the text tower (0.7 % of the step) and the CLS row of the video tower (one row per clip
+// whose own rounding errors do not average out, while those of the ~1.5 k patch keys it attends do).  Both run their
+// linear layers through this kernel - exact fp32 products, fp32 accumulate, bitwise an fmaf chain per output - beside
+// the bf16 MFMA kernels that keep every large GEMM.  /root/reference/OATrans/model/oa_model.py:106-133 (compute_text,
+// compute_video, the projections), video_transformer.py:46-50,102,133 for the CLS rows.
+//
+// Outputs: out32 (optional) and up to two bf16 copies for the bf16 backward path:
+//   act 0: out32 = out16 = y            act 1 (GELU): out32 = out16 = gelu(y), out16b = gelu'(y)
+//   act 2: ReLU applied to A on load (txt_proj = Sequential(ReLU, Linear), oa_model.py:68-70)
+// The next K-step's global loads are in flight while the current one is multiplied.  157 TF/s is the chip's f32 matrix
+// peak; this kernel carries <= ~100 GFLOP per step on side streams and is latency-, not throughput-critical.
+#include "common.h"
+
+namespace oat {
+
+struct LinArgs {
+  const float* A; int lda;
+  const float* W; int ldw;
+  const float* bias;
+  int M, N, K;
+  float* out32; int ldo;
+  bf16* out16; int ld16;
+  bf16* out16b; int ld16b;
+  const float* resid; int ldr;
+};
+
+// Two tile configurations, one code path:
+//   small (M <= 64: the CLS lane, the projections)  32 x 64 x 64, waves 1 x 4, 2 x 1 MFMA tiles per wave: few rows, so
+//       the K loop is a chain of dependent global loads - long K-steps keep it short (K = 3072 in 48 steps)
+//   large (the text tower, M = B * L)              128 x 128 x 16, waves 2 x 2, 4 x 4 MFMA tiles per wave (8 LDS reads
+//       per 16 MFMAs)
+template <int ACT, int BM, int BN, int BK, int WM, int WN>
+__global__ __launch_bounds__(256) void linear_f32_kernel(LinArgs g) {
+  constexpr int PITCH = BK + 1, FM = BM / WM / 16, FN = BN / WN / 16, KQ = BK / 4;
+  constexpr int LA = BM * KQ / 256, LB = BN * KQ / 256;
+  static_assert(WM * WN == 4 && LA >= 1 && LB >= 1, "256 threads, at least one float4 per thread and operand");
+  __shared__ float sA[BM * PITCH], sB[BN * PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 ra[LA], rb[LB];
+  auto load = [&](int k0) {
+#pragma unroll
+    for (int l = 0; l < LA; ++l) {
+      const int idx = tid + l * 256, row = idx / KQ, kq = (idx % KQ) * 4;
+      f32x4 v = m0 + row < g.M ? *reinterpret_cast<const f32x4*>(g.A + (size_t)(m0 + row) * g.lda + k0 + kq) : zero;
+      if constexpr (ACT == 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      ra[l] = v;
+    }
+#pragma unroll
+    for (int l = 0; l < LB; ++l) {
+      const int idx = tid + l * 256, row = idx / KQ, kq = (idx % KQ) * 4;
+      rb[l] = n0 + row < g.N ? *reinterpret_cast<const f32x4*>(g.W + (size_t)(n0 + row) * g.ldw + k0 + kq) : zero;
+    }
+  };
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = zero;
+  const int fr = lane & 15, fk = lane >> 4;
+  load(0);
+  for (int k0 = 0; k0 < g.K; k0 += BK) {
+#pragma unroll
+    for (int l = 0; l < LA; ++l) {
+      const int idx = tid + l * 256, row = idx / KQ, kq = (idx % KQ) * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sA[row * PITCH + kq + e] = ra[l][e];
+    }
+#pragma unroll
+    for (int l = 0; l < LB; ++l) {
+      const int idx = tid + l * 256, row = idx / KQ, kq = (idx % KQ) * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sB[row * PITCH + kq + e] = rb[l][e];
+    }
+    __syncthreads();
+    if (k0 + BK < g.K) load(k0 + BK);
+#pragma unroll
+    for (int ks = 0; ks < BK / 4; ++ks) {
+      float fa[FM], fb[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) fa[i] = sA[(wm * FM * 16 + i * 16 + fr) * PITCH + ks * 4 + fk];
+#pragma unroll
+      for (int j = 0; j < FN; ++j) fb[j] = sB[(wn * FN * 16 + j * 16 + fr) * PITCH + ks * 4 + fk];
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // D[row = 4 * (lane >> 4) + r][col = lane & 15]
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int col = n0 + wn * FN * 16 + j * 16 + fr;
+      if (col >= g.N) continue;
+      const float b = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm * FM * 16 + i * 16 + fk * 4 + r;
+        if (row >= g.M) continue;
+        float y = acc[i][j][r] + b;
+        float dg = 0.f;
+        if constexpr (ACT == 1) {
+          float gl;
+          gelu_both(y, gl, dg);
+          y = gl;
+        }
+        if (g.resid) y += g.resid[(size_t)row * g.ldr + col];
+        if (g.out32) g.out32[(size_t)row * g.ldo + col] = y;
+        if (g.out16) g.out16[(size_t)row * g.ld16 + col] = f2bf(y);
+        if constexpr (ACT == 1) {
+          if (g.out16b) g.out16b[(size_t)row * g.ld16b + col] = f2bf(dg);
+        }
+      }
+    }
+}
+
+template <int ACT>
+static void launch_linear(const LinArgs& g, hipStream_t s) {
+  if (g.M <= 64 && g.K % 64 == 0) {
+    hipLaunchKernelGGL((linear_f32_kernel<ACT, 32, 64, 64, 1, 4>), dim3((g.N + 63) / 64, (g.M + 31) / 32), dim3(256), 0, s, g);
+  } else {
+    hipLaunchKernelGGL((linear_f32_kernel<ACT, 128, 128, 16, 2, 2>), dim3((g.N + 127) / 128, (g.M + 127) / 128), dim3(256), 0, s, g);
+  }
+}
+
+}  // namespace oat
+
+extern "C" int oat_linear_f32(const float* A, int lda, const float* W, int ldw, const float* bias, int M, int N, int K,
+                              float* out32, int ldo, void* out16, int ld16, void* out16b, int ld16b,
+                              const float* resid, int ldr, int act, void* stream) {
+  using namespace oat;
+  if (M <= 0 || N <= 0 || K <= 0) { set_error("linear_f32: empty problem"); return -1; }
+  if (K % 16 != 0 || lda % 4 != 0 || ldw % 4 != 0) { set_error("linear_f32: K % 16, lda % 4, ldw % 4 must be 0"); return -2; }
+  if (!A || !W || (!out32 && !out16)) { set_error("linear_f32: null pointer"); return -4; }
+  if (act < 0 || act > 2) { set_error("linear_f32: unknown activation"); return -5; }
+  LinArgs g{A, lda, W, ldw, bias, M, N, K, out32, ldo, (bf16*)out16, ld16, (bf16*)out16b, ld16b, resid, ldr};
+  hipStream_t s = (hipStream_t)stream;
+  if (act == 1) launch_linear<1>(g, s);
+  else if (act == 2) launch_linear<2>(g, s);
+  else launch_linear<0>(g, s);
+  return check_launch("linear_f32");
+}

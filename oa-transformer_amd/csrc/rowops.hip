@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                                                      const float* __restrict__ beta, bf16* y, int ldy,
                                                      float* y32, int ldy32, float* mean, float* rstd,
                                                      int M, int D, float eps, const bf16* add16, int ldadd,
-                                                     float* sum32, int ldsum) {
+                                                     float* sum32, int ldsum, const float* add32 = nullptr, int ldadd32 = 0) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
@@ -39,6 +39,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         if (add16) {
           const bf16x4 t = *reinterpret_cast<const bf16x4*>(add16 + (size_t)row * ldadd + c);
           v[i] += f32x4{bf2f(t[0]), bf2f(t[1]), bf2f(t[2]), bf2f(t[3])};
+          if (sum32) *reinterpret_cast<f32x4*>(sum32 + (size_t)row * ldsum + c) = v[i];
+        } else if (add32) {                        // fp32 addend (the precise CLS lane of the video tower)
+          v[i] += *reinterpret_cast<const f32x4*>(add32 + (size_t)row * ldadd32 + c);
           if (sum32) *reinterpret_cast<f32x4*>(sum32 + (size_t)row * ldsum + c) = v[i];
         }
         s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
@@ -391,6 +394,19 @@ extern "C" int oat_add_layernorm_fwd(const float* x, int ldx, const void* add16,
                                      float* mean, float* rstd, int M, int D, float eps, void* stream) {
   if (!add16) { set_error("add_layernorm_fwd: add16 is required"); return -4; }
   return ln_fwd_launch(x, ldx, gamma, beta, y, ldy, y32, ldy32, mean, rstd, M, D, eps, add16, ldadd, sum32, ldsum, stream);
+}
+
+// s = x + add32 (fp32) ; sum32 = s (may alias x) ; y / y32 = LN(s)
+extern "C" int oat_add32_layernorm_fwd(const float* x, int ldx, const float* add32, int ldadd, float* sum32, int ldsum,
+                                       const float* gamma, const float* beta, void* y, int ldy, float* y32, int ldy32,
+                                       float* mean, float* rstd, int M, int D, float eps, void* stream) {
+  if (!add32) { set_error("add32_layernorm_fwd: add32 is required"); return -4; }
+  if (M <= 0) return 0;
+  if (D % 4 || D > LN_MAXV * 256 || ldx % 4 || ldadd % 4 || (y && ldy % 4)) { set_error("layernorm_fwd: D%4==0, D<=1024 required"); return -3; }
+  const int blocks = (M + 3) / 4;
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta, (bf16*)y, ldy, y32,
+                     ldy32, mean, rstd, M, D, eps, (const bf16*)nullptr, 0, sum32, ldsum, add32, ldadd);
+  return check_launch("add32_layernorm_fwd");
 }
 
 static int ln_bwd_cap() {

@@ -66,6 +66,8 @@ struct TextArgs {
   bf16* dqkv; int lddqkv;
   int B, L, H, D;
   float scale;
+  const float* qkv32; int ldqkv32;  // forward only: fp32 q|k|v (precise path); qkv then holds their bf16 roundings
+  float* out32; int ldo32;          // forward only: precise context
 };
 
 // one 8-lane group per (b, h, i); groups laid out i-fastest
@@ -100,6 +102,40 @@ __global__ __launch_bounds__(256) void attn_text_fwd_kernel(TextArgs a) {
                        f2bf(o[4] * inv), f2bf(o[5] * inv), f2bf(o[6] * inv), f2bf(o[7] * inv)};
     *reinterpret_cast<bf16x8*>(a.out + row * a.ldo + col) = ob;
     if (pl == 0) a.lse[row * a.H + h] = (m + log2f(l)) * X_LN2;
+  }
+  // Precise path (forward value of the layer): the same attention on the fp32 q | k | v.  The bf16 results above - what
+  // backward differentiates and recomputes its probabilities from - stay exactly self-consistent.
+  if (a.qkv32 != nullptr) {
+    const float* qp = a.qkv32 + row * a.ldqkv32 + col;
+    const f32x4 q0 = *reinterpret_cast<const f32x4*>(qp), q1 = *reinterpret_cast<const f32x4*>(qp + 4);
+    float m2 = -INFINITY, l2 = 0.f, o2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int j = 0; j < a.L; ++j) {
+      if (a.mask[(size_t)b * a.L + j] == 0) continue;
+      const float* kp = a.qkv32 + ((size_t)b * a.L + j) * a.ldqkv32 + a.D + col;
+      const f32x4 k0 = *reinterpret_cast<const f32x4*>(kp), k1 = *reinterpret_cast<const f32x4*>(kp + 4);
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(kp + a.D), v1 = *reinterpret_cast<const f32x4*>(kp + a.D + 4);
+      float d = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d += q0[e] * k0[e];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d += q1[e] * k1[e];
+      const float s = xred8(d) * c2;
+      const float mn = fmaxf(m2, s);
+      const float alpha = exp2f(m2 - mn), p = exp2f(s - mn);
+      l2 = l2 * alpha + p;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o2[e] = o2[e] * alpha + p * v0[e];
+        o2[4 + e] = o2[4 + e] * alpha + p * v1[e];
+      }
+      m2 = mn;
+    }
+    if (valid) {
+      const float inv = 1.0f / l2;
+      float* op = a.out32 + row * a.ldo32 + col;
+      *reinterpret_cast<f32x4*>(op) = f32x4{o2[0] * inv, o2[1] * inv, o2[2] * inv, o2[3] * inv};
+      *reinterpret_cast<f32x4*>(op + 4) = f32x4{o2[4] * inv, o2[5] * inv, o2[6] * inv, o2[7] * inv};
+    }
   }
 }
 
@@ -200,13 +236,28 @@ extern "C" int oat_embed_bwd(const void* ids, const float* g, int ld, float* dwo
   return check_launch("embed_bwd");
 }
 
-extern "C" int oat_attn_text_fwd(const void* qkv, int ldqkv, const void* mask, void* out, int ldo, float* lse, int B,
-                                 int L, int H, int D, float scale, void* stream) {
-  if (D != H * 64) { set_error("attn_text: head_dim must be 64"); return -3; }
-  TextArgs a{(const bf16*)qkv, ldqkv, (const long long*)mask, (bf16*)out, ldo, lse, nullptr, nullptr, 0, nullptr, 0, B, L, H, D, scale};
-  const int groups = B * H * L;
+static int attn_text_fwd_launch(oat::TextArgs a, void* stream) {
+  using namespace oat;
+  if (a.D != a.H * 64) { set_error("attn_text: head_dim must be 64"); return -3; }
+  const int groups = a.B * a.H * a.L;
   hipLaunchKernelGGL(attn_text_fwd_kernel, dim3((groups + 31) / 32), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("attn_text_fwd");
+}
+extern "C" int oat_attn_text_fwd(const void* qkv, int ldqkv, const void* mask, void* out, int ldo, float* lse, int B,
+                                 int L, int H, int D, float scale, void* stream) {
+  oat::TextArgs a{(const bf16*)qkv, ldqkv, (const long long*)mask, (bf16*)out, ldo, lse, nullptr, nullptr, 0, nullptr, 0, B, L, H, D, scale,
+                  nullptr, 0, nullptr, 0};
+  return attn_text_fwd_launch(a, stream);
+}
+// As oat_attn_text_fwd, plus the PRECISE forward value: the same masked attention on fp32 q|k|v (qkv32; `qkv` holds their
+// bf16 roundings) written to out32.  out / lse stay the bf16-path results backward uses.
+extern "C" int oat_attn_text_fwd_dual(const void* qkv, int ldqkv, const float* qkv32, int ldqkv32, const void* mask, void* out,
+                                      int ldo, float* out32, int ldo32, float* lse, int B, int L, int H, int D, float scale,
+                                      void* stream) {
+  if (!qkv32 || !out32) { oat::set_error("attn_text_fwd_dual: null pointer"); return -4; }
+  oat::TextArgs a{(const bf16*)qkv, ldqkv, (const long long*)mask, (bf16*)out, ldo, lse, nullptr, nullptr, 0, nullptr, 0, B, L, H, D, scale,
+                  qkv32, ldqkv32, out32, ldo32};
+  return attn_text_fwd_launch(a, stream);
 }
 // delta: fp32 [B*L, H] scratch
 extern "C" int oat_attn_text_bwd(const void* qkv, int ldqkv, const void* mask, const void* out, int ldo,
@@ -214,7 +265,7 @@ extern "C" int oat_attn_text_bwd(const void* qkv, int ldqkv, const void* mask, c
                                  int B, int L, int H, int D, float scale, void* stream) {
   if (D != H * 64) { set_error("attn_text: head_dim must be 64"); return -3; }
   TextArgs a{(const bf16*)qkv, ldqkv, (const long long*)mask, (bf16*)out, ldo, (float*)lse, delta, (const bf16*)dout, lddo,
-             (bf16*)dqkv, lddqkv, B, L, H, D, scale};
+             (bf16*)dqkv, lddqkv, B, L, H, D, scale, nullptr, 0, nullptr, 0};
   const int groups = B * H * L;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(attn_text_bwd_q_kernel, dim3((groups + 31) / 32), dim3(256), 0, s, a);

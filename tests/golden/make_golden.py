@@ -368,8 +368,8 @@ def main():
     if "loss" in which:
         torch.save(gen_loss_cases(sim_matrix, NormSoftmaxLoss), os.path.join(HERE, "loss_cases.pt"))
         print("loss done")
-    if "full" in which:
-        for T in (1, 4):
+    if "full" in which or "full8" in which:
+        for T in ((8,) if "full8" in which else (1, 4, 8)):
             torch.save(gen_full(FrozenInTime, sim_matrix, NormSoftmaxLoss, T), os.path.join(HERE, f"full_T{T}.pt"))
             print("full", T, "done")
     restore_build_path()

@@ -419,3 +419,32 @@ def test_cast_bf16_multi_assembles_concatenated_shadows():
     assert torch.equal(cat, ref) and torch.equal(catT, ref.t().contiguous())
     assert torch.equal(s1, w1.bfloat16()) and torch.equal(s1T, w1.bfloat16().t().contiguous())
     assert torch.equal(only_t, q.bfloat16().t().contiguous())
+
+
+@pytest.mark.parametrize("M,N,K,act", [(32, 768, 768, 0), (32, 3072, 768, 1), (32, 768, 3072, 0), (1024, 2304, 768, 0),
+                                       (5, 256, 768, 2), (77, 192, 48, 1)])
+def test_linear_f32_matches_fp64(M, N, K, act):
+    """oat_linear_f32 (exact-f32 MFMA on fp32 master weights: text tower, CLS lane, projections) against an fp64
+    product: fp32-roundoff accuracy (1e-6 relative), the bf16 side outputs are the roundings of the fp32 result, the
+    GELU variant also emits gelu'(y) and act 2 applies ReLU to the input."""
+    from OATrans.ops import hip
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A = torch.randn(M, K, generator=g).cuda()
+    W = (torch.randn(N, K, generator=g) * K ** -0.5).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    resid = torch.randn(M, N, generator=g).cuda() if act == 0 else None
+    out32 = torch.full((M, N), 9.0, device="cuda")
+    out16 = torch.full((M, N), 9.0, device="cuda", dtype=torch.bfloat16)
+    out16b = torch.full((M, N), 9.0, device="cuda", dtype=torch.bfloat16) if act == 1 else None
+    hip.linear_f32(A, W, M, N, K, bias=bias, out32=out32, out16=out16, out16b=out16b, resid=resid, act=act)
+    Ad = A.double().clamp_min(0) if act == 2 else A.double()
+    y = Ad @ W.double().t() + bias.double()
+    if act == 1:
+        dg = 0.5 * (1 + torch.erf(y / 2 ** 0.5)) + y * torch.exp(-0.5 * y * y) / (2 * torch.pi) ** 0.5
+        y = torch.nn.functional.gelu(y)
+        assert (out16b.double() - dg).abs().max().item() < 1e-2
+    if resid is not None:
+        y = y + resid.double()
+    err = (out32.double() - y).abs().max().item()
+    assert err < 3e-5 * max(1.0, y.abs().max().item()), err
+    assert torch.equal(out16, out32.bfloat16())

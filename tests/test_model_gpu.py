@@ -152,11 +152,13 @@ def test_adamw_matches_published_algorithms(hf_style):
     assert torch.allclose(p.double(), pr, atol=2e-6, rtol=1e-5)
 
 
-def test_frozen_in_time_vitb_vs_reference_golden(golden_dir):
-    """The contract class at ViT-B/16 + DistilBERT-base geometry, 4 frames, against the outputs of
-    the reference's own oa_model.FrozenInTime (tests/golden/full_T4.pt)."""
+@pytest.mark.parametrize("frames", [1, 4, 8])
+def test_frozen_in_time_vitb_vs_reference_golden(golden_dir, frames):
+    """The contract class at ViT-B/16 + DistilBERT-base geometry against the outputs of the reference's own
+    oa_model.FrozenInTime (tests/golden/full_T{1,4,8}.pt): 1 frame = BASELINE config 1's geometry, 4 frames = config 2's,
+    8 frames = the headline shape of configs 3 / 4.  Stated tolerance (north_star): sim matrix <= 1e-3 max-abs."""
     from OATrans import model as module_arch
-    g = _golden(golden_dir, "full_T4.pt")
+    g = _golden(golden_dir, f"full_T{frames}.pt")
     T, B, L = g["T"], g["B"], g["L"]
     m = module_arch.FrozenInTime(
         video_params=dict(model="SpaceTimeTransformer", arch_config="base_patch16_224", num_frames=T, pretrained=True, time_init="rand"),
@@ -269,7 +271,7 @@ def test_eager_adamw_equals_step_after_backward():
         assert all(st['step'] == 4 for st in opt.state.values())
         results.append((losses, {n: p.detach().clone() for n, p in m.named_parameters()}))
     (l0, p0), (l1, p1) = results
-    assert max(abs(a - b) for a, b in zip(l0, l1)) < 2e-3, (l0, l1)
+    assert max(abs(a - b) for a, b in zip(l0, l1)) < 5e-3, (l0, l1)      # losses of 3-4.5: relative 1e-3
     assert l0[-1] < l0[0]
     for n in p0:
         # 4 steps of at most lr each; an element whose gradient sign flips with the atomics noise moves by <= 2 lr per step
@@ -377,3 +379,45 @@ def test_optimizer_resume_continues_the_trajectory():
     # a zero-moment restart at step 3 would move every weight by ~lr * sign(g): far outside the bound above
     exp_avg = next(iter(opt2.state.values()))["exp_avg"]
     assert exp_avg.abs().max().item() > 0
+
+
+def test_headline_batch_sim_matrix_vs_oracle_rows():
+    """The benchmarked shape itself - bs 32, 8 frames, ViT-B/16 + DistilBERT-base - against the CPU oracle: the HIP
+    path embeds all 32 pairs in one forward; the oracle (minutes per full batch on a CPU) embeds all 32 captions and
+    a SUBSET of 3 videos (samples are independent: no batch statistics anywhere in the model), and the corresponding
+    COLUMNS of the 32 x 32 sim matrix must agree within the stated 1e-3."""
+    from OATrans import model as module_arch
+    from oracle import oatrans_oracle as orc
+    T, B, L = 8, 32, 32
+    sd = si.frozen_state_dict(SEED, dict(num_frames=T), {})
+    m = module_arch.FrozenInTime(
+        video_params=dict(model="SpaceTimeTransformer", arch_config="base_patch16_224", num_frames=T, pretrained=True, time_init="rand"),
+        object_params=dict(model="", input_objects=False),
+        text_params=dict(model="pretrained/distilbert-base-uncased", pretrained=True, input="text"),
+        projection="minimal", load_checkpoint="")
+    r = m.load_state_dict(sd, strict=False)
+    assert not r.unexpected_keys and not r.missing_keys, r
+    m = m.cuda()
+    video = si.seeded_tensor(SEED, "bs32.video", (B, T, 3, 224, 224))
+    ids = si.seeded_ints(SEED, "bs32.ids", (B, L), 1000, 30000)
+    ids[:, 0] = 101
+    mask = torch.ones(B, L, dtype=torch.int64)
+    mask[5, 20:] = 0
+    mask[17, 9:] = 0
+    m.begin_step()
+    with torch.no_grad():
+        t, v = m({"video": video.cuda(), "text": {"input_ids": ids.cuda(), "attention_mask": mask.cuda()}})
+        sim = module_arch.sim_matrix(t, v).cpu()
+    cols = [0, 13, 31]
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    import torch.nn.functional as F
+    with torch.no_grad():
+        ot = orc.distilbert(ids, mask, sd)[:, 0]
+        ot = F.linear(F.relu(ot), sd["txt_proj.1.weight"], sd["txt_proj.1.bias"])
+        ocls, _ = orc.video_encoder(video[cols], sd)
+        ov = F.linear(ocls, sd["vid_proj.0.weight"], sd["vid_proj.0.bias"])
+        osim = orc.sim_matrix(ot, ov)
+    err = (sim[:, cols] - osim).abs().max().item()
+    print("bs32 8f sim-matrix max abs err on 3 video columns:", err, "text rel", rel(t, ot), "video rel", rel(v[cols], ov))
+    assert err <= 1e-3, err
+    assert rel(t, ot) < 1e-2 and rel(v[cols], ov) < 1e-2

@@ -168,3 +168,25 @@ def test_validation_epoch_reports_retrieval_metrics(tmp_path):
     trainer.init_val = False
     trainer.train()
     assert trainer.mnt_best != -float("inf"), "monitor 'max val_0_t2v_metrics_R1' never saw its key"
+
+
+def test_train_py_config1_full_depth(tmp_path):
+    """BASELINE config 1 through its own entry point: train.py -c frozen_1f_bs2.json (1 frame 224^2, ViT-B/16 with all 12
+    blocks + DistilBERT-base with all 6 layers, bs 2) trains an epoch, validates with the retrieval metrics and writes a
+    checkpoint (reference: train.py + trainer/trainer.py, the single-process path)."""
+    cfg = json.load(open(os.path.join(PKG, "configs/pt/synthetic/frozen_1f_bs2.json")))
+    cfg["trainer"].update(epochs=1, max_samples_per_epoch=8, save_dir=str(tmp_path / "exps"), save_period=1)
+    path = tmp_path / "cfg.json"
+    path.write_text(json.dumps(cfg))
+    r = subprocess.run([sys.executable, os.path.join(PKG, "train.py"), "-c", str(path)], cwd=str(tmp_path),
+                       capture_output=True, text=True, timeout=900)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0, out[-3000:]
+    assert "val_loss_0" in out and "Saving checkpoint" in out, out[-2000:]
+    assert "t2v_metrics" in out, out[-2000:]
+    ckpts = [os.path.join(d, f) for d, _, fs in os.walk(tmp_path / "exps") for f in fs if f == "checkpoint-epoch1.pth"]
+    assert len(ckpts) == 1, ckpts
+    ck = torch.load(ckpts[0], map_location="cpu", weights_only=False)
+    keys = list(ck["state_dict"])
+    assert "video_model.blocks.11.mlp.fc2.weight" in keys and "text_model.transformer.layer.5.ffn.lin2.weight" in keys
+    assert all(torch.isfinite(v).all() for v in ck["state_dict"].values() if v.is_floating_point())
