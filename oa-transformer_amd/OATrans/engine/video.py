@@ -120,7 +120,9 @@ class VideoEngine:
         self.shadow = {}
         self.shadow_versions = None
         self._cast = None
-        self.tail_split = os.environ.get("OAT_TAIL_SPLIT", "1") != "0"
+        # re-tile the last, mostly empty round of the N = 768 GEMMs as 128x128: measured equal with the ping-pong kernel
+        # (49.59 vs 49.67 ms per step; +5...9 % per launch with the lockstep kernel), so off by default: 36 fewer launches
+        self.tail_split = os.environ.get("OAT_TAIL_SPLIT", "0") != "0"
         self.wgrad_cus = int(os.environ.get("OAT_WGRAD_CUS", "192"))   # workgroup budget of a weight-gradient GEMM that shares its slot
         self.bwd_nt_grid = int(os.environ.get("OAT_BWD_NT_GRID", "0"), 0)   # gemm_nt grid during backward (0 = as in forward, 0xffff = one workgroup per tile)
         self.slot_delay_ns = int(os.environ.get("OAT_SLOT_DELAY_NS", "4000"))

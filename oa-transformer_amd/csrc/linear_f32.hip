@@ -31,11 +31,9 @@ struct LinArgs {
   const float* resid; int ldr;
 };
 
-// Two tile configurations, one code path:
-//   small (M <= 64: the CLS lane, the projections)  32 x 64 x 64, waves 1 x 4, 2 x 1 MFMA tiles per wave: few rows, so
-//       the K loop is a chain of dependent global loads - long K-steps keep it short (K = 3072 in 48 steps)
+// The LDS-tiled kernel (many rows):
 //   large (the text tower, M = B * L)              128 x 128 x 16, waves 2 x 2, 4 x 4 MFMA tiles per wave (8 LDS reads
-//       per 16 MFMAs)
+//       per 16 MFMAs); 64 x 64 x 16 when that would give fewer than 128 workgroups
 template <int ACT, int BM, int BN, int BK, int WM, int WN>
 __global__ __launch_bounds__(256) void linear_f32_kernel(LinArgs g) {
   constexpr int PITCH = BK + 1, FM = BM / WM / 16, FN = BN / WN / 16, KQ = BK / 4;
@@ -129,12 +127,86 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(LinArgs g) {
     }
 }
 
+// Few rows (M <= 64: the CLS lane, the projections): latency is everything, because these launches sit on a side stream
+// beside CU-filling GEMMs and only run in the gaps.  One workgroup per 32 rows x 16 output columns; its four waves split
+// K four ways (each wave streams its quarter of the two operand slabs straight from global memory into MFMA operands:
+// a float4 per lane covers four consecutive k of its row - the k order inside a 16-chunk is permuted identically for
+// both operands, which a dot product does not see) and their partial tiles are summed through LDS.  N / 16 workgroups,
+// 12 dependent load batches for K = 3072 instead of 48 K-steps.
+template <int ACT>
+__global__ __launch_bounds__(256) void linear_f32_small_kernel(LinArgs g) {
+  constexpr int CB = 6;                                   // 16-k chunks per load batch
+  __shared__ f32x4 sred[3][2][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 16;
+  const int kq = g.K >> 2, kbase = wave * kq;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  const bool ok0 = m0 + r < g.M, ok1 = m0 + 16 + r < g.M, okb = n0 + r < g.N;
+  const float* a0 = g.A + (size_t)(ok0 ? m0 + r : 0) * g.lda + kbase + 4 * q;
+  const float* a1 = g.A + (size_t)(ok1 ? m0 + 16 + r : 0) * g.lda + kbase + 4 * q;
+  const float* bw = g.W + (size_t)(okb ? n0 + r : 0) * g.ldw + kbase + 4 * q;
+  f32x4 acc[2] = {zero, zero};
+  for (int c0 = 0; c0 < kq; c0 += CB * 16) {
+    f32x4 va[2][CB], vb[CB];
+#pragma unroll
+    for (int c = 0; c < CB; ++c) {
+      const int k = c0 + c * 16;
+      const bool in = k < kq;
+      va[0][c] = (in && ok0) ? *reinterpret_cast<const f32x4*>(a0 + k) : zero;
+      va[1][c] = (in && ok1) ? *reinterpret_cast<const f32x4*>(a1 + k) : zero;
+      vb[c] = (in && okb) ? *reinterpret_cast<const f32x4*>(bw + k) : zero;
+      if constexpr (ACT == 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { va[0][c][e] = fmaxf(va[0][c][e], 0.f); va[1][c][e] = fmaxf(va[1][c][e], 0.f); }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CB; ++c)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[0][c][t], vb[c][t], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[1][c][t], vb[c][t], acc[1], 0, 0, 0);
+      }
+  }
+  if (wave > 0) { sred[wave - 1][0][lane] = acc[0]; sred[wave - 1][1][lane] = acc[1]; }
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    const f32x4 v = acc[f] + sred[0][f][lane] + sred[1][f][lane] + sred[2][f][lane];     // fixed order: deterministic
+    const int col = n0 + r;
+    if (col >= g.N) continue;
+    const float b = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int row = m0 + f * 16 + q * 4 + rr;
+      if (row >= g.M) continue;
+      float y = v[rr] + b;
+      float dg = 0.f;
+      if constexpr (ACT == 1) {
+        float gl;
+        gelu_both(y, gl, dg);
+        y = gl;
+      }
+      if (g.resid) y += g.resid[(size_t)row * g.ldr + col];
+      if (g.out32) g.out32[(size_t)row * g.ldo + col] = y;
+      if (g.out16) g.out16[(size_t)row * g.ld16 + col] = f2bf(y);
+      if constexpr (ACT == 1) {
+        if (g.out16b) g.out16b[(size_t)row * g.ld16b + col] = f2bf(dg);
+      }
+    }
+  }
+}
+
 template <int ACT>
 static void launch_linear(const LinArgs& g, hipStream_t s) {
   if (g.M <= 64 && g.K % 64 == 0) {
-    hipLaunchKernelGGL((linear_f32_kernel<ACT, 32, 64, 64, 1, 4>), dim3((g.N + 63) / 64, (g.M + 31) / 32), dim3(256), 0, s, g);
-  } else {
+    hipLaunchKernelGGL(linear_f32_small_kernel<ACT>, dim3((g.N + 15) / 16, (g.M + 31) / 32), dim3(256), 0, s, g);
+  } else if (((g.N + 127) / 128) * ((g.M + 127) / 128) >= 128) {
     hipLaunchKernelGGL((linear_f32_kernel<ACT, 128, 128, 16, 2, 2>), dim3((g.N + 127) / 128, (g.M + 127) / 128), dim3(256), 0, s, g);
+  } else {     // too few 128 x 128 tiles to occupy the GPU (text tower, N = 768: 48): quarter tiles
+    hipLaunchKernelGGL((linear_f32_kernel<ACT, 64, 64, 16, 2, 2>), dim3((g.N + 63) / 64, (g.M + 63) / 64), dim3(256), 0, s, g);
   }
 }
 
