@@ -259,8 +259,21 @@ def main():
     data = synthetic_batch(args, rank, device)
     step_args = argparse.Namespace(world_size=world, rank=rank, local_rank=local)
 
-    def step():
+    def eager_step():
         return step_impl(dp, loss_fn, opt, data, step_args)
+
+    # One rank: the step is captured into a hipGraph after its warm-up steps and replayed (trainer/graph_step.py - the
+    # ~1100 launches of a step cost 20-45 ms of host time when issued one by one).  More ranks: eager, RCCL collectives
+    # overlapped with backward.  OAT_GRAPH=0 forces the eager path.
+    use_graph = world == 1 and os.environ.get("OAT_GRAPH", "1") != "0"
+    if use_graph:
+        from OATrans.trainer.graph_step import GraphedStep
+        graphed = GraphedStep(step_impl, dp, loss_fn, opt, step_args, warmup=2)
+        step = lambda: graphed(data)
+        for _ in range(3):                 # 2 eager warm-up steps + the capture (+ first replay): outside any timed region
+            step()
+    else:
+        step = eager_step
 
     for _ in range(args.warmup):
         step()
@@ -297,10 +310,11 @@ def main():
         "step_mfma_frac": round(value / world * gf_pair / 1e3 / BF16_DENSE_PEAK_TFLOPS, 4),
         "final_loss": round(loss_val, 4),
         "host_enqueue_ms_per_step": round(host_elapsed / args.steps * 1e3, 2),
+        "launch_mode": "hipGraph replay (1 launch per step)" if use_graph else "eager (one launch per kernel)",
     }
     # one more, instrumented, step for the roofline figure.  EVERY rank runs it (its collectives need all of them);
     # rank 0 reports
-    by = instrumented_gemm_profile(step)
+    by = instrumented_gemm_profile(eager_step)       # eager: the wrappers must see every launch
     if rank == 0:
         if by:
             def entry(name, d):

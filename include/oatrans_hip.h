@@ -181,6 +181,12 @@ int oat_infonce(const float* t, const float* v, int n, int d, float temperature,
 /* transformers.AdamW (hf_style=1, train_dist_multi.py:66) or torch.optim.AdamW (0) over a flat range */
 int oat_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
               float eps, float weight_decay, int step, int hf_style, float gscale, void* stream);
+/* The same update with its step-dependent scalars on the device, so that a CAPTURED launch (hipGraph replay of a whole
+ * training step) stays valid: oat_adam_tick does *step += 1 and writes coef = {*lr, 1 - beta1^step, 1 - beta2^step};
+ * oat_adamw_dev reads lr and the bias corrections from coef.  step / lr / coef are caller-owned device memory. */
+int oat_adam_tick(int* step, const float* lr, float beta1, float beta2, float* coef, void* stream);
+int oat_adamw_dev(float* p, const float* g, float* m, float* v, size_t n, const float* coef, float beta1, float beta2,
+                  float eps, float weight_decay, int hf_style, float gscale, void* stream);
 
 /* ---- object-aware extras (mask-pool / region-sim einsums, BCE, pooled tails) -------------------------
  * oa_model_global_local.py:178,200 ; oa_model_region_mem.py:117,147-151 ; trainer_region_mem.py:97,166.

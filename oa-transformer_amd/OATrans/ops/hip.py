@@ -389,6 +389,16 @@ def adamw(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, hf_style=True, 
            "oat_adamw")
 
 
+def adam_tick(step, lr, beta1, beta2, coef):
+    _check(lib().oat_adam_tick(_ptr(step), _ptr(lr), _f(beta1), _f(beta2), _ptr(coef), _stream()), "oat_adam_tick")
+
+
+def adamw_dev(p, g, m, v, coef, beta1, beta2, eps, weight_decay, hf_style=True, gscale=1.0):
+    _check(lib().oat_adamw_dev(_ptr(p), _ptr(g), _ptr(m), _ptr(v), ctypes.c_size_t(p.numel()), _ptr(coef), _f(beta1),
+                               _f(beta2), _f(eps), _f(weight_decay), int(hf_style), _f(gscale), _stream()),
+           "oat_adamw_dev")
+
+
 def sim_matrix_fwd(t, v, eps=1e-8):
     n, d = t.shape
     m = v.shape[0]

@@ -23,6 +23,7 @@ class AdamW(torch.optim.Optimizer):
         self._runs = None
         self._stream = None          # eager mode: side stream the early launches run on
         self.eager_launches = 0      # launches issued from grad-ready announcements (introspection / tests)
+        self._dev = None             # capturable mode: per-group device state {step, lr, coef} (see enable_capture)
 
     def attach(self, model):
         """EAGER mode (opt-in, single rank): the engine modules announce gradient ranges as soon as the kernels that
@@ -62,8 +63,46 @@ class AdamW(torch.optim.Optimizer):
         r['done'].append((off, off + n))
         self.eager_launches += 1
 
+    # ---- capturable mode: the step-dependent scalars live on the device -------------------------------------------
+    def enable_capture(self):
+        """Keep step count, learning rate and bias corrections in device memory (oat_adam_tick / oat_adamw_dev) so that
+        step() can be captured once into a hipGraph and replayed: a captured kernel argument could not change from
+        step to step.  The arithmetic is the same (transformers.AdamW formula), powf evaluated on the device."""
+        if self._dev is not None:
+            return self
+        if not self._runs_valid():
+            self._build_runs()
+        self._dev = []
+        for gi, g in enumerate(self.param_groups):
+            runs = [r for r in self._runs if r['group'] == gi]
+            dev = runs[0]['params'][0].device if runs else torch.device('cuda')
+            cur = self.state[runs[0]['params'][0]]['step'] if runs else 0
+            self._dev.append(dict(step=torch.full((1,), int(cur), dtype=torch.int32, device=dev),
+                                  lr=torch.full((1,), float(g['lr']), dtype=torch.float32, device=dev),
+                                  coef=torch.zeros(3, dtype=torch.float32, device=dev), lr_host=float(g['lr'])))
+        return self
+
+    def sync_device_scalars(self):
+        """Before replaying a captured step: push a learning rate the trainer changed (trainer_dist.py:117-122)."""
+        for g, d in zip(self.param_groups, self._dev or []):
+            if float(g['lr']) != d['lr_host']:
+                d['lr'].fill_(float(g['lr']))
+                d['lr_host'] = float(g['lr'])
+
+    def note_replayed_step(self):
+        """A captured step() was replayed: advance the host-side step counters (state_dict / resume)."""
+        for r in self._runs or []:
+            step = self.state[r['params'][0]]['step'] + 1
+            for p in r['params']:
+                self.state[p]['step'] = step
+
     def _launch(self, r, a, b):
         g = self.param_groups[r['group']]
+        if self._dev is not None:
+            hip.adamw_dev(r['flat_p'][a:b], r['flat_g'][a:b], r['m'][a:b], r['v'][a:b], self._dev[r['group']]['coef'],
+                          g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], hf_style=self.hf_style,
+                          gscale=self.grad_scale)
+            return
         step = self.state[r['params'][0]]['step'] + 1
         hip.adamw(r['flat_p'][a:b], r['flat_g'][a:b], r['m'][a:b], r['v'][a:b], g['lr'], g['betas'][0], g['betas'][1],
                   g['eps'], g['weight_decay'], step, hf_style=self.hf_style, gscale=self.grad_scale)
@@ -124,7 +163,13 @@ class AdamW(torch.optim.Optimizer):
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         if not self._runs_valid():
+            if self._dev is not None:
+                raise hip.OatError("AdamW: parameter / gradient buffers moved after enable_capture()")
             self._build_runs()
+        if self._dev is not None:
+            self.sync_device_scalars()
+            for g, d in zip(self.param_groups, self._dev):
+                hip.adam_tick(d['step'], d['lr'], g['betas'][0], g['betas'][1], d['coef'])
         for r in self._runs:
             pos = 0
             for a, b in sorted(r['done']):       # ranges already updated under backward (eager mode)

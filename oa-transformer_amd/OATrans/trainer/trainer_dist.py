@@ -9,6 +9,7 @@ Contract of /root/reference/OATrans/trainer/trainer_dist.py:
 Differences by construction: a single packed all-gather, gradient all-reduce over flat buffers on a side
 stream, no per-step `.item()` host syncs (losses are accumulated on the device, read once per log step).
 """
+import os
 import time
 
 import numpy as np
@@ -67,9 +68,21 @@ class Multi_Trainer_dist(Multi_BaseTrainer_dist):
         data['video'] = data['video'].to(self.device, non_blocking=True)
         return data
 
+    step_impl = staticmethod(hot_step)
+
     def train_step(self, data):
-        """forward -> gather -> sim -> loss -> backward -> grad sync -> step; returns the device loss."""
-        return hot_step(self.model, self.loss, self.optimizer, data, self.args)
+        """forward -> gather -> sim -> loss -> backward -> grad sync -> step; returns the device loss.
+        OAT_GRAPH_STEP=1 (one rank): the step is captured per input signature and replayed as one hipGraph launch
+        (trainer/graph_step.py); meant for fixed-shape batches (captions padded to a fixed length)."""
+        if self.args.world_size == 1 and os.environ.get("OAT_GRAPH_STEP", "0") == "1":
+            if getattr(self, "_graphed", None) is None:
+                try:
+                    from OATrans.trainer.graph_step import GraphedStep
+                except ImportError:
+                    from trainer.graph_step import GraphedStep
+                self._graphed = GraphedStep(type(self).step_impl, self.model, self.loss, self.optimizer, self.args)
+            return self._graphed(data)
+        return type(self).step_impl(self.model, self.loss, self.optimizer, data, self.args)
 
     def _train_epoch(self, epoch):
         self.model.train()

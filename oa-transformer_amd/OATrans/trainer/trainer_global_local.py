@@ -21,8 +21,7 @@ class Multi_Trainer_dist(_Base):
             data[k] = data[k].to(self.device)
         return data
 
-    def train_step(self, data):
-        return global_local_step(self.model, self.loss, self.optimizer, data, self.args)
+    step_impl = staticmethod(global_local_step)
 
     def _val_batch(self, data):
         """trainer_global_local.py:296-362 of the reference: short-text and tag-padded-text losses against the video

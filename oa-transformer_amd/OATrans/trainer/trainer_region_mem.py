@@ -19,8 +19,7 @@ class Multi_Trainer_dist(_Base):
         data['patch_masks'] = data['patch_masks'].to(self.device)
         return data
 
-    def train_step(self, data):
-        return region_mem_step(self.model, self.loss, self.optimizer, data, self.args)
+    step_impl = staticmethod(region_mem_step)
 
     def _val_batch(self, data):
         """trainer_region_mem.py:226-263 of the reference: InfoNCE(text, video) + BCE_sum(region_sim, patch_mask) / rows

@@ -117,8 +117,22 @@ __global__ void gemb_kernel(const float* G, const float* bn, const float* an, co
 }
 
 // ---------------------------------------------------------------- AdamW over a flat fp32 range
+// `coef` (optional, device memory): {lr, 1 - b1^step, 1 - b2^step} written by adam_tick_kernel - the step-dependent
+// scalars then live on the device and a captured launch (hipGraph replay) stays valid from step to step.
+__global__ void adam_tick_kernel(int* step, const float* lr, float b1, float b2, float* coef) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const int t = *step + 1;
+    *step = t;
+    coef[0] = *lr;
+    coef[1] = 1.f - powf(b1, (float)t);
+    coef[2] = 1.f - powf(b2, (float)t);
+  }
+}
+
 __global__ void adamw_kernel(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2,
-                             float eps, float wd, float bc1, float bc2, int hf_style, float gscale) {
+                             float eps, float wd, float bc1, float bc2, int hf_style, float gscale,
+                             const float* coef = nullptr) {
+  if (coef != nullptr) { lr = coef[0]; bc1 = coef[1]; bc2 = coef[2]; }
   const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
   for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
     if (i + 4 <= n) {
@@ -215,6 +229,25 @@ extern "C" int oat_infonce(const float* t, const float* v, int n, int d, float t
   return 0;
 }
 
+// Device-resident step state for captured (hipGraph) training steps: *step += 1; coef = {*lr, 1 - b1^step, 1 - b2^step}.
+extern "C" int oat_adam_tick(int* step, const float* lr, float beta1, float beta2, float* coef, void* stream) {
+  if (!step || !lr || !coef) { set_error("adam_tick: null pointer"); return -4; }
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step, lr, beta1, beta2, coef);
+  return check_launch("adam_tick");
+}
+// oat_adamw with the step-dependent scalars read from `coef` (device memory, see oat_adam_tick).
+extern "C" int oat_adamw_dev(float* p, const float* g, float* m, float* v, size_t n, const float* coef, float beta1,
+                             float beta2, float eps, float weight_decay, int hf_style, float gscale, void* stream) {
+  if (n == 0) return 0;
+  if (!coef) { set_error("adamw_dev: null pointer"); return -4; }
+  size_t blocks = (n / 4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, 0.f, beta1,
+                     beta2, eps, weight_decay, 1.f, 1.f, hf_style, gscale, coef);
+  return check_launch("adamw_dev");
+}
+
 // One AdamW step over a flat fp32 range.  step >= 1.  hf_style = 1: transformers.AdamW; 0: torch.optim.AdamW.
 // gscale multiplies the gradient first (1/world_size when gradients were SUM-all-reduced).
 extern "C" int oat_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
@@ -226,6 +259,6 @@ extern "C" int oat_adamw(float* p, const float* g, float* m, float* v, size_t n,
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1,
-                     beta2, eps, weight_decay, bc1, bc2, hf_style, gscale);
+                     beta2, eps, weight_decay, bc1, bc2, hf_style, gscale, (const float*)nullptr);
   return check_launch("adamw");
 }

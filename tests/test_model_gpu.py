@@ -421,3 +421,50 @@ def test_headline_batch_sim_matrix_vs_oracle_rows():
     print("bs32 8f sim-matrix max abs err on 3 video columns:", err, "text rel", rel(t, ot), "video rel", rel(v[cols], ov))
     assert err <= 1e-3, err
     assert rel(t, ot) < 1e-2 and rel(v[cols], ov) < 1e-2
+
+
+def test_graphed_step_matches_eager_steps():
+    """trainer/graph_step.py: the training step captured into one hipGraph (ctypes launches, side streams, autograd
+    backward, AdamW with device-resident step state) and replayed must walk the same trajectory as eager stepping:
+    same losses step by step (up to the fp32-atomics noise of the CLS-row gradients), same parameters, a changing
+    learning rate honoured, a second input signature captured separately."""
+    import argparse
+    import copy
+    from OATrans import model as module_arch
+    from OATrans.optim import AdamW
+    from OATrans.parallel import HipDataParallel
+    from OATrans.trainer.graph_step import GraphedStep
+    from OATrans.trainer.step import hot_step
+    sa = argparse.Namespace(world_size=1, rank=0, local_rank=0)
+    loss_fn = module_arch.NormSoftmaxLoss()
+    base = _small_frozen(seed=2, depth=2)
+    batches = [_batch(seed=10 + i) for i in range(7)]
+    other = _batch(B=2, T=2, L=7, seed=99)
+    results = []
+    for graphed in (False, True):
+        m = copy.deepcopy(base)
+        for sub in (m.video_model, m.text_model):
+            sub.flatten_parameters()
+        dp = HipDataParallel(m)
+        opt = AdamW([p for p in m.parameters() if p.requires_grad], lr=1e-4)
+        stepper = GraphedStep(hot_step, dp, loss_fn, opt, sa, warmup=2) if graphed else \
+            (lambda d: hot_step(dp, loss_fn, opt, d, sa))
+        losses = []
+        for i, b in enumerate(batches):
+            if i == 5:
+                for g in opt.param_groups:
+                    g["lr"] = 3e-5                       # the trainer's per-epoch schedule (trainer_dist.py:117-122)
+            losses.append(stepper(b).item())
+        for _ in range(4):                               # a second input signature: 2 eager steps, then its own graph
+            losses.append(stepper(other).item())
+        torch.cuda.synchronize()
+        if graphed:
+            assert stepper.replays == 5 + 2 and len(stepper._graphs) == 2
+        assert all(st["step"] == 11 for st in opt.state.values())
+        results.append((losses, {n: p.detach().clone() for n, p in m.named_parameters()}))
+    (l0, p0), (l1, p1) = results
+    assert max(abs(a - b) for a, b in zip(l0, l1)) < 5e-3, (l0, l1)
+    for n in p0:
+        d = (p0[n] - p1[n]).abs()
+        assert d.max().item() <= 11 * 2e-4 + 1e-6, (n, d.max().item())
+        assert d.mean().item() < 2e-5, (n, d.mean().item())
