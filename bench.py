@@ -30,12 +30,15 @@ import torch.distributed as dist  # noqa: E402
 BF16_DENSE_PEAK_TFLOPS = 2500.0          # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 
 
-def flops_per_pair(T, N=196, D=768, depth=12, Lt=32):  # noqa: E302
-    """Algorithmic fwd+bwd FLOPs per video-text pair (1 MAC = 2 FLOP, bwd = 2x fwd)."""
-    S = 1 + T * N
-    video = 2 * T * N * D * D + depth * (32 * S * D * D + 4 * D * (2 * S + N * T * (T + 1) + T * N * (N + 1))) + 2 * D * 256
+def flops_per_pair(T, N=196, D=768, depth=12, Lt=32, clips=None, text_passes=1):  # noqa: E302
+    """Algorithmic fwd+bwd FLOPs per video-text pair (1 MAC = 2 FLOP, bwd = 2x fwd).
+    clips: frame counts of the clips one sample sends through the video encoder (default (T,); the object-aware
+    variants add a one-frame object clip); text_passes: DistilBERT passes per sample (global_local: caption + tags)."""
+    def video(T):
+        S = 1 + T * N
+        return 2 * T * N * D * D + depth * (32 * S * D * D + 4 * D * (2 * S + N * T * (T + 1) + T * N * (N + 1))) + 2 * D * 256
     text = 6 * (24 * Lt * D * D + 4 * Lt * Lt * D) + 2 * D * 256
-    return 3 * (video + text)
+    return 3 * (sum(video(t) for t in (clips or (T,))) + text_passes * text)
 
 
 def build(args, device):
@@ -47,8 +50,8 @@ def build(args, device):
            "global_local": module_arch.oa_model_global_local.FrozenInTime}[args.variant]
     model = cls(
         video_params=dict(model="SpaceTimeTransformer", arch_config="base_patch16_224",
-                          num_frames=args.frames if args.variant == "frozen" else max(1, args.frames // 2),
-                          pretrained=True, time_init="rand", two_outputs=False,
+                          num_frames=args.frames, pretrained=True, time_init="rand", two_outputs=False,
+                          object_clip="native",
                           **({"arch_kwargs": {"img_size": args.res}} if args.res != 224 else {})),
         object_params=dict(model="", input_objects=False),
         text_params=dict(model="pretrained/distilbert-base-uncased", pretrained=True, input="text"),
@@ -74,6 +77,8 @@ def build(args, device):
 def synthetic_batch(args, rank, device):
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     B, T, L = args.batch, args.frames, 32
+    if args.variant != "frozen":
+        T += 1                      # frame 0 = the object frame (its 10 / 5 box masks are in patch_masks), then the clip
     video = torch.randn(B, T, 3, args.res, args.res, generator=g).to(torch.bfloat16).to(device)
     ids = torch.randint(1000, 30000, (B, L), generator=g)
     ids[:, 0], ids[:, -1] = 101, 102
@@ -233,14 +238,12 @@ def main():
                          "synthetic batch spike at that value, which says nothing about throughput but makes final_loss useless)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", choices=["frozen", "region_mem", "global_local"], default="frozen",
-                    help="frozen = oa_model.FrozenInTime (headline); the OA variants view the F input frames as 2B clips of "
-                         "F/2 frames (object stream + video stream); their mask-pool / region-BCE shapes are only valid "
-                         "for F = 2, exactly as in the reference")
+                    help="frozen = oa_model.FrozenInTime (headline).  The OA variants (BASELINE config 3) take one object "
+                         "frame (box masks on its 14x14 patch grid) + a --frames clip per sample, both through the same "
+                         "encoder weights ('native' object-clip layout, oa_model_global_local.py docstring)")
     args = ap.parse_args()
-    if args.variant != "frozen" and args.frames != 2:
-        print(f"### --variant {args.variant}: patch masks live on one frame's 14x14 grid, so the OA clips are single-frame "
-              "(2 input frames = object frame + video frame, SURVEY.md 8a a16); running with --frames 2", file=sys.stderr)
-        args.frames = 2
+    if args.variant != "frozen" and args.res != 224:
+        raise SystemExit("the object-aware variants rasterise boxes on the 14x14 patch grid of a 224^2 frame (reference datasets)")
     world = int(os.environ.get("WORLD_SIZE", 1))
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -295,14 +298,19 @@ def main():
     loss_val = float(loss.item())
     pairs = world * args.batch * args.steps
     value = pairs / elapsed
-    gf_pair = flops_per_pair(args.frames, N=(args.res // 16) ** 2) / 1e9
+    oa = args.variant != "frozen"
+    gf_pair = flops_per_pair(args.frames, N=(args.res // 16) ** 2, clips=(1, args.frames) if oa else None,
+                             text_passes=2 if args.variant == "global_local" else 1) / 1e9
+    n_obj = {"region_mem": 5, "global_local": 10}.get(args.variant)
+    clip_txt = f"{args.frames}-frame + {n_obj} obj (one object frame with {n_obj} box masks + the {args.frames}-frame clip, same encoder)" \
+        if oa else f"{args.frames}-frame"
     cls_name = {"frozen": "oa_model", "region_mem": "oa_model_region_mem", "global_local": "oa_model_global_local"}[args.variant]
     out = {
         "metric": "video-text pairs/sec fwd+bwd, 8-frame ViT-B/16, 1/2/4/8 MI355X",
         "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"[{args.variant}] {args.frames}-frame {args.res}^2 ViT-B/16 SpaceTimeTransformer + DistilBERT-base ({cls_name}.FrozenInTime), "
+        "config": {"workload": f"[{args.variant}] {clip_txt} {args.res}^2 ViT-B/16 SpaceTimeTransformer + DistilBERT-base ({cls_name}.FrozenInTime), "
                                f"bs {args.batch}/GPU, Lt 32, fwd+bwd+AdamW, InfoNCE over all-gathered embeddings",
                    "per_gpu_batch": args.batch, "global_batch": world * args.batch, "frames": args.frames,
                    "parallelism": f"dp{world}", "gflop_per_pair": round(gf_pair, 1)},

@@ -155,8 +155,10 @@ class VideoEngine:
         self._cast.run()                                          # all 73 W / W^T shadows in one launch
         self.shadow_versions = sig
 
-    def plan(self, B, T, N, dev):
-        key = (B, T, N, str(dev))
+    def plan(self, B, T, N, dev, call=0):
+        """One plan per clip shape AND per call of a step: the object-aware models encode two clips (object frame,
+        video) through the same weights in one step, and each forward's activations must survive to its backward."""
+        key = (B, T, N, str(dev), call)
         if key not in self.plans:
             self.plans[key] = _Plan(B, T, N, self.D, self.Hd, self.H, self.depth, self.Kp, dev)
         return self.plans[key]
@@ -169,7 +171,7 @@ class VideoEngine:
         return self._streams
 
     # ------------------------------------------------------------------ forward
-    def forward(self, video, params, need_patches=False, sig=None, region_layer=None):
+    def forward(self, video, params, need_patches=False, sig=None, region_layer=None, call=0):
         """video [B,T,C,R,R] fp32|bf16 -> (cls_normed fp32 [B,D], patches_normed fp32 [B*T*N, D] | None, run).
         region_layer=K additionally leaves region_norm(x after block K)[patch rows] in run.region
         (oa_video_transformer_region.py:364-376)."""
@@ -181,7 +183,7 @@ class VideoEngine:
         self.refresh_shadows(params, sig)
         dev = video.device
         st = self._get_streams(dev)
-        pl = self.plan(B, T, N, dev)
+        pl = self.plan(B, T, N, dev, call)
         pl.side = st["side"]
         pl.video = video.contiguous()
         if self.cls_lane and pl.lane is None:
@@ -347,8 +349,9 @@ class VideoEngine:
                           mean=pl.rstats[0], rstd=pl.rstats[1])
 
     # ------------------------------------------------------------------ backward
-    def backward(self, run, params, grads, d_cls, d_patches=None, d_region=None, ready=None):
-        """Writes every video parameter gradient into `grads`.  d_cls fp32 [B,D]; d_patches fp32 [B*T*N, D] or
+    def backward(self, run, params, grads, d_cls, d_patches=None, d_region=None, ready=None, accumulate=False):
+        """Writes every video parameter gradient into `grads` (accumulate=True: ADDS to them - the second and later
+        backward of a step in which the encoder ran more than once).  d_cls fp32 [B,D]; d_patches fp32 [B*T*N, D] or
         None (contract class oa_model.FrozenInTime discards patch outputs); d_region fp32 [B*T*N, D] =
         gradient of run.region (enters the residual stream below block `region_layer`).
 
@@ -361,6 +364,7 @@ class VideoEngine:
         st = self._get_streams(run.G.device)
         pl = run.pl
         pl.hbm = st["hbm"] if self.bwd_side else None
+        pl.acc = bool(accumulate)
         pl.cls_side.zero_()          # once per backward; every attn_cls_finalize leaves it zero for the next one
         self._final_bwd(pl, run, params, grads, d_cls.contiguous(), d_patches, d_region)
         if run.region_layer is not None:
@@ -413,11 +417,11 @@ class VideoEngine:
         if done is not None:
             torch.cuda.current_stream().wait_event(done)
 
-    def _wgrad(self, P, Q, rows, n1, n2, w, b):
+    def _wgrad(self, P, Q, rows, n1, n2, w, b, acc=False):
         need = hip.lib().oat_gemm_tn_workspace_bytes(rows, n1, n2) // 4     # exact for this (rows, shape)
         if self._tn_ws is None or self._tn_ws.numel() < need:
             self._tn_ws = torch.empty(need, dtype=torch.float32, device=P.device)   # one slab workspace, grown on demand
-        hip.gemm_tn(P, Q, rows, n1, n2, w, bias_out=b, ws=self._tn_ws)
+        hip.gemm_tn(P, Q, rows, n1, n2, w, bias_out=b, ws=self._tn_ws, accumulate=acc)
 
     def _final_bwd(self, pl, run, params, grads, d_cls, d_patches, d_region):
         D = self.D
@@ -428,13 +432,14 @@ class VideoEngine:
         if run.need_patches and d_patches is not None:
             dn = torch.cat([d_patches, d_cls], dim=0).contiguous()
             hip.layernorm_bwd(dn, pl.x_final, pl.fstats[0], pl.fstats[1], params["norm.weight"], M, D, dx=G, dx16=g16,
-                              dgamma=grads["norm.weight"], dbeta=grads["norm.bias"])
+                              dgamma=grads["norm.weight"], dbeta=grads["norm.bias"], accumulate=pl.acc)
         else:
             G[:BTN].zero_()
             g16[:BTN].zero_()
             hip.layernorm_bwd(d_cls, pl.x_final[BTN:], pl.fstats[0][BTN:], pl.fstats[1][BTN:], params["norm.weight"], B, D,
-                              dx=G[BTN:], dx16=g16[BTN:], dgamma=grads["norm.weight"], dbeta=grads["norm.bias"])
-        if run.region_layer is not None and d_region is None:
+                              dx=G[BTN:], dx16=g16[BTN:], dgamma=grads["norm.weight"], dbeta=grads["norm.bias"],
+                              accumulate=pl.acc)
+        if run.region_layer is not None and d_region is None and not pl.acc:
             for k in ("region_norm.weight", "region_norm.bias"):
                 grads[k].zero_()
 
@@ -451,7 +456,7 @@ class VideoEngine:
             # region tokens branch off the output of block rl-1: add their gradient to the stream
             hip.layernorm_bwd(d_region.contiguous(), a.out, pl.rstats[0], pl.rstats[1], params["region_norm.weight"],
                               BTN, D, dx=G, dx16=ga, dres=G, dgamma=grads["region_norm.weight"],
-                              dbeta=grads["region_norm.bias"])
+                              dbeta=grads["region_norm.bias"], accumulate=pl.acc)
         x = pl.blocks[i - 1].out if i > 0 else pl.x0
         p = lambda s: params[f"blocks.{i}.{s}"]
         gr = lambda s: grads[f"blocks.{i}.{s}"]
@@ -463,8 +468,8 @@ class VideoEngine:
         hip.gemm_nt(d_h, wT("mlp.fc1"), M, D, Hd, hip.EPI_BF16, pl.d_a)
         s1 = self._slot(pl, lambda: hip.layernorm_bwd(
             pl.d_a, a.y, st[4], st[5], p("norm2.weight"), M, D, dx=G, dx16=gb, dres=G,
-            dgamma=gr("norm2.weight"), dbeta=gr("norm2.bias")),                               # G = dL/dy
-            [lambda: self._wgrad(ga, a.g, M, D, Hd, gr("mlp.fc2.weight"), gr("mlp.fc2.bias"))])
+            dgamma=gr("norm2.weight"), dbeta=gr("norm2.bias"), accumulate=pl.acc),                               # G = dL/dy
+            [lambda: self._wgrad(ga, a.g, M, D, Hd, gr("mlp.fc2.weight"), gr("mlp.fc2.bias"), pl.acc)])
         self._join(s1)
         # ---- space attention: y = x + proj(attn(LN1(xt)))
         hip.gemm_nt(gb, wT("attn.proj"), M, D, D, hip.EPI_BF16, pl.d_o)
@@ -473,14 +478,14 @@ class VideoEngine:
             hip.attn_space_bwd(a.qkv_s, a.o_s, a.lse_s, pl.d_o, d_qkv_s, pl.cls_side, B, T, N, H, D, self.scale)
             hip.attn_cls_finalize(pl.cls_side, d_qkv_s, B, T, N, H, D)
         s2 = self._slot(pl, space_bwd,
-                        [lambda: self._wgrad(d_h, a.a2, M, Hd, D, gr("mlp.fc1.weight"), gr("mlp.fc1.bias"))])
+                        [lambda: self._wgrad(d_h, a.a2, M, Hd, D, gr("mlp.fc1.weight"), gr("mlp.fc1.bias"), pl.acc)])
         self._join(s2)
         hip.gemm_nt(d_qkv_s, wT("attn.qkv"), M, D, 3 * D, hip.EPI_BF16, pl.d_a)
         # G <- dL/dy + dL/dxt (both reach x directly); gc <- dL/dxt alone (feeds the time branch)
         s3 = self._slot(pl, lambda: hip.layernorm_bwd(
             pl.d_a, a.xt, st[2], st[3], p("norm1.weight"), M, D, dx=G, dx16=gc, dres=G, dx16_excl_res=True,
-            dgamma=gr("norm1.weight"), dbeta=gr("norm1.bias")),
-            [lambda: self._wgrad(d_qkv_s, a.a1, M, 3 * D, D, gr("attn.qkv.weight"), gr("attn.qkv.bias"))])
+            dgamma=gr("norm1.weight"), dbeta=gr("norm1.bias"), accumulate=pl.acc),
+            [lambda: self._wgrad(d_qkv_s, a.a1, M, 3 * D, D, gr("attn.qkv.weight"), gr("attn.qkv.bias"), pl.acc)])
         self._join(s3)
         # ---- time attention: xt = x + proj(attn(LN3(x)))
         hip.gemm_nt(gc, wT("timeattn.proj"), M, D, D, hip.EPI_BF16, pl.d_o)
@@ -489,14 +494,14 @@ class VideoEngine:
             hip.attn_time_bwd(a.qkv_t, a.o_t, a.lse_t, pl.d_o, d_qkv_t, pl.cls_side, B, T, N, H, D, self.scale)
             hip.attn_cls_finalize(pl.cls_side, d_qkv_t, B, T, N, H, D)
         s4 = self._slot(pl, time_bwd,
-                        [lambda: self._wgrad(gb, a.o_s, M, D, D, gr("attn.proj.weight"), gr("attn.proj.bias")),
-                         lambda: self._wgrad(gc, a.o_t, M, D, D, gr("timeattn.proj.weight"), gr("timeattn.proj.bias"))])
+                        [lambda: self._wgrad(gb, a.o_s, M, D, D, gr("attn.proj.weight"), gr("attn.proj.bias"), pl.acc),
+                         lambda: self._wgrad(gc, a.o_t, M, D, D, gr("timeattn.proj.weight"), gr("timeattn.proj.bias"), pl.acc)])
         self._join(s4)
         hip.gemm_nt(d_qkv_t, wT("timeattn.qkv"), M, D, 3 * D, hip.EPI_BF16, pl.d_a)
         s5 = self._slot(pl, lambda: hip.layernorm_bwd(
             pl.d_a, x, st[0], st[1], p("norm3.weight"), M, D, dx=G, dx16=ga_next, dres=G,
-            dgamma=gr("norm3.weight"), dbeta=gr("norm3.bias")),                               # G = dL/dx
-            [lambda: self._wgrad(d_qkv_t, a.a3, M, 3 * D, D, gr("timeattn.qkv.weight"), gr("timeattn.qkv.bias"))])
+            dgamma=gr("norm3.weight"), dbeta=gr("norm3.bias"), accumulate=pl.acc),                               # G = dL/dx
+            [lambda: self._wgrad(d_qkv_t, a.a3, M, 3 * D, D, gr("timeattn.qkv.weight"), gr("timeattn.qkv.bias"), pl.acc)])
         self._join(s5)
 
     def _embed_bwd(self, pl, grads):
@@ -506,14 +511,15 @@ class VideoEngine:
         BTN = M - B
         G = pl.G
         gw = grads["patch_embed.proj.weight"]
-        self._wgrad(pl.ga[(-1) % 3], pl.cols, BTN, D, self.Kp, gw.view(D, self.Kp), grads["patch_embed.proj.bias"])
+        self._wgrad(pl.ga[(-1) % 3], pl.cols, BTN, D, self.Kp, gw.view(D, self.Kp), grads["patch_embed.proj.bias"], pl.acc)
         hip.periodic_rowsum(G, B, T * N, D, pl.Gp)
         gpos = grads["pos_embed"].view(N + 1, D)
         gt = grads["temporal_embed"].view(-1, D)
         gcls = grads["cls_token"].view(1, D)
-        hip.periodic_rowsum(pl.Gp, T, N, D, gpos[1:])
-        if T < gt.shape[0]:
+        acc = pl.acc
+        hip.periodic_rowsum(pl.Gp, T, N, D, gpos[1:], accumulate=acc)
+        if T < gt.shape[0] and not acc:
             gt[T:].zero_()
-        hip.grouped_rowsum(pl.Gp, T, N, D, gt[:T])
-        hip.grouped_rowsum(G[BTN:], 1, B, D, gcls)
-        gpos[:1].copy_(gcls)             # pos_embed[0] only ever meets the CLS token
+        hip.grouped_rowsum(pl.Gp, T, N, D, gt[:T], accumulate=acc)
+        hip.grouped_rowsum(G[BTN:], 1, B, D, gcls, accumulate=acc)
+        gpos[:1].copy_(gcls)             # pos_embed[0] only ever meets the CLS token: its gradient IS cls_token's

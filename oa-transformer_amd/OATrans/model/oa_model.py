@@ -82,6 +82,7 @@ class FrozenInTime(BaseModel):
 
     def begin_step(self):
         self.text_model.begin_step()
+        self.video_model.begin_step()
 
     def forward(self, data, aug=False, return_embeds=True):
         # the two towers are independent until the loss: the (small, launch-bound) text tower runs on its

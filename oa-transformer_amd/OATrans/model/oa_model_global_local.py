@@ -4,7 +4,17 @@ object tags) with pooling tok0 + mean(tok1:) (:217); 2B-clip video stream; local
 region_feat = vid_local_proj(patch_masks @ object patches) (:178), tags_feat = text_local_proj(tags_masks
 @ pad-text tokens) (:200).  The reference builds tags_masks with a Python loop over B x O on the host
 (:183-196); here it is one device kernel.  `cross_model = CrossModalityFusion()` (:143) is undefined in the
-reference and never used in forward - it is not reproduced."""
+reference and never used in forward - it is not reproduced.
+
+Object clip layouts (`video_params['object_clip']`):
+  'interleaved'  the reference's: data['video'] [B, F, ...] is VIEWED as 2B clips of F/2 frames (:170) - the even
+                 clips are called object images, the odd ones videos.  Only F = 2 gives what the names say.
+  'native'       data['video'] = [object frame | T video frames] (F = 1 + T): the one-frame object clip and the
+                 T-frame video clip go through the SAME encoder weights as two calls (gradients of the second
+                 accumulate into the first's); mask-pooling and the region similarity are unchanged.  This is the
+                 form config 3 of BASELINE.json needs at 8 frames ("8-frame + 10 obj"); at F = 2 both layouts are
+                 the same computation (tests/test_oa_gpu.py pins native against the F = 2 goldens).
+  'auto' (default)  native when F is odd, interleaved otherwise."""
 import os
 
 import torch
@@ -17,6 +27,27 @@ from .oa_layers import mask_pool, mean_rows, mix
 from .oa_model import BaseModel, FrozenInTime as _Plain, VIT_INIT
 from .oa_video_transformer_global_local import SpaceTimeTransformer
 from .text_transformer import DistilBertHIP
+
+
+def encode_object_and_video(model, v):
+    """Shared by the global+local and the region-memory models: run the video encoder over the object clip and the
+    video clip of every sample.  Returns (object_emb, object_region, video_emb, video_region) where *_region are
+    whatever `model.compute_video` returns second."""
+    layout = model.video_params.get('object_clip', 'auto')
+    F = v.size(1)
+    if layout == 'auto':
+        layout = 'native' if F % 2 else 'interleaved'
+    if layout == 'interleaved':
+        v = v.view(v.size(0) * 2, -1, v.size(2), v.size(3), v.size(4))     # oa_model_global_local.py:170
+        emb, region = model.compute_video(v)
+        return emb[0::2], region[0::2], emb[1::2], region[1::2]
+    if layout != 'native':
+        raise ValueError(f"object_clip = {layout!r}: expected 'auto', 'interleaved' or 'native'")
+    if F < 2:
+        raise ValueError("native object clip layout needs the object frame and at least one video frame")
+    obj_emb, obj_region = model.compute_video(v[:, :1])
+    vid_emb, vid_region = model.compute_video(v[:, 1:])
+    return obj_emb, obj_region, vid_emb, vid_region
 
 
 class FrozenInTime(BaseModel):
@@ -63,15 +94,16 @@ class FrozenInTime(BaseModel):
 
     def begin_step(self):
         self.text_model.begin_step()
+        self.video_model.begin_step()
+
+    def encode_clips(self, v):
+        """data['video'] -> (object_emb, object_region, video_emb, video_region) in the configured clip layout."""
+        return encode_object_and_video(self, v)
 
     def forward(self, data, return_embeds=True):
         text_embeddings, text_tokens = self.compute_text(data['text'])
         pad_text_embeddings, pad_tokens = self.compute_text(data['pad_text'])
-        v = data['video']
-        v = v.view(v.size(0) * 2, -1, v.size(2), v.size(3), v.size(4))
-        vision_embeddings, vision_region = self.compute_video(v)
-        object_image_embeddings, object_region = vision_embeddings[0::2], vision_region[0::2]
-        video_embeddings, video_region = vision_embeddings[1::2], vision_region[1::2]
+        object_image_embeddings, object_region, video_embeddings, video_region = self.encode_clips(data['video'])
         region_feat = mask_pool(data['patch_masks'].float(), object_region)
         n_txt = data['text']['attention_mask'].sum(dim=1)
         tags_masks = hip.tag_masks(data['object_token_masks'].to(torch.int64), n_txt.to(torch.int64), pad_tokens.shape[1])

@@ -1,6 +1,7 @@
 """FrozenInTime, region-memory variant
 (/root/reference/OATrans/model/oa_model_region_mem.py:19-151): the input holds F = 2*T' frames per
-sample; `view(2B, T', ...)` makes even clips the "object frames" and odd clips the video (:109-115).
+sample; `view(2B, T', ...)` makes even clips the "object frames" and odd clips the video (:109-115) - or, in the
+'native' clip layout (oa_model_global_local.py docstring), frame 0 is the object frame and frames 1..T the video.
 vid_proj is applied to the CLS and to every block-6 region token; the video embedding is
 (cls + mean regions)/2; region_sim = sigmoid(text-region x object-region^T)."""
 import os
@@ -12,6 +13,7 @@ from ..utils.util import state_dict_data_parallel_fix
 from .layers import HipLinear, ReLULinear, sim_matrix  # noqa: F401
 from .oa_layers import mean_rows, mix, region_sim
 from .oa_model import BaseModel, FrozenInTime as _Plain, VIT_INIT
+from .oa_model_global_local import encode_object_and_video
 from .oa_video_transformer_region import SpaceTimeTransformer
 from .text_transformer import DistilBertHIP
 
@@ -56,14 +58,13 @@ class FrozenInTime(BaseModel):
 
     def begin_step(self):
         self.text_model.begin_step()
+        self.video_model.begin_step()
 
     def forward(self, data, aug=False, return_embeds=True):
         text_embeddings = self.compute_text(data['text'])
-        v = data['video']
-        v = v.view(v.size(0) * 2, -1, v.size(2), v.size(3), v.size(4))
-        vision_embeddings, vision_region = self.compute_video(v)
-        object_region = vision_region[0::2]
-        video_embeddings, video_region = vision_embeddings[1::2], vision_region[1::2]
+        # clip layouts ('interleaved' = the reference's view(2B, F/2), 'native' = object frame + T-frame video):
+        # oa_model_global_local.encode_object_and_video
+        _, object_region, video_embeddings, video_region = encode_object_and_video(self, data['video'])
         text_region = self.txt_proj_2(data['text_region_embedding'].float())
         video_embeddings = mix(video_embeddings, mean_rows(video_region), 0.5, 0.5)
         return text_embeddings, video_embeddings, self.compute_region_sim(object_region, text_region)

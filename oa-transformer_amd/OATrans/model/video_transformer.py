@@ -68,14 +68,19 @@ class _PatchEmbed(nn.Module):
 
 class _EncoderFn(torch.autograd.Function):
     """Bridges the explicit schedules into autograd.  Parameter gradients are written by the
-    kernels straight into persistent `.grad` buffers (overwrite semantics, one call per step),
-    so the function returns None for them."""
+    kernels straight into persistent `.grad` buffers, so the function returns None for them.  The first backward of
+    a step overwrites them, later ones (the encoder ran more than once: object clip + video clip of the object-aware
+    models) accumulate; `begin_step()` of the owning model resets the call counters."""
 
     @staticmethod
     def forward(ctx, module, video, need_patches, region_layer, *params):
         eng = module._engine
         pd = module._param_data()
-        cls, patches, plan = eng.forward(video, pd, need_patches, module._weights_signature(), region_layer)
+        call = 0
+        if module._track_calls:              # a forward that will be differentiated keeps its own activation plan
+            call = module._fwd_calls
+            module._fwd_calls += 1
+        cls, patches, plan = eng.forward(video, pd, need_patches, module._weights_signature(), region_layer, call=call)
         ctx.module, ctx.plan = module, plan
         ctx.set_materialize_grads(False)
         B, D = video.shape[0], cls.shape[-1]
@@ -93,9 +98,17 @@ class _EncoderFn(torch.autograd.Function):
             d_patches = d_patches.reshape(-1, D).float()
         if d_region is not None:
             d_region = d_region.reshape(-1, D).float()
-        ready = module._announce if module.grad_ready_hook is not None else None
+        accumulate = module._bwd_calls > 0
+        module._bwd_calls += 1
+        # a block's gradients are final - and may go to the all-reduce / eager optimiser - only in the LAST backward of
+        # the step (earlier clips have been accumulated by then); if a clip's output never receives a gradient the
+        # ranges stay unannounced and are handled after backward (GradSync.all_reduce / AdamW.step)
+        last = module._bwd_calls >= module._fwd_calls
+        ready = module._announce if (module.grad_ready_hook is not None and last) else None
         module._engine.backward(plan, module._param_data(), module._grad_views(), d_cls.float(), d_patches, d_region,
-                                ready=ready)
+                                ready=ready, accumulate=accumulate)
+        if last:
+            module._fwd_calls = module._bwd_calls = 0        # step complete without begin_step(): start over
         return (None, None, None, None) + (None,) * module._n_params
 
 
@@ -138,6 +151,8 @@ class SpaceTimeTransformer(EngineModule):
             self.apply(self._init_weights)
         self.need_patch_tokens = True
         self.region_layer = None
+        self._fwd_calls = self._bwd_calls = 0
+        self._track_calls = True
         self._engine = VideoEngine(depth, embed_dim, num_heads, mlp_ratio, self.patch_embed.patch_size[0], in_chans,
                                    num_frames)
 
@@ -150,6 +165,10 @@ class SpaceTimeTransformer(EngineModule):
             nn.init.constant_(m.bias, 0)
             nn.init.constant_(m.weight, 1.0)
 
+    def begin_step(self):
+        """A new training step: the next backward overwrites the gradient buffers."""
+        self._fwd_calls = self._bwd_calls = 0
+
     @torch.jit.ignore
     def no_weight_decay(self):
         return {'pos_embed', 'cls_token'}
@@ -159,6 +178,7 @@ class SpaceTimeTransformer(EngineModule):
             raise hip.OatError("SpaceTimeTransformer runs on MI355X only (no CPU path); use the oracle for CPU")
         hip.lib()
         params = [p for _, p in self._engine_params()]
+        self._track_calls = torch.is_grad_enabled()
         cls, patches, region = _EncoderFn.apply(self, x, bool(self.need_patch_tokens), self.region_layer, *params)
         if self.region_layer is not None:
             return cls, patches, region

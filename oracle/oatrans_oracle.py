@@ -242,19 +242,37 @@ def video_encoder_gl(video, p, num_heads=12, pre="video_model."):
     return gl_tail(_ln(x, p, pre + "norm", 1e-6))
 
 
+def _object_and_video_clips(video, encode, object_clip):
+    """The clip layouts of the object-aware models.  'interleaved' is the reference's own
+    (oa_model_global_local.py:170 / oa_model_region_mem.py:109): [B, F] frames viewed as 2B clips of F/2 frames, even
+    clips = object images, odd clips = videos.  'native' (BASELINE.json config 3, "8-frame + 10 obj"; no reference
+    line - the reference's view() cannot express it) takes frame 0 as a one-frame object clip and frames 1..T as the
+    video clip and encodes both with the same weights; everything downstream is unchanged.  At F = 2 the two
+    layouts are the same computation (tests/test_oracle_cpu.py).  `encode(clips) -> (emb, region)`."""
+    if object_clip == "interleaved":
+        B = video.shape[0]
+        emb, region = encode(video.reshape(B * 2, -1, *video.shape[2:]))
+        return emb[0::2], region[0::2], emb[1::2], region[1::2]
+    assert object_clip == "native", object_clip
+    obj_emb, obj_region = encode(video[:, :1])
+    vid_emb, vid_region = encode(video[:, 1:])
+    return obj_emb, obj_region, vid_emb, vid_region
+
+
 def _relu_lin(x, p, name):
     return F.linear(F.relu(x), p[name + ".1.weight"], p[name + ".1.bias"])
 
 
-def region_mem_forward(p, video, input_ids, attention_mask, text_region_embedding, num_heads=12, text_heads=12):
+def region_mem_forward(p, video, input_ids, attention_mask, text_region_embedding, num_heads=12, text_heads=12,
+                       object_clip="interleaved"):
     """oa_model_region_mem.FrozenInTime.forward (oa_model_region_mem.py:105-123,141-151)."""
     t = _relu_lin(distilbert(input_ids, attention_mask, p, n_heads=text_heads)[:, 0], p, "txt_proj")
-    B = video.shape[0]
-    v = video.reshape(B * 2, -1, *video.shape[2:])
-    cls, region = video_encoder_region(v, p, num_heads)
     proj = lambda z: F.linear(z, p["vid_proj.0.weight"], p["vid_proj.0.bias"])
-    emb, reg = proj(cls), proj(region)
-    obj_region, vid_emb, vid_region = reg[0::2], emb[1::2], reg[1::2]
+
+    def encode(v):
+        cls, region = video_encoder_region(v, p, num_heads)
+        return proj(cls), proj(region)
+    _, obj_region, vid_emb, vid_region = _object_and_video_clips(video, encode, object_clip)
     treg = _relu_lin(text_region_embedding, p, "txt_proj_2")
     video_emb = (vid_emb + vid_region.mean(dim=1)) / 2
     return t, video_emb, region_sim(treg, obj_region)
@@ -278,18 +296,19 @@ def tag_masks(object_token_masks, n_txt, L):
     return ((pos >= base + starts[:, :, None]) & (pos < base + ends[:, :, None])).float()
 
 
-def gl_forward(p, video, text, pad_text, patch_masks, object_token_masks, num_heads=12, text_heads=12):
+def gl_forward(p, video, text, pad_text, patch_masks, object_token_masks, num_heads=12, text_heads=12,
+               object_clip="interleaved"):
     """oa_model_global_local.FrozenInTime.forward (oa_model_global_local.py:149-208, :210-221)."""
     def compute_text(ids, mask):
         h = distilbert(ids, mask, p, n_heads=text_heads)
         return _relu_lin(h[:, 0] + h[:, 1:].mean(dim=1), p, "txt_proj"), h
     t, ttok = compute_text(*text)
     pt, ptok = compute_text(*pad_text)
-    B = video.shape[0]
-    v = video.reshape(B * 2, -1, *video.shape[2:])
-    emb, region = video_encoder_gl(v, p, num_heads)
-    emb = F.linear(emb, p["vid_proj.0.weight"], p["vid_proj.0.bias"])
-    obj_emb, obj_region, vid_emb, vid_region = emb[0::2], region[0::2], emb[1::2], region[1::2]
+
+    def encode(v):
+        emb, region = video_encoder_gl(v, p, num_heads)
+        return F.linear(emb, p["vid_proj.0.weight"], p["vid_proj.0.bias"]), region
+    obj_emb, obj_region, vid_emb, vid_region = _object_and_video_clips(video, encode, object_clip)
     region_feat = mask_pool(patch_masks.float(), obj_region)
     tm = tag_masks(object_token_masks, text[1].sum(dim=1), ptok.shape[1])
     tags_feat = mask_pool(tm, ptok)

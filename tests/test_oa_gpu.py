@@ -81,12 +81,16 @@ def _cuda(d):
     return {k: v.cuda() for k, v in d.items()}
 
 
-def test_region_mem_model_vs_reference_golden(golden_dir):
+@pytest.mark.parametrize("layout", ["interleaved", "native"])
+def test_region_mem_model_vs_reference_golden(golden_dir, layout):
+    """layout='native' (object clip and video clip as two encoder calls, second backward accumulating) is the same
+    computation as the reference's at F = 2, so the reference goldens pin it too - gradients included."""
     from OATrans.model.oa_layers import bce_sum
     from OATrans.model.oa_model_region_mem import FrozenInTime
     from OATrans.model import NormSoftmaxLoss, sim_matrix
     g = _golden(golden_dir, "oa_region_mem.pt")
-    m = FrozenInTime(dict(model="SpaceTimeTransformer", arch_config="base_patch16_224", num_frames=1, pretrained=True, time_init="rand"),
+    m = FrozenInTime(dict(model="SpaceTimeTransformer", arch_config="base_patch16_224", num_frames=1, pretrained=True, time_init="rand",
+                          object_clip=layout),
                      dict(model="", input_objects=False), dict(model="pretrained/distilbert-base-uncased", pretrained=True, input="text"))
     r = m.load_state_dict(region_params(), strict=False)
     assert not r.unexpected_keys and not r.missing_keys, r
@@ -111,12 +115,14 @@ def test_region_mem_model_vs_reference_golden(golden_dir):
     check_probe(m, g["grad_probe"], tol=1e-1)
 
 
-def test_global_local_model_vs_reference_golden(golden_dir):
+@pytest.mark.parametrize("layout", ["interleaved", "native"])
+def test_global_local_model_vs_reference_golden(golden_dir, layout):
     from OATrans.model.oa_model_global_local import FrozenInTime
     from OATrans.model import NormSoftmaxLoss, sim_matrix
     from OATrans.model.oa_layers import mean_rows
     g = _golden(golden_dir, "oa_global_local.pt")
-    m = FrozenInTime(dict(model="SpaceTimeTransformer", arch_config="base_patch16_224", num_frames=1, pretrained=True, time_init="rand", two_outputs=False),
+    m = FrozenInTime(dict(model="SpaceTimeTransformer", arch_config="base_patch16_224", num_frames=1, pretrained=True, time_init="rand", two_outputs=False,
+                          object_clip=layout),
                      dict(model="", input_objects=False), dict(model="pretrained/distilbert-base-uncased", pretrained=True, input="text"))
     r = m.load_state_dict(gl_params(), strict=False)
     assert not r.unexpected_keys and not r.missing_keys, r
@@ -137,6 +143,97 @@ def test_global_local_model_vs_reference_golden(golden_dir):
     assert all(e < 1e-2 for e in errs.values()), errs
     assert abs(loss.item() - g["loss"].item()) < 3e-2 * max(1.0, abs(g["loss"].item()))
     check_probe(m, g["grad_probe"])
+
+
+def _oracle_grads(p, loss):
+    loss.backward()
+    return {k: v.grad for k, v in p.items() if v.grad is not None}
+
+
+def _check_grads_vs_oracle(model, og, tol=5e-2, skip=("object_embed",)):
+    """Every parameter gradient against the oracle's autograd: norm within `tol`, direction cosine >= 0.99 (tensors
+    whose oracle gradient is ~0 are skipped; bs 2 leaves heavy cancellation in the last-layer CLS parameters)."""
+    bad = []
+    for k, prm in model.named_parameters():
+        if any(s in k for s in skip) or k not in og or og[k].norm() < 1e-6:
+            continue
+        g = prm.grad
+        assert g is not None, k
+        g, r = g.detach().float().cpu().flatten(), og[k].flatten()
+        nerr = abs(g.norm() - r.norm()).item() / r.norm().item()
+        cos = torch.dot(g, r).item() / (g.norm().item() * r.norm().item() + 1e-30)
+        if nerr > tol or cos < 0.99:
+            bad.append((k, round(nerr, 4), round(cos, 4)))
+    assert not bad, bad[:10]
+
+
+@pytest.mark.parametrize("variant", ["global_local", "region_mem"])
+def test_native_object_clip_4_frames_vs_oracle(variant):
+    """BASELINE config 3's shape class at test size: one object frame + a 4-frame clip through the same 12-block
+    encoder (two encoder calls, the second backward accumulating into the first's gradients) against the fp32 oracle
+    run of the same graph (oracle components pinned by the reference goldens, its native layout by
+    test_native_clip_layout_is_the_reference_at_two_frames).  Tolerances: embeddings rel-L2 <= 1e-2, loss rel <= 3e-2,
+    gradients norm <= 5e-2 / cosine >= 0.99."""
+    from OATrans.model import NormSoftmaxLoss, sim_matrix
+    from OATrans.model.oa_layers import bce_sum, mean_rows
+    from OATrans.utils import seeded_init as si
+    from oracle import oatrans_oracle as orc
+    torch.set_num_threads(8)
+    T = 4
+    d = oa_inputs(F=T + 1)
+    if variant == "global_local":
+        from OATrans.model.oa_model_global_local import FrozenInTime
+        p = gl_params()
+    else:
+        from OATrans.model.oa_model_region_mem import FrozenInTime
+        p = region_params()
+    p["video_model.temporal_embed"] = si.seeded_tensor(SEED, "oa.temporal4", (1, T, 768)) * 0.02
+    m = FrozenInTime(dict(model="SpaceTimeTransformer", arch_config="base_patch16_224", num_frames=T, pretrained=True, time_init="rand",
+                          two_outputs=False),
+                     dict(model="", input_objects=False), dict(model="pretrained/distilbert-base-uncased", pretrained=True, input="text"))
+    r = m.load_state_dict(p, strict=False)
+    assert not r.unexpected_keys and not r.missing_keys, r
+    m = m.cuda()
+    m.set_device(torch.device("cuda"))
+    dc = _cuda(d)
+    po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    L = NormSoftmaxLoss()
+    for step in range(2):            # twice: the second step must OVERWRITE (not keep accumulating into) the gradients
+        m.begin_step()
+        for prm in m.parameters():               # what optim.AdamW.zero_grad does: loose (autograd-accumulated) grads only
+            if not getattr(prm, "_oat_engine_grad", False):
+                prm.grad = None
+        if variant == "global_local":
+            t, pt, v, ov, extra = m({"video": dc["video"], "text": {"input_ids": dc["ids"], "attention_mask": dc["mask"]},
+                                     "pad_text": {"input_ids": dc["pids"], "attention_mask": dc["pmask"]},
+                                     "patch_masks": dc["patch_masks"], "object_token_masks": dc["otm"], "object_token_len": dc["otm"][:, -1]})
+            rf, tf = extra[4], extra[5]
+            loss = L(sim_matrix(t, v)) + L(sim_matrix(pt, v)) + L(sim_matrix(mean_rows(rf), mean_rows(tf)))
+            # the object clip's CLS output is returned but enters no loss in the reference trainer either; add a small term
+            # so that BOTH clips send a CLS gradient through the encoder
+            loss = loss + 0.1 * ov.square().mean()
+        else:
+            t, v, rsim = m({"video": dc["video"], "text": {"input_ids": dc["ids"], "attention_mask": dc["mask"]},
+                            "text_region_embedding": dc["treg"]})
+            rs, pm = rsim.reshape(-1, rsim.size(-1)), dc["region_masks"].reshape(-1, 196)
+            loss = L(sim_matrix(t, v)) + 0.1 * bce_sum(rs, pm) / rs.size(0)
+        loss.backward()
+    torch.cuda.synchronize()
+    if variant == "global_local":
+        ot, opt_, ov_, oov, orf, otf = orc.gl_forward(po, d["video"], (d["ids"], d["mask"]), (d["pids"], d["pmask"]),
+                                                      d["patch_masks"], d["otm"], object_clip="native")
+        oloss = orc.gl_loss(ot, opt_, ov_, orf, otf) + 0.1 * oov.square().mean()
+        pairs = ((t, ot), (pt, opt_), (v, ov_), (ov, oov), (rf, orf), (tf, otf))
+    else:
+        ot, ov_, orsim = orc.region_mem_forward(po, d["video"], d["ids"], d["mask"], d["treg"], object_clip="native")
+        oloss = orc.region_mem_loss(ot, ov_, orsim, d["region_masks"])
+        pairs = ((t, ot), (v, ov_))
+        assert (rsim.cpu() - orsim.detach()).abs().max() < 5e-2 and (rsim.cpu() - orsim.detach()).abs().mean() < 2e-3
+    errs = [rel(a.detach(), b.detach()) for a, b in pairs]
+    print(variant, "native 1+4 frames: rel errs", errs, "loss", loss.item(), oloss.item())
+    assert all(e < 1e-2 for e in errs), errs
+    assert abs(loss.item() - oloss.item()) < 3e-2 * max(1.0, abs(oloss.item()))
+    _check_grads_vs_oracle(m, _oracle_grads(po, oloss), tol=1e-1 if variant == "region_mem" else 5e-2)
 
 
 @pytest.mark.parametrize("variant", ["region_mem", "global_local"])

@@ -97,6 +97,25 @@ def test_global_local_vs_reference(golden_dir):
     check_probe(p, g["grad_probe"])
 
 
+def test_native_clip_layout_is_the_reference_at_two_frames():
+    """The 'native' object-clip layout (object frame + T-frame video, BASELINE config 3) has no reference line of its
+    own; at F = 2 it must be the same computation as the reference's view(2B, F/2) - which the goldens above pin."""
+    torch.set_num_threads(8)
+    d = oa_inputs()
+    with torch.no_grad():
+        p = gl_params()
+        a = orc.gl_forward(p, d["video"], (d["ids"], d["mask"]), (d["pids"], d["pmask"]), d["patch_masks"], d["otm"])
+        b = orc.gl_forward(p, d["video"], (d["ids"], d["mask"]), (d["pids"], d["pmask"]), d["patch_masks"], d["otm"],
+                           object_clip="native")
+        for x, y in zip(a, b):
+            assert torch.allclose(x, y, atol=2e-5, rtol=1e-5)
+        p = region_params()
+        a = orc.region_mem_forward(p, d["video"], d["ids"], d["mask"], d["treg"])
+        b = orc.region_mem_forward(p, d["video"], d["ids"], d["mask"], d["treg"], object_clip="native")
+        for x, y in zip(a, b):
+            assert torch.allclose(x, y, atol=2e-5, rtol=1e-5)
+
+
 def test_tag_masks_matches_the_reference_loop():
     otm = torch.tensor([[1, 3, 4], [2, 3, 5]])
     n_txt = torch.tensor([8, 6])
