@@ -288,13 +288,18 @@ def main():
         loss = step()
     host_elapsed = time.perf_counter() - t0            # host-side enqueue time (GPU still running)
     torch.cuda.synchronize()
+    own = time.perf_counter() - t0                     # this rank's own finish time (before the closing barrier)
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    rank_ms = [own / args.steps * 1e3]
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
+        owns = [torch.zeros(1, device=device, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(owns, torch.tensor([own], device=device, dtype=torch.float64))
+        rank_ms = [o.item() / args.steps * 1e3 for o in owns]
     loss_val = float(loss.item())
     pairs = world * args.batch * args.steps
     value = pairs / elapsed
@@ -318,6 +323,9 @@ def main():
         "step_mfma_frac": round(value / world * gf_pair / 1e3 / BF16_DENSE_PEAK_TFLOPS, 4),
         "final_loss": round(loss_val, 4),
         "host_enqueue_ms_per_step": round(host_elapsed / args.steps * 1e3, 2),
+        "ranks_in_group": dist.get_world_size() if world > 1 else 1,
+        "rank_ms_per_step": [round(x, 3) for x in rank_ms],
+        "grad_exchange_dtype": os.environ.get("OAT_GRAD_DTYPE", "fp32"),
         "launch_mode": "hipGraph replay (1 launch per step)" if use_graph else "eager (one launch per kernel)",
     }
     # one more, instrumented, step for the roofline figure.  EVERY rank runs it (its collectives need all of them);

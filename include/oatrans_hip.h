@@ -154,12 +154,25 @@ int oat_attn_text_fwd(const void* qkv, int ldqkv, const void* mask, void* out, i
                       int L, int H, int D, float scale, void* stream);
 /* The same, plus the precise forward value: identical masked attention on the fp32 q|k|v in qkv32 (whose bf16 roundings
  * are `qkv`), written to out32.  out / lse remain the bf16-path results that oat_attn_text_bwd recomputes from. */
+/* drop_p > 0 (training mode): dropout on the attention probabilities, mask element ((b*H + h)*L + i)*L + j of site
+ * `drop_site` under the device rng state `rng` (see oat_rng_tick); the backward must be given the same three values. */
 int oat_attn_text_fwd_dual(const void* qkv, int ldqkv, const float* qkv32, int ldqkv32, const void* mask, void* out,
                            int ldo, float* out32, int ldo32, float* lse, int B, int L, int H, int D, float scale,
-                           void* stream);
+                           float drop_p, const void* rng, unsigned drop_site, void* stream);
 int oat_attn_text_bwd(const void* qkv, int ldqkv, const void* mask, const void* out, int ldo,
                       const float* lse, float* delta_scratch, const void* dout, int lddo, void* dqkv,
-                      int lddqkv, int B, int L, int H, int D, float scale, void* stream);
+                      int lddqkv, int B, int L, int H, int D, float scale, float drop_p, const void* rng,
+                      unsigned drop_site, void* stream);
+/* ---- dropout of the text tower's training mode (HF DistilBERT nn.Dropout sites: embeddings, attention probabilities,
+ * ffn output; reference call site oa_model.py:56,113-121).  Counter-based Philox4x32-10 masks: element idx of `site`
+ * draws word idx%4 of philox(counter = (idx/4 lo, idx/4 hi, site, offset), key = seed); rng = device uint64[2] =
+ * {seed, offset}.  Nothing is stored: forward and backward regenerate the mask. */
+int oat_rng_tick(void* rng, void* stream);                       /* offset += 1 (once per forward call) */
+/* out = x * mask (+ resid), as fp32 (out32) and / or bf16 (out16); in place allowed */
+int oat_dropout(const float* x, int ldx, const float* resid, int ldr, float* out32, int ldo, void* out16, int ld16, int M,
+                int D, float p, const void* rng, unsigned site, void* stream);
+int oat_dropout_mask(float* out, long long n, float p, const void* rng, unsigned site, void* stream);   /* multipliers of [0, n) */
+int oat_philox4x32_10(const void* in_6words_each, void* out_4words_each, int n, void* stream);         /* known-answer access */
 /* txt_proj's ReLU (oa_model.py:68) */
 int oat_relu_bf16(const float* x, int ldx, void* y_bf16, int ldy, int M, int D, void* stream);
 int oat_relu_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx, int M, int D, void* stream);

@@ -21,6 +21,7 @@ def smoke_step():
     sd = si.frozen_state_dict(seed, vshape, tshape, proj_dim=256)
     dev = torch.device("cuda:0")
     txt = DistilBertHIP(dict(vocab_size=500, max_position_embeddings=32, n_layers=2, n_heads=2, dim=128, hidden_dim=512))
+    txt.eval()                      # parity against the (eval-mode) oracle: training-mode dropout off
     txt.load_state_dict({k[11:]: v for k, v in sd.items() if k.startswith("text_model.")})
     vid = SpaceTimeTransformer(img_size=32, patch_size=16, embed_dim=128, depth=2, num_heads=2, num_frames=2, time_init="rand")
     vid.head = torch.nn.Identity()

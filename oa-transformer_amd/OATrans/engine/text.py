@@ -4,8 +4,9 @@ The reference calls HF transformers' DistilBertModel (third party; call sites
 /root/reference/OATrans/model/oa_model.py:27,113-121).  Its published algorithm - learned
 word + position embeddings -> LayerNorm(1e-12) -> n x post-LN [MHSA with key mask, FFN(GELU)] -
 is executed here with the same GEMM / LayerNorm kernels as the video encoder plus the masked
-attention and embedding kernels of csrc/text.hip.  Dropout is the identity (the parity
-configuration is eval mode; SURVEY.md 'parity traps').
+attention and embedding kernels of csrc/text.hip.  In training mode (`drop` given to forward) HF's three dropout sites
+are active - after the embedding LayerNorm, on the attention probabilities, after ffn.lin2 - with counter-based
+Philox masks (csrc/rng.h) that backward regenerates; eval mode (the parity configuration of the goldens) has none.
 
 Rows are (b, l) -> b * L + l.  FORWARD runs in fp32 end to end (oat_linear_f32 on the fp32 master weights, the precise
 path of oat_attn_text_fwd_dual): the tower is 0.7 % of the step's FLOPs, runs on its own stream beside the video
@@ -52,6 +53,8 @@ class _TextPlan:
         self.delta = torch.zeros(Mp, H, dtype=torch.float32, device=dev)
         self.gqkv_w = torch.zeros(3 * D, D, dtype=torch.float32, device=dev)
         self.gqkv_b = torch.zeros(3 * D, dtype=torch.float32, device=dev)
+        self.rng = torch.zeros(2, dtype=torch.int64, device=dev)       # {seed, offset} this forward drew its masks with
+        self.drop = None                                               # (p_hidden, p_attention) of the last forward
 
 
 class TextEngine:
@@ -110,8 +113,15 @@ class TextEngine:
             self.plans[key] = _TextPlan(B, L, self.D, self.Hd, self.H, self.n_layers, dev)
         return self.plans[key]
 
-    def forward(self, input_ids, attention_mask, params, sig=None, slot=0):
-        """-> (last_hidden fp32 view [B, L, D], plan)."""
+    @staticmethod
+    def site(layer, kind):
+        """Mask site numbers: 0 = embeddings; layer i: 1 + 2i = attention probabilities, 2 + 2i = ffn output."""
+        return 0 if kind == "emb" else 1 + 2 * layer + (0 if kind == "attn" else 1)
+
+    def forward(self, input_ids, attention_mask, params, sig=None, slot=0, drop=None):
+        """-> (last_hidden fp32 view [B, L, D], plan).  drop = (p_hidden, p_attention, rng_state) switches the training-
+        mode dropout on: rng_state (hip.new_rng_state) is ticked and copied into the plan, so this call's backward sees
+        the masks of this call whatever runs in between."""
         B, L = input_ids.shape
         D, Hd, H = self.D, self.Hd, self.H
         self.refresh_shadows(params, sig)
@@ -123,6 +133,15 @@ class TextEngine:
                       params["embeddings.position_embeddings.weight"], pl.emb, M, L, D)
         hip.layernorm_fwd(pl.emb, params["embeddings.LayerNorm.weight"], params["embeddings.LayerNorm.bias"], M, D,
                           1e-12, y=pl.x0_16, y32=pl.x0, mean=pl.estats[0], rstd=pl.estats[1])
+        ph = pa = 0.0
+        pl.drop = None
+        if drop is not None and (drop[0] > 0 or drop[1] > 0):
+            ph, pa, state = drop
+            hip.rng_tick(state)
+            pl.rng.copy_(state)
+            pl.drop = (ph, pa)
+            if ph > 0:
+                hip.dropout(pl.x0, M, D, ph, pl.rng, self.site(0, "emb"), out32=pl.x0, out16=pl.x0_16)
         x = pl.x0
         for i, a in enumerate(pl.layers):
             b = f"transformer.layer.{i}."
@@ -130,14 +149,19 @@ class TextEngine:
             for j, l in enumerate(("q_lin", "k_lin", "v_lin")):
                 hip.linear_f32(x, p(f"attention.{l}.weight"), M, D, D, bias=p(f"attention.{l}.bias"),
                                out32=a.qkv32[:, j * D:(j + 1) * D], out16=a.qkv[:, j * D:(j + 1) * D])
-            hip.attn_text_fwd_dual(a.qkv, a.qkv32, pl.mask, a.ctx, a.ctx32, a.lse, B, L, H, D, self.scale)
+            hip.attn_text_fwd_dual(a.qkv, a.qkv32, pl.mask, a.ctx, a.ctx32, a.lse, B, L, H, D, self.scale,
+                                   drop_p=pa, rng=pl.rng if pa > 0 else None, site=self.site(i, "attn"))
             hip.linear_f32(a.ctx32, p("attention.out_lin.weight"), M, D, D, bias=p("attention.out_lin.bias"),
                            out32=a.s, resid=x)
             hip.layernorm_fwd(a.s, p("sa_layer_norm.weight"), p("sa_layer_norm.bias"), M, D, 1e-12, y=a.x1_16,
                               y32=a.x1, mean=a.stats[0], rstd=a.stats[1])
             hip.linear_f32(a.x1, p("ffn.lin1.weight"), M, Hd, D, bias=p("ffn.lin1.bias"), out32=a.g32, out16=a.g,
                            out16b=a.h, act=hip.LIN_GELU)                 # a.g = gelu(h), a.h = gelu'(h) for backward
-            hip.linear_f32(a.g32, p("ffn.lin2.weight"), M, D, Hd, bias=p("ffn.lin2.bias"), out32=a.f, resid=a.x1)
+            if ph > 0:                                                   # f = x1 + dropout(lin2(.))
+                hip.linear_f32(a.g32, p("ffn.lin2.weight"), M, D, Hd, bias=p("ffn.lin2.bias"), out32=a.f)
+                hip.dropout(a.f, M, D, ph, pl.rng, self.site(i, "ffn"), resid=a.x1, out32=a.f)
+            else:
+                hip.linear_f32(a.g32, p("ffn.lin2.weight"), M, D, Hd, bias=p("ffn.lin2.bias"), out32=a.f, resid=a.x1)
             hip.layernorm_fwd(a.f, p("output_layer_norm.weight"), p("output_layer_norm.bias"), M, D, 1e-12,
                               y=a.x2_16, y32=a.x2, mean=a.stats[2], rstd=a.stats[3])
             x = a.x2
@@ -151,6 +175,7 @@ class TextEngine:
         G, g16 = pl.G, pl.g16
         G[:M].copy_(d_hidden.reshape(M, D))
         acc = accumulate
+        ph, pa = pl.drop if pl.drop is not None else (0.0, 0.0)
         for i in reversed(range(self.n_layers)):
             a = pl.layers[i]
             x16 = pl.layers[i - 1].x2_16 if i > 0 else pl.x0_16
@@ -162,6 +187,8 @@ class TextEngine:
             hip.layernorm_bwd(G, a.f, a.stats[2], a.stats[3], p("output_layer_norm.weight"), M, D, dx=G, dx16=g16,
                               dgamma=gr("output_layer_norm.weight"), dbeta=gr("output_layer_norm.bias"),
                               accumulate=acc)                                              # G = dL/df
+            if ph > 0:                       # lin2's output met the mask; the residual path (G) did not
+                hip.dropout(G, M, D, ph, pl.rng, self.site(i, "ffn"), out16=g16)
             hip.gemm_tn(g16, a.g, M, D, Hd, gr("ffn.lin2.weight"), accumulate=acc, bias_out=gr("ffn.lin2.bias"))
             hip.gemm_nt(g16, wT("ffn.lin2"), M, Hd, D, hip.EPI_MUL_AUX, pl.d_h, aux=a.h)
             hip.gemm_tn(pl.d_h, a.x1_16, M, Hd, D, gr("ffn.lin1.weight"), accumulate=acc, bias_out=gr("ffn.lin1.bias"))
@@ -172,7 +199,8 @@ class TextEngine:
             hip.gemm_tn(g16, a.ctx, M, D, D, gr("attention.out_lin.weight"), accumulate=acc,
                         bias_out=gr("attention.out_lin.bias"))
             hip.gemm_nt(g16, wT("attention.out_lin"), M, D, D, hip.EPI_BF16, pl.d_ctx)
-            hip.attn_text_bwd(a.qkv, pl.mask, a.ctx, a.lse, pl.delta, pl.d_ctx, pl.d_qkv, B, L, H, D, self.scale)
+            hip.attn_text_bwd(a.qkv, pl.mask, a.ctx, a.lse, pl.delta, pl.d_ctx, pl.d_qkv, B, L, H, D, self.scale,
+                              drop_p=pa, rng=pl.rng if pa > 0 else None, site=self.site(i, "attn"))
             hip.gemm_tn(pl.d_qkv, x16, M, 3 * D, D, pl.gqkv_w, bias_out=pl.gqkv_b)
             for k, l in enumerate(("q_lin", "k_lin", "v_lin")):
                 gw, gb = gr(f"attention.{l}.weight"), gr(f"attention.{l}.bias")
@@ -183,7 +211,9 @@ class TextEngine:
                     gw.copy_(pl.gqkv_w[k * D:(k + 1) * D])
                     gb.copy_(pl.gqkv_b[k * D:(k + 1) * D])
             hip.gemm_nt(pl.d_qkv, wT("qkv"), M, D, 3 * D, hip.EPI_F32, G, resid=G)          # G = dL/dx
-        # embeddings: x0 = LN(word[ids] + pos[l])
+        # embeddings: x0 = dropout(LN(word[ids] + pos[l]))
+        if ph > 0:
+            hip.dropout(G, M, D, ph, pl.rng, self.site(0, "emb"), out32=G)
         hip.layernorm_bwd(G, pl.emb, pl.estats[0], pl.estats[1], params["embeddings.LayerNorm.weight"], M, D, dx=G,
                           dgamma=grads["embeddings.LayerNorm.weight"], dbeta=grads["embeddings.LayerNorm.bias"],
                           accumulate=acc)

@@ -13,7 +13,10 @@ from ..engine.module import EngineModule
 from ..engine.text import TextEngine
 from ..ops import hip
 
-DEFAULT_CONFIG = dict(vocab_size=30522, max_position_embeddings=512, n_layers=6, n_heads=12, dim=768, hidden_dim=3072)
+# dropout / attention_dropout: distilbert-base-uncased's config.json values; active in training mode only (the reference
+# calls text_model.train(), oa_model.py:56, and the trainers model.train()), identity under .eval()
+DEFAULT_CONFIG = dict(vocab_size=30522, max_position_embeddings=512, n_layers=6, n_heads=12, dim=768, hidden_dim=3072,
+                      dropout=0.1, attention_dropout=0.1)
 
 
 class _Attn(nn.Module):
@@ -55,7 +58,7 @@ class _HiddenFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, input_ids, attention_mask, call_idx, *params):
         hidden, plan = module._engine.forward(input_ids, attention_mask, module._param_data(),
-                                              module._weights_signature(), slot=call_idx)
+                                              module._weights_signature(), slot=call_idx, drop=module._dropout_args(input_ids.device))
         ctx.module, ctx.plan, ctx.call_idx = module, plan, call_idx
         return hidden.clone()
 
@@ -88,6 +91,23 @@ class DistilBertHIP(EngineModule):
         self._engine = TextEngine(cfg["n_layers"], cfg["dim"], cfg["n_heads"], cfg["hidden_dim"])
         self._bwd_calls = 0
         self._fwd_calls = 0
+        self._rng_state = None
+        self.dropout_seed = None             # None: drawn from torch's generator (torch.manual_seed governs it) on first use
+
+    def _dropout_args(self, device):
+        """(p_hidden, p_attention, device rng state) in training mode, None in eval mode or with both rates 0."""
+        ph, pa = float(self.config.dropout), float(self.config.attention_dropout)
+        if not self.training or (ph <= 0 and pa <= 0):
+            return None
+        if self._rng_state is None or self._rng_state.device != device:
+            seed = self.dropout_seed if self.dropout_seed is not None else int(torch.randint(0, 2 ** 62, (1,)).item())
+            self._rng_state = hip.new_rng_state(seed, device)
+        return ph, pa, self._rng_state
+
+    def set_dropout_seed(self, seed):
+        """Restart the mask stream: the same seed, the same sequence of forward calls -> the same masks."""
+        self.dropout_seed = int(seed)
+        self._rng_state = None
 
     @classmethod
     def from_pretrained(cls, path):

@@ -329,10 +329,43 @@ def attn_text_fwd(qkv, mask, out, lse, B, L, H, D, scale):
                                    H, D, _f(scale), _stream()), "oat_attn_text_fwd")
 
 
-def attn_text_fwd_dual(qkv, qkv32, mask, out, out32, lse, B, L, H, D, scale):
+def attn_text_fwd_dual(qkv, qkv32, mask, out, out32, lse, B, L, H, D, scale, drop_p=0.0, rng=None, site=0):
     _check(lib().oat_attn_text_fwd_dual(_ptr(qkv), qkv.stride(0), _ptr(qkv32), qkv32.stride(0), _ptr(mask), _ptr(out),
                                         out.stride(0), _ptr(out32), out32.stride(0), _ptr(lse), B, L, H, D, _f(scale),
-                                        _stream()), "oat_attn_text_fwd_dual")
+                                        _f(drop_p), _ptr(rng), ctypes.c_uint(site), _stream()), "oat_attn_text_fwd_dual")
+
+
+def new_rng_state(seed, device):
+    """Device-resident dropout state {seed, offset} (int64[2]); oat_rng_tick advances the offset."""
+    return torch.tensor([int(seed) & 0x7fffffffffffffff, 0], dtype=torch.int64, device=device)
+
+
+def rng_tick(state):
+    _check(lib().oat_rng_tick(_ptr(state), _stream()), "oat_rng_tick")
+
+
+def dropout(x, M, D, p, rng, site, resid=None, out32=None, out16=None):
+    s0 = lambda t: t.stride(0) if t is not None else 0
+    _check(lib().oat_dropout(_ptr(x), x.stride(0), _ptr(resid), s0(resid), _ptr(out32), s0(out32), _ptr(out16), s0(out16),
+                             M, D, _f(p), _ptr(rng), ctypes.c_uint(site), _stream()), "oat_dropout")
+
+
+def dropout_mask(n, p, rng, site):
+    out = torch.empty(n, dtype=torch.float32, device=rng.device)
+    _check(lib().oat_dropout_mask(_ptr(out), ctypes.c_longlong(n), _f(p), _ptr(rng), ctypes.c_uint(site), _stream()),
+           "oat_dropout_mask")
+    return out
+
+
+def philox4x32_10(words):
+    """words: int64 [n, 6] (4 counter words, 2 key words, each < 2^32) -> int64 [n, 4]."""
+    inp = words.to(torch.int64).contiguous()
+    n = inp.shape[0]
+    i32 = (inp & 0xffffffff).to(torch.int64)
+    i32 = torch.where(i32 >= 2 ** 31, i32 - 2 ** 32, i32).to(torch.int32).contiguous()
+    out = torch.empty(n, 4, dtype=torch.int32, device=inp.device)
+    _check(lib().oat_philox4x32_10(_ptr(i32), _ptr(out), n, _stream()), "oat_philox4x32_10")
+    return out.to(torch.int64) & 0xffffffff
 
 
 LIN_NONE, LIN_GELU, LIN_RELU_IN = 0, 1, 2
@@ -346,10 +379,10 @@ def linear_f32(A, W, M, N, K, bias=None, out32=None, out16=None, out16b=None, re
                                 int(act), _stream()), "oat_linear_f32")
 
 
-def attn_text_bwd(qkv, mask, out, lse, delta, dout, dqkv, B, L, H, D, scale):
+def attn_text_bwd(qkv, mask, out, lse, delta, dout, dqkv, B, L, H, D, scale, drop_p=0.0, rng=None, site=0):
     _check(lib().oat_attn_text_bwd(_ptr(qkv), qkv.stride(0), _ptr(mask), _ptr(out), out.stride(0), _ptr(lse),
                                    _ptr(delta), _ptr(dout), dout.stride(0), _ptr(dqkv), dqkv.stride(0), B, L, H, D,
-                                   _f(scale), _stream()), "oat_attn_text_bwd")
+                                   _f(scale), _f(drop_p), _ptr(rng), ctypes.c_uint(site), _stream()), "oat_attn_text_bwd")
 
 
 def relu_bf16(x, y, M, D):

@@ -70,12 +70,23 @@ class GradSync:
     so at 2 GPUs one link carries the whole 600 MB exchange: hidden behind backward it costs nothing, after
     backward it would cost ~10 ms.  `all_reduce()` (after backward) reduces whatever was not announced,
     waits for the asynchronous work and applies the 1/W mean.  Every rank issues the same collectives in the
-    same order (the launch schedule is deterministic)."""
+    same order (the launch schedule is deterministic).
 
-    def __init__(self, model, bucket_mb=256, overlap=True, force=False):
+    grad_dtype=torch.bfloat16 (or OAT_GRAD_DTYPE=bf16): the exchange carries bf16 - half the bytes on the per-link-bound
+    xGMI ring.  Each range is cast into a staging buffer, summed by RCCL in bf16 and written back to the fp32 gradient.
+    Error: one rounding at the cast (2^-9 relative per element) plus one per ring addition, so |error| <=
+    (W + 1) * 2^-9 * max|partial sum| per element; the fp32 default is exact up to summation order (what DDP gives)."""
+
+    def __init__(self, model, bucket_mb=256, overlap=True, force=False, grad_dtype=None, bucket_elems=None):
+        import os
         self.model = model
         self.force = force           # issue the collectives even in a 1-rank group (exercises the RCCL path on one GPU)
-        self.bucket = int(bucket_mb * (1 << 20) // 4)
+        self.bucket = int(bucket_elems) if bucket_elems else int(bucket_mb * (1 << 20) // 4)
+        if grad_dtype is None:
+            grad_dtype = {"bf16": torch.bfloat16, "fp32": torch.float32}[os.environ.get("OAT_GRAD_DTYPE", "fp32")]
+        if grad_dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("grad_dtype: torch.float32 or torch.bfloat16")
+        self.grad_dtype = grad_dtype
         self._pending = []           # async work handles of this step
         self._covered = []           # [byte_lo, byte_hi) address ranges already handed to RCCL this step
         W, _ = world()
@@ -105,8 +116,15 @@ class GradSync:
         if (W == 1 and not self.force) or hi <= lo:
             return
         flat = module.flat_grad()[lo:hi]
-        self._pending.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
+        self._pending.append(self._start(flat))
         self._covered.append((flat.data_ptr(), flat.data_ptr() + 4 * flat.numel()))
+
+    def _start(self, flat):
+        """Asynchronous sum of one range; returns (work, staging buffer or None, range)."""
+        if self.grad_dtype == torch.float32:
+            return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), None, flat
+        stage = flat.to(self.grad_dtype)
+        return dist.all_reduce(stage, op=dist.ReduceOp.SUM, async_op=True), stage, flat
 
     def ranges(self):
         """Maximal contiguous gradient ranges (engine modules expose one each; loose params singly)."""
@@ -143,8 +161,10 @@ class GradSync:
         flats = self.ranges()
         rest = [piece for f in flats for piece in self._uncovered(f)]
         self._reduce(rest)               # the few loose ranges: on the current stream (RCCL runs them on its own)
-        for work in self._pending:
+        for work, stage, flat in self._pending:
             work.wait()                      # device-side: the current stream waits for RCCL's stream
+            if stage is not None:
+                flat.copy_(stage)
         self._pending, self._covered = [], []
         if average:
             for f in flats:
@@ -153,7 +173,13 @@ class GradSync:
     def _reduce(self, flats):
         for f in flats:
             for s in range(0, f.numel(), self.bucket):
-                dist.all_reduce(f[s:s + self.bucket], op=dist.ReduceOp.SUM)
+                piece = f[s:s + self.bucket]
+                if self.grad_dtype == torch.float32:
+                    dist.all_reduce(piece, op=dist.ReduceOp.SUM)
+                else:
+                    stage = piece.to(self.grad_dtype)
+                    dist.all_reduce(stage, op=dist.ReduceOp.SUM)
+                    piece.copy_(stage)
 
 
 class HipDataParallel(nn.Module):

@@ -8,7 +8,10 @@
 // lane p holding dims [8p, 8p+8) of the 64-dim head (same idiom as attn_time.hip).
 // Masked keys (attention_mask == 0) are skipped, which equals HF's masked_fill(finfo.min)
 // whenever a row has at least one unmasked key (always true: token 0 = [CLS]).
-#include "common.h"
+// Training mode: dropout on the attention probabilities (HF MultiHeadSelfAttention).  With P' = P o m (m = 0 or
+// 1/(1-p), element ((b*H + h)*L + i)*L + j of the layer's site, rng.h) and O = P' V:  dP = m o (dO V^T),
+// delta_i = sum_j P_ij dP_ij = dO_i . O_i as without dropout, dV_j = sum_i P'_ij dO_i; the softmax statistics are untouched.
+#include "rng.h"
 
 namespace oat {
 
@@ -68,7 +71,12 @@ struct TextArgs {
   float scale;
   const float* qkv32; int ldqkv32;  // forward only: fp32 q|k|v (precise path); qkv then holds their bf16 roundings
   float* out32; int ldo32;          // forward only: precise context
+  DropSite drop;                    // drop.rng == nullptr: no dropout (eval mode)
 };
+OAT_DEV float attn_drop(const TextArgs& a, int b, int h, int i, int j) {
+  if (a.drop.rng == nullptr) return 1.f;
+  return drop_mult(a.drop, (((unsigned long long)b * a.H + h) * a.L + i) * a.L + j);
+}
 
 // one 8-lane group per (b, h, i); groups laid out i-fastest
 __global__ __launch_bounds__(256) void attn_text_fwd_kernel(TextArgs a) {
@@ -92,8 +100,9 @@ __global__ __launch_bounds__(256) void attn_text_fwd_kernel(TextArgs a) {
     const float mn = fmaxf(m, s);
     const float alpha = exp2f(m - mn), p = exp2f(s - mn);
     l = l * alpha + p;
+    const float pd = p * attn_drop(a, b, h, i, j);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = o[e] * alpha + p * bf2f(vv[e]);
+    for (int e = 0; e < 8; ++e) o[e] = o[e] * alpha + pd * bf2f(vv[e]);
     m = mn;
   }
   if (valid) {
@@ -123,10 +132,11 @@ __global__ __launch_bounds__(256) void attn_text_fwd_kernel(TextArgs a) {
       const float mn = fmaxf(m2, s);
       const float alpha = exp2f(m2 - mn), p = exp2f(s - mn);
       l2 = l2 * alpha + p;
+      const float pd = p * attn_drop(a, b, h, i, j);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        o2[e] = o2[e] * alpha + p * v0[e];
-        o2[4 + e] = o2[4 + e] * alpha + p * v1[e];
+        o2[e] = o2[e] * alpha + pd * v0[e];
+        o2[4 + e] = o2[4 + e] * alpha + pd * v1[e];
       }
       m2 = mn;
     }
@@ -162,7 +172,7 @@ __global__ __launch_bounds__(256) void attn_text_bwd_q_kernel(TextArgs a) {
     const bf16x8 kk = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + a.D + col);
     const bf16x8 vv = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + 2 * a.D + col);
     const float p = exp2f(xred8(xdot8(q, kk)) * c2 - lse2);
-    const float ds = p * (xred8(xdot8(go, vv)) - delta) * a.scale;
+    const float ds = p * (xred8(xdot8(go, vv)) * attn_drop(a, b, h, i, j) - delta) * a.scale;
 #pragma unroll
     for (int e = 0; e < 8; ++e) dq[e] += ds * bf2f(kk[e]);
   }
@@ -194,9 +204,11 @@ __global__ __launch_bounds__(256) void attn_text_bwd_kv_kernel(TextArgs a) {
       const bf16x8 q = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + col);
       const bf16x8 go = *reinterpret_cast<const bf16x8*>(a.dout + r * a.lddo + col);
       const float p = exp2f(xred8(xdot8(q, kk)) * c2 - a.lse[r * a.H + h] * X_LOG2E);
-      const float ds = p * (xred8(xdot8(go, vv)) - a.delta[r * a.H + h]) * a.scale;
+      const float mij = attn_drop(a, b, h, i, j);
+      const float ds = p * (xred8(xdot8(go, vv)) * mij - a.delta[r * a.H + h]) * a.scale;
+      const float pd = p * mij;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { dk[e] += ds * bf2f(q[e]); dv[e] += p * bf2f(go[e]); }
+      for (int e = 0; e < 8; ++e) { dk[e] += ds * bf2f(q[e]); dv[e] += pd * bf2f(go[e]); }
     }
   }
   if (valid) {
@@ -246,26 +258,32 @@ static int attn_text_fwd_launch(oat::TextArgs a, void* stream) {
 extern "C" int oat_attn_text_fwd(const void* qkv, int ldqkv, const void* mask, void* out, int ldo, float* lse, int B,
                                  int L, int H, int D, float scale, void* stream) {
   oat::TextArgs a{(const bf16*)qkv, ldqkv, (const long long*)mask, (bf16*)out, ldo, lse, nullptr, nullptr, 0, nullptr, 0, B, L, H, D, scale,
-                  nullptr, 0, nullptr, 0};
+                  nullptr, 0, nullptr, 0, DropSite{nullptr, 0, 0, 1.f}};
   return attn_text_fwd_launch(a, stream);
 }
 // As oat_attn_text_fwd, plus the PRECISE forward value: the same masked attention on fp32 q|k|v (qkv32; `qkv` holds their
 // bf16 roundings) written to out32.  out / lse stay the bf16-path results backward uses.
+// drop_p > 0 with a device rng state (oat_rng_tick): dropout on the probabilities, site `drop_site` (training mode).
 extern "C" int oat_attn_text_fwd_dual(const void* qkv, int ldqkv, const float* qkv32, int ldqkv32, const void* mask, void* out,
                                       int ldo, float* out32, int ldo32, float* lse, int B, int L, int H, int D, float scale,
-                                      void* stream) {
+                                      float drop_p, const void* rng, unsigned drop_site, void* stream) {
   if (!qkv32 || !out32) { oat::set_error("attn_text_fwd_dual: null pointer"); return -4; }
+  if (drop_p > 0.f && !rng) { oat::set_error("attn_text_fwd_dual: dropout needs an rng state"); return -4; }
   oat::TextArgs a{(const bf16*)qkv, ldqkv, (const long long*)mask, (bf16*)out, ldo, lse, nullptr, nullptr, 0, nullptr, 0, B, L, H, D, scale,
-                  qkv32, ldqkv32, out32, ldo32};
+                  qkv32, ldqkv32, out32, ldo32,
+                  drop_p > 0.f ? oat::make_drop_site(rng, drop_site, drop_p) : oat::DropSite{nullptr, 0, 0, 1.f}};
   return attn_text_fwd_launch(a, stream);
 }
 // delta: fp32 [B*L, H] scratch
 extern "C" int oat_attn_text_bwd(const void* qkv, int ldqkv, const void* mask, const void* out, int ldo,
                                  const float* lse, float* delta, const void* dout, int lddo, void* dqkv, int lddqkv,
-                                 int B, int L, int H, int D, float scale, void* stream) {
+                                 int B, int L, int H, int D, float scale, float drop_p, const void* rng, unsigned drop_site,
+                                 void* stream) {
   if (D != H * 64) { set_error("attn_text: head_dim must be 64"); return -3; }
+  if (drop_p > 0.f && !rng) { set_error("attn_text_bwd: dropout needs an rng state"); return -4; }
   TextArgs a{(const bf16*)qkv, ldqkv, (const long long*)mask, (bf16*)out, ldo, (float*)lse, delta, (const bf16*)dout, lddo,
-             (bf16*)dqkv, lddqkv, B, L, H, D, scale, nullptr, 0, nullptr, 0};
+             (bf16*)dqkv, lddqkv, B, L, H, D, scale, nullptr, 0, nullptr, 0,
+             drop_p > 0.f ? make_drop_site(rng, drop_site, drop_p) : DropSite{nullptr, 0, 0, 1.f}};
   const int groups = B * H * L;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(attn_text_bwd_q_kernel, dim3((groups + 31) / 32), dim3(256), 0, s, a);

@@ -133,8 +133,53 @@ def video_encoder(video, p, num_heads=12, depth=None, pre="video_model.", return
 
 
 # --------------------------------------------------------------------------- text encoder
-def distilbert(input_ids, attention_mask, p, n_heads=12, pre="text_model."):
-    """HF DistilBertModel.forward(...).last_hidden_state, eval mode (dropout off).
+def philox4x32_10(counter, key):
+    """Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11; Random123).
+    counter: uint64 array [..., 4] of 32-bit words, key: [..., 2].  numpy, vectorised.  Pinned by Random123's
+    known-answer vectors in tests/test_oracle_cpu.py; the HIP generator (csrc/rng.h) is checked against this one."""
+    import numpy as np
+    c = np.asarray(counter, dtype=np.uint64) & np.uint64(0xffffffff)
+    k = np.asarray(key, dtype=np.uint64) & np.uint64(0xffffffff)
+    c0, c1, c2, c3 = (c[..., i].copy() for i in range(4))
+    k0, k1 = k[..., 0].copy(), k[..., 1].copy()
+    m32 = np.uint64(0xffffffff)
+    for _ in range(10):
+        p0 = np.uint64(0xD2511F53) * c0
+        p1 = np.uint64(0xCD9E8D57) * c2
+        c0, c1, c2, c3 = ((p1 >> np.uint64(32)) ^ c1 ^ k0) & m32, p1 & m32, ((p0 >> np.uint64(32)) ^ c3 ^ k1) & m32, p0 & m32
+        k0 = (k0 + np.uint64(0x9E3779B9)) & m32
+        k1 = (k1 + np.uint64(0xBB67AE85)) & m32
+    return np.stack([c0, c1, c2, c3], axis=-1)
+
+
+def dropout_multipliers(n, p_drop, seed, offset, site):
+    """The dropout multipliers (0 or 1/(1-p)) of elements [0, n) of a mask site, as the HIP kernels draw them
+    (csrc/rng.h): element idx takes word idx % 4 of philox(counter = (idx//4 lo, idx//4 hi, site, offset lo),
+    key = (seed lo, seed hi)) and is dropped when the word < p * 2^32."""
+    import numpy as np
+    q = np.arange((n + 3) // 4, dtype=np.uint64)
+    ctr = np.stack([q & np.uint64(0xffffffff), q >> np.uint64(32), np.full_like(q, site), np.full_like(q, offset & 0xffffffff)], axis=-1)
+    key = np.broadcast_to(np.array([seed & 0xffffffff, (seed >> 32) & 0xffffffff], dtype=np.uint64), (len(q), 2))
+    words = philox4x32_10(ctr, key).reshape(-1)[:n]
+    thresh = min(int(p_drop * 4294967296.0), 4294967295)
+    return torch.from_numpy(np.where(words < np.uint64(thresh), 0.0, 1.0 / (1.0 - np.float32(p_drop))).astype(np.float32))
+
+
+def distilbert_dropout_masks(B, L, D, n_heads, n_layers, p_hidden, p_attn, seed, offset):
+    """Every training-mode mask of one DistilBERT forward, keyed as distilbert(dropout=...) expects; site numbering of
+    engine/text.py: 0 = embeddings, 1 + 2i = attention probabilities of layer i, 2 + 2i = its ffn output."""
+    m = {"emb": dropout_multipliers(B * L * D, p_hidden, seed, offset, 0).view(B, L, D)}
+    for i in range(n_layers):
+        m["attn", i] = dropout_multipliers(B * n_heads * L * L, p_attn, seed, offset, 1 + 2 * i).view(B, n_heads, L, L)
+        m["ffn", i] = dropout_multipliers(B * L * D, p_hidden, seed, offset, 2 + 2 * i).view(B, L, D)
+    return m
+
+
+def distilbert(input_ids, attention_mask, p, n_heads=12, pre="text_model.", dropout=None):
+    """HF DistilBertModel.forward(...).last_hidden_state.  dropout=None: eval mode.  dropout = dict of multiplier
+    tensors {"emb": [B,L,D], ("attn", i): [B,H,L,L], ("ffn", i): [B,L,D]}: training mode with THESE masks at HF's
+    three nn.Dropout sites (Embeddings.forward after LayerNorm; MultiHeadSelfAttention on the softmax weights;
+    FFN after lin2 - transformers/models/distilbert/modeling_distilbert.py).
     Third-party code (transformers); restated from its published algorithm and
     validated numerically against transformers 5.15 eager attention in
     tests/golden/make_golden.py."""
@@ -142,6 +187,8 @@ def distilbert(input_ids, attention_mask, p, n_heads=12, pre="text_model."):
     x = p[pre + "embeddings.word_embeddings.weight"][input_ids] \
         + p[pre + "embeddings.position_embeddings.weight"][:L].unsqueeze(0)
     x = _ln(x, p, pre + "embeddings.LayerNorm", 1e-12)
+    if dropout is not None:
+        x = x * dropout["emb"]
     D = x.shape[-1]
     d = D // n_heads
     n_layers = 1 + max(int(k[len(pre) + 18:].split(".")[0]) for k in p if k.startswith(pre + "transformer.layer."))
@@ -154,9 +201,14 @@ def distilbert(input_ids, attention_mask, p, n_heads=12, pre="text_model."):
         v = _lin(x, p, b + "attention.v_lin").reshape(B, L, n_heads, d).transpose(1, 2)
         s = (q @ k.transpose(-1, -2)) / math.sqrt(d)
         s = s.masked_fill(~keep, neg)
-        ctx = (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(B, L, D)
+        w = torch.softmax(s, dim=-1)
+        if dropout is not None:
+            w = w * dropout["attn", i]
+        ctx = (w @ v).transpose(1, 2).reshape(B, L, D)
         x = _ln(_lin(ctx, p, b + "attention.out_lin") + x, p, b + "sa_layer_norm", 1e-12)
         f = _lin(F.gelu(_lin(x, p, b + "ffn.lin1")), p, b + "ffn.lin2")
+        if dropout is not None:
+            f = f * dropout["ffn", i]
         x = _ln(f + x, p, b + "output_layer_norm", 1e-12)
     return x
 
@@ -248,7 +300,7 @@ def _object_and_video_clips(video, encode, object_clip):
     clips = object images, odd clips = videos.  'native' (BASELINE.json config 3, "8-frame + 10 obj"; no reference
     line - the reference's view() cannot express it) takes frame 0 as a one-frame object clip and frames 1..T as the
     video clip and encodes both with the same weights; everything downstream is unchanged.  At F = 2 the two
-    layouts are the same computation (tests/test_oracle_cpu.py).  `encode(clips) -> (emb, region)`."""
+    layouts are the same computation (tests/test_oracle_oa_golden.py).  `encode(clips) -> (emb, region)`."""
     if object_clip == "interleaved":
         B = video.shape[0]
         emb, region = encode(video.reshape(B * 2, -1, *video.shape[2:]))

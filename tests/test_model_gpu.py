@@ -56,6 +56,7 @@ def test_small_chain_vs_reference_golden(golden_dir):
     g = _golden(golden_dir, "small_chain.pt")
     sd = si.frozen_state_dict(SEED, SMALL_VIDEO, SMALL_TEXT, proj_dim=64)
     txt = DistilBertHIP(dict(vocab_size=1000, max_position_embeddings=64, n_layers=2, n_heads=2, dim=128, hidden_dim=512))
+    txt.eval()                      # the golden is an eval-mode run (dropout off)
     r = txt.load_state_dict({k[len("text_model."):]: v for k, v in sd.items() if k.startswith("text_model.")})
     vid = SpaceTimeTransformer(img_size=48, patch_size=16, embed_dim=128, depth=2, num_heads=2, num_frames=3, time_init="rand")
     vid.head = torch.nn.Identity()
@@ -165,6 +166,7 @@ def test_frozen_in_time_vitb_vs_reference_golden(golden_dir, frames):
         object_params=dict(model="", input_objects=False),
         text_params=dict(model="pretrained/distilbert-base-uncased", pretrained=True, input="text"),
         projection="minimal", load_checkpoint="")
+    m.text_model.eval()          # parity runs in eval mode (the goldens' DistilBERT has dropout off)
     r = m.load_state_dict(si.frozen_state_dict(SEED, dict(num_frames=T), {}), strict=False)
     assert not r.unexpected_keys and not r.missing_keys, r
     m = m.cuda()
@@ -212,6 +214,7 @@ def test_ragged_shapes_take_optimiser_steps():
         object_params=dict(model="", input_objects=False),
         text_params=dict(model="pretrained/distilbert-base-uncased", pretrained=True, input="text", config=dict(n_layers=1)),
         projection="minimal", load_checkpoint="").cuda()
+    m.text_model.eval()          # parity runs in eval mode (the goldens' DistilBERT has dropout off)
     m.set_device(torch.device("cuda"))
     for sub in (m.video_model, m.text_model):
         sub.flatten_parameters()
@@ -248,6 +251,7 @@ def test_eager_adamw_equals_step_after_backward():
         object_params=dict(model="", input_objects=False),
         text_params=dict(model="pretrained/distilbert-base-uncased", pretrained=True, input="text", config=dict(n_layers=2)),
         projection="minimal", load_checkpoint="")
+    base.text_model.eval()          # parity runs in eval mode (the goldens' DistilBERT has dropout off)
     sa = argparse.Namespace(world_size=1, rank=0, local_rank=0)
     g = torch.Generator().manual_seed(5)
     B, T, L = 4, 2, 12
@@ -289,6 +293,7 @@ def _small_frozen(seed=0, frames=2, depth=2, n_layers=1):
         object_params=dict(model="", input_objects=False),
         text_params=dict(model="pretrained/distilbert-base-uncased", pretrained=True, input="text", config=dict(n_layers=n_layers)),
         projection="minimal", load_checkpoint="").cuda()
+    m.text_model.eval()          # parity runs in eval mode (the goldens' DistilBERT has dropout off)
     m.set_device(torch.device("cuda"))
     for sub in (m.video_model, m.text_model):
         sub.flatten_parameters()
@@ -395,6 +400,7 @@ def test_headline_batch_sim_matrix_vs_oracle_rows():
         object_params=dict(model="", input_objects=False),
         text_params=dict(model="pretrained/distilbert-base-uncased", pretrained=True, input="text"),
         projection="minimal", load_checkpoint="")
+    m.text_model.eval()          # parity runs in eval mode (the goldens' DistilBERT has dropout off)
     r = m.load_state_dict(sd, strict=False)
     assert not r.unexpected_keys and not r.missing_keys, r
     m = m.cuda()

@@ -92,6 +92,7 @@ def test_region_mem_model_vs_reference_golden(golden_dir, layout):
     m = FrozenInTime(dict(model="SpaceTimeTransformer", arch_config="base_patch16_224", num_frames=1, pretrained=True, time_init="rand",
                           object_clip=layout),
                      dict(model="", input_objects=False), dict(model="pretrained/distilbert-base-uncased", pretrained=True, input="text"))
+    m.text_model.eval()          # parity runs in eval mode (the goldens' DistilBERT has dropout off)
     r = m.load_state_dict(region_params(), strict=False)
     assert not r.unexpected_keys and not r.missing_keys, r
     m = m.cuda()
@@ -124,6 +125,7 @@ def test_global_local_model_vs_reference_golden(golden_dir, layout):
     m = FrozenInTime(dict(model="SpaceTimeTransformer", arch_config="base_patch16_224", num_frames=1, pretrained=True, time_init="rand", two_outputs=False,
                           object_clip=layout),
                      dict(model="", input_objects=False), dict(model="pretrained/distilbert-base-uncased", pretrained=True, input="text"))
+    m.text_model.eval()          # parity runs in eval mode (the goldens' DistilBERT has dropout off)
     r = m.load_state_dict(gl_params(), strict=False)
     assert not r.unexpected_keys and not r.missing_keys, r
     m = m.cuda()
@@ -191,6 +193,7 @@ def test_native_object_clip_4_frames_vs_oracle(variant):
     m = FrozenInTime(dict(model="SpaceTimeTransformer", arch_config="base_patch16_224", num_frames=T, pretrained=True, time_init="rand",
                           two_outputs=False),
                      dict(model="", input_objects=False), dict(model="pretrained/distilbert-base-uncased", pretrained=True, input="text"))
+    m.text_model.eval()          # parity runs in eval mode (the goldens' DistilBERT has dropout off)
     r = m.load_state_dict(p, strict=False)
     assert not r.unexpected_keys and not r.missing_keys, r
     m = m.cuda()

@@ -164,6 +164,57 @@ def test_two_rank_overlapped_gradient_sync():
     assert got == [0, 1]
 
 
+def _four_rank_worker(rank, world, port, q, grad_dtype):
+    """W = 4, a bucket size (7 elements) that divides no range, ranges announced in two pieces + loose parameters."""
+    from OATrans.parallel import GradSync
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    torch.manual_seed(1)
+    toy = _FlatToy()
+    loose = torch.nn.Parameter(torch.zeros(23))
+    model = torch.nn.ModuleDict({"toy": toy})
+    model.register_parameter("loose", loose)
+    sync = GradSync(model, overlap=True, bucket_elems=7, grad_dtype=grad_dtype)
+    views = toy._grad_views()
+    loose.grad = torch.zeros(23)
+    g = torch.Generator().manual_seed(5)
+    per_rank = [{n: torch.randn(v.shape, generator=g) for n, v in views.items()} for _ in range(world)]
+    loose_rank = [torch.randn(23, generator=g) for _ in range(world)]
+    for step in range(2):
+        for n, v in views.items():
+            v.copy_(per_rank[rank][n])
+        loose.grad.copy_(loose_rank[rank])
+        toy._announce(("blocks.1.", "norm."))               # overlapped piece; blocks.0 + loose are left to all_reduce()
+        sync.all_reduce(average=True)
+        tol = 0.0 if grad_dtype == torch.float32 else (world + 1) * 2.0 ** -9
+        for n, v in views.items():
+            want = sum(per_rank[r][n] for r in range(world)) / world
+            bound = tol * sum(per_rank[r][n].abs() for r in range(world)) / world + 1e-6
+            assert ((v - want).abs() <= bound).all(), (n, (v - want).abs().max())
+        want = sum(loose_rank) / world
+        bound = tol * sum(l.abs() for l in loose_rank) / world + 1e-6
+        assert ((loose.grad - want).abs() <= bound).all()
+    q.put(rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("grad_dtype", [torch.float32, torch.bfloat16])
+def test_four_rank_gradient_sync_with_ragged_buckets(grad_dtype):
+    """4 ranks over gloo: every gradient element is averaged exactly once although the 7-element buckets split every
+    range raggedly; with the bf16 exchange the result stays inside the stated (W + 1) * 2^-9 bound."""
+    world, port = 4, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_four_rank_worker, args=(r, world, port, q, grad_dtype)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got == [0, 1, 2, 3]
+
+
 def _broadcast_worker(rank, world, port, q):
     from OATrans.parallel import HipDataParallel
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
