@@ -38,6 +38,7 @@ def _model():
         text_params=dict(model="pretrained/distilbert-base-uncased", pretrained=True, input="text", config=dict(n_layers=1)),
         projection="minimal", load_checkpoint="").cuda()
     m.set_device(torch.device("cuda"))
+    m.text_model.eval()          # dropout masks are drawn per local row: 2 x 2 rows and 1 x 4 rows would see different masks
     for sub in (m.video_model, m.text_model):
         sub.flatten_parameters()
     return m

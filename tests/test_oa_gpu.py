@@ -299,3 +299,39 @@ def test_loader_device_masks_equal_host_rasterisation():
     host = dl.make_batch(11)
     dev = dl.make_batch(11, torch.device("cuda"))
     assert dev["patch_masks"].is_cuda and torch.equal(dev["patch_masks"].cpu(), host["patch_masks"])
+
+
+def test_object_batch_collate_rasterises_detector_boxes_on_device(golden_dir):
+    """data_loader/object_inputs.ObjectBatch: detector .npz -> 6-d box features (host, pinned by oa_inputs.pt) -> patch
+    masks on the GPU, equal to the reference's per-sample numpy rasterisation (oracle functions pinned by
+    oa_patch_masks.pt), for both OA variants; clips packed [object frame | T frames]."""
+    import random
+    import numpy as np
+    from OATrans.data_loader import object_inputs as oi
+    from oracle import oa_inputs_oracle as oio
+    from oracle import oatrans_oracle as orc
+    g = torch.load(os.path.join(golden_dir, "oa_inputs.pt"), map_location="cpu", weights_only=False)
+    classes = oi.parse_vocab(g["vocab_lines"])
+    lens = g["token_lens"].numpy()
+    T, R = 4, 32
+    gl, rm, want_gl, want_rm = [], [], [], []
+    for k, c in enumerate(g["npz"][:4]):
+        tags, ids, feats = oi.read_bboxs_tags(os.path.join(golden_dir, c["file"]), classes, top_k=10, v=1)
+        ends, total = oi.object_tags_masks(ids, lens)
+        clip = oi.pack_clip(torch.randn(T + 1 - (k % 2), 3, R, R), T, R)          # odd samples: one frame failed to decode
+        gl.append(dict(video=clip, bboxs=feats, object_token_masks=ends, object_token_len=total, text="a caption", pad_text="a caption" + tags))
+        want_gl.append(orc.patch_masks_from_bbox(feats.clone()))
+        sel = oi.select_region_classes(ids, 5, rng=random.Random(100 + k))
+        mem = torch.randn(len(classes), 512)
+        rm.append(dict(video=clip, bboxs=feats, box_class=ids, sel_class=sel, text_region_embedding=oi.region_embeddings(mem, sel)))
+        masks, sel_o = oio.patch_all_masks_region(feats.numpy(), list(ids), 5, rng=random.Random(100 + k))
+        assert [int(s) for s in sel_o] == sel
+        want_rm.append(torch.from_numpy(masks.astype(np.float32)))
+    b = oi.ObjectBatch("global_local")(gl, "cuda")
+    assert b["video"].shape == (4, T + 1, 3, R, R) and b["video"].is_cuda and not b["video"][1, T].any()
+    assert torch.equal(b["patch_masks"].cpu(), torch.stack([torch.as_tensor(w).float() for w in want_gl]))
+    assert b["object_token_masks"].shape == (4, 10) and b["object_token_len"].tolist() == [int(s["object_token_len"]) for s in gl]
+    assert b["pad_text"][0].startswith("a caption ")
+    r = oi.ObjectBatch("region_mem")(rm, "cuda")
+    assert torch.equal(r["patch_masks"].cpu(), torch.stack(want_rm))
+    assert r["text_region_embedding"].shape == (4, 5, 512)
