@@ -163,6 +163,28 @@ int oat_attn_text_bwd(const void* qkv, int ldqkv, const void* mask, const void* 
                       const float* lse, float* delta_scratch, const void* dout, int lddo, void* dqkv,
                       int lddqkv, int B, int L, int H, int D, float scale, float drop_p, const void* rng,
                       unsigned drop_site, void* stream);
+/* ---- OCP fp8 (e4m3fn) forward GEMMs, per-tensor scaled (BASELINE.json config 5; stands where the bf16 oat_gemm_nt
+ * serves the nn.Linear forwards of video_transformer.py:46-50,102,133).  A quantisation site owns three device floats:
+ * amax (running max |x| of this step), qscale (q = sat(x * qscale)), dq = 1 / qscale. */
+int oat_fp8_quant(const void* x, int is_bf16, int ldx, void* out8, int ld8, int M, int K, const float* qscale,
+                  float* amax_or_null, void* stream);                 /* quantise with *qscale, record amax of x */
+int oat_fp8_amax(const void* x, int is_bf16, int ldx, int M, int K, float* amax, void* stream);
+int oat_fp8_chunk_elems(void);
+/* many contiguous bf16 matrices in one launch; desc rows int64 {src, dst, n, site, first_block}, owner: block -> row */
+int oat_fp8_multi(const void* desc, const int* owner, int total_blocks, const float* qscale, float* amax, int quant,
+                  void* stream);
+int oat_fp8_update_scales(float* amax, float* qscale, float* dq, int n_sites, float margin, void* stream);
+/* C = dq_a dq_b (A8 . B8^T) + bias ; epi 0 (bf16 out) or 5 (out = gelu'(h), out2 = gelu(h)); K % 256 == 0,
+ * N % 256 == 0, N <= 4096, M >= 256; lda / ldb in elements (bytes) */
+int oat_gemm_nt_f8(const void* A8, const void* B8, int M, int N, int K, int lda, int ldb, int epi, void* out, int ldc,
+                   void* out2, int ld2, const float* bias, const float* dq_a, const float* dq_b,
+                   void* out8_or_null, int ld8, const float* q_out, float* amax_out,   /* epi 5: e4m3 copy of out2 */
+                   void* stream);
+/* LayerNorm (optionally of x + add16, sum32 = the sum) writing y as bf16 AND as e4m3 (y8 = sat(y * *qscale)), amax of y
+ * recorded: the producer-side quantisation of the fp8 GEMM operand */
+int oat_layernorm_fwd_f8(const float* x, int ldx, const void* add16_or_null, int ldadd, float* sum32, int ldsum,
+                         const float* gamma, const float* beta, void* y, int ldy, void* y8, int ld8, const float* qscale,
+                         float* amax, float* mean, float* rstd, int M, int D, float eps, void* stream);
 /* ---- dropout of the text tower's training mode (HF DistilBERT nn.Dropout sites: embeddings, attention probabilities,
  * ffn output; reference call site oa_model.py:56,113-121).  Counter-based Philox4x32-10 masks: element idx of `site`
  * draws word idx%4 of philox(counter = (idx/4 lo, idx/4 hi, site, offset), key = seed); rng = device uint64[2] =

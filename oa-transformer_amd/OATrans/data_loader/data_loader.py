@@ -57,12 +57,12 @@ class _SyntheticLoader:
         op = self.object_params
         if op.get('input_objects') or op.get('pseudo_labels') or op.get('input_object_bboxs'):
             # object-aware fields in the formats the reference datasets emit:
-            #   patch_masks        [B, O, 196] 0/1 - boxes rasterised on the 14x14 patch grid
+            #   patch_masks        [B, O, (R/16)^2] 0/1 - boxes rasterised on the patch grid (14x14 at 224^2)
             #                      (base_dataset_global_local.py:348-356); region_mem uses O = 5 (:233-247)
             #   object_token_masks [B, O] cumulative tag-token ends, object_token_len [B]
             #   pad_text           caption + object tags, pre-tokenised
             #   text_region_embedding [B, 5, 512] (CLIP text features of 5 sampled classes)
-            O, g14 = int(op.get('num_objects', 10)), 14
+            O, g14 = int(op.get('num_objects', 10)), R // 16        # patch grid of the frame: 14 at 224^2, 21 at 336^2
             x0 = torch.randint(0, g14 - 1, (B, O), generator=g)
             y0 = torch.randint(0, g14 - 1, (B, O), generator=g)
             x1 = x0 + 1 + torch.randint(0, g14, (B, O), generator=g) % (g14 - x0)

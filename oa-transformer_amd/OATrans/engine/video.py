@@ -132,6 +132,12 @@ class VideoEngine:
         # (~27 GB/s per CU), so on the quarter of the CUs a GEMM leaves them they take 2-2.5x as long - what the overlap
         # gains, the partition loses.  Default: every kernel alone on the GPU, in order, on the caller's stream.
         self.bwd_side = os.environ.get("OAT_BWD_SIDE", "0") != "0"
+        # fp8 forward (BASELINE.json config 5): the six linears of every block run on OCP e4m3 operands with per-tensor
+        # delayed scaling (csrc/fp8.hip, gemm_nt_pp.hip PPF_F8); attention, LayerNorm, the CLS lane, the loss and the
+        # whole backward stay bf16 / fp32.  Set by OAT_FP8=1 or by the caller (bench.py --dtype fp8).
+        self.fp8 = os.environ.get("OAT_FP8", "0") != "0"
+        self.fp8_margin = float(os.environ.get("OAT_FP8_MARGIN", "1.0"))
+        self._f8 = None
         self._streams = None
         self._tn_ws = None
 
@@ -154,6 +160,81 @@ class VideoEngine:
             self._cast = hip.CastTable(entries)
         self._cast.run()                                          # all 73 W / W^T shadows in one launch
         self.shadow_versions = sig
+        if self.fp8:
+            self._refresh_fp8_weights()
+
+    # ------------------------------------------------------------------ fp8 forward
+    F8_LINEARS = ("timeattn.qkv", "timeattn.proj", "attn.qkv", "attn.proj", "mlp.fc1", "mlp.fc2")
+
+    def _fp8_state(self, dev):
+        """Quantisation sites: block i, linear j -> weight site 12 i + j, activation (GEMM input) site 12 i + 6 + j.
+        amax / qscale / dq are rows of one device tensor."""
+        if self._f8 is None:
+            n = 12 * self.depth
+            st = torch.zeros(3, n, dtype=torch.float32, device=dev)
+            self._f8 = dict(n=n, amax=st[0], qscale=st[1], dq=st[2], w8={}, table=None, primed=set(), key=None)
+        return self._f8
+
+    def _refresh_fp8_weights(self):
+        """e4m3 copies of the six weight matrices of every block, from their bf16 shadows, scaled by their CURRENT amax
+        (3 launches for all 72: amax, scales, quantise)."""
+        names = [(i, j, f"blocks.{i}.{l}.weight") for i in range(self.depth) for j, l in enumerate(self.F8_LINEARS)]
+        dev = self.shadow[names[0][2]][0].device
+        f8 = self._fp8_state(dev)
+        key = tuple(self.shadow[n][0].data_ptr() for _, _, n in names)
+        if f8["key"] != key:
+            entries = []
+            for i, j, n in names:
+                w16 = self.shadow[n][0]
+                f8["w8"][n] = torch.empty(w16.shape, dtype=torch.uint8, device=dev)
+                entries.append((w16, f8["w8"][n], 12 * i + j))
+            f8["table"], f8["key"] = hip.Fp8Table(entries), key
+        f8["table"].run(f8["qscale"], f8["amax"], quant=False)
+        hip.fp8_update_scales(f8["amax"], f8["qscale"], f8["dq"], f8["n"], 1.0)       # activation sites: amax == 0, untouched
+        f8["table"].run(f8["qscale"], f8["amax"], quant=True)
+
+    def _f8_site(self, i, j):
+        """(qscale, amax, dq) one-element views of activation site (block i, linear j)."""
+        f8, s = self._f8, 12 * i + 6 + j
+        return f8["qscale"][s:s + 1], f8["amax"][s:s + 1], f8["dq"][s:s + 1]
+
+    def _f8_primed(self, i, j):
+        """Has the input of linear j of block i been seen (does its delayed scale exist)?  Producers quantise in their own
+        epilogue only then; the very first step quantises in a separate pass with the CURRENT amax."""
+        return self.fp8 and (12 * i + 6 + j) in self._f8["primed"]
+
+    def _ln_f8(self, pl, i, j, x, gamma, beta, y, mean, rstd, add16=None, sum32=None):
+        """LayerNorm whose output feeds linear j of block i: bf16 y (kept for backward) and its e4m3 copy in pl.x8."""
+        q, am, _ = self._f8_site(i, j)
+        hip.layernorm_fwd_f8(x, gamma, beta, pl.M, self.D, 1e-6, y, pl.x8, q, am, mean, rstd, add16=add16, sum32=sum32)
+
+    def _linear_f8(self, pl, i, j, x16, K, N, epi, out, bias, out2=None, quantised=False):
+        """out = x16 @ W^T + bias on fp8 operands.  quantised=True: the producer already left e4m3(x16) in pl.x8 /
+        pl.x8_wide; otherwise the bf16 input is quantised here (delayed scale; first use: current scale).  The fc1 launch
+        (j == 4) also leaves e4m3(gelu) for fc2 in pl.x8_wide once fc2's site is primed."""
+        f8 = self._f8
+        site, wsite = 12 * i + 6 + j, 12 * i + j
+        x8 = pl.x8_wide if K == self.Hd else pl.x8
+        M = pl.M
+        q, am, dq = self._f8_site(i, j)
+        if not quantised:
+            if site not in f8["primed"]:
+                hip.fp8_amax(x16, M, K, am)
+                hip.fp8_update_scales(am, q, dq, 1, self.fp8_margin)
+                f8["primed"].add(site)
+            hip.fp8_quant(x16, x8, M, K, q, am)
+        w8 = f8["w8"][f"blocks.{i}.{self.F8_LINEARS[j]}.weight"]
+        kw = {}
+        if j == 4 and self._f8_primed(i, 5):
+            q5, am5, _ = self._f8_site(i, 5)
+            kw = dict(out8=pl.x8_wide, q_out=q5, amax_out=am5)
+        hip.gemm_nt_f8(x8, w8, M, N, K, epi, out, dq, f8["dq"][wsite:wsite + 1], out2=out2, bias=bias, **kw)
+        return bool(kw)
+
+    def _fp8_end_of_forward(self):
+        """Next step's activation scales from this step's amax (weight sites saw no amax: unchanged)."""
+        f8 = self._f8
+        hip.fp8_update_scales(f8["amax"], f8["qscale"], f8["dq"], f8["n"], self.fp8_margin)
 
     def plan(self, B, T, N, dev, call=0):
         """One plan per clip shape AND per call of a step: the object-aware models encode two clips (object frame,
@@ -195,12 +276,17 @@ class VideoEngine:
         # every GEMM has the GPU to itself: the third, 31 %-full round of the N = 768 GEMMs (591 tiles on 256 CUs) is
         # re-tiled as 128x128 (see gemm_nt.hip)
         hip.gemm_set_tail_split(self.tail_split)
+        if self.fp8 and getattr(pl, "x8", None) is None:
+            pl.x8 = torch.zeros(pl.Mp, self.D, dtype=torch.uint8, device=dev)          # fp8 GEMM inputs (one in flight)
+            pl.x8_wide = torch.zeros(pl.Mp, self.Hd, dtype=torch.uint8, device=dev)
         self._embed(pl, params, C, R)
         pend = None
         for i in range(self.depth):
             pend = self._block_fwd(pl, i, params, pend, region_layer)
         run = _Run(pl, need_patches, region_layer)
         out = self._final_fwd(pl, params, need_patches, region_layer)
+        if self.fp8:
+            self._fp8_end_of_forward()
         pl.video = None
         hip.gemm_set_tail_split(False)
         return out[0], out[1], run
@@ -248,9 +334,13 @@ class VideoEngine:
         w = lambda s: self.shadow[f"blocks.{i}.{s}.weight"][0]
         st = a.stats
         lane = pl.lane
+        q3 = self._f8_primed(i, 0)          # fp8: LayerNorm outputs are quantised by the LayerNorm kernel itself
         if pend is None:
             x = pl.x0
-            hip.layernorm_fwd(x, p("norm3.weight"), p("norm3.bias"), M, D, 1e-6, y=a.a3, mean=st[0], rstd=st[1])
+            if q3:
+                self._ln_f8(pl, i, 0, x, p("norm3.weight"), p("norm3.bias"), a.a3, st[0], st[1])
+            else:
+                hip.layernorm_fwd(x, p("norm3.weight"), p("norm3.bias"), M, D, 1e-6, y=a.a3, mean=st[0], rstd=st[1])
             if lane is not None:                         # the lane starts from the embedding's CLS rows
                 e0 = torch.cuda.Event()
                 e0.record(torch.cuda.current_stream())
@@ -259,8 +349,11 @@ class VideoEngine:
                     lane["x"].copy_(x[BTN:M])
                 self._lane_ln(pl, lane["x"], None, None, p("norm3.weight"), p("norm3.bias"), lane["a32"])
         else:
-            hip.add_layernorm_fwd(pend.y, br, pend.out, p("norm3.weight"), p("norm3.bias"), M, D, 1e-6, y=a.a3,
-                                  mean=st[0], rstd=st[1])
+            if q3:
+                self._ln_f8(pl, i, 0, pend.y, p("norm3.weight"), p("norm3.bias"), a.a3, st[0], st[1], add16=br, sum32=pend.out)
+            else:
+                hip.add_layernorm_fwd(pend.y, br, pend.out, p("norm3.weight"), p("norm3.bias"), M, D, 1e-6, y=a.a3,
+                                      mean=st[0], rstd=st[1])
             x = pend.out
             if lane is not None:                         # x = y + mlp of the previous block
                 self._lane_ln(pl, lane["y"], lane["br32"], lane["x"], p("norm3.weight"), p("norm3.bias"), lane["a32"])
@@ -269,17 +362,31 @@ class VideoEngine:
         # ---- time attention
         if lane is not None:
             self._lane_linear(pl, lane["a32"], p("timeattn.qkv.weight")[:D], p("timeattn.qkv.bias")[:D], D, D, lane["q32"])
-        hip.gemm_nt(a.a3, w("timeattn.qkv"), M, 3 * D, D, hip.EPI_BF16, a.qkv_t, bias=p("timeattn.qkv.bias"))
+        f8 = self.fp8
+        if f8:
+            self._linear_f8(pl, i, 0, a.a3, D, 3 * D, hip.EPI_BF16, a.qkv_t, p("timeattn.qkv.bias"), quantised=q3)
+        else:
+            hip.gemm_nt(a.a3, w("timeattn.qkv"), M, 3 * D, D, hip.EPI_BF16, a.qkv_t, bias=p("timeattn.qkv.bias"))
         self._attention(pl, hip.attn_time_fwd, a.qkv_t, a.o_t, a.lse_t)
         if lane is not None:
             self._lane_linear(pl, lane["o32"], p("timeattn.proj.weight"), p("timeattn.proj.bias"), D, D, lane["br32"])
             self._lane_ln(pl, lane["x"], lane["br32"], lane["xt"], p("norm1.weight"), p("norm1.bias"), lane["a32"])
             self._lane_linear(pl, lane["a32"], p("attn.qkv.weight")[:D], p("attn.qkv.bias")[:D], D, D, lane["q32"])
-        hip.gemm_nt(a.o_t, w("timeattn.proj"), M, D, D, hip.EPI_BF16, br, bias=p("timeattn.proj.bias"))
-        hip.add_layernorm_fwd(x, br, a.xt, p("norm1.weight"), p("norm1.bias"), M, D, 1e-6, y=a.a1, mean=st[2],
-                              rstd=st[3])                                           # xt = x + time
+        if f8:
+            self._linear_f8(pl, i, 1, a.o_t, D, D, hip.EPI_BF16, br, p("timeattn.proj.bias"))
+        else:
+            hip.gemm_nt(a.o_t, w("timeattn.proj"), M, D, D, hip.EPI_BF16, br, bias=p("timeattn.proj.bias"))
+        q1 = self._f8_primed(i, 2)
+        if q1:
+            self._ln_f8(pl, i, 2, x, p("norm1.weight"), p("norm1.bias"), a.a1, st[2], st[3], add16=br, sum32=a.xt)
+        else:
+            hip.add_layernorm_fwd(x, br, a.xt, p("norm1.weight"), p("norm1.bias"), M, D, 1e-6, y=a.a1, mean=st[2],
+                                  rstd=st[3])                                       # xt = x + time
         # ---- space attention
-        hip.gemm_nt(a.a1, w("attn.qkv"), M, 3 * D, D, hip.EPI_BF16, a.qkv_s, bias=p("attn.qkv.bias"))
+        if f8:
+            self._linear_f8(pl, i, 2, a.a1, D, 3 * D, hip.EPI_BF16, a.qkv_s, p("attn.qkv.bias"), quantised=q1)
+        else:
+            hip.gemm_nt(a.a1, w("attn.qkv"), M, 3 * D, D, hip.EPI_BF16, a.qkv_s, bias=p("attn.qkv.bias"))
         self._attention(pl, hip.attn_space_fwd, a.qkv_s, a.o_s, a.lse_s)
         if lane is not None:
             self._lane_linear(pl, lane["o32"], p("attn.proj.weight"), p("attn.proj.bias"), D, D, lane["br32"])
@@ -287,13 +394,24 @@ class VideoEngine:
             self._lane_ln(pl, lane["x"], lane["br32"], lane["y"], p("norm2.weight"), p("norm2.bias"), lane["a32"])
             self._lane_linear(pl, lane["a32"], p("mlp.fc1.weight"), p("mlp.fc1.bias"), Hd, D, lane["g32"], act=hip.LIN_GELU)
             self._lane_linear(pl, lane["g32"], p("mlp.fc2.weight"), p("mlp.fc2.bias"), D, Hd, lane["br32"])
-        hip.gemm_nt(a.o_s, w("attn.proj"), M, D, D, hip.EPI_BF16, br, bias=p("attn.proj.bias"))
+        if f8:
+            self._linear_f8(pl, i, 3, a.o_s, D, D, hip.EPI_BF16, br, p("attn.proj.bias"))
+        else:
+            hip.gemm_nt(a.o_s, w("attn.proj"), M, D, D, hip.EPI_BF16, br, bias=p("attn.proj.bias"))
         # space residual comes from x, NOT from x + time (video_transformer.py:170)
-        hip.add_layernorm_fwd(x, br, a.y, p("norm2.weight"), p("norm2.bias"), M, D, 1e-6, y=a.a2, mean=st[4],
-                              rstd=st[5])                                           # y = x + space
+        q2 = self._f8_primed(i, 4)
+        if q2:
+            self._ln_f8(pl, i, 4, x, p("norm2.weight"), p("norm2.bias"), a.a2, st[4], st[5], add16=br, sum32=a.y)
+        else:
+            hip.add_layernorm_fwd(x, br, a.y, p("norm2.weight"), p("norm2.bias"), M, D, 1e-6, y=a.a2, mean=st[4],
+                                  rstd=st[5])                                       # y = x + space
         # ---- MLP
-        hip.gemm_nt(a.a2, w("mlp.fc1"), M, Hd, D, hip.EPI_GELU_GRAD, a.h, out2=a.g, bias=p("mlp.fc1.bias"))
-        hip.gemm_nt(a.g, w("mlp.fc2"), M, D, Hd, hip.EPI_BF16, br, bias=p("mlp.fc2.bias"))
+        if f8:
+            gq = self._linear_f8(pl, i, 4, a.a2, D, Hd, hip.EPI_GELU_GRAD, a.h, p("mlp.fc1.bias"), out2=a.g, quantised=q2)
+            self._linear_f8(pl, i, 5, a.g, Hd, D, hip.EPI_BF16, br, p("mlp.fc2.bias"), quantised=gq)
+        else:
+            hip.gemm_nt(a.a2, w("mlp.fc1"), M, Hd, D, hip.EPI_GELU_GRAD, a.h, out2=a.g, bias=p("mlp.fc1.bias"))
+            hip.gemm_nt(a.g, w("mlp.fc2"), M, D, Hd, hip.EPI_BF16, br, bias=p("mlp.fc2.bias"))
         return a                                                                    # out = y + br, formed lazily
 
     def _final_fwd(self, pl, params, need_patches, region_layer):

@@ -335,6 +335,58 @@ def attn_text_fwd_dual(qkv, qkv32, mask, out, out32, lse, B, L, H, D, scale, dro
                                         _f(drop_p), _ptr(rng), ctypes.c_uint(site), _stream()), "oat_attn_text_fwd_dual")
 
 
+# ---- fp8 (OCP e4m3fn) forward GEMMs ------------------------------------------------------------------------------
+def fp8_quant(x, out8, M, K, qscale, amax=None):
+    _check(lib().oat_fp8_quant(_ptr(x), int(x.dtype == torch.bfloat16), x.stride(0), _ptr(out8), out8.stride(0), M, K,
+                               _ptr(qscale), _ptr(amax), _stream()), "oat_fp8_quant")
+
+
+def fp8_amax(x, M, K, amax):
+    _check(lib().oat_fp8_amax(_ptr(x), int(x.dtype == torch.bfloat16), x.stride(0), M, K, _ptr(amax), _stream()), "oat_fp8_amax")
+
+
+def fp8_update_scales(amax, qscale, dq, n, margin=1.0):
+    _check(lib().oat_fp8_update_scales(_ptr(amax), _ptr(qscale), _ptr(dq), n, _f(margin), _stream()), "oat_fp8_update_scales")
+
+
+class Fp8Table:
+    """Descriptor table for oat_fp8_multi: (src bf16 contiguous, dst uint8 same numel, site) per matrix."""
+
+    def __init__(self, entries):
+        chunk = lib().oat_fp8_chunk_elems()
+        rows, owner, blocks = [], [], 0
+        for src, dst, site in entries:
+            n = src.numel()
+            assert n % 8 == 0 and src.is_contiguous() and dst.is_contiguous() and dst.numel() == n
+            rows.append([src.data_ptr(), dst.data_ptr(), n, site, blocks])
+            nb = (n + chunk - 1) // chunk
+            owner.append(torch.full((nb,), len(rows) - 1, dtype=torch.int32))
+            blocks += nb
+        dev = entries[0][0].device
+        self.table = torch.tensor(rows, dtype=torch.int64).to(dev)
+        self.owner = torch.cat(owner).to(dev)
+        self.blocks, self.keep = blocks, entries
+
+    def run(self, qscale, amax, quant):
+        _check(lib().oat_fp8_multi(_ptr(self.table), _ptr(self.owner), self.blocks, _ptr(qscale), _ptr(amax), int(quant),
+                                   _stream()), "oat_fp8_multi")
+
+
+def gemm_nt_f8(A8, B8, M, N, K, epi, out, dq_a, dq_b, out2=None, bias=None, out8=None, q_out=None, amax_out=None):
+    _check(lib().oat_gemm_nt_f8(_ptr(A8), _ptr(B8), M, N, K, A8.stride(0), B8.stride(0), int(epi), _ptr(out), out.stride(0),
+                                _ptr(out2), out2.stride(0) if out2 is not None else 0, _ptr(bias), _ptr(dq_a), _ptr(dq_b),
+                                _ptr(out8), out8.stride(0) if out8 is not None else 0, _ptr(q_out), _ptr(amax_out),
+                                _stream()), "oat_gemm_nt_f8")
+
+
+def layernorm_fwd_f8(x, gamma, beta, M, D, eps, y, y8, qscale, amax, mean, rstd, add16=None, sum32=None):
+    """y = LN(x [+ add16]) as bf16 and as e4m3 (y8); sum32 = x + add16 when add16 is given."""
+    s0 = lambda t: t.stride(0) if t is not None else 0
+    _check(lib().oat_layernorm_fwd_f8(_ptr(x), x.stride(0), _ptr(add16), s0(add16), _ptr(sum32), s0(sum32), _ptr(gamma),
+                                      _ptr(beta), _ptr(y), y.stride(0), _ptr(y8), y8.stride(0), _ptr(qscale), _ptr(amax),
+                                      _ptr(mean), _ptr(rstd), M, D, _f(eps), _stream()), "oat_layernorm_fwd_f8")
+
+
 def new_rng_state(seed, device):
     """Device-resident dropout state {seed, offset} (int64[2]); oat_rng_tick advances the offset."""
     return torch.tensor([int(seed) & 0x7fffffffffffffff, 0], dtype=torch.int64, device=device)

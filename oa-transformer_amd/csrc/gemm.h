@@ -27,6 +27,11 @@ struct GemmArgs {
   int row0;            // first row of this launch inside the caller's problem (tail launches; used by resid_mod)
   int* ctr;            // persistent launch: 8 per-XCD tile counters of THIS launch (zero on entry), or nullptr = static walk
   int* ctr_reset;      // counters of a launch far in the future, zeroed by this one
+  const float* dq_a;   // fp8 launches: device scalars, dequantisation scale of A and of B (value = quantised * dq)
+  const float* dq_b;
+  void* out8; int ld8;     // fp8 launches, EPI_GELU_GRAD: optional e4m3 copy of out2 (the next GEMM's operand) ...
+  const float* q_out;      // ... quantised with this device scalar,
+  float* amax_out;         // ... its max |value| recorded here
 };
 
 constexpr int BK = 64;
@@ -48,5 +53,8 @@ int launch_tn_pp(const TnArgs& g, int flags, hipStream_t s);
 // gemm_nt_pp.hip.  pp_supported: does the ping-pong kernel cover this launch (epilogue, shape)?
 bool pp_supported(int epi, const GemmArgs& g);
 int launch_pp(int epi, const GemmArgs& g, int grid_slots, int flags, hipStream_t s);
+// the same kernel on OCP fp8 (e4m3) operands with per-tensor scales (GemmArgs::dq_a / dq_b)
+bool pp_f8_supported(int epi, const GemmArgs& g);
+int launch_pp_f8(int epi, const GemmArgs& g, int grid_slots, hipStream_t s);
 
 }  // namespace oat

@@ -30,6 +30,7 @@
 // drain under the next tile's K loop (vmcnt retires loads and stores in issue order on gfx950; the first six waits
 // after an interior epilogue allow its NST stores on top of the 12 pieces).
 #include "gemm.h"
+#include "fp8.h"
 #include <type_traits>
 
 namespace oat {
@@ -40,7 +41,20 @@ constexpr int PP_A1 = 32768, PP_B0 = 65536, PP_BIAS = 131072;
 constexpr int PP_MAXN = 4096;                       // bias vector kept in LDS
 constexpr int PP_LDS = PP_BIAS + PP_MAXN * 4;
 
-enum : int { PPF_PRIO = 1, PPF_NOSTAGGER = 2, PPF_LGKM = 4, PPF_BONUS = 8, PPF_NOEPI = 16, PPF_PH2 = 32, PPF_WIDE = 64 };
+enum : int { PPF_PRIO = 1, PPF_NOSTAGGER = 2, PPF_LGKM = 4, PPF_BONUS = 8, PPF_NOEPI = 16, PPF_PH2 = 32, PPF_WIDE = 64,
+             PPF_F8 = 128 };
+
+// PPF_F8: OCP fp8 (e4m3) operands, per-tensor scaled.  A K-tile is still 128 BYTES of every row - now 128 k - so the
+// staging stream, the LDS layout, the swizzle, the region refill and every wait count are those of the bf16 kernel; a
+// lane's MFMA operand becomes the 32 consecutive k of its row group (chunks 2 fk, 2 fk + 1: lane l of
+// v_mfma_f32_16x16x128_f8f6f4 holds row l & 15, k = 32 (l >> 4) .. + 31; scripts/dev/fp8_probe) and one MFMA does the
+// work of four bf16 ones in twice the time.  The accumulators hold the product of the QUANTISED operands; the epilogue
+// multiplies by the two dequantisation scales (device scalars, GemmArgs::dq_a / dq_b), the bias enters pre-divided.
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+OAT_DEV i32x8 f8_operand(const bf16x8 lo, const bf16x8 hi) {
+  return __builtin_shufflevector(__builtin_bit_cast(i32x4, lo), __builtin_bit_cast(i32x4, hi), 0, 1, 2, 3, 4, 5, 6, 7);
+}
 
 // In-place MFMA (D = C register block).  hipcc otherwise gives the second k-half's MFMAs fresh destination registers
 // (it renames around the dependent pair), which costs up to 32 VGPRs in a 32-MFMA interval and spills at the 256 limit.
@@ -53,21 +67,35 @@ OAT_DEV void mfma_inplace(f32x4& c, const bf16x8 a, const bf16x8 b) {
 // Epilogue of one 256x256 tile (no LDS, no barriers): lane (fk, frow) owns rows 16 i + 4 fk + r and the 4 consecutive
 // columns 4 frow + j of its wave tile, so 16 consecutive lanes store one 128-byte line per row.  Returns whether the
 // tile was an interior one (then exactly NST = 32 (64 for EPI_GELU_GRAD) store instructions were issued per lane).
-template <int EPI, bool WIDE = false>
-OAT_DEV bool pp_epilogue(const GemmArgs& g, const f32x4 (&acc)[8][4], int m0, int n0, int wm, int wn, int lane) {
+template <int EPI, bool WIDE = false, bool F8 = false>
+OAT_DEV bool pp_epilogue(const GemmArgs& g, const f32x4 (&acc)[8][4], int m0, int n0, int wm, int wn, int lane, float dq = 1.f) {
   // lane-constant store offsets are derived from an opaque copy of the lane id: hoisted out of the tile loop they would
   // sit in VGPRs through the K loop, which has none to spare
   asm volatile("" : "+v"(lane));
   const int frow = lane & 15, fk = lane >> 4;
   const int wrow0 = m0 + wm * 128, wcol00 = n0 + wn * 64;
-  auto finish = [&](const f32x4 v, const bf16x4 a, bf16x4& o, bf16x4& o2) {
+  constexpr bool Q8 = F8 && EPI == EPI_GELU_GRAD;      // optional e4m3 copy of gelu(h) for the fc2 GEMM
+  uint8_t* const o8 = Q8 ? reinterpret_cast<uint8_t*>(g.out8) : nullptr;
+  const float q8 = (Q8 && o8) ? g.q_out[0] : 0.f;
+  float m8 = 0.f;
+  uint32_t w8 = 0;                                     // the 4 quantised values of the last finish() call
+  auto finish = [&](f32x4 v, const bf16x4 a, bf16x4& o, bf16x4& o2) {
+    if constexpr (F8) v *= dq;
     if constexpr (EPI == EPI_GELU_GRAD) {
+      float gq[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float gl, dg;
         gelu_both(v[e], gl, dg);
         o[e] = f2bf(dg);
         o2[e] = f2bf(gl);
+        gq[e] = gl;
+      }
+      if constexpr (Q8) {
+        if (o8) {
+          m8 = fmaxf(fmaxf(m8, fmaxf(fabsf(gq[0]), fabsf(gq[1]))), fmaxf(fabsf(gq[2]), fabsf(gq[3])));
+          w8 = pack_fp8x4(gq[0] * q8, gq[1] * q8, gq[2] * q8, gq[3] * q8);
+        }
       }
     } else if constexpr (EPI == EPI_MUL_AUX) {
 #pragma unroll
@@ -147,6 +175,9 @@ OAT_DEV bool pp_epilogue(const GemmArgs& g, const f32x4 (&acc)[8][4], int m0, in
         const uint32_t rr = (uint32_t)(i * 16 + r);
         *reinterpret_cast<bf16x4*>(ob + (size_t)(rr * (uint32_t)g.ldc * 2) + lo) = o;
         if constexpr (EPI == EPI_GELU_GRAD) *reinterpret_cast<bf16x4*>(ob2 + (size_t)(rr * (uint32_t)g.ld2 * 2) + lo2) = o2;
+        if constexpr (Q8) {
+          if (o8) *reinterpret_cast<uint32_t*>(o8 + (size_t)(wrow0 + i * 16 + fk * 4 + r) * g.ld8 + wcol00 + frow * 4) = w8;
+        }
       }
     }
   } else {
@@ -163,8 +194,14 @@ OAT_DEV bool pp_epilogue(const GemmArgs& g, const f32x4 (&acc)[8][4], int m0, in
           finish(v, a, o, o2);
           if constexpr (EPI == EPI_GELU_GRAD) *reinterpret_cast<bf16x4*>((bf16*)g.out2 + (size_t)row * g.ld2 + col) = o2;
           *reinterpret_cast<bf16x4*>((bf16*)g.out + (size_t)row * g.ldc + col) = o;
+          if constexpr (Q8) {
+            if (o8) *reinterpret_cast<uint32_t*>(o8 + (size_t)row * g.ld8 + col) = w8;
+          }
         }
       }
+  }
+  if constexpr (Q8) {
+    if (o8) amax_commit_wave(m8, g.amax_out);
   }
   return interior;
 }
@@ -173,6 +210,8 @@ template <int EPI, int FL>
 __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs g) {
   constexpr bool PRIO = FL & PPF_PRIO, STAGGER = !(FL & PPF_NOSTAGGER), LGKM = FL & PPF_LGKM, BONUS = FL & PPF_BONUS;
   constexpr bool NOEPI = FL & PPF_NOEPI;
+  constexpr bool F8 = FL & PPF_F8;
+  constexpr int ESH = F8 ? 0 : 1;                               // log2(bytes per operand element)
   constexpr int NST = EPI == EPI_GELU_GRAD ? 64 : 32;           // stores per lane of an interior epilogue
   constexpr int WB = 12 + NST > 63 ? 63 : 12 + NST;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -180,9 +219,14 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs g) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;                      // wave tile: rows wm*128.., columns wn*64..
   const int ntn = g.N >> 8, ntm = (g.M + 255) >> 8, nwg = ntm * ntn;
-  const int nk = g.K >> 6;
+  const int nk = g.K >> (7 - ESH);                                      // K-tiles of 128 bytes per row
   const int ntl = (nwg - 1 - (int)blockIdx.x) / (int)gridDim.x + 1;     // tiles this workgroup walks
   const int S = ntl * nk;                                               // its stream of K-tiles
+  float dq = 1.f, inv_dq = 1.f;
+  if constexpr (F8) {
+    dq = g.dq_a[0] * g.dq_b[0];
+    inv_dq = 1.f / dq;
+  }
   struct Tile { int m0, n0; };
   auto tile_of = [&](int t) __attribute__((always_inline)) {
     const int w = blockIdx.x + t * gridDim.x;
@@ -194,14 +238,14 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs g) {
 
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   float* const sbias = reinterpret_cast<float*>(smem + PP_BIAS);
-  for (int i = tid; i < g.N; i += 512) sbias[i] = g.bias ? g.bias[i] : 0.f;
+  for (int i = tid; i < g.N; i += 512) sbias[i] = g.bias ? g.bias[i] * inv_dq : 0.f;
 
   // ---- staging.  One LDS-DMA piece = 8 tile rows x 128 B.  Per K-tile a wave stages two pieces of each class:
   //   a0 = A rows {0..63, 128..191} (first halves of the two wave rows), a1 = the other A rows,
   //   b0 = B rows with (row >> 5) even (first halves of the four wave columns), b1 = the others.
   const int srow = lane >> 3;
   const uint32_t c16_0 = (uint32_t)(((lane & 7) ^ (srow >> 1)) << 4);          // 16-byte chunk, source-side swizzle
-  const uint32_t lda2 = (uint32_t)g.lda * 2u, ldb2 = (uint32_t)g.ldb * 2u;
+  const uint32_t lda2 = (uint32_t)g.lda << ESH, ldb2 = (uint32_t)g.ldb << ESH;  // row strides in bytes
   int pa[2], pb[2];                                                             // piece index of (class 0, e)
   uint32_t boff[2][2];
 #pragma unroll
@@ -218,12 +262,14 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs g) {
   }
   // staging cursor: K-tile cs = s + 2 of the stream
   int ckt = 0, ctl = 0, crmax;
-  const bf16 *ca, *cb;
+  const char *ca, *cb;                         // byte cursors: a K-tile is 128 bytes of every row in both formats
+  const char* const A0 = reinterpret_cast<const char*>(g.A);
+  const char* const B0 = reinterpret_cast<const char*>(g.B);
   uint32_t lda2c = lda2, bmask = ~0u;          // zeroed once the stream is exhausted (see `advance`)
   {
     const Tile t = tile_of(0);
-    ca = g.A + (size_t)t.m0 * g.lda;
-    cb = g.B + (size_t)t.n0 * g.ldb;
+    ca = A0 + (size_t)t.m0 * lda2;
+    cb = B0 + (size_t)t.n0 * ldb2;
     crmax = g.M - 1 - t.m0;
   }
   // Past the last K-tile of the stream the cursor stays where it is and the pieces degenerate to re-reads of ONE
@@ -231,15 +277,15 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs g) {
   // stays uniform to the end, for 2 K-tiles of dummy pieces per workgroup and launch.
   auto advance = [&]() __attribute__((always_inline)) {
     ++ckt;
-    ca += 64;
-    cb += 64;
+    ca += 128;
+    cb += 128;
     if (ckt == nk) {                            // selects, not branches: every path assigns every cursor variable
       const bool more = ctl + 1 < ntl;
       ctl += more ? 1 : 0;
       const Tile t = tile_of(ctl);
       ckt = more ? 0 : nk - 1;
-      ca = more ? g.A + (size_t)t.m0 * g.lda : ca - 64;
-      cb = more ? g.B + (size_t)t.n0 * g.ldb : cb - 64;
+      ca = more ? A0 + (size_t)t.m0 * lda2 : ca - 128;
+      cb = more ? B0 + (size_t)t.n0 * ldb2 : cb - 128;
       crmax = g.M - 1 - t.m0;
       lda2c = more ? lda2c : 0u;
       bmask = more ? bmask : 0x7fu;
@@ -267,7 +313,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs g) {
   uint32_t pA[2], pB[2];
 #pragma unroll
   for (int kk = 0; kk < 2; ++kk) {
-    const int ch = ((kk * 4 + fk) ^ sw) << 4;
+    const int ch = ((F8 ? fk * 2 + kk : kk * 4 + fk) ^ sw) << 4;   // bf16: k = 32 kk + 8 fk .. ; fp8: k = 32 fk + 16 kk ..
     pA[kk] = lds0 + (wm * 128 + frow) * 128 + ch;
     pB[kk] = lds0 + PP_B0 + (wn * 64 + frow) * 128 + ch;
   }
@@ -302,14 +348,24 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs g) {
   };
   auto mma = [&](const bf16x8 (&fa)[2][4], const bf16x8 (&fb)[2][2], int ah, int bh) __attribute__((always_inline)) {
     if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
+    if constexpr (F8) {
+      // constant zero scale operands select the UNSCALED v_mfma_f32_16x16x128_f8f6f4 (cbsz = blgp = 0: e4m3 x e4m3)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[ah * 4 + i][bh * 2 + j] =
-              __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kk][i], fb[kk][j], acc[ah * 4 + i][bh * 2 + j], 0, 0, 0);
+          acc[ah * 4 + i][bh * 2 + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
+              f8_operand(fa[0][i], fa[1][i]), f8_operand(fb[0][j], fb[1][j]), acc[ah * 4 + i][bh * 2 + j], 0, 0, 0, 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[ah * 4 + i][bh * 2 + j] =
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kk][i], fb[kk][j], acc[ah * 4 + i][bh * 2 + j], 0, 0, 0);
+    }
     if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -372,7 +428,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs g) {
       prev_interior = false;
       continue;
     }
-    prev_interior = pp_epilogue<EPI>(g, acc, m0, n0, wm, wn, lane);
+    prev_interior = pp_epilogue<EPI, false, F8>(g, acc, m0, n0, wm, wn, lane, dq);
     __builtin_amdgcn_sched_barrier(0);
   }
   if (STAGGER && wm == 0) __builtin_amdgcn_s_barrier();  // pairs with group 1's extra barrier
@@ -599,6 +655,21 @@ int launch_pp_cfg(const GemmArgs& g, int grid_slots, hipStream_t s) {
 }
 
 }  // namespace
+
+bool pp_f8_supported(int epi, const GemmArgs& g) {
+  if (epi != EPI_BF16 && epi != EPI_GELU_GRAD) return false;
+  const int nk = g.K / 128;
+  return g.K % 128 == 0 && g.N % 256 == 0 && g.N <= PP_MAXN && nk >= 2 && nk % 2 == 0 && g.M >= 256 && g.lda % 16 == 0 &&
+         g.ldb % 16 == 0 && g.lda < (1 << 23) && g.ldb < (1 << 23) && g.dq_a && g.dq_b;
+}
+
+// fp8 (e4m3 x e4m3) operands: A [M, K] and B [N, K] one byte per element, lda / ldb in elements (= bytes)
+int launch_pp_f8(int epi, const GemmArgs& g, int grid_slots, hipStream_t s) {
+  constexpr int FL = PPF_PRIO | PPF_BONUS | PPF_LGKM | PPF_F8;
+  if (!pp_f8_supported(epi, g)) { set_error("gemm_nt_f8: shape / epilogue not covered (K % 256, N % 256, N <= 4096, M >= 256, EPI_BF16 | EPI_GELU_GRAD)"); return -3; }
+  if (epi == EPI_GELU_GRAD) return launch_pp_cfg<EPI_GELU_GRAD, FL>(g, grid_slots, s);
+  return launch_pp_cfg<EPI_BF16, FL>(g, grid_slots, s);
+}
 
 bool pp_supported(int epi, const GemmArgs& g) {
   if (epi != EPI_BF16 && epi != EPI_GELU_GRAD && epi != EPI_MUL_AUX) return false;

@@ -7,6 +7,7 @@
 //   VideoPatchEmbed conv     :69-75            (im2col feeding the patch GEMM)
 //   cls/pos/temporal tables  :313-324
 #include "common.h"
+#include "fp8.h"
 #include <stdlib.h>
 
 namespace oat {
@@ -19,14 +20,20 @@ constexpr int LN_MAXV = 4;   // up to 4 float4 per lane -> D <= 1024
 // output of the preceding GEMM) and s is also written to `sum32` (the new fp32 residual stream).  This
 // moves the fp32 read-modify-write of the stream out of the GEMM epilogue (where it runs un-overlapped
 // at ~2.3 TB/s) into this streaming kernel (5.5+ TB/s) without adding bytes.
+// fp8 forward (fp8.hip): y8 != nullptr additionally writes the normalised row as OCP e4m3, quantised with the site's
+// delayed scale *qscale, and records max |y| for the next step's scale.
+struct LnF8 { uint8_t* y8; int ld8; const float* qscale; float* amax; };
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int ldx,
                                                      const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, bf16* y, int ldy,
                                                      float* y32, int ldy32, float* mean, float* rstd,
                                                      int M, int D, float eps, const bf16* add16, int ldadd,
-                                                     float* sum32, int ldsum, const float* add32 = nullptr, int ldadd32 = 0) {
+                                                     float* sum32, int ldsum, const float* add32 = nullptr, int ldadd32 = 0,
+                                                     LnF8 f8 = LnF8{nullptr, 0, nullptr, nullptr}) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
+  const float qs = f8.y8 ? f8.qscale[0] : 0.f;
+  float m8 = 0.f;
   for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
     const float* xr = x + (size_t)row * ldx;
     f32x4 v[LN_MAXV];
@@ -73,9 +80,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
           *reinterpret_cast<bf16x4*>(y + (size_t)row * ldy + c) = ob;
         }
         if (y32) *reinterpret_cast<f32x4*>(y32 + (size_t)row * ldy32 + c) = o;
+        if (f8.y8) {
+          m8 = fmaxf(fmaxf(m8, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+          *reinterpret_cast<uint32_t*>(f8.y8 + (size_t)row * f8.ld8 + c) = pack_fp8x4(o[0] * qs, o[1] * qs, o[2] * qs, o[3] * qs);
+        }
       }
     }
   }
+  if (f8.y8) amax_commit(m8, f8.amax);        // block-uniform branch (kernel argument)
 }
 
 // ------------------------------------------------------------------ LayerNorm backward
@@ -371,6 +383,9 @@ __global__ __launch_bounds__(256) void cast_bf16_multi_kernel(const CastDesc* de
 
 using namespace oat;
 
+static int ln_fwd_launch_f8(const float* x, int ldx, const float* gamma, const float* beta, void* y, int ldy, float* mean,
+                            float* rstd, int M, int D, float eps, const void* add16, int ldadd, float* sum32, int ldsum,
+                            oat::LnF8 f8, void* stream);
 static int ln_fwd_launch(const float* x, int ldx, const float* gamma, const float* beta, void* y, int ldy, float* y32,
                          int ldy32, float* mean, float* rstd, int M, int D, float eps, const void* add16, int ldadd,
                          float* sum32, int ldsum, void* stream) {
@@ -394,6 +409,27 @@ extern "C" int oat_add_layernorm_fwd(const float* x, int ldx, const void* add16,
                                      float* mean, float* rstd, int M, int D, float eps, void* stream) {
   if (!add16) { set_error("add_layernorm_fwd: add16 is required"); return -4; }
   return ln_fwd_launch(x, ldx, gamma, beta, y, ldy, y32, ldy32, mean, rstd, M, D, eps, add16, ldadd, sum32, ldsum, stream);
+}
+
+// LayerNorm with the fp8 copy of its output for an fp8 GEMM: y (bf16, kept for backward) and y8 = e4m3(y * *qscale),
+// amax of y recorded.  add16 optional (then sum32 = x + add16 as in oat_add_layernorm_fwd).
+static int ln_fwd_launch_f8(const float* x, int ldx, const float* gamma, const float* beta, void* y, int ldy, float* mean,
+                            float* rstd, int M, int D, float eps, const void* add16, int ldadd, float* sum32, int ldsum,
+                            oat::LnF8 f8, void* stream) {
+  if (M <= 0) return 0;
+  if (D % 4 || D > LN_MAXV * 256 || ldx % 4 || (y && ldy % 4) || f8.ld8 % 4) { set_error("layernorm_fwd_f8: D%4==0, D<=1024 required"); return -3; }
+  if (!f8.y8 || !f8.qscale || !f8.amax) { set_error("layernorm_fwd_f8: null pointer"); return -4; }
+  int blocks = (M + 3) / 4; if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta, (bf16*)y, ldy,
+                     (float*)nullptr, 0, mean, rstd, M, D, eps, (const bf16*)add16, ldadd, sum32, ldsum, (const float*)nullptr, 0, f8);
+  return check_launch("layernorm_fwd_f8");
+}
+extern "C" int oat_layernorm_fwd_f8(const float* x, int ldx, const void* add16_or_null, int ldadd, float* sum32, int ldsum,
+                                    const float* gamma, const float* beta, void* y, int ldy, void* y8, int ld8,
+                                    const float* qscale, float* amax, float* mean, float* rstd, int M, int D, float eps,
+                                    void* stream) {
+  return ln_fwd_launch_f8(x, ldx, gamma, beta, y, ldy, mean, rstd, M, D, eps, add16_or_null, ldadd, sum32, ldsum,
+                          oat::LnF8{(uint8_t*)y8, ld8, qscale, amax}, stream);
 }
 
 // s = x + add32 (fp32) ; sum32 = s (may alias x) ; y / y32 = LN(s)

@@ -1,0 +1,100 @@
+"""fp8 forward path (BASELINE.json config 5) on a real MI355X.
+Kernel level: the e4m3 conversion equals torch.float8_e4m3fn bit for bit, oat_gemm_nt_f8 equals an fp32 matmul of the
+SAME quantised operands up to its bf16 output rounding, and stays within 4 % rel-L2 of the unquantised product.
+Model level: the contract class with fp8 forward linears against the reference golden; stated (looser) tolerance:
+embeddings rel-L2 <= 5e-2, sim matrix <= 3e-2 max-abs, loss <= 5e-2 (bf16 path: 1e-2 / 1e-3 / 2e-2)."""
+import os
+
+import pytest
+import torch
+
+from OATrans.utils import seeded_init as si
+
+pytestmark = pytest.mark.gpu
+SEED = 20240917
+
+
+def _quantise(x):
+    from OATrans.ops import hip
+    R, C = x.shape
+    st = torch.zeros(3, device="cuda")
+    hip.fp8_amax(x, R, C, st[0:1])
+    amax = st[0].item()
+    hip.fp8_update_scales(st[0:1], st[1:2], st[2:3], 1, 1.0)
+    q = torch.empty(R, C, dtype=torch.uint8, device="cuda")
+    hip.fp8_quant(x, q, R, C, st[1:2], st[0:1])
+    return q, st, amax
+
+
+@pytest.mark.parametrize("shape", [(512, 256, 256), (1000, 768, 768), (4113, 512, 3072)])
+def test_fp8_quantise_and_gemm(shape):
+    from OATrans.ops import hip
+    m, n, k = shape
+    torch.manual_seed(1)
+    mp = (m + 255) // 256 * 256
+    A = (torch.randn(mp, k, device="cuda") * 3).bfloat16()
+    B = (torch.randn(n, k, device="cuda") * k ** -0.5).bfloat16()
+    bias = torch.randn(n, device="cuda")
+    A8, sa, amax_a = _quantise(A)
+    B8, sb, _ = _quantise(B)
+    assert abs(amax_a - A.float().abs().max().item()) == 0.0 and abs(sa[0].item() - amax_a) == 0.0     # amax re-recorded by quant
+    assert abs(sa[1].item() * amax_a - 448.0) < 1e-3 and abs(sa[1].item() * sa[2].item() - 1.0) < 1e-6
+    want = (A.float() * sa[1]).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+    assert torch.equal(A8, want)                                  # OCP e4m3fn, saturating
+    Aq = A8.view(torch.float8_e4m3fn).float() * sa[2]
+    Bq = B8.view(torch.float8_e4m3fn).float() * sb[2]
+    ref_q = Aq[:m] @ Bq.t() + bias
+    ref = A[:m].float() @ B.float().t() + bias
+    out = torch.full((mp, n), 7.0, device="cuda", dtype=torch.bfloat16)
+    hip.gemm_nt_f8(A8, B8, m, n, k, hip.EPI_BF16, out, sa[2:3], sb[2:3], bias=bias)
+    assert (out[m:] == 7.0).all()
+    assert (out[:m].float() - ref_q).abs().max().item() <= 2 ** -8 * ref_q.abs().max().item() + 1e-3      # bf16 rounding of the output
+    assert ((out[:m].float() - ref).norm() / ref.norm()).item() < 4e-2
+    o1 = torch.empty(mp, n, device="cuda", dtype=torch.bfloat16)
+    o2 = torch.empty_like(o1)
+    hip.gemm_nt_f8(A8, B8, m, n, k, hip.EPI_GELU_GRAD, o1, sa[2:3], sb[2:3], out2=o2, bias=bias)
+    assert (o2[:m].float() - torch.nn.functional.gelu(ref_q)).abs().max().item() <= 2 ** -7 * ref_q.abs().max().item() + 1e-2
+    with pytest.raises(hip.OatError):
+        hip.gemm_nt_f8(A8, B8, m, n - 8, k, hip.EPI_BF16, out, sa[2:3], sb[2:3])          # N % 256 != 0: refused, not approximated
+
+
+@pytest.mark.parametrize("frames", [4])
+def test_frozen_in_time_fp8_forward_vs_reference_golden(golden_dir, frames):
+    from OATrans import model as module_arch
+    g = torch.load(os.path.join(golden_dir, f"full_T{frames}.pt"), map_location="cpu", weights_only=False)
+    T, B, L = g["T"], g["B"], g["L"]
+    m = module_arch.FrozenInTime(
+        video_params=dict(model="SpaceTimeTransformer", arch_config="base_patch16_224", num_frames=T, pretrained=True, time_init="rand"),
+        object_params=dict(model="", input_objects=False),
+        text_params=dict(model="pretrained/distilbert-base-uncased", pretrained=True, input="text"),
+        projection="minimal", load_checkpoint="")
+    m.text_model.eval()
+    m.load_state_dict(si.frozen_state_dict(SEED, dict(num_frames=T), {}), strict=False)
+    m = m.cuda()
+    m.video_model._engine.fp8 = True
+    video = si.seeded_tensor(SEED, f"full.video.{T}", (B, T, 3, 224, 224)).cuda()
+    ids = si.seeded_ints(SEED, f"full.ids.{T}", (B, L), 1000, 30000)
+    ids[:, 0] = 101
+    rel = lambda a, b: ((a.float().cpu() - b).norm() / b.norm()).item()
+    for step in range(2):                       # step 0: current scaling (first use of every site), step 1: delayed scales
+        m.begin_step()
+        for prm in m.parameters():               # loose (autograd-accumulated) gradients: what optim.AdamW.zero_grad clears
+            if not getattr(prm, "_oat_engine_grad", False):
+                prm.grad = None
+        t, v = m({"video": video, "text": {"input_ids": ids.cuda(), "attention_mask": g["mask"].cuda()}})
+        sim = module_arch.sim_matrix(t, v)
+        loss = module_arch.NormSoftmaxLoss()(sim)
+        loss.backward()
+        torch.cuda.synchronize()
+        sim_err = (sim.detach().cpu() - g["sim"]).abs().max().item()
+        print(f"fp8 step {step}: video rel {rel(v.detach(), g['video']):.4f} sim err {sim_err:.4f} loss {loss.item():.4f} vs {g['loss'].item():.4f}")
+        assert rel(v.detach(), g["video"]) < 5e-2
+        assert sim_err <= 3e-2
+        assert abs(loss.item() - g["loss"].item()) < 5e-2
+    f8 = m.video_model._engine._f8
+    assert len(f8["primed"]) == 6 * 12 and bool((f8["dq"] > 0).all())
+    # gradients flow through the bf16 backward: norms within 10 % of the reference's
+    params = dict(m.named_parameters())
+    bad = [(k, abs(params[k].grad.norm().item() - pr["norm"].item()) / pr["norm"].item()) for k, pr in g["grad_probe"].items()
+           if pr["norm"] > 1e-6 and abs(params[k].grad.norm().item() - pr["norm"].item()) / pr["norm"].item() > 1e-1]
+    assert len(bad) <= 2, bad[:8]
