@@ -163,6 +163,24 @@ int oat_attn_text_bwd(const void* qkv, int ldqkv, const void* mask, const void* 
                       const float* lse, float* delta_scratch, const void* dout, int lddo, void* dqkv,
                       int lddqkv, int B, int L, int H, int D, float scale, float drop_p, const void* rng,
                       unsigned drop_site, void* stream);
+/* ---- launch tape: record the launches of a schedule once, replay them from C (csrc/tape.hip).  Stands where the reference
+ * relies on PyTorch's eager dispatcher for every op of the step (model/video_transformer.py:303-351 forward, autograd for
+ * backward).  Between oat_tape_begin and oat_tape_end (same thread) every oat_* launch is executed AND recorded with its
+ * arguments; pointers and scalars are baked in, so a tape is valid while the buffers it touches stay where they are. */
+int oat_tape_begin(void);
+void oat_tape_abort(void);
+void oat_tape_pause(int on);                  /* launches issued while paused run but are not recorded */
+int oat_tape_mark(void);                      /* close a segment; returns its index */
+int oat_tape_end(void);                       /* returns the tape id >= 0 */
+int oat_tape_segments(int id);
+int oat_tape_ops(int id);
+int oat_tape_replay(int id, int seg_lo, int seg_hi);   /* segments [seg_lo, seg_hi); seg_hi < 0: to the end */
+int oat_tape_free(int id);
+/* stream / memory operations of a schedule, recordable like launches */
+int oat_stream_edge(void* from_stream, void* to_stream);      /* `to` waits for what is on `from` now */
+int oat_memset_async(void* dst, int byte_value, size_t bytes, void* stream);
+int oat_copy_async(void* dst, const void* src, size_t bytes, void* stream);
+
 /* ---- OCP fp8 (e4m3fn) forward GEMMs, per-tensor scaled (BASELINE.json config 5; stands where the bf16 oat_gemm_nt
  * serves the nn.Linear forwards of video_transformer.py:46-50,102,133).  A quantisation site owns three device floats:
  * amax (running max |x| of this step), qscale (q = sat(x * qscale)), dq = 1 / qscale. */

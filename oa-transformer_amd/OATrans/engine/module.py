@@ -43,13 +43,25 @@ class EngineModule(nn.Module):
         return flat
 
     def _engine_params(self):
+        """[(state_dict name, Parameter)] in flat-buffer order.  Called several times per step: the list is cached
+        together with where every Parameter hangs (owner module, attribute) and re-validated by identity - walking
+        named_parameters() of the ViT costs 0.4 ms a call."""
+        cache = self.__dict__.get("_pairs_cache")
+        if cache is not None and all(o._parameters.get(a) is p for o, a, p in cache[1]):
+            return cache[0]
         names = getattr(self, "_names", None)
         if names is None:
             names = [n for n, _ in self.named_parameters() if not n.startswith(tuple(self._skip_prefixes) or ("\0",))]
             self._names = names
             self._n_params = len(names)
         d = dict(self.named_parameters())
-        return [(n, d[n]) for n in names]
+        pairs = [(n, d[n]) for n in names]
+        where = []
+        for n, prm in pairs:
+            owner_path, _, attr = n.rpartition(".")
+            where.append((self.get_submodule(owner_path) if owner_path else self, attr, prm))
+        self.__dict__["_pairs_cache"] = (pairs, where)
+        return pairs
 
     def _param_data(self):
         return {n: p.data for n, p in self._engine_params()}

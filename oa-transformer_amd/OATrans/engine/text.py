@@ -14,6 +14,8 @@ tower, and with bf16 operands its ~6e-3 embedding error alone would use up the 1
 also leaves the bf16 copies (LayerNorm outputs, q|k|v, context, GELU and its derivative) that BACKWARD - bf16 MFMA
 GEMMs as in engine/video.py - reads, so backward differentiates one self-consistent bf16 function.
 """
+import os
+
 import torch
 
 from ..ops import hip
@@ -51,10 +53,12 @@ class _TextPlan:
         self.d_ctx = torch.zeros(Mp, D, dtype=torch.bfloat16, device=dev)
         self.d_qkv = torch.zeros(Mp, 3 * D, dtype=torch.bfloat16, device=dev)
         self.delta = torch.zeros(Mp, H, dtype=torch.float32, device=dev)
-        self.gqkv_w = torch.zeros(3 * D, D, dtype=torch.float32, device=dev)
-        self.gqkv_b = torch.zeros(3 * D, dtype=torch.float32, device=dev)
         self.rng = torch.zeros(2, dtype=torch.int64, device=dev)       # {seed, offset} this forward drew its masks with
         self.drop = None                                               # (p_hidden, p_attention) of the last forward
+        # static copies of the inputs (ids, mask, incoming gradient): the schedules replay from launch tapes
+        self.ids = torch.zeros(B, L, dtype=torch.int64, device=dev)
+        self.mask = torch.zeros(B, L, dtype=torch.int64, device=dev)
+        self.tape_fwd = self.tape_bwd = None
 
 
 class TextEngine:
@@ -66,6 +70,7 @@ class TextEngine:
             raise hip.OatError("the HIP attention kernels are built for head_dim 64")
         self.scale = 64 ** -0.5
         self.plans, self.shadow, self.versions = {}, {}, None
+        self.use_tape = os.environ.get("OAT_TAPE", "1") != "0"
 
     def refresh_shadows(self, params, sig=None):
         names = []
@@ -127,19 +132,56 @@ class TextEngine:
         self.refresh_shadows(params, sig)
         pl = self.plan(B, L, input_ids.device, slot)
         M = pl.M
-        pl.ids = input_ids.contiguous()
-        pl.mask = attention_mask.to(torch.int64).contiguous()
+        pl.ids.copy_(input_ids)
+        pl.mask.copy_(attention_mask)
+        ph = pa = 0.0
+        pl.drop = None
+        state = None
+        if drop is not None and (drop[0] > 0 or drop[1] > 0):
+            ph, pa, state = drop
+            pl.drop = (ph, pa)
+        key = self._tape_key(pl, params, None, ph, pa, state.data_ptr() if state is not None else 0)
+        x = self._taped(pl, "tape_fwd", key, lambda: self._forward_body(pl, params, ph, pa, state))
+        return x[:M].view(B, L, D), pl
+
+    def _tape_key(self, pl, params, grads, *flags):
+        if not self.use_tape:
+            return None
+        ptrs = tuple(t.data_ptr() for t in params.values())
+        gptr = next(iter(grads.values())).data_ptr() if grads else 0
+        return (torch.cuda.current_stream().cuda_stream, ptrs, gptr, flags)
+
+    @staticmethod
+    def _taped(pl, slot, key, body):
+        """Run the launch schedule `body`, recording its tape the first time and replaying it afterwards (csrc/tape.hip)."""
+        if key is None:
+            return body()
+        held = getattr(pl, slot)
+        if held is not None and held[0] == key:
+            hip.tape_replay(held[1])
+            return held[2]
+        if held is not None:
+            hip.tape_free(held[1])
+            setattr(pl, slot, None)
+        hip.tape_begin()
+        try:
+            out = body()
+        except BaseException:
+            hip.tape_abort()
+            raise
+        setattr(pl, slot, (key, hip.tape_end(), out))
+        return out
+
+    def _forward_body(self, pl, params, ph, pa, state):
+        B, L, M = pl.B, pl.L, pl.M
+        D, Hd, H = self.D, self.Hd, self.H
         hip.embed_fwd(pl.ids, params["embeddings.word_embeddings.weight"],
                       params["embeddings.position_embeddings.weight"], pl.emb, M, L, D)
         hip.layernorm_fwd(pl.emb, params["embeddings.LayerNorm.weight"], params["embeddings.LayerNorm.bias"], M, D,
                           1e-12, y=pl.x0_16, y32=pl.x0, mean=pl.estats[0], rstd=pl.estats[1])
-        ph = pa = 0.0
-        pl.drop = None
-        if drop is not None and (drop[0] > 0 or drop[1] > 0):
-            ph, pa, state = drop
+        if state is not None:
             hip.rng_tick(state)
-            pl.rng.copy_(state)
-            pl.drop = (ph, pa)
+            hip.copy_(pl.rng, state)
             if ph > 0:
                 hip.dropout(pl.x0, M, D, ph, pl.rng, self.site(0, "emb"), out32=pl.x0, out16=pl.x0_16)
         x = pl.x0
@@ -165,17 +207,21 @@ class TextEngine:
             hip.layernorm_fwd(a.f, p("output_layer_norm.weight"), p("output_layer_norm.bias"), M, D, 1e-12,
                               y=a.x2_16, y32=a.x2, mean=a.stats[2], rstd=a.stats[3])
             x = a.x2
-        return x[:M].view(B, L, D), pl
+        return x
 
     def backward(self, pl, params, grads, d_hidden, accumulate=False):
         """d_hidden: fp32 [B, L, D] gradient of last_hidden_state.  Writes (or accumulates) every
         text parameter gradient into `grads`."""
+        M, D = pl.M, self.D
+        pl.G[:M].copy_(d_hidden.reshape(M, D))
+        ph, pa = pl.drop if pl.drop is not None else (0.0, 0.0)
+        key = self._tape_key(pl, params, grads, "bwd", bool(accumulate), ph, pa)
+        self._taped(pl, "tape_bwd", key, lambda: self._backward_body(pl, params, grads, bool(accumulate), ph, pa))
+
+    def _backward_body(self, pl, params, grads, acc, ph, pa):
         B, L, M = pl.B, pl.L, pl.M
         D, Hd, H = self.D, self.Hd, self.H
         G, g16 = pl.G, pl.g16
-        G[:M].copy_(d_hidden.reshape(M, D))
-        acc = accumulate
-        ph, pa = pl.drop if pl.drop is not None else (0.0, 0.0)
         for i in reversed(range(self.n_layers)):
             a = pl.layers[i]
             x16 = pl.layers[i - 1].x2_16 if i > 0 else pl.x0_16
@@ -201,15 +247,9 @@ class TextEngine:
             hip.gemm_nt(g16, wT("attention.out_lin"), M, D, D, hip.EPI_BF16, pl.d_ctx)
             hip.attn_text_bwd(a.qkv, pl.mask, a.ctx, a.lse, pl.delta, pl.d_ctx, pl.d_qkv, B, L, H, D, self.scale,
                               drop_p=pa, rng=pl.rng if pa > 0 else None, site=self.site(i, "attn"))
-            hip.gemm_tn(pl.d_qkv, x16, M, 3 * D, D, pl.gqkv_w, bias_out=pl.gqkv_b)
-            for k, l in enumerate(("q_lin", "k_lin", "v_lin")):
-                gw, gb = gr(f"attention.{l}.weight"), gr(f"attention.{l}.bias")
-                if acc:
-                    gw.add_(pl.gqkv_w[k * D:(k + 1) * D])
-                    gb.add_(pl.gqkv_b[k * D:(k + 1) * D])
-                else:
-                    gw.copy_(pl.gqkv_w[k * D:(k + 1) * D])
-                    gb.copy_(pl.gqkv_b[k * D:(k + 1) * D])
+            for k, l in enumerate(("q_lin", "k_lin", "v_lin")):      # q | k | v gradients are separate tensors: three GEMMs
+                hip.gemm_tn(pl.d_qkv[:, k * D:(k + 1) * D], x16, M, D, D, gr(f"attention.{l}.weight"), accumulate=acc,
+                            bias_out=gr(f"attention.{l}.bias"))
             hip.gemm_nt(pl.d_qkv, wT("qkv"), M, D, 3 * D, hip.EPI_F32, G, resid=G)          # G = dL/dx
         # embeddings: x0 = dropout(LN(word[ids] + pos[l]))
         if ph > 0:
@@ -219,9 +259,9 @@ class TextEngine:
                           accumulate=acc)
         gword = grads["embeddings.word_embeddings.weight"]
         if not acc:
-            gword.zero_()
+            hip.zero_(gword)
         hip.embed_bwd(pl.ids, G, gword, M, D)
         gpos = grads["embeddings.position_embeddings.weight"]
         if not acc:
-            gpos[L:].zero_()
+            hip.zero_(gpos[L:])
         hip.periodic_rowsum(G, B, L, D, gpos[:L], accumulate=acc)

@@ -80,6 +80,10 @@ class _Plan:
         self.cls_side = torch.zeros(B, H, 3, 64, dtype=torch.float32, device=dev)
         self.Gp = torch.zeros(T * N, D, dtype=torch.float32, device=dev)
         self.side = self.video = self.x_final = None      # set per call
+        self.video_buf = None                             # static copy of the input clip
+        self.tape_fwd = self.tape_bwd = None              # (key, tape id, outputs, segments)
+        self.dn = torch.zeros(Mp, D, dtype=torch.float32, device=dev)     # static copy of the output gradients
+        self.d_region_buf = None
         self.lane = None                                  # fp32 buffers of the precise CLS lane (VideoEngine.forward)
 
 
@@ -137,9 +141,12 @@ class VideoEngine:
         # whole backward stay bf16 / fp32.  Set by OAT_FP8=1 or by the caller (bench.py --dtype fp8).
         self.fp8 = os.environ.get("OAT_FP8", "0") != "0"
         self.fp8_margin = float(os.environ.get("OAT_FP8_MARGIN", "1.0"))
+        # launch tapes (csrc/tape.hip): forward and backward are recorded once per plan and replayed from C
+        self.use_tape = os.environ.get("OAT_TAPE", "1") != "0"
         self._f8 = None
         self._streams = None
         self._tn_ws = None
+        self._tn_retired = []
 
     # ------------------------------------------------------------------ weights / plans / streams
     def refresh_shadows(self, params, sig=None):
@@ -266,7 +273,13 @@ class VideoEngine:
         st = self._get_streams(dev)
         pl = self.plan(B, T, N, dev, call)
         pl.side = st["side"]
-        pl.video = video.contiguous()
+        # the clip is copied into a plan-owned buffer: every launch of the schedule then has static arguments and the
+        # schedule can be replayed from its tape (csrc/tape.hip)
+        if pl.video_buf is None or pl.video_buf.dtype != video.dtype or pl.video_buf.shape != video.shape:
+            pl.video_buf = torch.empty(video.shape, dtype=video.dtype, device=dev)
+            pl.tape_fwd = None
+        pl.video_buf.copy_(video)
+        pl.video = pl.video_buf
         if self.cls_lane and pl.lane is None:
             z = lambda c: torch.zeros(B, c, dtype=torch.float32, device=dev)
             pl.lane = dict(x=z(self.D), xt=z(self.D), y=z(self.D), out=z(self.D), a32=z(self.D), q32=z(self.D), o32=z(self.D),
@@ -275,21 +288,80 @@ class VideoEngine:
             pl.lane = None
         # every GEMM has the GPU to itself: the third, 31 %-full round of the N = 768 GEMMs (591 tiles on 256 CUs) is
         # re-tiled as 128x128 (see gemm_nt.hip)
-        hip.gemm_set_tail_split(self.tail_split)
         if self.fp8 and getattr(pl, "x8", None) is None:
             pl.x8 = torch.zeros(pl.Mp, self.D, dtype=torch.uint8, device=dev)          # fp8 GEMM inputs (one in flight)
             pl.x8_wide = torch.zeros(pl.Mp, self.Hd, dtype=torch.uint8, device=dev)
-        self._embed(pl, params, C, R)
-        pend = None
-        for i in range(self.depth):
-            pend = self._block_fwd(pl, i, params, pend, region_layer)
         run = _Run(pl, need_patches, region_layer)
-        out = self._final_fwd(pl, params, need_patches, region_layer)
-        if self.fp8:
-            self._fp8_end_of_forward()
-        pl.video = None
-        hip.gemm_set_tail_split(False)
+
+        def body():
+            hip.gemm_set_tail_split(self.tail_split)
+            self._embed(pl, params, C, R)
+            pend = None
+            for i in range(self.depth):
+                pend = self._block_fwd(pl, i, params, pend, region_layer)
+            out = self._final_fwd(pl, params, need_patches, region_layer)
+            if self.fp8:
+                self._fp8_end_of_forward()
+            hip.gemm_set_tail_split(False)
+            return out
+
+        key = self._tape_key(pl, params, None, need_patches, region_layer, C, R)
+        out = self._taped(pl, "tape_fwd", key, body)
         return out[0], out[1], run
+
+    # ------------------------------------------------------------------ launch tapes
+    def _tape_key(self, pl, params, grads, *flags):
+        """Everything a recorded schedule depends on besides the plan itself: the streams, where parameters / gradients
+        live, the option flags and the state of the fp8 sites."""
+        if not self.use_tape or self.bwd_side:       # the slot schedule (bwd_side) orders its streams with torch events
+            return None
+        ptrs = tuple(t.data_ptr() for t in params.values())
+        gptr = next(iter(grads.values())).data_ptr() if grads else 0
+        f8 = (len(self._f8["primed"]), self._f8["key"]) if (self.fp8 and self._f8) else None
+        return (torch.cuda.current_stream().cuda_stream, pl.side.cuda_stream, ptrs, gptr, self.fp8, f8, self.cls_lane,
+                self.tail_split, self.bwd_side, self.bwd_nt_grid, hip.gemm_get_variant(), flags)
+
+    @staticmethod
+    def _announce_segment(ready, prefixes, recording):
+        """End of a backward segment while the schedule runs live: close the tape segment, then let the host callback
+        (gradient all-reduce / eager optimiser) issue its own work unrecorded."""
+        if recording:
+            hip.lib().oat_tape_mark()
+            hip.lib().oat_tape_pause(1)
+        try:
+            ready(prefixes)
+        finally:
+            if recording:
+                hip.lib().oat_tape_pause(0)
+
+    def _taped(self, pl, slot, key, body, segments=None):
+        """Run `body` (a launch schedule without host-side data dependence) - the first time with the tape recording,
+        afterwards by replaying the tape.  segments: callback(k) run after segment k when the schedule was recorded
+        with marks (the gradient announcements of backward)."""
+        if key is None:
+            return body()
+        held = getattr(pl, slot, None)
+        if held is not None and held[0] == key:
+            _, tid, out, nseg = held
+            if segments is None:
+                hip.tape_replay(tid)
+            else:
+                for k in range(nseg):
+                    hip.tape_replay(tid, k, k + 1)
+                    segments(k)
+            return out
+        if held is not None:
+            hip.tape_free(held[1])
+            setattr(pl, slot, None)
+        hip.tape_begin()
+        try:
+            out = body()
+        except BaseException:
+            hip.tape_abort()
+            raise
+        tid = hip.tape_end()
+        setattr(pl, slot, (key, tid, out, hip.lib().oat_tape_segments(tid)))
+        return out
 
     def _embed(self, pl, params, C, R):
         B, T, N, D = pl.B, pl.T, pl.N, self.D
@@ -342,11 +414,9 @@ class VideoEngine:
             else:
                 hip.layernorm_fwd(x, p("norm3.weight"), p("norm3.bias"), M, D, 1e-6, y=a.a3, mean=st[0], rstd=st[1])
             if lane is not None:                         # the lane starts from the embedding's CLS rows
-                e0 = torch.cuda.Event()
-                e0.record(torch.cuda.current_stream())
-                pl.side.wait_event(e0)
+                hip.stream_edge(torch.cuda.current_stream(), pl.side)
                 with torch.cuda.stream(pl.side):
-                    lane["x"].copy_(x[BTN:M])
+                    hip.copy_(lane["x"], x[BTN:M])
                 self._lane_ln(pl, lane["x"], None, None, p("norm3.weight"), p("norm3.bias"), lane["a32"])
         else:
             if q3:
@@ -433,10 +503,7 @@ class VideoEngine:
         cls_out = pl.normed[BTN:M]
         if lane is not None:                              # the CLS embedding comes from the lane's fp32 rows
             self._lane_ln(pl, lane["y"], lane["br32"], lane["x"], g, bt, lane["out"])
-            ev = torch.cuda.Event()
-            with torch.cuda.stream(pl.side):
-                ev.record(pl.side)
-            torch.cuda.current_stream().wait_event(ev)
+            hip.stream_edge(pl.side, torch.cuda.current_stream())
             cls_out = lane["out"]
         return cls_out, (pl.normed[:BTN] if need_patches else None)
 
@@ -444,18 +511,14 @@ class VideoEngine:
         """Patch attention on the caller's stream, the independent CLS-query attention (it only writes the
         CLS rows of out / lse, and the lane's precise context) concurrently on the side stream."""
         cur = torch.cuda.current_stream()
-        ev = torch.cuda.Event()
-        ev.record(cur)                                   # qkv is complete
-        pl.side.wait_event(ev)
+        hip.stream_edge(cur, pl.side)                    # qkv is complete
         with torch.cuda.stream(pl.side):
             if pl.lane is not None:
                 hip.attn_cls_fwd_dual(qkv, out, lse, pl.lane["q32"], pl.lane["o32"], pl.B, pl.T, pl.N, self.H, self.D, self.scale)
             else:
                 hip.attn_cls_fwd(qkv, out, lse, pl.B, pl.T, pl.N, self.H, self.D, self.scale)
-            done = torch.cuda.Event()
-            done.record(pl.side)
         patch_kernel(qkv, out, lse, pl.B, pl.T, pl.N, self.H, self.D, self.scale)
-        cur.wait_event(done)
+        hip.stream_edge(pl.side, cur)
 
     def _region_tap(self, pl, params, x):
         """region_norm(x after block K)[patch rows] (oa_video_transformer_region.py:364-376)."""
@@ -483,26 +546,47 @@ class VideoEngine:
         pl = run.pl
         pl.hbm = st["hbm"] if self.bwd_side else None
         pl.acc = bool(accumulate)
-        pl.cls_side.zero_()          # once per backward; every attn_cls_finalize leaves it zero for the next one
-        self._final_bwd(pl, run, params, grads, d_cls.contiguous(), d_patches, d_region)
         if run.region_layer is not None:
             ready = None                     # region_norm gradients arrive out of block order: reduce after backward
-        hip.gemm_set_tail_split(self.tail_split and not self.bwd_side)
-        hip.gemm_tn_set_variant((self.wgrad_cus << 16) if self.bwd_side else 0)
-        nt_prev = hip.gemm_get_variant()
-        if self.bwd_nt_grid and (nt_prev >> 16) == 0:
-            hip.gemm_set_variant((nt_prev & 0xffff) | (self.bwd_nt_grid << 16))
-        for i in reversed(range(self.depth)):
-            self._block_bwd(pl, i, run, params, grads, d_region)
-            if ready is not None:
-                ready((f"blocks.{i}.", "norm.") if i == self.depth - 1 else (f"blocks.{i}.",))
-        self._embed_bwd(pl, grads)
-        if ready is not None:
-            ready(("cls_token", "pos_embed", "temporal_embed", "patch_embed."))
-        hip.gemm_tn_set_variant(0)
-        hip.gemm_set_tail_split(False)
-        if hip.gemm_get_variant() != nt_prev:
-            hip.gemm_set_variant(nt_prev)
+        # the incoming gradients go into plan-owned buffers (static launch arguments: the schedule replays from its tape)
+        BTN = pl.M - pl.B
+        pl.dn[BTN:pl.M].copy_(d_cls)
+        have_patches = run.need_patches and d_patches is not None
+        if have_patches:
+            pl.dn[:BTN].copy_(d_patches)
+        if d_region is not None:
+            if pl.d_region_buf is None:
+                pl.d_region_buf = torch.empty(BTN, self.D, dtype=torch.float32, device=run.G.device)
+            pl.d_region_buf.copy_(d_region)
+            d_region = pl.d_region_buf
+        prefixes = [(f"blocks.{i}.", "norm.") if i == self.depth - 1 else (f"blocks.{i}.",) for i in reversed(range(self.depth))]
+        prefixes.append(("cls_token", "pos_embed", "temporal_embed", "patch_embed."))
+        use_marks = ready is not None
+
+        def body():
+            hip.zero_(pl.cls_side)       # once per backward; every attn_cls_finalize leaves it zero for the next one
+            self._final_bwd(pl, run, params, grads, have_patches, d_region)
+            hip.gemm_set_tail_split(self.tail_split and not self.bwd_side)
+            hip.gemm_tn_set_variant((self.wgrad_cus << 16) if self.bwd_side else 0)
+            nt_prev = hip.gemm_get_variant()
+            if self.bwd_nt_grid and (nt_prev >> 16) == 0:
+                hip.gemm_set_variant((nt_prev & 0xffff) | (self.bwd_nt_grid << 16))
+            for k, i in enumerate(reversed(range(self.depth))):
+                self._block_bwd(pl, i, run, params, grads, d_region)
+                if use_marks:
+                    self._announce_segment(ready, prefixes[k], recording)
+            self._embed_bwd(pl, grads)
+            if use_marks:
+                self._announce_segment(ready, prefixes[-1], recording)
+            hip.gemm_tn_set_variant(0)
+            hip.gemm_set_tail_split(False)
+            if hip.gemm_get_variant() != nt_prev:
+                hip.gemm_set_variant(nt_prev)
+
+        key = self._tape_key(pl, params, grads, "bwd", run.need_patches, run.region_layer, have_patches, d_region is not None,
+                             pl.acc, use_marks)
+        recording = key is not None
+        self._taped(pl, "tape_bwd", key, body, segments=(lambda k: ready(prefixes[k])) if use_marks else None)
 
     def _slot(self, pl, fn, wgrads=()):
         """One slot of backward: the weight-gradient GEMMs `wgrads` (callables) on the caller's stream and, beside
@@ -538,28 +622,30 @@ class VideoEngine:
     def _wgrad(self, P, Q, rows, n1, n2, w, b, acc=False):
         need = hip.lib().oat_gemm_tn_workspace_bytes(rows, n1, n2) // 4     # exact for this (rows, shape)
         if self._tn_ws is None or self._tn_ws.numel() < need:
+            if self._tn_ws is not None:
+                self._tn_retired.append(self._tn_ws)       # launch tapes recorded so far still point at it
             self._tn_ws = torch.empty(need, dtype=torch.float32, device=P.device)   # one slab workspace, grown on demand
         hip.gemm_tn(P, Q, rows, n1, n2, w, bias_out=b, ws=self._tn_ws, accumulate=acc)
 
-    def _final_bwd(self, pl, run, params, grads, d_cls, d_patches, d_region):
+    def _final_bwd(self, pl, run, params, grads, have_patches, d_region):
+        """pl.dn holds dL/d(normed output): rows [:BTN] the patch tokens (when they received a gradient), [BTN:] the CLS rows."""
         D = self.D
         B, M = pl.B, pl.M
         BTN = M - B
         G = pl.G
         g16 = pl.ga[(self.depth - 1) % 3]
-        if run.need_patches and d_patches is not None:
-            dn = torch.cat([d_patches, d_cls], dim=0).contiguous()
-            hip.layernorm_bwd(dn, pl.x_final, pl.fstats[0], pl.fstats[1], params["norm.weight"], M, D, dx=G, dx16=g16,
+        if have_patches:
+            hip.layernorm_bwd(pl.dn, pl.x_final, pl.fstats[0], pl.fstats[1], params["norm.weight"], M, D, dx=G, dx16=g16,
                               dgamma=grads["norm.weight"], dbeta=grads["norm.bias"], accumulate=pl.acc)
         else:
-            G[:BTN].zero_()
-            g16[:BTN].zero_()
-            hip.layernorm_bwd(d_cls, pl.x_final[BTN:], pl.fstats[0][BTN:], pl.fstats[1][BTN:], params["norm.weight"], B, D,
+            hip.zero_(G[:BTN])
+            hip.zero_(g16[:BTN])
+            hip.layernorm_bwd(pl.dn[BTN:], pl.x_final[BTN:], pl.fstats[0][BTN:], pl.fstats[1][BTN:], params["norm.weight"], B, D,
                               dx=G[BTN:], dx16=g16[BTN:], dgamma=grads["norm.weight"], dbeta=grads["norm.bias"],
                               accumulate=pl.acc)
         if run.region_layer is not None and d_region is None and not pl.acc:
             for k in ("region_norm.weight", "region_norm.bias"):
-                grads[k].zero_()
+                hip.zero_(grads[k])
 
     def _block_bwd(self, pl, i, run, params, grads, d_region):
         B, T, N, M = pl.B, pl.T, pl.N, pl.M
@@ -572,7 +658,7 @@ class VideoEngine:
         rl = run.region_layer
         if rl is not None and d_region is not None and i + 1 == rl:
             # region tokens branch off the output of block rl-1: add their gradient to the stream
-            hip.layernorm_bwd(d_region.contiguous(), a.out, pl.rstats[0], pl.rstats[1], params["region_norm.weight"],
+            hip.layernorm_bwd(d_region, a.out, pl.rstats[0], pl.rstats[1], params["region_norm.weight"],
                               BTN, D, dx=G, dx16=ga, dres=G, dgamma=grads["region_norm.weight"],
                               dbeta=grads["region_norm.bias"], accumulate=pl.acc)
         x = pl.blocks[i - 1].out if i > 0 else pl.x0
@@ -637,7 +723,7 @@ class VideoEngine:
         acc = pl.acc
         hip.periodic_rowsum(pl.Gp, T, N, D, gpos[1:], accumulate=acc)
         if T < gt.shape[0] and not acc:
-            gt[T:].zero_()
+            hip.zero_(gt[T:])
         hip.grouped_rowsum(pl.Gp, T, N, D, gt[:T], accumulate=acc)
         hip.grouped_rowsum(G[BTN:], 1, B, D, gcls, accumulate=acc)
-        gpos[:1].copy_(gcls)             # pos_embed[0] only ever meets the CLS token: its gradient IS cls_token's
+        hip.copy_(gpos[:1], gcls)        # pos_embed[0] only ever meets the CLS token: its gradient IS cls_token's

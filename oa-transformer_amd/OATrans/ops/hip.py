@@ -140,6 +140,8 @@ def tn_workspace(device, M, N1, N2):
     key = _stream_key(device)
     ws = _tn_ws.get(key)
     if ws is None or ws.numel() * 4 < need:
+        if ws is not None:
+            _retired.append(ws)          # recorded launch tapes may still point at it: outgrown workspaces are never freed
         ws = torch.empty(need // 4, dtype=torch.float32, device=device)
         _tn_ws[key] = ws
     return ws
@@ -185,12 +187,15 @@ def add32_layernorm_fwd(x, add32, sum32, gamma, beta, M, D, eps, y=None, y32=Non
 
 
 _part_ws = {}
+_retired = []
 
 
 def _partials(device, n):
     key = _stream_key(device)
     ws = _part_ws.get(key)
     if ws is None or ws.numel() < n:
+        if ws is not None:
+            _retired.append(ws)
         ws = torch.empty(n, dtype=torch.float32, device=device)
         _part_ws[key] = ws
     return ws
@@ -333,6 +338,54 @@ def attn_text_fwd_dual(qkv, qkv32, mask, out, out32, lse, B, L, H, D, scale, dro
     _check(lib().oat_attn_text_fwd_dual(_ptr(qkv), qkv.stride(0), _ptr(qkv32), qkv32.stride(0), _ptr(mask), _ptr(out),
                                         out.stride(0), _ptr(out32), out32.stride(0), _ptr(lse), B, L, H, D, _f(scale),
                                         _f(drop_p), _ptr(rng), ctypes.c_uint(site), _stream()), "oat_attn_text_fwd_dual")
+
+
+# ---- launch tape ----------------------------------------------------------------------------------------------------
+def tape_begin():
+    _check(lib().oat_tape_begin(), "oat_tape_begin")
+
+
+def tape_abort():
+    lib().oat_tape_abort()
+
+
+def tape_mark():
+    seg = lib().oat_tape_mark()
+    if seg < 0:
+        _check(seg, "oat_tape_mark")
+    return seg
+
+
+def tape_end():
+    tid = lib().oat_tape_end()
+    if tid < 0:
+        _check(tid, "oat_tape_end")
+    return tid
+
+
+def tape_replay(tid, seg_lo=0, seg_hi=-1):
+    _check(lib().oat_tape_replay(tid, seg_lo, seg_hi), "oat_tape_replay")
+
+
+def tape_free(tid):
+    lib().oat_tape_free(tid)
+
+
+def stream_edge(src_stream, dst_stream):
+    """Everything enqueued on dst_stream from now on waits for what is on src_stream now (torch streams)."""
+    _check(lib().oat_stream_edge(ctypes.c_void_p(src_stream.cuda_stream), ctypes.c_void_p(dst_stream.cuda_stream)), "oat_stream_edge")
+
+
+def zero_(t):
+    """t.zero_() as a recordable launch (t contiguous)."""
+    assert t.is_contiguous()
+    _check(lib().oat_memset_async(_ptr(t), 0, ctypes.c_size_t(t.numel() * t.element_size()), _stream()), "oat_memset_async")
+
+
+def copy_(dst, src):
+    """dst.copy_(src) for contiguous tensors of one dtype and size, as a recordable launch."""
+    assert dst.is_contiguous() and src.is_contiguous() and dst.dtype == src.dtype and dst.numel() == src.numel()
+    _check(lib().oat_copy_async(_ptr(dst), _ptr(src), ctypes.c_size_t(dst.numel() * dst.element_size()), _stream()), "oat_copy_async")
 
 
 # ---- fp8 (OCP e4m3fn) forward GEMMs ------------------------------------------------------------------------------

@@ -553,7 +553,7 @@ static int launch_fwd(const SpaceArgs& a, hipStream_t s) {
   const int lds = 2 * NKT * 16 * 128;
   static bool set = false;
   if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_space_fwd_kernel<NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
-  hipLaunchKernelGGL(attn_space_fwd_kernel<NKT>, dim3(a.B * a.T * a.H), dim3(FWD_THREADS), lds, s, a);
+  OAT_LAUNCH(attn_space_fwd_kernel<NKT>, dim3(a.B * a.T * a.H), dim3(FWD_THREADS), lds, s, a);
   return check_launch("attn_space_fwd");
 }
 template <int NKT, bool BIG = false, int WIDE = 0>
@@ -561,7 +561,7 @@ static int launch_bwd(const SpaceArgs& a, hipStream_t s) {
   const int lds = (BIG ? 2 : 4) * NKT * 16 * 128 + 2 * NKT * 16 * 4;
   static bool set = false;
   if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_space_bwd_kernel<NKT, BIG, WIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
-  hipLaunchKernelGGL((attn_space_bwd_kernel<NKT, BIG, WIDE>), dim3(a.B * a.T * a.H), dim3(WIDE == 1 ? 1024 : BWD_THREADS), lds, s, a);
+  OAT_LAUNCH((attn_space_bwd_kernel<NKT, BIG, WIDE>), dim3(a.B * a.T * a.H), dim3(WIDE == 1 ? 1024 : BWD_THREADS), lds, s, a);
   return check_launch("attn_space_bwd");
 }
 // tuning hook.  0 (default): 97..223 patches -> two 8-wave workgroups per CU on the two-tile layout, one tile per wave;
@@ -571,7 +571,7 @@ static int g_space_variant = 0;
 // time-attention backward through the MFMA kernel: one single-wave workgroup per (sample, group of 16 / T positions, head)
 template <int TT>
 static int launch_time_bwd(const SpaceArgs& a, int blocks, int lds, hipStream_t s) {
-  hipLaunchKernelGGL((attn_space_bwd_kernel<2, false, 3, true, TT>), dim3(blocks), dim3(64), lds, s, a);
+  OAT_LAUNCH((attn_space_bwd_kernel<2, false, 3, true, TT>), dim3(blocks), dim3(64), lds, s, a);
   return check_launch("attn_time_bwd_mfma");
 }
 int g_time_gpw = 4;        // position groups per workgroup (tuning: oat_attn_time_set_variant bits 8-15)
@@ -642,7 +642,7 @@ extern "C" int oat_attn_space_set_variant(int v) { g_space_variant = v; return 0
 
 extern "C" int oat_attn_cls_finalize(float* cls_side, void* dqkv, int lddqkv, int B, int T, int N, int H, int D,
                                      void* stream) {
-  hipLaunchKernelGGL(attn_cls_finalize_kernel, dim3(B * H), dim3(192), 0, (hipStream_t)stream, cls_side, (bf16*)dqkv,
+  OAT_LAUNCH(attn_cls_finalize_kernel, dim3(B * H), dim3(192), 0, (hipStream_t)stream, cls_side, (bf16*)dqkv,
                      lddqkv, B, H, D, (size_t)B * T * N);
   return check_launch("attn_cls_finalize");
 }

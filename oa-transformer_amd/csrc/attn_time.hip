@@ -459,16 +459,16 @@ extern "C" void oat_attn_time_set_variant(int v) { g_time_two_pass = v & 0xff; i
 
 #define OAT_TIME_DISPATCH(KERNEL)                                                                     \
   switch (T) {                                                                                        \
-    case 1: hipLaunchKernelGGL(KERNEL<1>, dim3(blocks), dim3(256), 0, s, a); break;                   \
-    case 2: hipLaunchKernelGGL(KERNEL<2>, dim3(blocks), dim3(256), 0, s, a); break;                   \
-    case 3: hipLaunchKernelGGL(KERNEL<3>, dim3(blocks), dim3(256), 0, s, a); break;                   \
-    case 4: hipLaunchKernelGGL(KERNEL<4>, dim3(blocks), dim3(256), 0, s, a); break;                   \
-    case 5: hipLaunchKernelGGL(KERNEL<5>, dim3(blocks), dim3(256), 0, s, a); break;                   \
-    case 6: hipLaunchKernelGGL(KERNEL<6>, dim3(blocks), dim3(256), 0, s, a); break;                   \
-    case 7: hipLaunchKernelGGL(KERNEL<7>, dim3(blocks), dim3(256), 0, s, a); break;                   \
-    case 8: hipLaunchKernelGGL(KERNEL<8>, dim3(blocks), dim3(256), 0, s, a); break;                   \
-    case 12: hipLaunchKernelGGL(KERNEL<12>, dim3(blocks), dim3(256), 0, s, a); break;                 \
-    case 16: hipLaunchKernelGGL(KERNEL<16>, dim3(blocks), dim3(256), 0, s, a); break;                 \
+    case 1: OAT_LAUNCH(KERNEL<1>, dim3(blocks), dim3(256), 0, s, a); break;                   \
+    case 2: OAT_LAUNCH(KERNEL<2>, dim3(blocks), dim3(256), 0, s, a); break;                   \
+    case 3: OAT_LAUNCH(KERNEL<3>, dim3(blocks), dim3(256), 0, s, a); break;                   \
+    case 4: OAT_LAUNCH(KERNEL<4>, dim3(blocks), dim3(256), 0, s, a); break;                   \
+    case 5: OAT_LAUNCH(KERNEL<5>, dim3(blocks), dim3(256), 0, s, a); break;                   \
+    case 6: OAT_LAUNCH(KERNEL<6>, dim3(blocks), dim3(256), 0, s, a); break;                   \
+    case 7: OAT_LAUNCH(KERNEL<7>, dim3(blocks), dim3(256), 0, s, a); break;                   \
+    case 8: OAT_LAUNCH(KERNEL<8>, dim3(blocks), dim3(256), 0, s, a); break;                   \
+    case 12: OAT_LAUNCH(KERNEL<12>, dim3(blocks), dim3(256), 0, s, a); break;                 \
+    case 16: OAT_LAUNCH(KERNEL<16>, dim3(blocks), dim3(256), 0, s, a); break;                 \
     default: set_error("attn_time: supported frame counts are 1-8, 12, 16"); return -3;               \
   }
 
@@ -501,7 +501,7 @@ extern "C" int oat_attn_time_bwd(const void* qkv, int ldqkv, const void* out, in
       static bool attr = false; \
       if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_time_bwd_lds_kernel<TT>), \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; } \
-      hipLaunchKernelGGL(attn_time_bwd_lds_kernel<TT>, dim3(blocks), dim3(256), LDS, s, a); break; }
+      OAT_LAUNCH(attn_time_bwd_lds_kernel<TT>, dim3(blocks), dim3(256), LDS, s, a); break; }
     switch (T) {
       OAT_TIME_LDS(1) OAT_TIME_LDS(2) OAT_TIME_LDS(3) OAT_TIME_LDS(4) OAT_TIME_LDS(5) OAT_TIME_LDS(6) OAT_TIME_LDS(7)
       OAT_TIME_LDS(8)
@@ -518,7 +518,7 @@ extern "C" int oat_attn_cls_fwd(const void* qkv, int ldqkv, void* out, int ldo, 
                                 int D, float scale, void* stream) {
   if (D != H * 64) { set_error("attn_cls: head_dim must be 64"); return -3; }
   TimeArgs a{(const bf16*)qkv, ldqkv, (bf16*)out, ldo, lse, nullptr, 0, nullptr, 0, nullptr, B, T, N, H, D, scale};
-  hipLaunchKernelGGL(attn_cls_fwd_kernel, dim3(B * H), dim3(256), 0, (hipStream_t)stream, a);
+  OAT_LAUNCH(attn_cls_fwd_kernel, dim3(B * H), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("attn_cls_fwd");
 }
 
@@ -528,6 +528,6 @@ extern "C" int oat_attn_cls_fwd_dual(const void* qkv, int ldqkv, void* out, int 
   if (D != H * 64) { set_error("attn_cls: head_dim must be 64"); return -3; }
   if (!q32 || !o32) { set_error("attn_cls_fwd_dual: null pointer"); return -4; }
   TimeArgs a{(const bf16*)qkv, ldqkv, (bf16*)out, ldo, lse, nullptr, 0, nullptr, 0, nullptr, B, T, N, H, D, scale};
-  hipLaunchKernelGGL(attn_cls_fwd_dual_kernel, dim3(B * H), dim3(256), 0, (hipStream_t)stream, a, q32, ldq32, o32, ldo32);
+  OAT_LAUNCH(attn_cls_fwd_dual_kernel, dim3(B * H), dim3(256), 0, (hipStream_t)stream, a, q32, ldq32, o32, ldo32);
   return check_launch("attn_cls_fwd_dual");
 }

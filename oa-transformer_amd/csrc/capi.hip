@@ -31,7 +31,7 @@ __global__ void delay_kernel(int ticks) {
 
 extern "C" int oat_delay(int nanoseconds, void* stream) {
   if (nanoseconds <= 0) return 0;
-  hipLaunchKernelGGL(oat::delay_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (nanoseconds + 9) / 10);
+  OAT_LAUNCH(oat::delay_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (nanoseconds + 9) / 10);
   return oat::check_launch("delay");
 }
 

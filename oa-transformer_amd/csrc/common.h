@@ -6,6 +6,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <functional>
 
 typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -20,6 +21,19 @@ namespace oat {
 
 void set_error(const char* msg);     // defined in capi.hip; thread-local message
 int check_launch(const char* what);  // hipGetLastError -> error code
+
+// ---- launch tape (tape.hip).  Every kernel launch of the library goes through oat::launch.  While a tape is being
+// recorded on the calling thread (oat_tape_begin .. oat_tape_end) the launch is executed AND appended to the tape with
+// its arguments; oat_tape_replay re-issues the recorded launches from C, with no Python, ctypes or argument marshalling
+// in between (a training step is ~1100 launches; issued one by one from Python they cost 20-45 ms of host time).
+bool tape_recording();
+void tape_push(std::function<void()>&& op);
+template <class K, class... A>
+inline void launch(K kernel, dim3 grid, dim3 block, unsigned lds, hipStream_t s, A... args) {
+  hipLaunchKernelGGL(kernel, grid, block, lds, s, args...);
+  if (tape_recording()) tape_push([=] { hipLaunchKernelGGL(kernel, grid, block, lds, s, args...); });
+}
+#define OAT_LAUNCH(...) ::oat::launch(__VA_ARGS__)
 
 OAT_DEV float bf2f(bf16 v) { return static_cast<float>(v); }
 OAT_DEV bf16 f2bf(float v) { return static_cast<bf16>(v); }

@@ -46,7 +46,7 @@ using namespace oat;
 
 extern "C" int oat_rng_tick(void* rng, void* stream) {
   if (!rng) { set_error("rng_tick: null state"); return -4; }
-  hipLaunchKernelGGL(rng_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)rng);
+  OAT_LAUNCH(rng_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)rng);
   return check_launch("rng_tick");
 }
 
@@ -57,7 +57,7 @@ extern "C" int oat_dropout(const float* x, int ldx, const float* resid, int ldr,
   if (D % 4 || ldx % 4 || (resid && ldr % 4) || (out32 && ldo % 4)) { set_error("dropout: D and row strides must be multiples of 4"); return -3; }
   if (!(p >= 0.f && p < 1.f)) { set_error("dropout: p must be in [0, 1)"); return -3; }
   const int quads = M * (D / 4);
-  hipLaunchKernelGGL(dropout_kernel, dim3((quads + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, ldx, resid, ldr, out32, ldo,
+  OAT_LAUNCH(dropout_kernel, dim3((quads + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, ldx, resid, ldr, out32, ldo,
                      (bf16*)out16, ld16, M, D, make_drop_site(rng, site, p));
   return check_launch("dropout");
 }
@@ -66,7 +66,7 @@ extern "C" int oat_dropout(const float* x, int ldx, const float* resid, int ldr,
 extern "C" int oat_dropout_mask(float* out, long long n, float p, const void* rng, unsigned site, void* stream) {
   if (n <= 0) return 0;
   if (!out || !rng) { set_error("dropout_mask: null pointer"); return -4; }
-  hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, n,
+  OAT_LAUNCH(dropout_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, n,
                      make_drop_site(rng, site, p));
   return check_launch("dropout_mask");
 }
@@ -74,6 +74,6 @@ extern "C" int oat_dropout_mask(float* out, long long n, float p, const void* rn
 // Known-answer access to the generator: in = n x (4 counter words, 2 key words), out = n x 4 words.
 extern "C" int oat_philox4x32_10(const void* in, void* out, int n, void* stream) {
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(philox_kat_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const uint32_t*)in, (uint32_t*)out, n);
+  OAT_LAUNCH(philox_kat_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const uint32_t*)in, (uint32_t*)out, n);
   return check_launch("philox4x32_10");
 }

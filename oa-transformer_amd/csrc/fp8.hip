@@ -99,8 +99,8 @@ extern "C" int oat_fp8_quant(const void* x, int is_bf16, int ldx, void* out8, in
   if (K % 8 || ldx % 8 || ld8 % 8) { set_error("fp8_quant: K, ldx, ld8 must be multiples of 8"); return -3; }
   const long long quads = (long long)M * (K / 8);
   const int grid = (int)((quads + 255) / 256 < 2048 ? (quads + 255) / 256 : 2048);
-  if (is_bf16) hipLaunchKernelGGL((fp8_quant_kernel<true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, (uint8_t*)out8, ld8, M, K, qscale, amax);
-  else hipLaunchKernelGGL((fp8_quant_kernel<false, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, (uint8_t*)out8, ld8, M, K, qscale, amax);
+  if (is_bf16) OAT_LAUNCH((fp8_quant_kernel<true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, (uint8_t*)out8, ld8, M, K, qscale, amax);
+  else OAT_LAUNCH((fp8_quant_kernel<false, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, (uint8_t*)out8, ld8, M, K, qscale, amax);
   return check_launch("fp8_quant");
 }
 extern "C" int oat_fp8_amax(const void* x, int is_bf16, int ldx, int M, int K, float* amax, void* stream) {
@@ -109,8 +109,8 @@ extern "C" int oat_fp8_amax(const void* x, int is_bf16, int ldx, int M, int K, f
   if (K % 8 || ldx % 8) { set_error("fp8_amax: K, ldx must be multiples of 8"); return -3; }
   const long long quads = (long long)M * (K / 8);
   const int grid = (int)((quads + 255) / 256 < 2048 ? (quads + 255) / 256 : 2048);
-  if (is_bf16) hipLaunchKernelGGL((fp8_quant_kernel<true, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, nullptr, 0, M, K, nullptr, amax);
-  else hipLaunchKernelGGL((fp8_quant_kernel<false, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, nullptr, 0, M, K, nullptr, amax);
+  if (is_bf16) OAT_LAUNCH((fp8_quant_kernel<true, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, nullptr, 0, M, K, nullptr, amax);
+  else OAT_LAUNCH((fp8_quant_kernel<false, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, nullptr, 0, M, K, nullptr, amax);
   return check_launch("fp8_amax");
 }
 extern "C" int oat_fp8_chunk_elems(void) { return F8_CHUNK; }
@@ -119,15 +119,15 @@ extern "C" int oat_fp8_multi(const void* desc, const int* owner, int total_block
                              void* stream) {
   if (total_blocks <= 0) return 0;
   if (!desc || !owner || !amax || (quant && !qscale)) { set_error("fp8_multi: null pointer"); return -4; }
-  if (quant) hipLaunchKernelGGL((fp8_multi_kernel<true>), dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, (const F8Desc*)desc, owner, qscale, amax);
-  else hipLaunchKernelGGL((fp8_multi_kernel<false>), dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, (const F8Desc*)desc, owner, qscale, amax);
+  if (quant) OAT_LAUNCH((fp8_multi_kernel<true>), dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, (const F8Desc*)desc, owner, qscale, amax);
+  else OAT_LAUNCH((fp8_multi_kernel<false>), dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, (const F8Desc*)desc, owner, qscale, amax);
   return check_launch("fp8_multi");
 }
 extern "C" int oat_fp8_update_scales(float* amax, float* qscale, float* dq, int n, float margin, void* stream) {
   if (n <= 0) return 0;
   if (!amax || !qscale || !dq) { set_error("fp8_update_scales: null pointer"); return -4; }
   if (!(margin >= 1.f)) { set_error("fp8_update_scales: margin must be >= 1"); return -3; }
-  hipLaunchKernelGGL(fp8_update_scales_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, amax, qscale, dq, n, margin);
+  OAT_LAUNCH(fp8_update_scales_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, amax, qscale, dq, n, margin);
   return check_launch("fp8_update_scales");
 }
 

@@ -654,7 +654,7 @@ static int launch_cfg(const GemmArgs& g, hipStream_t s) {
       }
     }
   }
-  hipLaunchKernelGGL((gemm_nt_kernel<EPI, WM, WN, TM, TN, NSA, SPREAD, PIPE>), dim3(grid), dim3(WM * WN * 64), LDS, s, a);
+  OAT_LAUNCH((gemm_nt_kernel<EPI, WM, WN, TM, TN, NSA, SPREAD, PIPE>), dim3(grid), dim3(WM * WN * 64), LDS, s, a);
   return check_launch("gemm_nt");
 }
 

@@ -649,8 +649,8 @@ int launch_pp_cfg(const GemmArgs& g, int grid_slots, hipStream_t s) {
   }
   const int nwg = ((g.M + 255) / 256) * (g.N / 256);
   const int grid = nwg < grid_slots ? nwg : grid_slots;
-  if constexpr (FL & PPF_PH2) hipLaunchKernelGGL((gemm_nt_pp2_kernel<EPI, FL>), dim3(grid), dim3(512), PP_LDS, s, g);
-  else hipLaunchKernelGGL((gemm_nt_pp_kernel<EPI, FL>), dim3(grid), dim3(512), PP_LDS, s, g);
+  if constexpr (FL & PPF_PH2) OAT_LAUNCH((gemm_nt_pp2_kernel<EPI, FL>), dim3(grid), dim3(512), PP_LDS, s, g);
+  else OAT_LAUNCH((gemm_nt_pp_kernel<EPI, FL>), dim3(grid), dim3(512), PP_LDS, s, g);
   return check_launch("gemm_nt_pp");
 }
 

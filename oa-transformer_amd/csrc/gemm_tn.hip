@@ -216,7 +216,7 @@ static int reduce_slabs(const TnArgs& g, int splits, float* out, float* bias_out
   const int n4 = g.N1 * g.N2 / 4, nb4 = bias_out ? g.N1 / 4 : 0;
   int blocks = (n4 + nb4 + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(tn_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)g.slabs, out, n4, splits,
+  OAT_LAUNCH(tn_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)g.slabs, out, n4, splits,
                      (size_t)g.N1 * g.N2 / 4, (const float*)g.bias_slabs, bias_out, nb4, accumulate);
   return check_launch("gemm_tn_reduce");
 }
@@ -232,7 +232,7 @@ static int launch_tn(TnArgs g, int splits, float* out, float* bias_out, int accu
                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_tn_kernel<WM, WN, TM, TN>), dim3(tiles * splits), dim3(WM * WN * 64), LDS, s, g);
+  OAT_LAUNCH((gemm_tn_kernel<WM, WN, TM, TN>), dim3(tiles * splits), dim3(WM * WN * 64), LDS, s, g);
   int rc = check_launch("gemm_tn");
   if (rc) return rc;
   return reduce_slabs(g, splits, out, bias_out, accumulate, s);

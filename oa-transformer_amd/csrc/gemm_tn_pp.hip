@@ -267,7 +267,7 @@ int launch_tn_pp_cfg(const TnArgs& g, hipStream_t s) {
     attr_set = true;
   }
   const int tiles = (g.N1 / 256) * (g.N2 / 256);
-  hipLaunchKernelGGL((gemm_tn_pp_kernel<FL>), dim3(tiles * g.splits), dim3(512), TP_LDS, s, g);
+  OAT_LAUNCH((gemm_tn_pp_kernel<FL>), dim3(tiles * g.splits), dim3(512), TP_LDS, s, g);
   return check_launch("gemm_tn_pp");
 }
 

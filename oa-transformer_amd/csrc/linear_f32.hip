@@ -202,11 +202,11 @@ __global__ __launch_bounds__(256) void linear_f32_small_kernel(LinArgs g) {
 template <int ACT>
 static void launch_linear(const LinArgs& g, hipStream_t s) {
   if (g.M <= 64 && g.K % 64 == 0) {
-    hipLaunchKernelGGL(linear_f32_small_kernel<ACT>, dim3((g.N + 15) / 16, (g.M + 31) / 32), dim3(256), 0, s, g);
+    OAT_LAUNCH(linear_f32_small_kernel<ACT>, dim3((g.N + 15) / 16, (g.M + 31) / 32), dim3(256), 0, s, g);
   } else if (((g.N + 127) / 128) * ((g.M + 127) / 128) >= 128) {
-    hipLaunchKernelGGL((linear_f32_kernel<ACT, 128, 128, 16, 2, 2>), dim3((g.N + 127) / 128, (g.M + 127) / 128), dim3(256), 0, s, g);
+    OAT_LAUNCH((linear_f32_kernel<ACT, 128, 128, 16, 2, 2>), dim3((g.N + 127) / 128, (g.M + 127) / 128), dim3(256), 0, s, g);
   } else {     // too few 128 x 128 tiles to occupy the GPU (text tower, N = 768: 48): quarter tiles
-    hipLaunchKernelGGL((linear_f32_kernel<ACT, 64, 64, 16, 2, 2>), dim3((g.N + 63) / 64, (g.M + 63) / 64), dim3(256), 0, s, g);
+    OAT_LAUNCH((linear_f32_kernel<ACT, 64, 64, 16, 2, 2>), dim3((g.N + 63) / 64, (g.M + 63) / 64), dim3(256), 0, s, g);
   }
 }
 

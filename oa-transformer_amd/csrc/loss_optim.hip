@@ -180,9 +180,9 @@ extern "C" int oat_sim_matrix_fwd(const float* t, const float* v, int n, int m, 
   if (n <= 0 || m <= 0 || d <= 0) { set_error("sim_matrix: empty problem"); return -1; }
   hipStream_t s = (hipStream_t)stream;
   float* tn = ws; float* vn = tn + (size_t)n * d; float* tnrm = vn + (size_t)m * d; float* vnrm = tnrm + n;
-  hipLaunchKernelGGL(l2norm_rows_kernel, dim3(n), dim3(256), 0, s, t, tn, tnrm, n, d, eps);
-  hipLaunchKernelGGL(l2norm_rows_kernel, dim3(m), dim3(256), 0, s, v, vn, vnrm, m, d, eps);
-  hipLaunchKernelGGL(sim_kernel, dim3((m + 15) / 16, (n + 15) / 16), dim3(256), 0, s, tn, vn, sim, n, m, d);
+  OAT_LAUNCH(l2norm_rows_kernel, dim3(n), dim3(256), 0, s, t, tn, tnrm, n, d, eps);
+  OAT_LAUNCH(l2norm_rows_kernel, dim3(m), dim3(256), 0, s, v, vn, vnrm, m, d, eps);
+  OAT_LAUNCH(sim_kernel, dim3((m + 15) / 16, (n + 15) / 16), dim3(256), 0, s, tn, vn, sim, n, m, d);
   return check_launch("sim_matrix_fwd");
 }
 // dt [tl, d] = d/d t[t0 : t0+tl], dv [vl, d] = d/d v[v0 : v0+vl] given G = dL/dsim [n, m]
@@ -192,8 +192,8 @@ extern "C" int oat_sim_matrix_bwd(const float* G, const float* ws, int n, int m,
   if (t0 < 0 || t0 + tl > n || v0 < 0 || v0 + vl > m) { set_error("sim_matrix_bwd: row range outside the matrix"); return -2; }
   hipStream_t s = (hipStream_t)stream;
   const float* tn = ws; const float* vn = tn + (size_t)n * d; const float* tnrm = vn + (size_t)m * d; const float* vnrm = tnrm + n;
-  if (dt && tl > 0) hipLaunchKernelGGL(gemb_kernel, dim3(tl), dim3(256), d * sizeof(float), s, G, vn, tn, tnrm, dt, n, m, d, t0, 0);
-  if (dv && vl > 0) hipLaunchKernelGGL(gemb_kernel, dim3(vl), dim3(256), d * sizeof(float), s, G, tn, vn, vnrm, dv, n, m, d, v0, 1);
+  if (dt && tl > 0) OAT_LAUNCH(gemb_kernel, dim3(tl), dim3(256), d * sizeof(float), s, G, vn, tn, tnrm, dt, n, m, d, t0, 0);
+  if (dv && vl > 0) OAT_LAUNCH(gemb_kernel, dim3(vl), dim3(256), d * sizeof(float), s, G, tn, vn, vnrm, dv, n, m, d, v0, 1);
   return check_launch("sim_matrix_bwd");
 }
 // NormSoftmaxLoss (loss.py:13-25) on a square sim matrix: loss[1] and, if G != NULL, G = dloss/dsim.  ws: 2n floats
@@ -203,9 +203,9 @@ extern "C" int oat_norm_softmax_loss(const float* sim, int n, float temperature,
   hipStream_t s = (hipStream_t)stream;
   float* lse_r = ws; float* lse_c = ws + n;
   const float inv_tau = 1.f / temperature;
-  hipLaunchKernelGGL(lse_kernel, dim3(2 * n), dim3(256), 0, s, sim, lse_r, lse_c, n, inv_tau);
-  hipLaunchKernelGGL(loss_kernel, dim3(1), dim3(256), 0, s, sim, lse_r, lse_c, loss, n, inv_tau);
-  if (G) hipLaunchKernelGGL(gsim_kernel, dim3((n * n + 255) / 256), dim3(256), 0, s, sim, lse_r, lse_c, G, n, inv_tau);
+  OAT_LAUNCH(lse_kernel, dim3(2 * n), dim3(256), 0, s, sim, lse_r, lse_c, n, inv_tau);
+  OAT_LAUNCH(loss_kernel, dim3(1), dim3(256), 0, s, sim, lse_r, lse_c, loss, n, inv_tau);
+  if (G) OAT_LAUNCH(gsim_kernel, dim3((n * n + 255) / 256), dim3(256), 0, s, sim, lse_r, lse_c, G, n, inv_tau);
   return check_launch("norm_softmax_loss");
 }
 
@@ -232,7 +232,7 @@ extern "C" int oat_infonce(const float* t, const float* v, int n, int d, float t
 // Device-resident step state for captured (hipGraph) training steps: *step += 1; coef = {*lr, 1 - b1^step, 1 - b2^step}.
 extern "C" int oat_adam_tick(int* step, const float* lr, float beta1, float beta2, float* coef, void* stream) {
   if (!step || !lr || !coef) { set_error("adam_tick: null pointer"); return -4; }
-  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step, lr, beta1, beta2, coef);
+  OAT_LAUNCH(adam_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step, lr, beta1, beta2, coef);
   return check_launch("adam_tick");
 }
 // oat_adamw with the step-dependent scalars read from `coef` (device memory, see oat_adam_tick).
@@ -243,7 +243,7 @@ extern "C" int oat_adamw_dev(float* p, const float* g, float* m, float* v, size_
   size_t blocks = (n / 4 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, 0.f, beta1,
+  OAT_LAUNCH(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, 0.f, beta1,
                      beta2, eps, weight_decay, 1.f, 1.f, hf_style, gscale, coef);
   return check_launch("adamw_dev");
 }
@@ -258,7 +258,7 @@ extern "C" int oat_adamw(float* p, const float* g, float* m, float* v, size_t n,
   size_t blocks = (n / 4 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1,
+  OAT_LAUNCH(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1,
                      beta2, eps, weight_decay, bc1, bc2, hf_style, gscale, (const float*)nullptr);
   return check_launch("adamw");
 }

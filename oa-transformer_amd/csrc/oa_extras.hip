@@ -105,41 +105,41 @@ extern "C" int oat_bmm_strided(const float* A, const float* Bm, float* C, int nb
   if (nb <= 0 || I <= 0 || J <= 0 || K <= 0) { set_error("bmm_strided: empty problem"); return -1; }
   if (nb > 65535) { set_error("bmm_strided: batch > 65535"); return -3; }
   BmmArgs a{A, Bm, C, nb, I, J, K, sAb, sAi, sAk, sBb, sBk, sBj, sCb, sCi, sCj, sigmoid, accumulate};
-  hipLaunchKernelGGL(bmm_strided_kernel, dim3((J + 15) / 16, (I + 15) / 16, nb), dim3(256), 0, (hipStream_t)stream, a);
+  OAT_LAUNCH(bmm_strided_kernel, dim3((J + 15) / 16, (I + 15) / 16, nb), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("bmm_strided");
 }
 extern "C" int oat_sigmoid_bwd(const float* s, const float* ds, float* dz, size_t n, void* stream) {
   if (n == 0) return 0;
   int blocks = (int)((n + 255) / 256); if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, s, ds, dz, n);
+  OAT_LAUNCH(sigmoid_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, s, ds, dz, n);
   return check_launch("sigmoid_bwd");
 }
 // partial: workspace of 256 floats
 extern "C" int oat_bce_sum(const float* p, const float* y, size_t n, float* loss, float* partial, void* stream) {
   if (n == 0) { set_error("bce_sum: empty"); return -1; }
   int blocks = (int)((n + 255) / 256); if (blocks > 256) blocks = 256;
-  hipLaunchKernelGGL(bce_sum_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, y, n, partial);
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, blocks, loss);
+  OAT_LAUNCH(bce_sum_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, y, n, partial);
+  OAT_LAUNCH(sum_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, blocks, loss);
   return check_launch("bce_sum");
 }
 extern "C" int oat_bce_bwd(const float* p, const float* y, const float* g, float* dp, size_t n, void* stream) {
   if (n == 0) return 0;
   int blocks = (int)((n + 255) / 256); if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(bce_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, y, g, dp, n);
+  OAT_LAUNCH(bce_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, y, g, dp, n);
   return check_launch("bce_bwd");
 }
 extern "C" int oat_grouped_broadcast(const float* src, int lds_, float* dst, int ldd, int G, int R, int D, float scale,
                                      int accumulate, void* stream) {
   if (G <= 0 || R <= 0) return 0;
   if (D % 4 || lds_ % 4 || ldd % 4) { set_error("grouped_broadcast: D%4 required"); return -3; }
-  hipLaunchKernelGGL(grouped_broadcast_kernel, dim3((unsigned)((size_t)G * R)), dim3(192), 0, (hipStream_t)stream, src,
+  OAT_LAUNCH(grouped_broadcast_kernel, dim3((unsigned)((size_t)G * R)), dim3(192), 0, (hipStream_t)stream, src,
                      lds_, dst, ldd, R, D, scale, accumulate);
   return check_launch("grouped_broadcast");
 }
 extern "C" int oat_axpby(const float* a, const float* b, float* out, size_t n, float alpha, float beta, void* stream) {
   if (n == 0) return 0;
   int blocks = (int)((n + 255) / 256); if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(axpby_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b, out, n, alpha, beta);
+  OAT_LAUNCH(axpby_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b, out, n, alpha, beta);
   return check_launch("axpby");
 }
 
@@ -188,14 +188,14 @@ extern "C" int oat_patch_masks(const float* bbox, int ldb, const int* box_class,
   if (P <= 0 || P * P > 1024) { set_error("patch_masks: patch grid must be 1..32 cells per side"); return -3; }
   if ((box_class == nullptr) != (sel_class == nullptr)) { set_error("patch_masks: box_class and sel_class go together"); return -4; }
   if (!box_class && O != NB) { set_error("patch_masks: one mask per box needs O == NB"); return -3; }
-  hipLaunchKernelGGL(patch_masks_kernel, dim3(B * O), dim3((P * P + 63) / 64 * 64), 0, (hipStream_t)stream, bbox, ldb,
+  OAT_LAUNCH(patch_masks_kernel, dim3(B * O), dim3((P * P + 63) / 64 * 64), 0, (hipStream_t)stream, bbox, ldb,
                      box_class, sel_class, out, NB, O, P);
   return check_launch("patch_masks");
 }
 
 extern "C" int oat_tag_masks(const void* ends, const void* ntxt, float* out, int B, int O, int L, void* stream) {
   if (B <= 0 || O <= 0 || L <= 0) return 0;
-  hipLaunchKernelGGL(oat::tag_masks_kernel, dim3(B * O), dim3(64), 0, (hipStream_t)stream, (const long long*)ends,
+  OAT_LAUNCH(oat::tag_masks_kernel, dim3(B * O), dim3(64), 0, (hipStream_t)stream, (const long long*)ends,
                      (const long long*)ntxt, out, B, O, L);
   return oat::check_launch("tag_masks");
 }

@@ -28,8 +28,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                                                      const float* __restrict__ beta, bf16* y, int ldy,
                                                      float* y32, int ldy32, float* mean, float* rstd,
                                                      int M, int D, float eps, const bf16* add16, int ldadd,
-                                                     float* sum32, int ldsum, const float* add32 = nullptr, int ldadd32 = 0,
-                                                     LnF8 f8 = LnF8{nullptr, 0, nullptr, nullptr}) {
+                                                     float* sum32, int ldsum, const float* add32, int ldadd32, LnF8 f8) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const float qs = f8.y8 ? f8.qscale[0] : 0.f;
@@ -394,8 +393,9 @@ static int ln_fwd_launch(const float* x, int ldx, const float* gamma, const floa
   static int cap = 0;
   if (cap == 0) { const char* e = getenv("OAT_LN_FWD_BLOCKS"); cap = e ? atoi(e) : 4096; if (cap < 1) cap = 4096; }
   int blocks = (M + 3) / 4; if (blocks > cap) blocks = cap;
-  hipLaunchKernelGGL(ln_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta,
-                     (bf16*)y, ldy, y32, ldy32, mean, rstd, M, D, eps, (const bf16*)add16, ldadd, sum32, ldsum);
+  OAT_LAUNCH(ln_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta,
+             (bf16*)y, ldy, y32, ldy32, mean, rstd, M, D, eps, (const bf16*)add16, ldadd, sum32, ldsum, (const float*)nullptr, 0,
+             oat::LnF8{nullptr, 0, nullptr, nullptr});
   return check_launch("layernorm_fwd");
 }
 extern "C" int oat_layernorm_fwd(const float* x, int ldx, const float* gamma, const float* beta, void* y,
@@ -420,7 +420,7 @@ static int ln_fwd_launch_f8(const float* x, int ldx, const float* gamma, const f
   if (D % 4 || D > LN_MAXV * 256 || ldx % 4 || (y && ldy % 4) || f8.ld8 % 4) { set_error("layernorm_fwd_f8: D%4==0, D<=1024 required"); return -3; }
   if (!f8.y8 || !f8.qscale || !f8.amax) { set_error("layernorm_fwd_f8: null pointer"); return -4; }
   int blocks = (M + 3) / 4; if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(ln_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta, (bf16*)y, ldy,
+  OAT_LAUNCH(ln_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta, (bf16*)y, ldy,
                      (float*)nullptr, 0, mean, rstd, M, D, eps, (const bf16*)add16, ldadd, sum32, ldsum, (const float*)nullptr, 0, f8);
   return check_launch("layernorm_fwd_f8");
 }
@@ -440,8 +440,8 @@ extern "C" int oat_add32_layernorm_fwd(const float* x, int ldx, const float* add
   if (M <= 0) return 0;
   if (D % 4 || D > LN_MAXV * 256 || ldx % 4 || ldadd % 4 || (y && ldy % 4)) { set_error("layernorm_fwd: D%4==0, D<=1024 required"); return -3; }
   const int blocks = (M + 3) / 4;
-  hipLaunchKernelGGL(ln_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta, (bf16*)y, ldy, y32,
-                     ldy32, mean, rstd, M, D, eps, (const bf16*)nullptr, 0, sum32, ldsum, add32, ldadd);
+  OAT_LAUNCH(ln_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta, (bf16*)y, ldy, y32,
+                     ldy32, mean, rstd, M, D, eps, (const bf16*)nullptr, 0, sum32, ldsum, add32, ldadd, oat::LnF8{nullptr, 0, nullptr, nullptr});
   return check_launch("add32_layernorm_fwd");
 }
 
@@ -464,21 +464,21 @@ extern "C" int oat_layernorm_bwd(const void* dy, int dy_is_bf16, int lddy, const
   const int blocks = oat_ln_bwd_blocks(M);
   hipStream_t s = (hipStream_t)stream;
   if (dy_is_bf16)
-    hipLaunchKernelGGL(ln_bwd_kernel<true>, dim3(blocks), dim3(256), 0, s, dy, lddy, x, ldx, mean, rstd, gamma, dres,
+    OAT_LAUNCH(ln_bwd_kernel<true>, dim3(blocks), dim3(256), 0, s, dy, lddy, x, ldx, mean, rstd, gamma, dres,
                        lddres, dx, lddx, (bf16*)dx16, lddx16, dx16_excl_res, part, M, D);
   else
-    hipLaunchKernelGGL(ln_bwd_kernel<false>, dim3(blocks), dim3(256), 0, s, dy, lddy, x, ldx, mean, rstd, gamma, dres,
+    OAT_LAUNCH(ln_bwd_kernel<false>, dim3(blocks), dim3(256), 0, s, dy, lddy, x, ldx, mean, rstd, gamma, dres,
                        lddres, dx, lddx, (bf16*)dx16, lddx16, dx16_excl_res, part, M, D);
   int rc = check_launch("layernorm_bwd");
   if (rc || !part) return rc;
   if (dgamma && dbeta)
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * D + 31) / 32), dim3(1024), 0, s, part, blocks, (size_t)2 * D, dgamma,
+    OAT_LAUNCH(reduce_partials_kernel, dim3((2 * D + 31) / 32), dim3(1024), 0, s, part, blocks, (size_t)2 * D, dgamma,
                        2 * D, accumulate, dbeta, D);
   else if (dgamma)
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((D + 31) / 32), dim3(1024), 0, s, part, blocks, (size_t)2 * D, dgamma, D,
+    OAT_LAUNCH(reduce_partials_kernel, dim3((D + 31) / 32), dim3(1024), 0, s, part, blocks, (size_t)2 * D, dgamma, D,
                        accumulate, (float*)nullptr, D);
   else if (dbeta)
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((D + 31) / 32), dim3(1024), 0, s, part + D, blocks, (size_t)2 * D, dbeta, D,
+    OAT_LAUNCH(reduce_partials_kernel, dim3((D + 31) / 32), dim3(1024), 0, s, part + D, blocks, (size_t)2 * D, dbeta, D,
                        accumulate, (float*)nullptr, D);
   return check_launch("layernorm_bwd_finish");
 }
@@ -493,9 +493,9 @@ extern "C" int oat_colsum(const void* A, int is_bf16, int lda, int M, int N, flo
   const int rows = oat_colsum_rows(M);
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((N + 255) / 256, rows);
-  if (is_bf16) hipLaunchKernelGGL(colsum_kernel<true>, grid, dim3(256), 0, s, A, lda, M, N, part);
-  else hipLaunchKernelGGL(colsum_kernel<false>, grid, dim3(256), 0, s, A, lda, M, N, part);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 31) / 32), dim3(1024), 0, s, part, rows, (size_t)N, out, N,
+  if (is_bf16) OAT_LAUNCH(colsum_kernel<true>, grid, dim3(256), 0, s, A, lda, M, N, part);
+  else OAT_LAUNCH(colsum_kernel<false>, grid, dim3(256), 0, s, A, lda, M, N, part);
+  OAT_LAUNCH(reduce_partials_kernel, dim3((N + 31) / 32), dim3(1024), 0, s, part, rows, (size_t)N, out, N,
                      accumulate, (float*)nullptr, N);
   return check_launch("colsum");
 }
@@ -503,13 +503,13 @@ extern "C" int oat_colsum(const void* A, int is_bf16, int lda, int M, int N, flo
 extern "C" int oat_periodic_rowsum(const float* in, int ld, int R, int P, int D, float* out, int accumulate, void* stream) {
   if (D % 4 || ld % 4) { set_error("periodic_rowsum: D%4 required"); return -3; }
   if (P <= 0) return 0;
-  hipLaunchKernelGGL(periodic_rowsum_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, in, ld, R, P, D, out, accumulate);
+  OAT_LAUNCH(periodic_rowsum_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, in, ld, R, P, D, out, accumulate);
   return check_launch("periodic_rowsum");
 }
 extern "C" int oat_grouped_rowsum(const float* in, int ld, int G, int R, int D, float* out, int accumulate, void* stream) {
   if (D % 4 || ld % 4) { set_error("grouped_rowsum: D%4 required"); return -3; }
   if (G <= 0) return 0;
-  hipLaunchKernelGGL(grouped_rowsum_kernel, dim3(G), dim3(256), 0, (hipStream_t)stream, in, ld, G, R, D, out, accumulate);
+  OAT_LAUNCH(grouped_rowsum_kernel, dim3(G), dim3(256), 0, (hipStream_t)stream, in, ld, G, R, D, out, accumulate);
   return check_launch("grouped_rowsum");
 }
 
@@ -518,33 +518,33 @@ extern "C" int oat_im2col(const void* video, int is_bf16, void* A, int BT, int C
   const size_t total = (size_t)BT * (R / ps) * (R / ps) * (C * ps * ps / 8);
   int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
   hipStream_t s = (hipStream_t)stream;
-  if (is_bf16) hipLaunchKernelGGL(im2col_kernel<true>, dim3(blocks), dim3(256), 0, s, video, (bf16*)A, BT, C, R, ps, lda);
-  else hipLaunchKernelGGL(im2col_kernel<false>, dim3(blocks), dim3(256), 0, s, video, (bf16*)A, BT, C, R, ps, lda);
+  if (is_bf16) OAT_LAUNCH(im2col_kernel<true>, dim3(blocks), dim3(256), 0, s, video, (bf16*)A, BT, C, R, ps, lda);
+  else OAT_LAUNCH(im2col_kernel<false>, dim3(blocks), dim3(256), 0, s, video, (bf16*)A, BT, C, R, ps, lda);
   return check_launch("im2col");
 }
 
 extern "C" int oat_pos_table(const float* pos, const float* temporal, const float* cls_token, float* table,
                              float* cls0, int T, int N, int D, void* stream) {
-  hipLaunchKernelGGL(pos_table_kernel, dim3(T * N + 1), dim3(256), 0, (hipStream_t)stream, pos, temporal, cls_token,
+  OAT_LAUNCH(pos_table_kernel, dim3(T * N + 1), dim3(256), 0, (hipStream_t)stream, pos, temporal, cls_token,
                      table, cls0, T, N, D);
   return check_launch("pos_table");
 }
 extern "C" int oat_broadcast_rows(const float* src, float* dst, int ld, int R, int D, void* stream) {
   if (R <= 0) return 0;
-  hipLaunchKernelGGL(broadcast_rows_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, src, dst, ld, R, D);
+  OAT_LAUNCH(broadcast_rows_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, src, dst, ld, R, D);
   return check_launch("broadcast_rows");
 }
 extern "C" int oat_cast_bf16_tile(void) { return CAST_TILE; }
 extern "C" int oat_cast_bf16_multi(const void* desc, int n_matrices, int total_tiles, const int* tile_matrix, void* stream) {
   if (n_matrices <= 0 || total_tiles <= 0) return 0;
   if (!desc) { set_error("cast_bf16_multi: null descriptor table"); return -4; }
-  hipLaunchKernelGGL(cast_bf16_multi_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream,
+  OAT_LAUNCH(cast_bf16_multi_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream,
                      (const CastDesc*)desc, n_matrices, tile_matrix);
   return check_launch("cast_bf16_multi");
 }
 extern "C" int oat_cast_bf16(const float* src, void* dst, void* dstT, int R, int C, void* stream) {
   if (R <= 0 || C <= 0) return 0;
-  hipLaunchKernelGGL(cast_bf16_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, (hipStream_t)stream, src,
+  OAT_LAUNCH(cast_bf16_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, (hipStream_t)stream, src,
                      (bf16*)dst, (bf16*)dstT, R, C);
   return check_launch("cast_bf16");
 }

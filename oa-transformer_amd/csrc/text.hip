@@ -238,13 +238,13 @@ extern "C" int oat_embed_fwd(const void* ids, const float* word, const float* po
                              int D, void* stream) {
   if (M <= 0) return 0;
   if (D % 4 || ld % 4) { set_error("embed_fwd: D%4 required"); return -3; }
-  hipLaunchKernelGGL(embed_fwd_kernel, dim3(M), dim3(192), 0, (hipStream_t)stream, (const long long*)ids, word, pos, out,
+  OAT_LAUNCH(embed_fwd_kernel, dim3(M), dim3(192), 0, (hipStream_t)stream, (const long long*)ids, word, pos, out,
                      ld, M, L, D);
   return check_launch("embed_fwd");
 }
 extern "C" int oat_embed_bwd(const void* ids, const float* g, int ld, float* dword, int M, int D, void* stream) {
   if (M <= 0) return 0;
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const long long*)ids, g, ld, dword, M, D);
+  OAT_LAUNCH(embed_bwd_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const long long*)ids, g, ld, dword, M, D);
   return check_launch("embed_bwd");
 }
 
@@ -252,7 +252,7 @@ static int attn_text_fwd_launch(oat::TextArgs a, void* stream) {
   using namespace oat;
   if (a.D != a.H * 64) { set_error("attn_text: head_dim must be 64"); return -3; }
   const int groups = a.B * a.H * a.L;
-  hipLaunchKernelGGL(attn_text_fwd_kernel, dim3((groups + 31) / 32), dim3(256), 0, (hipStream_t)stream, a);
+  OAT_LAUNCH(attn_text_fwd_kernel, dim3((groups + 31) / 32), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("attn_text_fwd");
 }
 extern "C" int oat_attn_text_fwd(const void* qkv, int ldqkv, const void* mask, void* out, int ldo, float* lse, int B,
@@ -286,19 +286,19 @@ extern "C" int oat_attn_text_bwd(const void* qkv, int ldqkv, const void* mask, c
              drop_p > 0.f ? make_drop_site(rng, drop_site, drop_p) : DropSite{nullptr, 0, 0, 1.f}};
   const int groups = B * H * L;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(attn_text_bwd_q_kernel, dim3((groups + 31) / 32), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(attn_text_bwd_kv_kernel, dim3((groups + 31) / 32), dim3(256), 0, s, a);
+  OAT_LAUNCH(attn_text_bwd_q_kernel, dim3((groups + 31) / 32), dim3(256), 0, s, a);
+  OAT_LAUNCH(attn_text_bwd_kv_kernel, dim3((groups + 31) / 32), dim3(256), 0, s, a);
   return check_launch("attn_text_bwd");
 }
 
 extern "C" int oat_relu_bf16(const float* x, int ldx, void* y, int ldy, int M, int D, void* stream) {
   if (M <= 0) return 0;
-  hipLaunchKernelGGL(relu_bf16_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, x, ldx, (bf16*)y, ldy, M, D);
+  OAT_LAUNCH(relu_bf16_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, x, ldx, (bf16*)y, ldy, M, D);
   return check_launch("relu_bf16");
 }
 extern "C" int oat_relu_bwd(const float* x, int ldx, const float* dy, int lddy, float* dx, int lddx, int M, int D,
                             void* stream) {
   if (M <= 0) return 0;
-  hipLaunchKernelGGL(relu_bwd_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, x, ldx, dy, lddy, dx, lddx, M, D);
+  OAT_LAUNCH(relu_bwd_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, x, ldx, dy, lddy, dx, lddx, M, D);
   return check_launch("relu_bwd");
 }

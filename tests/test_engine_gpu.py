@@ -164,3 +164,50 @@ def test_336_geometry_vs_oracle():
         ref = p["video_model." + k].grad
         e, c = rel(prm.grad, ref), cosine(prm.grad, ref)
         assert e < 3e-2 and c > 0.999, (k, e, c)
+
+
+def test_launch_tape_replays_the_same_training_trajectory():
+    """csrc/tape.hip: forward / backward schedules of both towers recorded once and replayed from C must walk the
+    trajectory of issuing every launch from Python: the same losses and parameters over several optimiser steps, with
+    changing inputs (static input buffers), a second batch shape (second plan, second tape) and the segment callbacks
+    of backward (gradient announcements) firing in order."""
+    import argparse
+    import copy
+    from OATrans import model as module_arch
+    from OATrans.ops import hip
+    from OATrans.optim import AdamW
+    from OATrans.parallel import HipDataParallel
+    from OATrans.trainer.step import hot_step
+    from tests.test_model_gpu import _batch, _small_frozen
+    sa = argparse.Namespace(world_size=1, rank=0, local_rank=0)
+    base = _small_frozen(seed=4, depth=2)
+    base.train()
+    batches = [_batch(seed=30 + i) for i in range(4)] + [_batch(B=2, T=2, L=7, seed=77)] * 2 + [_batch(seed=30)]
+    results = []
+    for taped in (False, True):
+        m = copy.deepcopy(base)
+        m.text_model.set_dropout_seed(5)              # training-mode dropout: the masks advance identically on both runs
+        for sub in (m.video_model, m.text_model):
+            sub.flatten_parameters()
+            sub._engine.use_tape = taped
+        dp = HipDataParallel(m)
+        opt = AdamW([p for p in m.parameters() if p.requires_grad], lr=1e-4)
+        announced = []
+        m.video_model.grad_ready_hook = lambda mod, lo, hi: announced.append((lo, hi))
+        losses = [hot_step(dp, module_arch.NormSoftmaxLoss(), opt, b, sa).item() for b in batches]
+        torch.cuda.synchronize()
+        if taped:
+            pl = next(iter(m.video_model._engine.plans.values()))
+            assert pl.tape_fwd is not None and pl.tape_bwd is not None
+            assert hip.lib().oat_tape_ops(pl.tape_fwd[1]) > 50 and pl.tape_bwd[3] == 2 + 1        # depth 2 + the embedding segment
+            assert len(m.video_model._engine.plans) == 2
+        results.append((losses, announced, {n: p.detach().clone() for n, p in m.named_parameters()}))
+    (l0, a0, p0), (l1, a1, p1) = results
+    # same kernels, same arguments, same order; the only run-to-run noise is the order of the fp32 atomics that sum the
+    # CLS-row gradients (present between two untaped runs as well)
+    assert l0[:2] == l1[:2], (l0, l1)
+    assert max(abs(a - b) for a, b in zip(l0, l1)) < 2e-3, (l0, l1)
+    assert a0 == a1 and len(a0) == 3 * len(batches)
+    for n in p0:
+        d = (p0[n] - p1[n]).abs()
+        assert d.max().item() <= len(batches) * 2e-4 + 1e-6 and d.mean().item() < 2e-5, (n, d.max().item(), d.mean().item())
