@@ -185,19 +185,26 @@ int oat_copy_async(void* dst, const void* src, size_t bytes, void* stream);
  * serves the nn.Linear forwards of video_transformer.py:46-50,102,133).  A quantisation site owns three device floats:
  * amax (running max |x| of this step), qscale (q = sat(x * qscale)), dq = 1 / qscale. */
 int oat_fp8_quant(const void* x, int is_bf16, int ldx, void* out8, int ld8, int M, int K, const float* qscale,
-                  float* amax_or_null, void* stream);                 /* quantise with *qscale, record amax of x */
+                  float* amax_or_null, int e5m2, void* stream);       /* quantise with *qscale (e4m3, or e5m2 for gradients), record amax of x */
 int oat_fp8_amax(const void* x, int is_bf16, int ldx, int M, int K, float* amax, void* stream);
 int oat_fp8_chunk_elems(void);
 /* many contiguous bf16 matrices in one launch; desc rows int64 {src, dst, n, site, first_block}, owner: block -> row */
 int oat_fp8_multi(const void* desc, const int* owner, int total_blocks, const float* qscale, float* amax, int quant,
                   void* stream);
-int oat_fp8_update_scales(float* amax, float* qscale, float* dq, int n_sites, float margin, void* stream);
+int oat_fp8_update_scales(float* amax, float* qscale, float* dq, int n_sites, float margin, int e5m2, void* stream);
 /* C = dq_a dq_b (A8 . B8^T) + bias ; epi 0 (bf16 out) or 5 (out = gelu'(h), out2 = gelu(h)); K % 256 == 0,
  * N % 256 == 0, N <= 4096, M >= 256; lda / ldb in elements (bytes) */
 int oat_gemm_nt_f8(const void* A8, const void* B8, int M, int N, int K, int lda, int ldb, int epi, void* out, int ldc,
                    void* out2, int ld2, const float* bias, const float* dq_a, const float* dq_b,
-                   void* out8_or_null, int ld8, const float* q_out, float* amax_out,   /* epi 5: e4m3 copy of out2 */
+                   int a_e5m2,                                  /* A8 holds e5m2 gradients (data-gradient GEMMs); B8 is e4m3 */
+                   const void* aux, int ldaux,                  /* epi 6 (EPI_MUL_AUX): out = (acc + bias) * aux */
+                   void* out8_or_null, int ld8, const float* q_out, float* amax_out,   /* epi 5: e4m3 copy of out2; epi 6: e5m2 copy of out */
                    void* stream);
+/* LayerNorm backward that also leaves dx16 as e5m2 (next data-gradient GEMM's operand) */
+int oat_layernorm_bwd_f8(const void* dy, int dy_is_bf16, int lddy, const float* x, int ldx, const float* mean,
+                         const float* rstd, const float* gamma, const float* dres, int lddres, float* dx, int lddx,
+                         void* dx16, int lddx16, int dx16_excl_res, float* dgamma, float* dbeta, int accumulate,
+                         float* part, int M, int D, void* dx8, int ld8, const float* qscale, float* amax, void* stream);
 /* LayerNorm (optionally of x + add16, sum32 = the sum) writing y as bf16 AND as e4m3 (y8 = sat(y * *qscale)), amax of y
  * recorded: the producer-side quantisation of the fp8 GEMM operand */
 int oat_layernorm_fwd_f8(const float* x, int ldx, const void* add16_or_null, int ldadd, float* sum32, int ldsum,

@@ -141,6 +141,12 @@ class VideoEngine:
         # whole backward stay bf16 / fp32.  Set by OAT_FP8=1 or by the caller (bench.py --dtype fp8).
         self.fp8 = os.environ.get("OAT_FP8", "0") != "0"
         self.fp8_margin = float(os.environ.get("OAT_FP8_MARGIN", "1.0"))
+        # OAT_FP8_BWD=1 (with fp8 on): the data-gradient GEMMs as well (dY as e5m2, W^T as e4m3; weight gradients stay
+        # bf16).  Off by default: measured EQUAL in time at the headline shape (49.58 vs 49.69 ms: what the six GEMMs gain,
+        # ~260 us per block, goes into quantising dY - the two d_qkv tensors take a 60 us pass each because the attention
+        # backward kernels do not write e5m2 themselves yet) while gradient norms drift from <= 5 % to 10-12 % off the
+        # fp32 reference in the lowest blocks (tests/test_fp8_gpu.py).
+        self.fp8_bwd = os.environ.get("OAT_FP8_BWD", "0") != "0"
         # launch tapes (csrc/tape.hip): forward and backward are recorded once per plan and replayed from C
         self.use_tape = os.environ.get("OAT_TAPE", "1") != "0"
         self._f8 = None
@@ -174,12 +180,13 @@ class VideoEngine:
     F8_LINEARS = ("timeattn.qkv", "timeattn.proj", "attn.qkv", "attn.proj", "mlp.fc1", "mlp.fc2")
 
     def _fp8_state(self, dev):
-        """Quantisation sites: block i, linear j -> weight site 12 i + j, activation (GEMM input) site 12 i + 6 + j.
-        amax / qscale / dq are rows of one device tensor."""
+        """Quantisation sites of block i, linear j: weight 18 i + j (e4m3, shared by W and W^T), forward input
+        18 i + 6 + j (e4m3), incoming gradient dY of that linear 18 i + 12 + j (e5m2).  amax / qscale / dq are rows of one
+        device tensor."""
         if self._f8 is None:
-            n = 12 * self.depth
+            n = 18 * self.depth
             st = torch.zeros(3, n, dtype=torch.float32, device=dev)
-            self._f8 = dict(n=n, amax=st[0], qscale=st[1], dq=st[2], w8={}, table=None, primed=set(), key=None)
+            self._f8 = dict(n=n, amax=st[0], qscale=st[1], dq=st[2], w8={}, wT8={}, table=None, qtable=None, primed=set(), key=None)
         return self._f8
 
     def _refresh_fp8_weights(self):
@@ -190,25 +197,29 @@ class VideoEngine:
         f8 = self._fp8_state(dev)
         key = tuple(self.shadow[n][0].data_ptr() for _, _, n in names)
         if f8["key"] != key:
-            entries = []
+            entries, tentries = [], []
             for i, j, n in names:
-                w16 = self.shadow[n][0]
+                w16, wT16 = self.shadow[n]
                 f8["w8"][n] = torch.empty(w16.shape, dtype=torch.uint8, device=dev)
-                entries.append((w16, f8["w8"][n], 12 * i + j))
+                f8["wT8"][n] = torch.empty(wT16.shape, dtype=torch.uint8, device=dev)
+                entries.append((w16, f8["w8"][n], 18 * i + j))
+                tentries.append((wT16, f8["wT8"][n], 18 * i + j))       # W^T (data-gradient operand): same values, same scale
             f8["table"], f8["key"] = hip.Fp8Table(entries), key
+            f8["qtable"] = hip.Fp8Table(entries + tentries) if self.fp8_bwd else f8["table"]
         f8["table"].run(f8["qscale"], f8["amax"], quant=False)
-        hip.fp8_update_scales(f8["amax"], f8["qscale"], f8["dq"], f8["n"], 1.0)       # activation sites: amax == 0, untouched
-        f8["table"].run(f8["qscale"], f8["amax"], quant=True)
+        hip.fp8_update_scales(f8["amax"], f8["qscale"], f8["dq"], f8["n"], 1.0)       # activation / gradient sites: amax == 0, untouched
+        f8["qtable"].run(f8["qscale"], f8["amax"], quant=True)
 
-    def _f8_site(self, i, j):
-        """(qscale, amax, dq) one-element views of activation site (block i, linear j)."""
-        f8, s = self._f8, 12 * i + 6 + j
+    def _f8_site(self, i, j, grad=False):
+        """(qscale, amax, dq) one-element views of the forward-input (grad=False) or incoming-gradient (grad=True) site of
+        linear j of block i."""
+        f8, s = self._f8, 18 * i + (12 if grad else 6) + j
         return f8["qscale"][s:s + 1], f8["amax"][s:s + 1], f8["dq"][s:s + 1]
 
-    def _f8_primed(self, i, j):
-        """Has the input of linear j of block i been seen (does its delayed scale exist)?  Producers quantise in their own
-        epilogue only then; the very first step quantises in a separate pass with the CURRENT amax."""
-        return self.fp8 and (12 * i + 6 + j) in self._f8["primed"]
+    def _f8_primed(self, i, j, grad=False):
+        """Has this GEMM operand been seen (does its delayed scale exist)?  Producers quantise in their own epilogue only
+        then; the very first step quantises in a separate pass with the CURRENT amax."""
+        return self.fp8 and (18 * i + (12 if grad else 6) + j) in self._f8["primed"]
 
     def _ln_f8(self, pl, i, j, x, gamma, beta, y, mean, rstd, add16=None, sum32=None):
         """LayerNorm whose output feeds linear j of block i: bf16 y (kept for backward) and its e4m3 copy in pl.x8."""
@@ -220,7 +231,7 @@ class VideoEngine:
         pl.x8_wide; otherwise the bf16 input is quantised here (delayed scale; first use: current scale).  The fc1 launch
         (j == 4) also leaves e4m3(gelu) for fc2 in pl.x8_wide once fc2's site is primed."""
         f8 = self._f8
-        site, wsite = 12 * i + 6 + j, 12 * i + j
+        site, wsite = 18 * i + 6 + j, 18 * i + j
         x8 = pl.x8_wide if K == self.Hd else pl.x8
         M = pl.M
         q, am, dq = self._f8_site(i, j)
@@ -237,6 +248,48 @@ class VideoEngine:
             kw = dict(out8=pl.x8_wide, q_out=q5, amax_out=am5)
         hip.gemm_nt_f8(x8, w8, M, N, K, epi, out, dq, f8["dq"][wsite:wsite + 1], out2=out2, bias=bias, **kw)
         return bool(kw)
+
+    def _dgrad_f8(self, pl, i, j, dy16, K, N, epi, out, aux=None, quantised=False, dy8=None):
+        """Data gradient of linear j of block i on fp8 operands: out = dY @ W (W^T shadow as e4m3, dY as e5m2).
+        quantised=True: the producer of dY already left its e5m2 copy in `dy8`.  The fc2 data gradient (j == 5,
+        EPI_MUL_AUX) leaves the e5m2 copy of ITS output for the fc1 data gradient once that site is primed."""
+        f8 = self._f8
+        site, wsite = 18 * i + 12 + j, 18 * i + j
+        M = pl.M
+        q, am, dq = self._f8_site(i, j, grad=True)
+        if dy8 is None:
+            dy8 = pl.x8_wide if K == self.Hd else (pl.x8_qkv if K == 3 * self.D else pl.x8)
+        if not quantised:
+            if site not in f8["primed"]:
+                hip.fp8_amax(dy16, M, K, am)
+                hip.fp8_update_scales(am, q, dq, 1, self.fp8_margin, e5m2=True)
+                f8["primed"].add(site)
+            hip.fp8_quant(dy16, dy8, M, K, q, am, e5m2=True)
+        wT8 = f8["wT8"][f"blocks.{i}.{self.F8_LINEARS[j]}.weight"]
+        kw = {}
+        if j == 5 and self._f8_primed(i, 4, grad=True):
+            q4, am4, _ = self._f8_site(i, 4, grad=True)
+            kw = dict(out8=pl.x8_wide, q_out=q4, amax_out=am4)
+        hip.gemm_nt_f8(dy8, wT8, M, N, K, epi, out, dq, f8["dq"][wsite:wsite + 1], a_e5m2=True, aux=aux, **kw)
+        return bool(kw)
+
+    def _ln_bwd(self, pl, i, j, dy, x, mean, rstd, gamma, dx16, dgamma, dbeta, dx8=None, **kw):
+        """LayerNorm backward whose bf16 output dx16 is the incoming gradient of linear j of block i: with fp8 backward
+        and a primed site it also writes the e5m2 copy (into dx8, default pl.x8).  Returns whether it did."""
+        M, D = pl.M, self.D
+        if i >= 0 and self.fp8 and self.fp8_bwd and self._f8_primed(i, j, grad=True):
+            q, am, _ = self._f8_site(i, j, grad=True)
+            hip.layernorm_bwd_f8(dy, x, mean, rstd, gamma, M, D, dx8 if dx8 is not None else pl.x8, q, am, dx=pl.G, dx16=dx16,
+                                 dres=pl.G, dgamma=dgamma, dbeta=dbeta, accumulate=pl.acc, **kw)
+            return True
+        hip.layernorm_bwd(dy, x, mean, rstd, gamma, M, D, dx=pl.G, dx16=dx16, dres=pl.G, dgamma=dgamma, dbeta=dbeta,
+                          accumulate=pl.acc, **kw)
+        return False
+
+    def _fp8_end_of_backward(self):
+        """Next step's gradient scales (e5m2) from this step's amax; the other sites saw no amax since their own update."""
+        f8 = self._f8
+        hip.fp8_update_scales(f8["amax"], f8["qscale"], f8["dq"], f8["n"], self.fp8_margin, e5m2=True)
 
     def _fp8_end_of_forward(self):
         """Next step's activation scales from this step's amax (weight sites saw no amax: unchanged)."""
@@ -291,6 +344,8 @@ class VideoEngine:
         if self.fp8 and getattr(pl, "x8", None) is None:
             pl.x8 = torch.zeros(pl.Mp, self.D, dtype=torch.uint8, device=dev)          # fp8 GEMM inputs (one in flight)
             pl.x8_wide = torch.zeros(pl.Mp, self.Hd, dtype=torch.uint8, device=dev)
+            pl.x8_qkv = torch.zeros(pl.Mp, 3 * self.D, dtype=torch.uint8, device=dev)      # e5m2 d_qkv (backward)
+            pl.ga8 = [torch.zeros(pl.Mp, self.D, dtype=torch.uint8, device=dev) for _ in range(3)]   # e5m2 copies of the ga ring
         run = _Run(pl, need_patches, region_layer)
 
         def body():
@@ -318,7 +373,7 @@ class VideoEngine:
         ptrs = tuple(t.data_ptr() for t in params.values())
         gptr = next(iter(grads.values())).data_ptr() if grads else 0
         f8 = (len(self._f8["primed"]), self._f8["key"]) if (self.fp8 and self._f8) else None
-        return (torch.cuda.current_stream().cuda_stream, pl.side.cuda_stream, ptrs, gptr, self.fp8, f8, self.cls_lane,
+        return (torch.cuda.current_stream().cuda_stream, pl.side.cuda_stream, ptrs, gptr, self.fp8, self.fp8_bwd, f8, self.cls_lane,
                 self.tail_split, self.bwd_side, self.bwd_nt_grid, hip.gemm_get_variant(), flags)
 
     @staticmethod
@@ -571,10 +626,14 @@ class VideoEngine:
             nt_prev = hip.gemm_get_variant()
             if self.bwd_nt_grid and (nt_prev >> 16) == 0:
                 hip.gemm_set_variant((nt_prev & 0xffff) | (self.bwd_nt_grid << 16))
+            f8b = self.fp8 and self.fp8_bwd and not self.bwd_side
+            pl.ga8_valid = None              # the top block's dL/d(out) comes from the final LayerNorm: quantised in a pass
             for k, i in enumerate(reversed(range(self.depth))):
-                self._block_bwd(pl, i, run, params, grads, d_region)
+                (self._block_bwd_f8 if f8b else self._block_bwd)(pl, i, run, params, grads, d_region)
                 if use_marks:
                     self._announce_segment(ready, prefixes[k], recording)
+            if f8b:
+                self._fp8_end_of_backward()
             self._embed_bwd(pl, grads)
             if use_marks:
                 self._announce_segment(ready, prefixes[-1], recording)
@@ -707,6 +766,56 @@ class VideoEngine:
             dgamma=gr("norm3.weight"), dbeta=gr("norm3.bias"), accumulate=pl.acc),                               # G = dL/dx
             [lambda: self._wgrad(d_qkv_t, a.a3, M, 3 * D, D, gr("timeattn.qkv.weight"), gr("timeattn.qkv.bias"), pl.acc)])
         self._join(s5)
+
+    def _block_bwd_f8(self, pl, i, run, params, grads, d_region):
+        """_block_bwd with the six data-gradient GEMMs on fp8 operands (dY e5m2, W^T e4m3; weight gradients stay bf16,
+        in order on the caller's stream).  Producers of dY write the e5m2 copy themselves once the site has a scale:
+        LayerNorm backward (gb, gc, the next block's ga), the fc2 data gradient's epilogue (d_h); the attention
+        backward outputs and the top block's ga take one quantisation pass."""
+        B, T, N, M = pl.B, pl.T, pl.N, pl.M
+        D, Hd, H = self.D, self.Hd, self.H
+        BTN = M - B
+        a = pl.blocks[i]
+        st8 = pl.sets[i % 2]
+        ga, ga_next = pl.ga[i % 3], pl.ga[(i - 1) % 3]
+        ga8, ga8_next = pl.ga8[i % 3], pl.ga8[(i - 1) % 3]
+        rl = run.region_layer
+        if rl is not None and d_region is not None and i + 1 == rl:
+            hip.layernorm_bwd(d_region, a.out, pl.rstats[0], pl.rstats[1], params["region_norm.weight"],
+                              BTN, D, dx=pl.G, dx16=ga, dres=pl.G, dgamma=grads["region_norm.weight"],
+                              dbeta=grads["region_norm.bias"], accumulate=pl.acc)
+            pl.ga8_valid = None                    # ga changed: its e5m2 copy is stale
+        x = pl.blocks[i - 1].out if i > 0 else pl.x0
+        p = lambda s: params[f"blocks.{i}.{s}"]
+        gr = lambda s: grads[f"blocks.{i}.{s}"]
+        st = a.stats
+        d_h, gb, d_qkv_s, gc, d_qkv_t = st8["d_h"], st8["gb"], st8["d_qkv_s"], st8["gc"], st8["d_qkv_t"]
+        # ---- MLP
+        dh_q = self._dgrad_f8(pl, i, 5, ga, D, Hd, hip.EPI_MUL_AUX, d_h, aux=a.h, quantised=pl.ga8_valid == i, dy8=ga8)
+        self._dgrad_f8(pl, i, 4, d_h, Hd, D, hip.EPI_BF16, pl.d_a, quantised=dh_q)
+        gb_q = self._ln_bwd(pl, i, 3, pl.d_a, a.y, st[4], st[5], p("norm2.weight"), gb, gr("norm2.weight"), gr("norm2.bias"))
+        self._wgrad(ga, a.g, M, D, Hd, gr("mlp.fc2.weight"), gr("mlp.fc2.bias"), pl.acc)
+        # ---- space attention
+        self._dgrad_f8(pl, i, 3, gb, D, D, hip.EPI_BF16, pl.d_o, quantised=gb_q)
+        hip.attn_space_bwd(a.qkv_s, a.o_s, a.lse_s, pl.d_o, d_qkv_s, pl.cls_side, B, T, N, H, D, self.scale)
+        hip.attn_cls_finalize(pl.cls_side, d_qkv_s, B, T, N, H, D)
+        self._wgrad(d_h, a.a2, M, Hd, D, gr("mlp.fc1.weight"), gr("mlp.fc1.bias"), pl.acc)
+        self._dgrad_f8(pl, i, 2, d_qkv_s, 3 * D, D, hip.EPI_BF16, pl.d_a)
+        gc_q = self._ln_bwd(pl, i, 1, pl.d_a, a.xt, st[2], st[3], p("norm1.weight"), gc, gr("norm1.weight"), gr("norm1.bias"),
+                            dx16_excl_res=True)
+        self._wgrad(d_qkv_s, a.a1, M, 3 * D, D, gr("attn.qkv.weight"), gr("attn.qkv.bias"), pl.acc)
+        # ---- time attention
+        self._dgrad_f8(pl, i, 1, gc, D, D, hip.EPI_BF16, pl.d_o, quantised=gc_q)
+        hip.attn_time_bwd(a.qkv_t, a.o_t, a.lse_t, pl.d_o, d_qkv_t, pl.cls_side, B, T, N, H, D, self.scale)
+        hip.attn_cls_finalize(pl.cls_side, d_qkv_t, B, T, N, H, D)
+        self._wgrad(gb, a.o_s, M, D, D, gr("attn.proj.weight"), gr("attn.proj.bias"), pl.acc)
+        self._wgrad(gc, a.o_t, M, D, D, gr("timeattn.proj.weight"), gr("timeattn.proj.bias"), pl.acc)
+        self._dgrad_f8(pl, i, 0, d_qkv_t, 3 * D, D, hip.EPI_BF16, pl.d_a)
+        # LayerNorm-3 backward writes dL/d(output of block i-1): the fc2 data gradient's operand of the NEXT block to run
+        nxt_q = self._ln_bwd(pl, i - 1, 5, pl.d_a, x, st[0], st[1], p("norm3.weight"), ga_next, gr("norm3.weight"),
+                             gr("norm3.bias"), dx8=ga8_next)
+        pl.ga8_valid = i - 1 if nxt_q else None
+        self._wgrad(d_qkv_t, a.a3, M, 3 * D, D, gr("timeattn.qkv.weight"), gr("timeattn.qkv.bias"), pl.acc)
 
     def _embed_bwd(self, pl, grads):
         """x0[patch] = cols @ Wp^T + b + pos[1+n] + temporal[f] ; x0[cls] = cls + pos[0]"""

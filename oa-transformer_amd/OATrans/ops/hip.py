@@ -389,17 +389,17 @@ def copy_(dst, src):
 
 
 # ---- fp8 (OCP e4m3fn) forward GEMMs ------------------------------------------------------------------------------
-def fp8_quant(x, out8, M, K, qscale, amax=None):
+def fp8_quant(x, out8, M, K, qscale, amax=None, e5m2=False):
     _check(lib().oat_fp8_quant(_ptr(x), int(x.dtype == torch.bfloat16), x.stride(0), _ptr(out8), out8.stride(0), M, K,
-                               _ptr(qscale), _ptr(amax), _stream()), "oat_fp8_quant")
+                               _ptr(qscale), _ptr(amax), int(e5m2), _stream()), "oat_fp8_quant")
 
 
 def fp8_amax(x, M, K, amax):
     _check(lib().oat_fp8_amax(_ptr(x), int(x.dtype == torch.bfloat16), x.stride(0), M, K, _ptr(amax), _stream()), "oat_fp8_amax")
 
 
-def fp8_update_scales(amax, qscale, dq, n, margin=1.0):
-    _check(lib().oat_fp8_update_scales(_ptr(amax), _ptr(qscale), _ptr(dq), n, _f(margin), _stream()), "oat_fp8_update_scales")
+def fp8_update_scales(amax, qscale, dq, n, margin=1.0, e5m2=False):
+    _check(lib().oat_fp8_update_scales(_ptr(amax), _ptr(qscale), _ptr(dq), n, _f(margin), int(e5m2), _stream()), "oat_fp8_update_scales")
 
 
 class Fp8Table:
@@ -425,11 +425,25 @@ class Fp8Table:
                                    _stream()), "oat_fp8_multi")
 
 
-def gemm_nt_f8(A8, B8, M, N, K, epi, out, dq_a, dq_b, out2=None, bias=None, out8=None, q_out=None, amax_out=None):
+def gemm_nt_f8(A8, B8, M, N, K, epi, out, dq_a, dq_b, out2=None, bias=None, out8=None, q_out=None, amax_out=None,
+               a_e5m2=False, aux=None):
+    s0 = lambda t: t.stride(0) if t is not None else 0
     _check(lib().oat_gemm_nt_f8(_ptr(A8), _ptr(B8), M, N, K, A8.stride(0), B8.stride(0), int(epi), _ptr(out), out.stride(0),
-                                _ptr(out2), out2.stride(0) if out2 is not None else 0, _ptr(bias), _ptr(dq_a), _ptr(dq_b),
-                                _ptr(out8), out8.stride(0) if out8 is not None else 0, _ptr(q_out), _ptr(amax_out),
-                                _stream()), "oat_gemm_nt_f8")
+                                _ptr(out2), s0(out2), _ptr(bias), _ptr(dq_a), _ptr(dq_b), int(a_e5m2), _ptr(aux), s0(aux),
+                                _ptr(out8), s0(out8), _ptr(q_out), _ptr(amax_out), _stream()), "oat_gemm_nt_f8")
+
+
+def layernorm_bwd_f8(dy, x, mean, rstd, gamma, M, D, dx8, qscale, amax, dx=None, dx16=None, dres=None, dgamma=None, dbeta=None,
+                     accumulate=False, dx16_excl_res=False):
+    """layernorm_bwd that also writes dx16 as e5m2 (dx8) with the site's delayed scale."""
+    part = None
+    if dgamma is not None or dbeta is not None:
+        part = _partials(x.device, lib().oat_ln_bwd_blocks(M) * 2 * D)
+    s0 = lambda t: t.stride(0) if t is not None else 0
+    _check(lib().oat_layernorm_bwd_f8(_ptr(dy), int(dy.dtype == torch.bfloat16), dy.stride(0), _ptr(x), x.stride(0), _ptr(mean),
+                                      _ptr(rstd), _ptr(gamma), _ptr(dres), s0(dres), _ptr(dx), s0(dx), _ptr(dx16), s0(dx16),
+                                      int(dx16_excl_res), _ptr(dgamma), _ptr(dbeta), int(accumulate), _ptr(part), M, D,
+                                      _ptr(dx8), dx8.stride(0), _ptr(qscale), _ptr(amax), _stream()), "oat_layernorm_bwd_f8")
 
 
 def layernorm_fwd_f8(x, gamma, beta, M, D, eps, y, y8, qscale, amax, mean, rstd, add16=None, sum32=None):

@@ -12,6 +12,19 @@ OAT_DEV uint32_t pack_fp8x4(float a, float b, float c, float d) {
   w = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(c, -F8_MAX), F8_MAX), fminf(fmaxf(d, -F8_MAX), F8_MAX), w, true);
   return (uint32_t)w;
 }
+// e5m2 ("bf8", largest finite 57344): the gradient format of the backward GEMMs
+constexpr float BF8_MAX = 57344.f;
+OAT_DEV uint32_t pack_bf8x4(float a, float b, float c, float d) {
+  int w = 0;
+  w = __builtin_amdgcn_cvt_pk_bf8_f32(fminf(fmaxf(a, -BF8_MAX), BF8_MAX), fminf(fmaxf(b, -BF8_MAX), BF8_MAX), w, false);
+  w = __builtin_amdgcn_cvt_pk_bf8_f32(fminf(fmaxf(c, -BF8_MAX), BF8_MAX), fminf(fmaxf(d, -BF8_MAX), BF8_MAX), w, true);
+  return (uint32_t)w;
+}
+template <bool E5M2>
+OAT_DEV uint32_t pack_f8x4(float a, float b, float c, float d) {
+  if constexpr (E5M2) return pack_bf8x4(a, b, c, d);
+  else return pack_fp8x4(a, b, c, d);
+}
 // One atomic per 256-thread block at most, and none when the block cannot raise the value: atomics on ONE address
 // serialise in the L2 (16 k of them - one per wave of a 4096-block launch - cost ~130 us, seven times the kernel itself).
 OAT_DEV void amax_commit(float m, float* amax) {

@@ -15,7 +15,7 @@
 namespace oat {
 
 // 8 elements per thread: x [M, K] (bf16 | f32, row stride ldx) -> out8 [M, K] (row stride ld8 bytes), amax of |x|
-template <bool BF16IN, bool QUANT>
+template <bool BF16IN, bool QUANT, bool E5M2 = false>
 __global__ __launch_bounds__(256) void fp8_quant_kernel(const void* x, int ldx, uint8_t* out8, int ld8, int M, int K,
                                                         const float* qscale, float* amax) {
   const int kq = K >> 3;
@@ -39,8 +39,8 @@ __global__ __launch_bounds__(256) void fp8_quant_kernel(const void* x, int ldx, 
     for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(v[e]));
     if constexpr (QUANT) {
       uint2 o;
-      o.x = pack_fp8x4(v[0] * qs, v[1] * qs, v[2] * qs, v[3] * qs);
-      o.y = pack_fp8x4(v[4] * qs, v[5] * qs, v[6] * qs, v[7] * qs);
+      o.x = pack_f8x4<E5M2>(v[0] * qs, v[1] * qs, v[2] * qs, v[3] * qs);
+      o.y = pack_f8x4<E5M2>(v[4] * qs, v[5] * qs, v[6] * qs, v[7] * qs);
       *reinterpret_cast<uint2*>(out8 + (size_t)r * ld8 + c) = o;
     }
   }
@@ -76,12 +76,12 @@ __global__ __launch_bounds__(256) void fp8_multi_kernel(const F8Desc* desc, cons
 }
 
 // amax -> qscale = 448 / (margin * amax), dq = 1 / qscale; amax cleared.  Sites that saw no data keep their scales.
-__global__ void fp8_update_scales_kernel(float* amax, float* qscale, float* dq, int n, float margin) {
+__global__ void fp8_update_scales_kernel(float* amax, float* qscale, float* dq, int n, float margin, float fmax) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float a = amax[i];
   if (a > 0.f && a < INFINITY) {
-    const float q = F8_MAX / (a * margin);
+    const float q = fmax / (a * margin);
     qscale[i] = q;
     dq[i] = 1.f / q;
   }
@@ -93,14 +93,18 @@ __global__ void fp8_update_scales_kernel(float* amax, float* qscale, float* dq, 
 using namespace oat;
 
 extern "C" int oat_fp8_quant(const void* x, int is_bf16, int ldx, void* out8, int ld8, int M, int K, const float* qscale,
-                             float* amax, void* stream) {
+                             float* amax, int e5m2, void* stream) {
   if (M <= 0 || K <= 0) return 0;
   if (!x || !out8 || !qscale) { set_error("fp8_quant: null pointer"); return -4; }
   if (K % 8 || ldx % 8 || ld8 % 8) { set_error("fp8_quant: K, ldx, ld8 must be multiples of 8"); return -3; }
   const long long quads = (long long)M * (K / 8);
   const int grid = (int)((quads + 255) / 256 < 2048 ? (quads + 255) / 256 : 2048);
-  if (is_bf16) OAT_LAUNCH((fp8_quant_kernel<true, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, (uint8_t*)out8, ld8, M, K, qscale, amax);
-  else OAT_LAUNCH((fp8_quant_kernel<false, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, (uint8_t*)out8, ld8, M, K, qscale, amax);
+  hipStream_t s = (hipStream_t)stream;
+  uint8_t* o = (uint8_t*)out8;
+  if (is_bf16 && e5m2) OAT_LAUNCH((fp8_quant_kernel<true, true, true>), dim3(grid), dim3(256), 0, s, x, ldx, o, ld8, M, K, qscale, amax);
+  else if (is_bf16) OAT_LAUNCH((fp8_quant_kernel<true, true, false>), dim3(grid), dim3(256), 0, s, x, ldx, o, ld8, M, K, qscale, amax);
+  else if (e5m2) OAT_LAUNCH((fp8_quant_kernel<false, true, true>), dim3(grid), dim3(256), 0, s, x, ldx, o, ld8, M, K, qscale, amax);
+  else OAT_LAUNCH((fp8_quant_kernel<false, true, false>), dim3(grid), dim3(256), 0, s, x, ldx, o, ld8, M, K, qscale, amax);
   return check_launch("fp8_quant");
 }
 extern "C" int oat_fp8_amax(const void* x, int is_bf16, int ldx, int M, int K, float* amax, void* stream) {
@@ -123,26 +127,31 @@ extern "C" int oat_fp8_multi(const void* desc, const int* owner, int total_block
   else OAT_LAUNCH((fp8_multi_kernel<false>), dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, (const F8Desc*)desc, owner, qscale, amax);
   return check_launch("fp8_multi");
 }
-extern "C" int oat_fp8_update_scales(float* amax, float* qscale, float* dq, int n, float margin, void* stream) {
+// e5m2 != 0: the sites hold gradients quantised to e5m2 (largest finite 57344) instead of e4m3 (448)
+extern "C" int oat_fp8_update_scales(float* amax, float* qscale, float* dq, int n, float margin, int e5m2, void* stream) {
   if (n <= 0) return 0;
   if (!amax || !qscale || !dq) { set_error("fp8_update_scales: null pointer"); return -4; }
   if (!(margin >= 1.f)) { set_error("fp8_update_scales: margin must be >= 1"); return -3; }
-  OAT_LAUNCH(fp8_update_scales_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, amax, qscale, dq, n, margin);
+  OAT_LAUNCH(fp8_update_scales_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, amax, qscale, dq, n, margin,
+             e5m2 ? BF8_MAX : F8_MAX);
   return check_launch("fp8_update_scales");
 }
 
 // C[M, N] = dq_a dq_b (A8[M, K] . B8[N, K]^T) + bias with the bf16-output epilogues of oat_gemm_nt (EPI_BF16 = 0,
 // EPI_GELU_GRAD = 5).  A8 / B8: OCP e4m3 bytes, lda / ldb in elements.  K % 256 == 0, N % 256 == 0, N <= 4096, M >= 256.
-// out8 (optional, EPI_GELU_GRAD only): e4m3 copy of out2 = gelu(h), quantised with *q_out, its amax recorded in *amax_out.
+// a_e5m2: A8 holds e5m2 bytes (gradients), B8 always e4m3.  epi: EPI_BF16, EPI_GELU_GRAD (out = gelu'(h), out2 = gelu(h)) or
+// EPI_MUL_AUX (out = (acc + bias) * aux).  out8 (optional): fp8 copy for the NEXT GEMM, quantised with *q_out, its amax
+// recorded in *amax_out - of out2 as e4m3 (EPI_GELU_GRAD) or of out as e5m2 (EPI_MUL_AUX).
 extern "C" int oat_gemm_nt_f8(const void* A8, const void* B8, int M, int N, int K, int lda, int ldb, int epi, void* out, int ldc,
-                              void* out2, int ld2, const float* bias, const float* dq_a, const float* dq_b, void* out8, int ld8,
-                              const float* q_out, float* amax_out, void* stream) {
-  if (out8 && (epi != EPI_GELU_GRAD || !q_out || !amax_out || ld8 % 4)) { set_error("gemm_nt_f8: out8 needs EPI_GELU_GRAD, q_out, amax_out, ld8 % 4 == 0"); return -4; }
+                              void* out2, int ld2, const float* bias, const float* dq_a, const float* dq_b, int a_e5m2,
+                              const void* aux, int ldaux, void* out8, int ld8, const float* q_out, float* amax_out, void* stream) {
+  if (out8 && ((epi != EPI_GELU_GRAD && epi != EPI_MUL_AUX) || !q_out || !amax_out || ld8 % 4)) { set_error("gemm_nt_f8: out8 needs EPI_GELU_GRAD / EPI_MUL_AUX, q_out, amax_out, ld8 % 4 == 0"); return -4; }
+  if (epi == EPI_MUL_AUX && !aux) { set_error("gemm_nt_f8: EPI_MUL_AUX needs aux"); return -4; }
   if (M <= 0 || N <= 0 || K <= 0) { set_error("gemm_nt_f8: empty problem"); return -1; }
   if (!A8 || !B8 || !out || !dq_a || !dq_b) { set_error("gemm_nt_f8: null pointer"); return -4; }
   if (epi == EPI_GELU_GRAD && !out2) { set_error("gemm_nt_f8: EPI_GELU_GRAD needs out2"); return -4; }
   if (ldc % 8 != 0) { set_error("gemm_nt_f8: ldc must be a multiple of 8"); return -3; }
-  GemmArgs g{(const bf16*)A8, (const bf16*)B8, M, N, K, lda, ldb, out, ldc, out2, ld2, bias, nullptr, 0, 0, nullptr, 0, 0, 0,
+  GemmArgs g{(const bf16*)A8, (const bf16*)B8, M, N, K, lda, ldb, out, ldc, out2, ld2, bias, nullptr, 0, 0, (const bf16*)aux, ldaux, 0, 0,
              nullptr, nullptr, dq_a, dq_b, out8, ld8, q_out, amax_out};
-  return launch_pp_f8(epi, g, 256, (hipStream_t)stream);
+  return launch_pp_f8(epi, g, 256, a_e5m2 != 0, (hipStream_t)stream);
 }

@@ -29,7 +29,7 @@ struct GemmArgs {
   int* ctr_reset;      // counters of a launch far in the future, zeroed by this one
   const float* dq_a;   // fp8 launches: device scalars, dequantisation scale of A and of B (value = quantised * dq)
   const float* dq_b;
-  void* out8; int ld8;     // fp8 launches, EPI_GELU_GRAD: optional e4m3 copy of out2 (the next GEMM's operand) ...
+  void* out8; int ld8;     // fp8 launches: optional copy for the next GEMM - e4m3 of out2 (EPI_GELU_GRAD) / e5m2 of out (EPI_MUL_AUX) ...
   const float* q_out;      // ... quantised with this device scalar,
   float* amax_out;         // ... its max |value| recorded here
 };
@@ -55,6 +55,6 @@ bool pp_supported(int epi, const GemmArgs& g);
 int launch_pp(int epi, const GemmArgs& g, int grid_slots, int flags, hipStream_t s);
 // the same kernel on OCP fp8 (e4m3) operands with per-tensor scales (GemmArgs::dq_a / dq_b)
 bool pp_f8_supported(int epi, const GemmArgs& g);
-int launch_pp_f8(int epi, const GemmArgs& g, int grid_slots, hipStream_t s);
+int launch_pp_f8(int epi, const GemmArgs& g, int grid_slots, bool a_e5m2, hipStream_t s);
 
 }  // namespace oat

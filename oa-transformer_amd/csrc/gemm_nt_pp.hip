@@ -42,7 +42,7 @@ constexpr int PP_MAXN = 4096;                       // bias vector kept in LDS
 constexpr int PP_LDS = PP_BIAS + PP_MAXN * 4;
 
 enum : int { PPF_PRIO = 1, PPF_NOSTAGGER = 2, PPF_LGKM = 4, PPF_BONUS = 8, PPF_NOEPI = 16, PPF_PH2 = 32, PPF_WIDE = 64,
-             PPF_F8 = 128 };
+             PPF_F8 = 128, PPF_A_BF8 = 256 };   // PPF_A_BF8: the A operand is e5m2 (gradients), B stays e4m3
 
 // PPF_F8: OCP fp8 (e4m3) operands, per-tensor scaled.  A K-tile is still 128 BYTES of every row - now 128 k - so the
 // staging stream, the LDS layout, the swizzle, the region refill and every wait count are those of the bf16 kernel; a
@@ -74,7 +74,8 @@ OAT_DEV bool pp_epilogue(const GemmArgs& g, const f32x4 (&acc)[8][4], int m0, in
   asm volatile("" : "+v"(lane));
   const int frow = lane & 15, fk = lane >> 4;
   const int wrow0 = m0 + wm * 128, wcol00 = n0 + wn * 64;
-  constexpr bool Q8 = F8 && EPI == EPI_GELU_GRAD;      // optional e4m3 copy of gelu(h) for the fc2 GEMM
+  constexpr bool Q8 = F8 && (EPI == EPI_GELU_GRAD || EPI == EPI_MUL_AUX);   // optional fp8 copy for the next GEMM:
+                                                       // e4m3 of gelu(h) (-> fc2) or e5m2 of the fc2 data gradient (-> fc1 dgrad)
   uint8_t* const o8 = Q8 ? reinterpret_cast<uint8_t*>(g.out8) : nullptr;
   const float q8 = (Q8 && o8) ? g.q_out[0] : 0.f;
   float m8 = 0.f;
@@ -98,8 +99,18 @@ OAT_DEV bool pp_epilogue(const GemmArgs& g, const f32x4 (&acc)[8][4], int m0, in
         }
       }
     } else if constexpr (EPI == EPI_MUL_AUX) {
+      float gq[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e] * bf2f(a[e]));
+      for (int e = 0; e < 4; ++e) {
+        gq[e] = v[e] * bf2f(a[e]);
+        o[e] = f2bf(gq[e]);
+      }
+      if constexpr (Q8) {
+        if (o8) {
+          m8 = fmaxf(fmaxf(m8, fmaxf(fabsf(gq[0]), fabsf(gq[1]))), fmaxf(fabsf(gq[2]), fabsf(gq[3])));
+          w8 = pack_bf8x4(gq[0] * q8, gq[1] * q8, gq[2] * q8, gq[3] * q8);
+        }
+      }
     } else {
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
@@ -211,6 +222,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs g) {
   constexpr bool PRIO = FL & PPF_PRIO, STAGGER = !(FL & PPF_NOSTAGGER), LGKM = FL & PPF_LGKM, BONUS = FL & PPF_BONUS;
   constexpr bool NOEPI = FL & PPF_NOEPI;
   constexpr bool F8 = FL & PPF_F8;
+  constexpr int CBSZ = (FL & PPF_A_BF8) ? 1 : 0;                // MFMA format code of A: 0 = e4m3, 1 = e5m2
   constexpr int ESH = F8 ? 0 : 1;                               // log2(bytes per operand element)
   constexpr int NST = EPI == EPI_GELU_GRAD ? 64 : 32;           // stores per lane of an interior epilogue
   constexpr int WB = 12 + NST > 63 ? 63 : 12 + NST;
@@ -355,7 +367,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           acc[ah * 4 + i][bh * 2 + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
-              f8_operand(fa[0][i], fa[1][i]), f8_operand(fb[0][j], fb[1][j]), acc[ah * 4 + i][bh * 2 + j], 0, 0, 0, 0, 0, 0);
+              f8_operand(fa[0][i], fa[1][i]), f8_operand(fb[0][j], fb[1][j]), acc[ah * 4 + i][bh * 2 + j], CBSZ, 0, 0, 0, 0, 0);
     } else {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
@@ -657,18 +669,19 @@ int launch_pp_cfg(const GemmArgs& g, int grid_slots, hipStream_t s) {
 }  // namespace
 
 bool pp_f8_supported(int epi, const GemmArgs& g) {
-  if (epi != EPI_BF16 && epi != EPI_GELU_GRAD) return false;
+  if (epi != EPI_BF16 && epi != EPI_GELU_GRAD && epi != EPI_MUL_AUX) return false;
   const int nk = g.K / 128;
   return g.K % 128 == 0 && g.N % 256 == 0 && g.N <= PP_MAXN && nk >= 2 && nk % 2 == 0 && g.M >= 256 && g.lda % 16 == 0 &&
          g.ldb % 16 == 0 && g.lda < (1 << 23) && g.ldb < (1 << 23) && g.dq_a && g.dq_b;
 }
 
 // fp8 (e4m3 x e4m3) operands: A [M, K] and B [N, K] one byte per element, lda / ldb in elements (= bytes)
-int launch_pp_f8(int epi, const GemmArgs& g, int grid_slots, hipStream_t s) {
-  constexpr int FL = PPF_PRIO | PPF_BONUS | PPF_LGKM | PPF_F8;
-  if (!pp_f8_supported(epi, g)) { set_error("gemm_nt_f8: shape / epilogue not covered (K % 256, N % 256, N <= 4096, M >= 256, EPI_BF16 | EPI_GELU_GRAD)"); return -3; }
-  if (epi == EPI_GELU_GRAD) return launch_pp_cfg<EPI_GELU_GRAD, FL>(g, grid_slots, s);
-  return launch_pp_cfg<EPI_BF16, FL>(g, grid_slots, s);
+int launch_pp_f8(int epi, const GemmArgs& g, int grid_slots, bool a_e5m2, hipStream_t s) {
+  constexpr int FL = PPF_PRIO | PPF_BONUS | PPF_LGKM | PPF_F8, FLG = FL | PPF_A_BF8;
+  if (!pp_f8_supported(epi, g)) { set_error("gemm_nt_f8: shape / epilogue not covered (K % 256, N % 256, N <= 4096, M >= 256, EPI_BF16 | EPI_GELU_GRAD | EPI_MUL_AUX)"); return -3; }
+  if (epi == EPI_GELU_GRAD) return launch_pp_cfg<EPI_GELU_GRAD, FL>(g, grid_slots, s);       // forward only: e4m3 x e4m3
+  if (epi == EPI_MUL_AUX) return a_e5m2 ? launch_pp_cfg<EPI_MUL_AUX, FLG>(g, grid_slots, s) : launch_pp_cfg<EPI_MUL_AUX, FL>(g, grid_slots, s);
+  return a_e5m2 ? launch_pp_cfg<EPI_BF16, FLG>(g, grid_slots, s) : launch_pp_cfg<EPI_BF16, FL>(g, grid_slots, s);
 }
 
 bool pp_supported(int epi, const GemmArgs& g) {

@@ -99,10 +99,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* dy_, int lddy, 
                                                      const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* dres,
                                                      int lddres, float* dx, int lddx, bf16* dx16, int lddx16,
-                                                     int dx16_excl_res, float* part, int M, int D) {
+                                                     int dx16_excl_res, float* part, int M, int D, LnF8 f8) {
   __shared__ float red[4][2][LN_MAXV * 256];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
+  const float qs = f8.y8 ? f8.qscale[0] : 0.f;        // fp8 backward: e5m2 copy of dx16 for the next data-gradient GEMM
+  float m8 = 0.f;
   f32x4 ag[LN_MAXV], ab[LN_MAXV];
 #pragma unroll
   for (int i = 0; i < LN_MAXV; ++i) { ag[i] = f32x4{0, 0, 0, 0}; ab[i] = f32x4{0, 0, 0, 0}; }
@@ -149,10 +151,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* dy_, int lddy, 
           const f32x4 w = dx16_excl_res ? o_nores : o;
           bf16x4 ob = {f2bf(w[0]), f2bf(w[1]), f2bf(w[2]), f2bf(w[3])};
           *reinterpret_cast<bf16x4*>(dx16 + (size_t)row * lddx16 + c) = ob;
+          if (f8.y8) {
+            m8 = fmaxf(fmaxf(m8, fmaxf(fabsf(w[0]), fabsf(w[1]))), fmaxf(fabsf(w[2]), fabsf(w[3])));
+            *reinterpret_cast<uint32_t*>(f8.y8 + (size_t)row * f8.ld8 + c) = pack_bf8x4(w[0] * qs, w[1] * qs, w[2] * qs, w[3] * qs);
+          }
         }
       }
     }
   }
+  if (f8.y8) amax_commit(m8, f8.amax);
   if (!part) return;
 #pragma unroll
   for (int i = 0; i < LN_MAXV; ++i) {
@@ -453,11 +460,35 @@ static int ln_bwd_cap() {
 extern "C" int oat_ln_bwd_blocks(int M) { int b = (M + 3) / 4; const int cap = ln_bwd_cap(); return b > cap ? cap : b; }
 
 // part: fp32 workspace of oat_ln_bwd_blocks(M) * 2 * D floats (or NULL to skip dgamma/dbeta)
+static int ln_bwd_launch(const void* dy, int dy_is_bf16, int lddy, const float* x, int ldx,
+                         const float* mean, const float* rstd, const float* gamma, const float* dres,
+                         int lddres, float* dx, int lddx, void* dx16, int lddx16, int dx16_excl_res,
+                         float* dgamma, float* dbeta, int accumulate, float* part, int M, int D, oat::LnF8 f8,
+                         void* stream);
 extern "C" int oat_layernorm_bwd(const void* dy, int dy_is_bf16, int lddy, const float* x, int ldx,
                                  const float* mean, const float* rstd, const float* gamma, const float* dres,
                                  int lddres, float* dx, int lddx, void* dx16, int lddx16, int dx16_excl_res,
                                  float* dgamma, float* dbeta, int accumulate, float* part, int M, int D,
                                  void* stream) {
+  return ln_bwd_launch(dy, dy_is_bf16, lddy, x, ldx, mean, rstd, gamma, dres, lddres, dx, lddx, dx16, lddx16, dx16_excl_res,
+                       dgamma, dbeta, accumulate, part, M, D, oat::LnF8{nullptr, 0, nullptr, nullptr}, stream);
+}
+// the same, with an e5m2 copy of dx16 (dx8 = sat(dx16 * *qscale), amax recorded): the producer-side quantisation of the
+// next fp8 data-gradient GEMM's operand
+extern "C" int oat_layernorm_bwd_f8(const void* dy, int dy_is_bf16, int lddy, const float* x, int ldx,
+                                    const float* mean, const float* rstd, const float* gamma, const float* dres,
+                                    int lddres, float* dx, int lddx, void* dx16, int lddx16, int dx16_excl_res,
+                                    float* dgamma, float* dbeta, int accumulate, float* part, int M, int D,
+                                    void* dx8, int ld8, const float* qscale, float* amax, void* stream) {
+  if (!dx16 || !dx8 || !qscale || !amax || ld8 % 4) { oat::set_error("layernorm_bwd_f8: dx16, dx8, qscale, amax required"); return -4; }
+  return ln_bwd_launch(dy, dy_is_bf16, lddy, x, ldx, mean, rstd, gamma, dres, lddres, dx, lddx, dx16, lddx16, dx16_excl_res,
+                       dgamma, dbeta, accumulate, part, M, D, oat::LnF8{(uint8_t*)dx8, ld8, qscale, amax}, stream);
+}
+static int ln_bwd_launch(const void* dy, int dy_is_bf16, int lddy, const float* x, int ldx,
+                         const float* mean, const float* rstd, const float* gamma, const float* dres,
+                         int lddres, float* dx, int lddx, void* dx16, int lddx16, int dx16_excl_res,
+                         float* dgamma, float* dbeta, int accumulate, float* part, int M, int D, oat::LnF8 f8,
+                         void* stream) {
   if (M <= 0) return 0;
   if (D % 4 || D > LN_MAXV * 256) { set_error("layernorm_bwd: D%4==0, D<=1024 required"); return -3; }
   if ((dgamma || dbeta) && !part) { set_error("layernorm_bwd: dgamma/dbeta need the partial workspace"); return -4; }
@@ -465,10 +496,10 @@ extern "C" int oat_layernorm_bwd(const void* dy, int dy_is_bf16, int lddy, const
   hipStream_t s = (hipStream_t)stream;
   if (dy_is_bf16)
     OAT_LAUNCH(ln_bwd_kernel<true>, dim3(blocks), dim3(256), 0, s, dy, lddy, x, ldx, mean, rstd, gamma, dres,
-                       lddres, dx, lddx, (bf16*)dx16, lddx16, dx16_excl_res, part, M, D);
+                       lddres, dx, lddx, (bf16*)dx16, lddx16, dx16_excl_res, part, M, D, f8);
   else
     OAT_LAUNCH(ln_bwd_kernel<false>, dim3(blocks), dim3(256), 0, s, dy, lddy, x, ldx, mean, rstd, gamma, dres,
-                       lddres, dx, lddx, (bf16*)dx16, lddx16, dx16_excl_res, part, M, D);
+                       lddres, dx, lddx, (bf16*)dx16, lddx16, dx16_excl_res, part, M, D, f8);
   int rc = check_launch("layernorm_bwd");
   if (rc || !part) return rc;
   if (dgamma && dbeta)

@@ -1,7 +1,7 @@
 """fp8 forward path (BASELINE.json config 5) on a real MI355X.
 Kernel level: the e4m3 conversion equals torch.float8_e4m3fn bit for bit, oat_gemm_nt_f8 equals an fp32 matmul of the
 SAME quantised operands up to its bf16 output rounding, and stays within 4 % rel-L2 of the unquantised product.
-Model level: the contract class with fp8 forward linears against the reference golden; stated (looser) tolerance:
+Model level: the contract class with fp8 forward linears AND fp8 data-gradient GEMMs against the reference golden; stated (looser) tolerance:
 embeddings rel-L2 <= 5e-2, sim matrix <= 3e-2 max-abs, loss <= 5e-2 (bf16 path: 1e-2 / 1e-3 / 2e-2)."""
 import os
 
@@ -58,8 +58,9 @@ def test_fp8_quantise_and_gemm(shape):
         hip.gemm_nt_f8(A8, B8, m, n - 8, k, hip.EPI_BF16, out, sa[2:3], sb[2:3])          # N % 256 != 0: refused, not approximated
 
 
+@pytest.mark.parametrize("fp8_bwd", [False, True])
 @pytest.mark.parametrize("frames", [4])
-def test_frozen_in_time_fp8_forward_vs_reference_golden(golden_dir, frames):
+def test_frozen_in_time_fp8_forward_vs_reference_golden(golden_dir, frames, fp8_bwd):
     from OATrans import model as module_arch
     g = torch.load(os.path.join(golden_dir, f"full_T{frames}.pt"), map_location="cpu", weights_only=False)
     T, B, L = g["T"], g["B"], g["L"]
@@ -72,6 +73,7 @@ def test_frozen_in_time_fp8_forward_vs_reference_golden(golden_dir, frames):
     m.load_state_dict(si.frozen_state_dict(SEED, dict(num_frames=T), {}), strict=False)
     m = m.cuda()
     m.video_model._engine.fp8 = True
+    m.video_model._engine.fp8_bwd = fp8_bwd          # also the six data-gradient GEMMs of every block (e5m2 x e4m3)
     video = si.seeded_tensor(SEED, f"full.video.{T}", (B, T, 3, 224, 224)).cuda()
     ids = si.seeded_ints(SEED, f"full.ids.{T}", (B, L), 1000, 30000)
     ids[:, 0] = 101
@@ -92,9 +94,17 @@ def test_frozen_in_time_fp8_forward_vs_reference_golden(golden_dir, frames):
         assert sim_err <= 3e-2
         assert abs(loss.item() - g["loss"].item()) < 5e-2
     f8 = m.video_model._engine._f8
-    assert len(f8["primed"]) == 6 * 12 and bool((f8["dq"] > 0).all())
-    # gradients flow through the bf16 backward: norms within 10 % of the reference's
+    # per block: 6 forward inputs (+ 6 incoming gradients with fp8 backward) have a delayed scale; every weight has one
+    assert len(f8["primed"]) == (12 if fp8_bwd else 6) * 12
+    dq = f8["dq"].view(12, 18)
+    assert bool((dq[:, :12 if not fp8_bwd else 18] > 0).all())
     params = dict(m.named_parameters())
-    bad = [(k, abs(params[k].grad.norm().item() - pr["norm"].item()) / pr["norm"].item()) for k, pr in g["grad_probe"].items()
-           if pr["norm"] > 1e-6 and abs(params[k].grad.norm().item() - pr["norm"].item()) / pr["norm"].item() > 1e-1]
-    assert len(bad) <= 2, bad[:8]
+    errs = {k: abs(params[k].grad.norm().item() - pr["norm"].item()) / pr["norm"].item() for k, pr in g["grad_probe"].items()
+            if pr["norm"] > 1e-6}
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:4]
+    print(f"fp8_bwd={fp8_bwd}: worst gradient-norm errors {worst}")
+    # bf16 backward behind an fp8 forward: <= 10 % (two stragglers allowed); e5m2 data gradients: <= 20 %
+    if fp8_bwd:
+        assert worst[0][1] < 0.2, worst
+    else:
+        assert sum(e > 0.1 for e in errs.values()) <= 2, worst
