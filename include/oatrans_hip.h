@@ -39,6 +39,9 @@ int oat_delay(int nanoseconds, void* stream);
  *      5 h=acc+bias (fp32): out(bf16)=gelu'(h), out2(bf16)=gelu(h) | 6 out(bf16)=(acc+bias)*aux[row,col]
  *      (5 + 6 are the MLP pair the engine uses: the derivative is evaluated once, in forward, next to the
  *      activation it shares its erf / exp with; backward only multiplies).
+ *      epi | 0x100 (with 5 / 6, shapes the ping-pong kernel covers: N % 256 == 0, N <= 4096, K / 64 even, M >= 256):
+ *      the derivative tensor - `out` of 5, `aux` of 6 - is 8-bit fixed point, q = round((g' + 0.135) * 255 / 1.27),
+ *      ONE byte per element with ldc / ldaux in bytes: half the traffic at bf16's own absolute error (0.0025).
  *      bias/resid/out2/aux may be NULL where unused. */
 int oat_gemm_nt(const void* A, const void* B, int M, int N, int K, int lda, int ldb, int epi,
                 void* out, int ldc, void* out2, int ld2, const float* bias, const float* resid,

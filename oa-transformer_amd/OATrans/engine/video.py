@@ -45,6 +45,7 @@ class _BlockActs:
         self.qkv_t, self.qkv_s = z16(3 * D), z16(3 * D)
         self.o_t, self.o_s = z16(D), z16(D)
         self.h, self.g = z16(Hd), z16(Hd)
+        self.h8 = None                       # 8-bit view of h (engine.h_u8)
         self.xt, self.y, self.out = z32(D), z32(D), z32(D)
         self.lse_t, self.lse_s = z32(H), z32(H)
         self.stats = torch.zeros(6, Mp, dtype=torch.float32, device=dev)   # mean/rstd of norm3, norm1, norm2
@@ -147,6 +148,8 @@ class VideoEngine:
         # backward kernels do not write e5m2 themselves yet) while gradient norms drift from <= 5 % to 10-12 % off the
         # fp32 reference in the lowest blocks (tests/test_fp8_gpu.py).
         self.fp8_bwd = os.environ.get("OAT_FP8_BWD", "0") != "0"
+        # the saved GELU derivative as 8-bit fixed point where the ping-pong GEMM serves the MLP pair (gemm_nt_pp.hip HU8_*)
+        self.h_u8 = os.environ.get("OAT_H_U8", "1") != "0"
         # launch tapes (csrc/tape.hip): forward and backward are recorded once per plan and replayed from C
         self.use_tape = os.environ.get("OAT_TAPE", "1") != "0"
         self._f8 = None
@@ -347,6 +350,10 @@ class VideoEngine:
             pl.x8_qkv = torch.zeros(pl.Mp, 3 * self.D, dtype=torch.uint8, device=dev)      # e5m2 d_qkv (backward)
             pl.ga8 = [torch.zeros(pl.Mp, self.D, dtype=torch.uint8, device=dev) for _ in range(3)]   # e5m2 copies of the ga ring
         run = _Run(pl, need_patches, region_layer)
+        pl.h_u8 = (self.h_u8 and pl.M >= 256 and self.Hd % 256 == 0 and self.Hd <= 4096 and self.D % 128 == 0 and self.D >= 128)
+        if pl.h_u8 and pl.blocks[0].h8 is None:
+            for a in pl.blocks:              # the bf16 buffer's first half, viewed as [Mp, Hd] bytes
+                a.h8 = a.h.view(torch.uint8).view(-1)[:pl.Mp * self.Hd].view(pl.Mp, self.Hd)
 
         def body():
             hip.gemm_set_tail_split(self.tail_split)
@@ -373,7 +380,7 @@ class VideoEngine:
         ptrs = tuple(t.data_ptr() for t in params.values())
         gptr = next(iter(grads.values())).data_ptr() if grads else 0
         f8 = (len(self._f8["primed"]), self._f8["key"]) if (self.fp8 and self._f8) else None
-        return (torch.cuda.current_stream().cuda_stream, pl.side.cuda_stream, ptrs, gptr, self.fp8, self.fp8_bwd, f8, self.cls_lane,
+        return (torch.cuda.current_stream().cuda_stream, pl.side.cuda_stream, ptrs, gptr, self.fp8, self.fp8_bwd, f8, self.cls_lane, self.h_u8,
                 self.tail_split, self.bwd_side, self.bwd_nt_grid, hip.gemm_get_variant(), flags)
 
     @staticmethod
@@ -532,10 +539,14 @@ class VideoEngine:
                                   rstd=st[5])                                       # y = x + space
         # ---- MLP
         if f8:
-            gq = self._linear_f8(pl, i, 4, a.a2, D, Hd, hip.EPI_GELU_GRAD, a.h, p("mlp.fc1.bias"), out2=a.g, quantised=q2)
+            gq = self._linear_f8(pl, i, 4, a.a2, D, Hd, hip.EPI_GELU_GRAD | (hip.EPI_U8 if pl.h_u8 else 0), a.h8 if pl.h_u8 else a.h,
+                                 p("mlp.fc1.bias"), out2=a.g, quantised=q2)
             self._linear_f8(pl, i, 5, a.g, Hd, D, hip.EPI_BF16, br, p("mlp.fc2.bias"), quantised=gq)
         else:
-            hip.gemm_nt(a.a2, w("mlp.fc1"), M, Hd, D, hip.EPI_GELU_GRAD, a.h, out2=a.g, bias=p("mlp.fc1.bias"))
+            if pl.h_u8:
+                hip.gemm_nt(a.a2, w("mlp.fc1"), M, Hd, D, hip.EPI_GELU_GRAD | hip.EPI_U8, a.h8, out2=a.g, bias=p("mlp.fc1.bias"))
+            else:
+                hip.gemm_nt(a.a2, w("mlp.fc1"), M, Hd, D, hip.EPI_GELU_GRAD, a.h, out2=a.g, bias=p("mlp.fc1.bias"))
             hip.gemm_nt(a.g, w("mlp.fc2"), M, D, Hd, hip.EPI_BF16, br, bias=p("mlp.fc2.bias"))
         return a                                                                    # out = y + br, formed lazily
 
@@ -727,7 +738,10 @@ class VideoEngine:
         st = a.stats
         d_h, gb, d_qkv_s, gc, d_qkv_t = st8["d_h"], st8["gb"], st8["d_qkv_s"], st8["gc"], st8["d_qkv_t"]
         # ---- MLP: out = y + fc2(gelu(fc1(LN2(y))))
-        hip.gemm_nt(ga, wT("mlp.fc2"), M, Hd, D, hip.EPI_MUL_AUX, d_h, aux=a.h)
+        if pl.h_u8:
+            hip.gemm_nt(ga, wT("mlp.fc2"), M, Hd, D, hip.EPI_MUL_AUX | hip.EPI_U8, d_h, aux=a.h8)
+        else:
+            hip.gemm_nt(ga, wT("mlp.fc2"), M, Hd, D, hip.EPI_MUL_AUX, d_h, aux=a.h)
         hip.gemm_nt(d_h, wT("mlp.fc1"), M, D, Hd, hip.EPI_BF16, pl.d_a)
         s1 = self._slot(pl, lambda: hip.layernorm_bwd(
             pl.d_a, a.y, st[4], st[5], p("norm2.weight"), M, D, dx=G, dx16=gb, dres=G,
@@ -791,7 +805,8 @@ class VideoEngine:
         st = a.stats
         d_h, gb, d_qkv_s, gc, d_qkv_t = st8["d_h"], st8["gb"], st8["d_qkv_s"], st8["gc"], st8["d_qkv_t"]
         # ---- MLP
-        dh_q = self._dgrad_f8(pl, i, 5, ga, D, Hd, hip.EPI_MUL_AUX, d_h, aux=a.h, quantised=pl.ga8_valid == i, dy8=ga8)
+        dh_q = self._dgrad_f8(pl, i, 5, ga, D, Hd, hip.EPI_MUL_AUX | (hip.EPI_U8 if pl.h_u8 else 0), d_h,
+                              aux=a.h8 if pl.h_u8 else a.h, quantised=pl.ga8_valid == i, dy8=ga8)
         self._dgrad_f8(pl, i, 4, d_h, Hd, D, hip.EPI_BF16, pl.d_a, quantised=dh_q)
         gb_q = self._ln_bwd(pl, i, 3, pl.d_a, a.y, st[4], st[5], p("norm2.weight"), gb, gr("norm2.weight"), gr("norm2.bias"))
         self._wgrad(ga, a.g, M, D, Hd, gr("mlp.fc2.weight"), gr("mlp.fc2.bias"), pl.acc)

@@ -74,6 +74,7 @@ def _f(x):
 
 
 EPI_BF16, EPI_F32, EPI_GELU_DUAL, EPI_DGELU, EPI_F32_BF16, EPI_GELU_GRAD, EPI_MUL_AUX = 0, 1, 2, 3, 4, 5, 6
+EPI_U8 = 0x100      # or-ed into EPI_GELU_GRAD / EPI_MUL_AUX: the saved GELU derivative is 8-bit fixed point (1 byte per element)
 
 
 def delay(nanoseconds):

@@ -145,6 +145,8 @@ extern "C" int oat_fp8_update_scales(float* amax, float* qscale, float* dq, int 
 extern "C" int oat_gemm_nt_f8(const void* A8, const void* B8, int M, int N, int K, int lda, int ldb, int epi, void* out, int ldc,
                               void* out2, int ld2, const float* bias, const float* dq_a, const float* dq_b, int a_e5m2,
                               const void* aux, int ldaux, void* out8, int ld8, const float* q_out, float* amax_out, void* stream) {
+  const int h_u8 = (epi >> 8) & 1;          // epi | 0x100: 8-bit GELU derivative (as in oat_gemm_nt)
+  epi &= 0xff;
   if (out8 && ((epi != EPI_GELU_GRAD && epi != EPI_MUL_AUX) || !q_out || !amax_out || ld8 % 4)) { set_error("gemm_nt_f8: out8 needs EPI_GELU_GRAD / EPI_MUL_AUX, q_out, amax_out, ld8 % 4 == 0"); return -4; }
   if (epi == EPI_MUL_AUX && !aux) { set_error("gemm_nt_f8: EPI_MUL_AUX needs aux"); return -4; }
   if (M <= 0 || N <= 0 || K <= 0) { set_error("gemm_nt_f8: empty problem"); return -1; }
@@ -152,6 +154,6 @@ extern "C" int oat_gemm_nt_f8(const void* A8, const void* B8, int M, int N, int 
   if (epi == EPI_GELU_GRAD && !out2) { set_error("gemm_nt_f8: EPI_GELU_GRAD needs out2"); return -4; }
   if (ldc % 8 != 0) { set_error("gemm_nt_f8: ldc must be a multiple of 8"); return -3; }
   GemmArgs g{(const bf16*)A8, (const bf16*)B8, M, N, K, lda, ldb, out, ldc, out2, ld2, bias, nullptr, 0, 0, (const bf16*)aux, ldaux, 0, 0,
-             nullptr, nullptr, dq_a, dq_b, out8, ld8, q_out, amax_out};
+             nullptr, nullptr, dq_a, dq_b, out8, ld8, q_out, amax_out, h_u8};
   return launch_pp_f8(epi, g, 256, a_e5m2 != 0, (hipStream_t)stream);
 }

@@ -32,6 +32,8 @@ struct GemmArgs {
   void* out8; int ld8;     // fp8 launches: optional copy for the next GEMM - e4m3 of out2 (EPI_GELU_GRAD) / e5m2 of out (EPI_MUL_AUX) ...
   const float* q_out;      // ... quantised with this device scalar,
   float* amax_out;         // ... its max |value| recorded here
+  int h_u8;                // the GELU-derivative tensor (out of EPI_GELU_GRAD / aux of EPI_MUL_AUX) is 8-bit fixed point,
+                           // one byte per element, ldc / ldaux in bytes (ping-pong kernel only; gemm_nt_pp.hip HU8_*)
 };
 
 constexpr int BK = 64;

@@ -724,6 +724,8 @@ extern "C" int oat_gemm_nt(const void* A, const void* B, int M, int N, int K, in
                            const float* bias, const float* resid, int ldr, int resid_mod,
                            const void* aux, int ldaux, void* stream) {
   using namespace oat;
+  const int h_u8 = (epi >> 8) & 1;          // epi | 0x100: the GELU-derivative tensor is 8-bit fixed point (gemm.h: h_u8)
+  epi &= 0xff;
   if (M <= 0 || N <= 0 || K <= 0) { set_error("gemm_nt: empty problem"); return -1; }
   if (K % BK != 0) { set_error("gemm_nt: K must be a multiple of 64"); return -2; }
   if (N % 8 != 0 || lda % 8 != 0 || ldb % 8 != 0 || ldc % 8 != 0) {
@@ -733,6 +735,16 @@ extern "C" int oat_gemm_nt(const void* A, const void* B, int M, int N, int K, in
   GemmArgs g{(const bf16*)A, (const bf16*)B, M, N, K, lda, ldb, out, ldc, out2, ld2,
              bias, resid, ldr, resid_mod, (const bf16*)aux, ldaux, g_dbg, 0, nullptr, nullptr};
   hipStream_t s = (hipStream_t)stream;
+  if (h_u8) {
+    g.h_u8 = 1;
+    if ((epi != EPI_GELU_GRAD && epi != EPI_MUL_AUX) || !pp_supported(epi, g)) {
+      set_error("gemm_nt: the 8-bit GELU derivative needs EPI_GELU_GRAD / EPI_MUL_AUX on a shape the ping-pong kernel covers");
+      return -3;
+    }
+    if ((epi == EPI_GELU_GRAD && !out2) || (epi == EPI_MUL_AUX && !aux)) { set_error("gemm_nt: missing out2 / aux"); return -4; }
+    const int slots = g_persist == 0xffff ? 0x7fffffff : g_persist > 0 ? g_persist : cu_count();
+    return launch_pp(epi, g, slots, 0, s);
+  }
   switch (epi) {
     case EPI_BF16: return launch<EPI_BF16>(g, s);
     case EPI_F32: return launch<EPI_F32>(g, s);

@@ -42,7 +42,22 @@ constexpr int PP_MAXN = 4096;                       // bias vector kept in LDS
 constexpr int PP_LDS = PP_BIAS + PP_MAXN * 4;
 
 enum : int { PPF_PRIO = 1, PPF_NOSTAGGER = 2, PPF_LGKM = 4, PPF_BONUS = 8, PPF_NOEPI = 16, PPF_PH2 = 32, PPF_WIDE = 64,
-             PPF_F8 = 128, PPF_A_BF8 = 256 };   // PPF_A_BF8: the A operand is e5m2 (gradients), B stays e4m3
+             PPF_F8 = 128, PPF_A_BF8 = 256,     // PPF_A_BF8: the A operand is e5m2 (gradients), B stays e4m3
+             PPF_HU8 = 512 };                   // the saved GELU derivative travels as 8-bit fixed point (see HU8_*)
+
+// gelu'(h) lies in [-0.129, 1.129].  As bf16 it costs 2 bytes per element to write (fc1 forward) and to read back (fc2 data
+// gradient) - 308 MB per launch each way, all of it on top of a GEMM that is otherwise MFMA-bound.  Stored as
+// q = round((g' + 0.135) * 255 / 1.27) in ONE byte the absolute error is <= 0.0025, the size of bf16's own rounding
+// error for values near 1 (2^-9 = 0.002), at half the traffic.
+constexpr float HU8_OFF = 0.135f, HU8_SCALE = 255.f / 1.27f, HU8_INV = 1.27f / 255.f;
+OAT_DEV uint32_t hu8_pack(float a, float b, float c, float d) {
+  auto q = [](float x) { return (uint32_t)__builtin_rintf(fminf(fmaxf((x + HU8_OFF) * HU8_SCALE, 0.f), 255.f)); };
+  return q(a) | (q(b) << 8) | (q(c) << 16) | (q(d) << 24);
+}
+OAT_DEV f32x4 hu8_unpack(uint32_t w) {
+  return f32x4{(float)(w & 255u) * HU8_INV - HU8_OFF, (float)((w >> 8) & 255u) * HU8_INV - HU8_OFF,
+               (float)((w >> 16) & 255u) * HU8_INV - HU8_OFF, (float)(w >> 24) * HU8_INV - HU8_OFF};
+}
 
 // PPF_F8: OCP fp8 (e4m3) operands, per-tensor scaled.  A K-tile is still 128 BYTES of every row - now 128 k - so the
 // staging stream, the LDS layout, the swizzle, the region refill and every wait count are those of the bf16 kernel; a
@@ -67,8 +82,12 @@ OAT_DEV void mfma_inplace(f32x4& c, const bf16x8 a, const bf16x8 b) {
 // Epilogue of one 256x256 tile (no LDS, no barriers): lane (fk, frow) owns rows 16 i + 4 fk + r and the 4 consecutive
 // columns 4 frow + j of its wave tile, so 16 consecutive lanes store one 128-byte line per row.  Returns whether the
 // tile was an interior one (then exactly NST = 32 (64 for EPI_GELU_GRAD) store instructions were issued per lane).
-template <int EPI, bool WIDE = false, bool F8 = false>
+template <int EPI, bool WIDE = false, bool F8 = false, bool HU8 = false>
 OAT_DEV bool pp_epilogue(const GemmArgs& g, const f32x4 (&acc)[8][4], int m0, int n0, int wm, int wn, int lane, float dq = 1.f) {
+  // HU8: the derivative tensor (out of EPI_GELU_GRAD, aux of EPI_MUL_AUX) is one byte per element, ldc / ldaux in bytes
+  constexpr int DSZ = (HU8 && EPI == EPI_GELU_GRAD) ? 1 : 2;      // bytes per element of `out`
+  constexpr int ASZ = (HU8 && EPI == EPI_MUL_AUX) ? 1 : 2;        // bytes per element of `aux`
+  uint32_t d8 = 0;                                                // HU8 + EPI_GELU_GRAD: the 4 derivative bytes of the last finish()
   // lane-constant store offsets are derived from an opaque copy of the lane id: hoisted out of the tile loop they would
   // sit in VGPRs through the K loop, which has none to spare
   asm volatile("" : "+v"(lane));
@@ -80,10 +99,10 @@ OAT_DEV bool pp_epilogue(const GemmArgs& g, const f32x4 (&acc)[8][4], int m0, in
   const float q8 = (Q8 && o8) ? g.q_out[0] : 0.f;
   float m8 = 0.f;
   uint32_t w8 = 0;                                     // the 4 quantised values of the last finish() call
-  auto finish = [&](f32x4 v, const bf16x4 a, bf16x4& o, bf16x4& o2) {
+  auto finish = [&](f32x4 v, const f32x4 a, bf16x4& o, bf16x4& o2) {
     if constexpr (F8) v *= dq;
     if constexpr (EPI == EPI_GELU_GRAD) {
-      float gq[4];
+      float gq[4], dq4[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float gl, dg;
@@ -91,7 +110,9 @@ OAT_DEV bool pp_epilogue(const GemmArgs& g, const f32x4 (&acc)[8][4], int m0, in
         o[e] = f2bf(dg);
         o2[e] = f2bf(gl);
         gq[e] = gl;
+        dq4[e] = dg;
       }
+      if constexpr (HU8) d8 = hu8_pack(dq4[0], dq4[1], dq4[2], dq4[3]);
       if constexpr (Q8) {
         if (o8) {
           m8 = fmaxf(fmaxf(m8, fmaxf(fabsf(gq[0]), fabsf(gq[1]))), fmaxf(fabsf(gq[2]), fabsf(gq[3])));
@@ -102,7 +123,7 @@ OAT_DEV bool pp_epilogue(const GemmArgs& g, const f32x4 (&acc)[8][4], int m0, in
       float gq[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        gq[e] = v[e] * bf2f(a[e]);
+        gq[e] = v[e] * a[e];
         o[e] = f2bf(gq[e]);
       }
       if constexpr (Q8) {
@@ -156,16 +177,23 @@ OAT_DEV bool pp_epilogue(const GemmArgs& g, const f32x4 (&acc)[8][4], int m0, in
   }
   if (interior) {
     const size_t t0 = (size_t)wrow0;
-    char* const ob = reinterpret_cast<char*>(g.out) + (t0 * g.ldc + wcol00) * 2;
+    char* const ob = reinterpret_cast<char*>(g.out) + (t0 * g.ldc + wcol00) * DSZ;
     char* const ob2 = EPI == EPI_GELU_GRAD ? reinterpret_cast<char*>(g.out2) + (t0 * g.ld2 + wcol00) * 2 : nullptr;
-    const char* const ab = EPI == EPI_MUL_AUX ? reinterpret_cast<const char*>(g.aux) + (t0 * g.ldaux + wcol00) * 2 : nullptr;
-    const uint32_t lo = (uint32_t)(fk * 4 * g.ldc + frow * 4) * 2;
+    const char* const ab = EPI == EPI_MUL_AUX ? reinterpret_cast<const char*>(g.aux) + (t0 * g.ldaux + wcol00) * ASZ : nullptr;
+    const uint32_t lo = (uint32_t)(fk * 4 * g.ldc + frow * 4) * DSZ;
     const uint32_t lo2 = EPI == EPI_GELU_GRAD ? (uint32_t)(fk * 4 * g.ld2 + frow * 4) * 2 : 0;
-    const uint32_t la = EPI == EPI_MUL_AUX ? (uint32_t)(fk * 4 * g.ldaux + frow * 4) * 2 : 0;
-    bf16x4 an[4] = {}, ac[4] = {};
+    const uint32_t la = EPI == EPI_MUL_AUX ? (uint32_t)(fk * 4 * g.ldaux + frow * 4) * ASZ : 0;
+    auto load_aux = [&](const char* ptr) -> f32x4 {
+      if constexpr (ASZ == 1) return hu8_unpack(*reinterpret_cast<const uint32_t*>(ptr));
+      else {
+        const bf16x4 t = *reinterpret_cast<const bf16x4*>(ptr);
+        return f32x4{bf2f(t[0]), bf2f(t[1]), bf2f(t[2]), bf2f(t[3])};
+      }
+    };
+    f32x4 an[4] = {}, ac[4] = {};
     if constexpr (EPI == EPI_MUL_AUX) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) an[r] = *reinterpret_cast<const bf16x4*>(ab + (size_t)(uint32_t)(r * g.ldaux * 2) + la);
+      for (int r = 0; r < 4; ++r) an[r] = load_aux(ab + (size_t)(uint32_t)(r * g.ldaux * ASZ) + la);
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -174,8 +202,7 @@ OAT_DEV bool pp_epilogue(const GemmArgs& g, const f32x4 (&acc)[8][4], int m0, in
         for (int r = 0; r < 4; ++r) ac[r] = an[r];
         if (i + 1 < 8) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            an[r] = *reinterpret_cast<const bf16x4*>(ab + (size_t)(uint32_t)(((i + 1) * 16 + r) * g.ldaux * 2) + la);
+          for (int r = 0; r < 4; ++r) an[r] = load_aux(ab + (size_t)(uint32_t)(((i + 1) * 16 + r) * g.ldaux * ASZ) + la);
         }
       }
 #pragma unroll
@@ -184,7 +211,8 @@ OAT_DEV bool pp_epilogue(const GemmArgs& g, const f32x4 (&acc)[8][4], int m0, in
         bf16x4 o, o2;
         finish(v, ac[r], o, o2);
         const uint32_t rr = (uint32_t)(i * 16 + r);
-        *reinterpret_cast<bf16x4*>(ob + (size_t)(rr * (uint32_t)g.ldc * 2) + lo) = o;
+        if constexpr (DSZ == 1) *reinterpret_cast<uint32_t*>(ob + (size_t)(rr * (uint32_t)g.ldc) + lo) = d8;
+        else *reinterpret_cast<bf16x4*>(ob + (size_t)(rr * (uint32_t)g.ldc * 2) + lo) = o;
         if constexpr (EPI == EPI_GELU_GRAD) *reinterpret_cast<bf16x4*>(ob2 + (size_t)(rr * (uint32_t)g.ld2 * 2) + lo2) = o2;
         if constexpr (Q8) {
           if (o8) *reinterpret_cast<uint32_t*>(o8 + (size_t)(wrow0 + i * 16 + fk * 4 + r) * g.ld8 + wcol00 + frow * 4) = w8;
@@ -200,11 +228,19 @@ OAT_DEV bool pp_epilogue(const GemmArgs& g, const f32x4 (&acc)[8][4], int m0, in
         const int row = wrow0 + i * 16 + fk * 4 + r;
         const f32x4 v = f32x4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
         if (row < g.M) {
-          bf16x4 o, o2, a = {};
-          if constexpr (EPI == EPI_MUL_AUX) a = *reinterpret_cast<const bf16x4*>(g.aux + (size_t)row * g.ldaux + col);
+          bf16x4 o, o2;
+          f32x4 a = {};
+          if constexpr (EPI == EPI_MUL_AUX) {
+            if constexpr (ASZ == 1) a = hu8_unpack(*reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(g.aux) + (size_t)row * g.ldaux + col));
+            else {
+              const bf16x4 t = *reinterpret_cast<const bf16x4*>(g.aux + (size_t)row * g.ldaux + col);
+              a = f32x4{bf2f(t[0]), bf2f(t[1]), bf2f(t[2]), bf2f(t[3])};
+            }
+          }
           finish(v, a, o, o2);
           if constexpr (EPI == EPI_GELU_GRAD) *reinterpret_cast<bf16x4*>((bf16*)g.out2 + (size_t)row * g.ld2 + col) = o2;
-          *reinterpret_cast<bf16x4*>((bf16*)g.out + (size_t)row * g.ldc + col) = o;
+          if constexpr (DSZ == 1) *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(g.out) + (size_t)row * g.ldc + col) = d8;
+          else *reinterpret_cast<bf16x4*>((bf16*)g.out + (size_t)row * g.ldc + col) = o;
           if constexpr (Q8) {
             if (o8) *reinterpret_cast<uint32_t*>(o8 + (size_t)row * g.ld8 + col) = w8;
           }
@@ -440,7 +476,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs g) {
       prev_interior = false;
       continue;
     }
-    prev_interior = pp_epilogue<EPI, false, F8>(g, acc, m0, n0, wm, wn, lane, dq);
+    prev_interior = pp_epilogue<EPI, false, F8, (FL & PPF_HU8) != 0>(g, acc, m0, n0, wm, wn, lane, dq);
     __builtin_amdgcn_sched_barrier(0);
   }
   if (STAGGER && wm == 0) __builtin_amdgcn_s_barrier();  // pairs with group 1's extra barrier
@@ -679,8 +715,12 @@ bool pp_f8_supported(int epi, const GemmArgs& g) {
 int launch_pp_f8(int epi, const GemmArgs& g, int grid_slots, bool a_e5m2, hipStream_t s) {
   constexpr int FL = PPF_PRIO | PPF_BONUS | PPF_LGKM | PPF_F8, FLG = FL | PPF_A_BF8;
   if (!pp_f8_supported(epi, g)) { set_error("gemm_nt_f8: shape / epilogue not covered (K % 256, N % 256, N <= 4096, M >= 256, EPI_BF16 | EPI_GELU_GRAD | EPI_MUL_AUX)"); return -3; }
-  if (epi == EPI_GELU_GRAD) return launch_pp_cfg<EPI_GELU_GRAD, FL>(g, grid_slots, s);       // forward only: e4m3 x e4m3
-  if (epi == EPI_MUL_AUX) return a_e5m2 ? launch_pp_cfg<EPI_MUL_AUX, FLG>(g, grid_slots, s) : launch_pp_cfg<EPI_MUL_AUX, FL>(g, grid_slots, s);
+  if (epi == EPI_GELU_GRAD)                                                                  // forward only: e4m3 x e4m3
+    return g.h_u8 ? launch_pp_cfg<EPI_GELU_GRAD, FL | PPF_HU8>(g, grid_slots, s) : launch_pp_cfg<EPI_GELU_GRAD, FL>(g, grid_slots, s);
+  if (epi == EPI_MUL_AUX) {
+    if (g.h_u8) return a_e5m2 ? launch_pp_cfg<EPI_MUL_AUX, FLG | PPF_HU8>(g, grid_slots, s) : launch_pp_cfg<EPI_MUL_AUX, FL | PPF_HU8>(g, grid_slots, s);
+    return a_e5m2 ? launch_pp_cfg<EPI_MUL_AUX, FLG>(g, grid_slots, s) : launch_pp_cfg<EPI_MUL_AUX, FL>(g, grid_slots, s);
+  }
   return a_e5m2 ? launch_pp_cfg<EPI_BF16, FLG>(g, grid_slots, s) : launch_pp_cfg<EPI_BF16, FL>(g, grid_slots, s);
 }
 
@@ -695,8 +735,8 @@ bool pp_supported(int epi, const GemmArgs& g) {
 int launch_pp(int epi, const GemmArgs& g, int grid_slots, int flags, hipStream_t s) {
   constexpr int DEF = PPF_PRIO | PPF_BONUS | PPF_LGKM;   // LGKM: measured free, and it makes the WAR spacing strict
   const int fl = DEF ^ flags;                    // a set bit toggles the default
-  if (epi == EPI_GELU_GRAD) return launch_pp_cfg<EPI_GELU_GRAD, DEF>(g, grid_slots, s);
-  if (epi == EPI_MUL_AUX) return launch_pp_cfg<EPI_MUL_AUX, DEF>(g, grid_slots, s);
+  if (epi == EPI_GELU_GRAD) return g.h_u8 ? launch_pp_cfg<EPI_GELU_GRAD, DEF | PPF_HU8>(g, grid_slots, s) : launch_pp_cfg<EPI_GELU_GRAD, DEF>(g, grid_slots, s);
+  if (epi == EPI_MUL_AUX) return g.h_u8 ? launch_pp_cfg<EPI_MUL_AUX, DEF | PPF_HU8>(g, grid_slots, s) : launch_pp_cfg<EPI_MUL_AUX, DEF>(g, grid_slots, s);
   switch (fl) {
     case DEF: return launch_pp_cfg<EPI_BF16, DEF>(g, grid_slots, s);
     case DEF ^ PPF_PRIO: return launch_pp_cfg<EPI_BF16, DEF ^ PPF_PRIO>(g, grid_slots, s);

@@ -1,13 +1,9 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-OUT=$PWD/gpurun_out/r2a; rm -rf $OUT; mkdir -p $OUT
-timeout 300 python scripts/step_breakdown.py > $OUT/breakdown.log 2>&1
+OUT=$PWD/gpurun_out/r2c; rm -rf $OUT; mkdir -p $OUT
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/stats_bench.log 2>&1
 T=$(find $OUT/stats -name "*kernel_trace.csv" | head -1)
 python scripts/trace_gaps.py $T > $OUT/gaps.log 2>&1
-S=$(find $OUT/stats -name "*kernel_stats.csv" | head -1)
-cp $S $OUT/kernel_stats.csv
-# keep the trace of one step only (size)
 python - <<PY
 import pandas as pd
 d = pd.read_csv("$T").sort_values("Start_Timestamp")
@@ -16,10 +12,20 @@ b=[ad[0]]
 for x,y in zip(ad,ad[1:]):
     if y-x>20e6: b.append(y)
 lo,hi=b[3],b[4]
-w=d[(d.Start_Timestamp>=lo)&(d.Start_Timestamp<hi)][["Kernel_Name","Stream_Id","Start_Timestamp","End_Timestamp","Workgroup_Size_X","Grid_Size_X"]].copy()
-w["Start_Timestamp"]-=lo; w["End_Timestamp"]-=lo
-w["Kernel_Name"]=w.Kernel_Name.str.slice(0,70)
-w.to_csv("$OUT/one_step_trace.csv",index=False)
+w=d[(d.Start_Timestamp>=lo)&(d.Start_Timestamp<hi)].copy()
+ms=w[w.Kernel_Name.str.contains("adamw")].Stream_Id.iloc[0]
+m=w[w.Stream_Id==ms].sort_values("Start_Timestamp")
+busy=(m.End_Timestamp-m.Start_Timestamp).sum()/1e6
+gaps=(m.Start_Timestamp.values[1:]-m.End_Timestamp.values[:-1])
+import numpy as np
+print("step %.2f ms; main stream: %d kernels, busy %.2f ms, sum of gaps %.2f ms (positive only %.2f), median gap %.1f us" % ((hi-lo)/1e6, len(m), busy, gaps.sum()/1e6, gaps[gaps>0].sum()/1e6, np.median(gaps)/1e3))
+m["name"]=m.Kernel_Name.str.replace("void oat::","").str.replace("(anonymous namespace)::","").str.slice(0,48)
+m["dur"]=(m.End_Timestamp-m.Start_Timestamp)/1e3
+m["gap_before"]=np.concatenate([[0],gaps])/1e3
+g=m.groupby("name").agg(n=("dur","size"),total_ms=("dur",lambda x:x.sum()/1e3),avg_us=("dur","mean"),gap_before_us=("gap_before","mean")).sort_values("total_ms",ascending=False)
+print(g.head(28).to_string())
+for sid,gg in w.groupby("Stream_Id"):
+    if sid!=ms: print("other stream",sid,"kernels",len(gg),"busy %.2f ms"%((gg.End_Timestamp-gg.Start_Timestamp).sum()/1e6), "from %.1f to %.1f ms"%((gg.Start_Timestamp.min()-lo)/1e6,(gg.End_Timestamp.max()-lo)/1e6))
 PY
 rm -rf $OUT/stats
-tail -6 $OUT/breakdown.log; head -12 $OUT/gaps.log
+head -12 $OUT/gaps.log

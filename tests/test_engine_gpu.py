@@ -205,7 +205,7 @@ def test_launch_tape_replays_the_same_training_trajectory():
     (l0, a0, p0), (l1, a1, p1) = results
     # same kernels, same arguments, same order; the only run-to-run noise is the order of the fp32 atomics that sum the
     # CLS-row gradients (present between two untaped runs as well)
-    assert l0[:2] == l1[:2], (l0, l1)
+    assert l0[0] == l1[0], (l0, l1)          # forward is deterministic; from step 1 on the atomics noise of step 0's gradients shows
     assert max(abs(a - b) for a, b in zip(l0, l1)) < 2e-3, (l0, l1)
     assert a0 == a1 and len(a0) == 3 * len(batches)
     for n in p0:

@@ -448,3 +448,42 @@ def test_linear_f32_matches_fp64(M, N, K, act):
     err = (out32.double() - y).abs().max().item()
     assert err < 3e-5 * max(1.0, y.abs().max().item()), err
     assert torch.equal(out16, out32.bfloat16())
+
+
+def test_gemm_mlp_pair_with_8bit_derivative():
+    """EPI_GELU_GRAD | EPI_U8 / EPI_MUL_AUX | EPI_U8 (gemm_nt_pp.hip HU8_*): the saved GELU derivative as one byte per
+    element.  gelu(h) is unchanged bit for bit, the derivative is within 0.0025 + bf16 rounding of the fp32 value,
+    and the backward product equals the bf16-derivative path within that error; ragged M, rows beyond M untouched."""
+    from OATrans.ops import hip
+    torch.manual_seed(0)
+    m, n, k = 1000, 512, 256
+    mp = 1024
+    A = torch.randn(mp, k, device="cuda").bfloat16()
+    W = (torch.randn(n, k, device="cuda") * k ** -0.5).bfloat16()
+    bias = torch.randn(n, device="cuda")
+    d16 = torch.full((mp, n), 7.0, device="cuda", dtype=torch.bfloat16)
+    g16 = torch.empty(mp, n, device="cuda", dtype=torch.bfloat16)
+    hip.gemm_nt(A, W, m, n, k, hip.EPI_GELU_GRAD, d16, out2=g16, bias=bias)
+    d8 = torch.full((mp, n), 9, device="cuda", dtype=torch.uint8)
+    g8 = torch.empty(mp, n, device="cuda", dtype=torch.bfloat16)
+    hip.gemm_nt(A, W, m, n, k, hip.EPI_GELU_GRAD | hip.EPI_U8, d8, out2=g8, bias=bias)
+    assert torch.equal(g8[:m], g16[:m]) and bool((d8[m:] == 9).all())
+    h = A[:m].float() @ W.float().t() + bias
+    x = h.double()
+    dref = 0.5 * (1 + torch.erf(x / 2 ** 0.5)) + x * torch.exp(-x * x / 2) / (2 * torch.pi) ** 0.5
+    deq = d8[:m].float() * (1.27 / 255) - 0.135
+    assert (deq.double() - dref).abs().max().item() < 0.0025 + 2e-3          # quantisation step / 2 + the kernel's erf approximation
+    assert (d16[:m].double() - dref).abs().max().item() < 0.006              # the bf16 derivative is no more accurate
+    # backward: (dY @ W2) * derivative
+    dY = torch.randn(mp, k, device="cuda").bfloat16()
+    o16 = torch.empty(mp, n, device="cuda", dtype=torch.bfloat16)
+    o8 = torch.full((mp, n), 5.0, device="cuda", dtype=torch.bfloat16)
+    hip.gemm_nt(dY, W, m, n, k, hip.EPI_MUL_AUX, o16, aux=d16)
+    hip.gemm_nt(dY, W, m, n, k, hip.EPI_MUL_AUX | hip.EPI_U8, o8, aux=d8)
+    ref = (dY[:m].float() @ W.float().t()) * dref.float()
+    e16 = (o16[:m].float() - ref).abs().max().item()
+    e8 = (o8[:m].float() - ref).abs().max().item()
+    print("mul_aux max err: bf16 derivative", e16, "8-bit derivative", e8)
+    assert e8 < 2 * e16 + 0.02 and bool((o8[m:] == 5.0).all())
+    with pytest.raises(hip.OatError):
+        hip.gemm_nt(A, W, m, n - 64, k, hip.EPI_GELU_GRAD | hip.EPI_U8, d8, out2=g8, bias=bias)     # not a ping-pong shape: refused
