@@ -47,6 +47,12 @@ int oat_gemm_nt(const void* A, const void* B, int M, int N, int K, int lda, int 
                 void* out, int ldc, void* out2, int ld2, const float* bias, const float* resid,
                 int ldr, int resid_mod, const void* aux, int ldaux, void* stream);
 
+/* Split-K of the last, less-than-half-full round of 256x256 tiles of the persistent ping-pong kernel (epi 0): its tiles are
+ * shared by 2-4 workgroups that leave fp32 partial tiles in `ws`; the last one to arrive sums them in a fixed order and
+ * runs the epilogue.  ws: caller-owned device memory (128 MiB covers every launch), 256 zeroed ints; NULL = off.
+ * Launches that use it must be ordered on one stream. */
+int oat_gemm_set_splitk_workspace(void* ws, size_t bytes, void* zeroed_256_ints);
+
 /* tuning hook.  bits 0-7: 0 = auto tile choice, 1 = force 128x128 (4 waves), 2 = force 256x256 (8 waves),
  * 3 = 256x256 with 4 hand-pipelined waves; bits 8-15: flags (ablations: 128 = static tile walk even with counters, 1 = skip the epilogue, 4 = all row panels write the first 1024
  * output rows, 8 = no global stores, 16 / 32 = every workgroup stages A / B tile 0; 64 = split the

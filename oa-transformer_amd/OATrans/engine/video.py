@@ -150,6 +150,11 @@ class VideoEngine:
         self.fp8_bwd = os.environ.get("OAT_FP8_BWD", "0") != "0"
         # the saved GELU derivative as 8-bit fixed point where the ping-pong GEMM serves the MLP pair (gemm_nt_pp.hip HU8_*)
         self.h_u8 = os.environ.get("OAT_H_U8", "1") != "0"
+        # split-K of the last, 31 %-full round of tiles of the N = 768 GEMMs (gemm_nt_pp.hip PPF_SPLITK).  Correct and
+        # deterministic, but the fix-up (256 KB write-through per workgroup, 2-3 partial tiles read back by the last arriver)
+        # costs ~30 us of the 22-43 us it saves: -5 us at K = 3072, +6 us at K = 2304 (scripts/bench_pp.py SPLITK=1): off
+        self.splitk = os.environ.get("OAT_SPLITK", "0") != "0"
+        self._splitk_set = False
         # launch tapes (csrc/tape.hip): forward and backward are recorded once per plan and replayed from C
         self.use_tape = os.environ.get("OAT_TAPE", "1") != "0"
         self._f8 = None
@@ -326,6 +331,9 @@ class VideoEngine:
         N = g * g
         self.refresh_shadows(params, sig)
         dev = video.device
+        if self.splitk and not self._splitk_set:
+            hip.enable_splitk(dev)               # the N = 768 GEMMs run 2.31 rounds of tiles: share the last round's K range
+            self._splitk_set = True
         st = self._get_streams(dev)
         pl = self.plan(B, T, N, dev, call)
         pl.side = st["side"]

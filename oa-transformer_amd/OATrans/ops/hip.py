@@ -94,6 +94,24 @@ def _ensure_tile_counters(device):
         _tile_counters[key] = buf
 
 
+_splitk_ws = {}
+
+
+def enable_splitk(device, on=True):
+    """Register (or drop) the split-K workspace of the ping-pong gemm_nt: the last, less-than-half-full round of tiles of a
+    persistent launch is shared among the idle workgroups (oat_gemm_set_splitk_workspace).  One process drives one GPU."""
+    if not on:
+        _check(lib().oat_gemm_set_splitk_workspace(ctypes.c_void_p(0), ctypes.c_size_t(0), ctypes.c_void_p(0)), "oat_gemm_set_splitk_workspace")
+        _splitk_ws.clear()
+        return
+    key = str(device)
+    if key not in _splitk_ws:
+        ws = torch.empty(128 << 20, dtype=torch.uint8, device=device)
+        ctr = torch.zeros(256, dtype=torch.int32, device=device)
+        _check(lib().oat_gemm_set_splitk_workspace(_ptr(ws), ctypes.c_size_t(ws.numel()), _ptr(ctr)), "oat_gemm_set_splitk_workspace")
+        _splitk_ws[key] = (ws, ctr)
+
+
 def gemm_nt(A, B, M, N, K, epi, out, out2=None, bias=None, resid=None, resid_mod=0, aux=None,
             lda=None, ldb=None, ldc=None, ld2=None, ldr=None, ldaux=None):
     """out[M,N] = A[M,K] @ B[N,K]^T (+epilogue).  Tensors may hold more rows than M."""

@@ -34,6 +34,7 @@ struct GemmArgs {
   float* amax_out;         // ... its max |value| recorded here
   int h_u8;                // the GELU-derivative tensor (out of EPI_GELU_GRAD / aux of EPI_MUL_AUX) is 8-bit fixed point,
                            // one byte per element, ldc / ldaux in bytes (ping-pong kernel only; gemm_nt_pp.hip HU8_*)
+  float* sk_ws; int* sk_ctr;   // split-K of the last round (gemm_nt_pp.hip): partial-tile workspace, zeroed per-tile counters
 };
 
 constexpr int BK = 64;

@@ -617,6 +617,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
 static int g_variant = 0, g_dbg = 0, g_persist = 0, g_tail = 0;
 constexpr unsigned CTR_SETS = 1024;           // counter sets in the caller's buffer (8 ints each); set s is zeroed by launch s - 512
 static int* g_ctr = nullptr;
+static float* g_sk_ws = nullptr;      // split-K workspace of the ping-pong kernel (oat_gemm_set_splitk_workspace)
+static int* g_sk_ctr = nullptr;
+static size_t g_sk_bytes = 0;
 static std::atomic<unsigned> g_seq{0};
 
 static int cu_count() {
@@ -665,6 +668,17 @@ template <int EPI>
 static int launch_big(const GemmArgs& g, hipStream_t s) {
   if ((g_variant == 4 || (g_variant == 0 && g_pp_default)) && pp_supported(EPI, g)) {
     const int slots = g_persist == 0xffff ? 0x7fffffff : g_persist > 0 ? g_persist : cu_count();
+    if (EPI == EPI_BF16 && g_sk_ws != nullptr && !(g_dbg & 128)) {
+      // split-K of the last round (gemm_nt_pp.hip): at most slots/2 tiles x 4 partials of 256 KB, 256 counters
+      const int nwg = ((g.M + 255) / 256) * (g.N / 256), grid = nwg < slots ? nwg : slots;
+      const int r = nwg % grid;
+      if (r > 0 && 2 * r <= grid && (size_t)r * 4 * (256 << 10) <= g_sk_bytes && r <= 256) {
+        GemmArgs a = g;
+        a.sk_ws = g_sk_ws;
+        a.sk_ctr = g_sk_ctr;
+        return launch_pp(EPI, a, slots, g_variant == 4 ? g_dbg : 0, s);
+      }
+    }
     return launch_pp(EPI, g, slots, g_variant == 4 ? g_dbg : 0, s);
   }
   return launch_cfg<EPI, 2, 4, 8, 4, 3, true>(g, s);
@@ -715,6 +729,16 @@ extern "C" int oat_gemm_set_tile_counters(void* zeroed_device_ints, size_t bytes
     return -3;
   }
   oat::g_ctr = static_cast<int*>(zeroed_device_ints);
+  return 0;
+}
+// Workspace of the split-K last round (see gemm_nt_pp.hip): `bytes` of device memory for fp32 partial tiles (128 MiB
+// covers every launch of up to 256 workgroups) and 256 ZEROED ints.  Caller-owned; nullptr switches the feature off.
+// One ping-pong GEMM at a time may use it (launches on ONE stream).
+extern "C" int oat_gemm_set_splitk_workspace(void* ws, size_t bytes, void* zeroed_256_ints) {
+  if (ws != nullptr && (!zeroed_256_ints || bytes < ((size_t)4 << 20))) { oat::set_error("gemm_set_splitk_workspace: need >= 4 MiB and 256 zeroed ints"); return -3; }
+  oat::g_sk_ws = static_cast<float*>(ws);
+  oat::g_sk_bytes = ws ? bytes : 0;
+  oat::g_sk_ctr = ws ? static_cast<int*>(zeroed_256_ints) : nullptr;
   return 0;
 }
 extern "C" void oat_gemm_set_variant(int v) { oat::g_variant = v & 0xff; oat::g_dbg = (v >> 8) & 0xff; oat::g_persist = (v >> 16) & 0xffff; }

@@ -39,11 +39,13 @@ namespace {
 
 constexpr int PP_A1 = 32768, PP_B0 = 65536, PP_BIAS = 131072;
 constexpr int PP_MAXN = 4096;                       // bias vector kept in LDS
-constexpr int PP_LDS = PP_BIAS + PP_MAXN * 4;
+constexpr int PP_FLAG = PP_BIAS + PP_MAXN * 4;      // one word: the split-K arrival count, broadcast to the workgroup
+constexpr int PP_LDS = PP_FLAG + 16;
 
 enum : int { PPF_PRIO = 1, PPF_NOSTAGGER = 2, PPF_LGKM = 4, PPF_BONUS = 8, PPF_NOEPI = 16, PPF_PH2 = 32, PPF_WIDE = 64,
              PPF_F8 = 128, PPF_A_BF8 = 256,     // PPF_A_BF8: the A operand is e5m2 (gradients), B stays e4m3
-             PPF_HU8 = 512 };                   // the saved GELU derivative travels as 8-bit fixed point (see HU8_*)
+             PPF_HU8 = 512,                     // the saved GELU derivative travels as 8-bit fixed point (see HU8_*)
+             PPF_SPLITK = 1024 };               // split-K of the last, partial round of tiles (see `sk_*` in the kernel)
 
 // gelu'(h) lies in [-0.129, 1.129].  As bf16 it costs 2 bytes per element to write (fc1 forward) and to read back (fc2 data
 // gradient) - 308 MB per launch each way, all of it on top of a GEMM that is otherwise MFMA-bound.  Stored as
@@ -268,8 +270,29 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs g) {
   const int wm = wave >> 2, wn = wave & 3;                      // wave tile: rows wm*128.., columns wn*64..
   const int ntn = g.N >> 8, ntm = (g.M + 255) >> 8, nwg = ntm * ntn;
   const int nk = g.K >> (7 - ESH);                                      // K-tiles of 128 bytes per row
-  const int ntl = (nwg - 1 - (int)blockIdx.x) / (int)gridDim.x + 1;     // tiles this workgroup walks
-  const int S = ntl * nk;                                               // its stream of K-tiles
+  // Split-K of the last round.  A persistent launch walks nwg tiles in rounds of gridDim.x; when the last round is less
+  // than half full (N = 768 at M = 50208: 591 tiles on 256 CUs = 2.31 rounds, the third one 79 tiles wide) most CUs
+  // idle through a whole tile time.  With PPF_SPLITK each tile of that round is shared by sk_S workgroups, each taking
+  // 1 / sk_S of the K range: they write their fp32 partial tiles to a workspace, count themselves on a per-tile counter,
+  // and the LAST one to arrive sums the partials in split order (deterministic), adds the bias and runs the epilogue.
+  // No workgroup ever waits for another one.  (ntl: tiles this workgroup walks.)
+  constexpr bool SPLITK = (FL & PPF_SPLITK) != 0;
+  const int grid = (int)gridDim.x, full = nwg / grid;
+  int sk_S = 1, sk_r = 0;
+  if constexpr (SPLITK) {
+    sk_r = nwg - full * grid;
+    if (g.sk_ws != nullptr && sk_r > 0 && 2 * sk_r <= grid) {
+      sk_S = grid / sk_r;
+      if (sk_S > 4) sk_S = 4;
+      while (sk_S > 1 && nk % (2 * sk_S) != 0) --sk_S;
+      if (nk * (sk_S - 1) < 12 * sk_S) sk_S = 1;          // too short a K range to pay for the fix-up
+    }
+  }
+  const bool sk_on = sk_S > 1;
+  const int sk_tile = sk_on ? (int)blockIdx.x % sk_r : 0, sk_split = sk_on ? (int)blockIdx.x / sk_r : 0;
+  const int sk_nk = sk_on ? nk / sk_S : nk;                             // K-tiles of a split tile
+  const int ntl = sk_on ? full + ((int)blockIdx.x < sk_r * sk_S ? 1 : 0)
+                        : (nwg - 1 - (int)blockIdx.x) / grid + 1;
   float dq = 1.f, inv_dq = 1.f;
   if constexpr (F8) {
     dq = g.dq_a[0] * g.dq_b[0];
@@ -277,7 +300,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs g) {
   }
   struct Tile { int m0, n0; };
   auto tile_of = [&](int t) __attribute__((always_inline)) {
-    const int w = blockIdx.x + t * gridDim.x;
+    const int w = (sk_on && t == full) ? full * grid + sk_tile : (int)blockIdx.x + t * grid;
     const int q = nwg >> 3, r = nwg & 7, xcd = w & 7, idx = w >> 3;
     const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;   // XCD-contiguous, bijective
     const int tm = bid / ntn;
@@ -309,7 +332,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs g) {
     }
   }
   // staging cursor: K-tile cs = s + 2 of the stream
-  int ckt = 0, ctl = 0, crmax;
+  int ckt = 0, ctl = 0, crmax, cnk = nk;       // cnk: K-tiles of the cursor's tile
   const char *ca, *cb;                         // byte cursors: a K-tile is 128 bytes of every row in both formats
   const char* const A0 = reinterpret_cast<const char*>(g.A);
   const char* const B0 = reinterpret_cast<const char*>(g.B);
@@ -327,13 +350,16 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs g) {
     ++ckt;
     ca += 128;
     cb += 128;
-    if (ckt == nk) {                            // selects, not branches: every path assigns every cursor variable
+    if (ckt == cnk) {                           // selects, not branches: every path assigns every cursor variable
       const bool more = ctl + 1 < ntl;
       ctl += more ? 1 : 0;
       const Tile t = tile_of(ctl);
-      ckt = more ? 0 : nk - 1;
-      ca = more ? A0 + (size_t)t.m0 * lda2 : ca - 128;
-      cb = more ? B0 + (size_t)t.n0 * ldb2 : cb - 128;
+      const bool split = sk_on && ctl == full;  // the next tile is this workgroup's share of a split one
+      const size_t koff = split ? (size_t)sk_split * sk_nk * 128 : 0;
+      ckt = more ? 0 : cnk - 1;
+      cnk = (more && split) ? sk_nk : cnk;
+      ca = more ? A0 + (size_t)t.m0 * lda2 + koff : ca - 128;
+      cb = more ? B0 + (size_t)t.n0 * ldb2 + koff : cb - 128;
       crmax = g.M - 1 - t.m0;
       lda2c = more ? lda2c : 0u;
       bmask = more ? bmask : 0x7fu;
@@ -457,15 +483,21 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs g) {
   for (int tl = 0; tl < ntl; ++tl) {
     const Tile tile = tile_of(tl);
     const int m0 = tile.m0, n0 = tile.n0;
+    const bool split_tile = SPLITK && sk_on && tl == full;      // always the last tile of the walk
     {
-      const f32x4 b = *reinterpret_cast<const f32x4*>(sbias + n0 + wn * 64 + frow * 4);
+      f32x4 b = *reinterpret_cast<const f32x4*>(sbias + n0 + wn * 64 + frow * 4);
+      if (split_tile) b = f32x4{0.f, 0.f, 0.f, 0.f};            // the bias joins the summed partials
 #pragma unroll
       for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{b[j], b[j], b[j], b[j]};
     }
+    const int nk_t = split_tile ? sk_nk : nk;
     pair(std::true_type{}, BONUS && prev_interior);
-    for (int kt = 2; kt < nk; kt += 2) pair(std::false_type{}, false);
+    for (int kt = 2; kt < nk_t; kt += 2) pair(std::false_type{}, false);
+    if constexpr (SPLITK) {
+      if (split_tile) break;                                    // its epilogue follows the loop (needs the whole workgroup)
+    }
     // ---- epilogue (no LDS, no barriers): lane (fk, frow) owns rows 16 i + 4 fk + r and the 4 consecutive columns
     // 4 frow + j of its wave tile, so 16 consecutive lanes store one 128-byte line per row
     if constexpr (NOEPI) {
@@ -481,6 +513,56 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs g) {
   }
   if (STAGGER && wm == 0) __builtin_amdgcn_s_barrier();  // pairs with group 1's extra barrier
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no LDS-DMA may outlive the workgroup's LDS allocation
+  if constexpr (SPLITK) {
+    if (sk_on && (int)blockIdx.x < sk_r * sk_S) {
+      // ---- split-K fix-up.  Partial tile layout: [wave][i][j][lane] x 4 floats - every (wave, i, j) is one 1 KB run.
+      const Tile tile = tile_of(full);
+      // The partials cross XCDs (the per-XCD L2s are not coherent with each other).  A release / acquire FENCE at agent
+      // scope would write back and invalidate the whole L2 - which holds megabytes of this launch's own output tiles:
+      // measured +100 us.  Instead every access to the workspace carries agent scope itself (sc1: stores write through,
+      // loads fetch from memory), ordered by vmcnt and the counter atomic.
+      float* const mine = g.sk_ws + ((size_t)(sk_tile * sk_S + sk_split) << 16);
+      const uint32_t slot = (uint32_t)(wave * 32 * 64 + lane) * 4u;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(mine + slot + (uint32_t)(i * 4 + j) * 256u), "v"(acc[i][j]) : "memory");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // written through before the arrival is counted
+      __syncthreads();
+      int* const sflag = reinterpret_cast<int*>(smem + PP_FLAG);
+      if (tid == 0) *sflag = __hip_atomic_fetch_add(g.sk_ctr + sk_tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      if (*sflag == sk_S - 1) {                          // last to arrive: every partial of this tile is complete
+        for (int sp = 0; sp < sk_S; ++sp) {
+          const float* src = g.sk_ws + ((size_t)(sk_tile * sk_S + sp) << 16) + slot;
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {         // 16 loads in flight per wait: 6-8 round trips in all
+            f32x4 t[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+              asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(t[q]) : "v"(src + (uint32_t)(half * 16 + q) * 256u) : "memory");
+            asm volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]), "+v"(t[8]),
+                           "+v"(t[9]), "+v"(t[10]), "+v"(t[11]), "+v"(t[12]), "+v"(t[13]), "+v"(t[14]), "+v"(t[15])
+                         :: "memory");
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+              const int i = (half * 16 + q) >> 2, j = q & 3;
+              acc[i][j] = sp == 0 ? t[q] : acc[i][j] + t[q];
+            }
+          }
+        }
+        const f32x4 b = *reinterpret_cast<const f32x4*>(sbias + tile.n0 + wn * 64 + frow * 4);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] += f32x4{b[j], b[j], b[j], b[j]};
+        if (tid == 0) g.sk_ctr[sk_tile] = 0;             // ready for the next launch (stream-ordered after this one)
+        pp_epilogue<EPI, false, F8, (FL & PPF_HU8) != 0>(g, acc, tile.m0, tile.n0, wm, wn, lane, dq);
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -737,6 +819,7 @@ int launch_pp(int epi, const GemmArgs& g, int grid_slots, int flags, hipStream_t
   const int fl = DEF ^ flags;                    // a set bit toggles the default
   if (epi == EPI_GELU_GRAD) return g.h_u8 ? launch_pp_cfg<EPI_GELU_GRAD, DEF | PPF_HU8>(g, grid_slots, s) : launch_pp_cfg<EPI_GELU_GRAD, DEF>(g, grid_slots, s);
   if (epi == EPI_MUL_AUX) return g.h_u8 ? launch_pp_cfg<EPI_MUL_AUX, DEF | PPF_HU8>(g, grid_slots, s) : launch_pp_cfg<EPI_MUL_AUX, DEF>(g, grid_slots, s);
+  if (fl == DEF && g.sk_ws != nullptr) return launch_pp_cfg<EPI_BF16, DEF | PPF_SPLITK>(g, grid_slots, s);
   switch (fl) {
     case DEF: return launch_pp_cfg<EPI_BF16, DEF>(g, grid_slots, s);
     case DEF ^ PPF_PRIO: return launch_pp_cfg<EPI_BF16, DEF ^ PPF_PRIO>(g, grid_slots, s);

@@ -127,7 +127,47 @@ def bench():
     hip.gemm_set_variant(0)
 
 
+def splitk():
+    """Split-K of the last round: result vs the plain ping-pong kernel (same products, other summation order: equal up to
+    the bf16 rounding of the output) and vs fp32, repeat-run determinism, timing on / off."""
+    torch.manual_seed(1)
+    ok = True
+    for (m, n, k) in SHAPES + [(M, 768, 1536), (30000, 768, 3072), (4096 + 17, 512, 2304)]:
+        mp = (m + 255) // 256 * 256
+        A = torch.randn(mp, k, device="cuda").bfloat16(); B = (torch.randn(n, k, device="cuda") * k ** -0.5).bfloat16()
+        bias = torch.randn(n, device="cuda")
+        o0 = torch.full((mp, n), 7.0, device="cuda", dtype=torch.bfloat16)
+        o1 = torch.full((mp, n), 7.0, device="cuda", dtype=torch.bfloat16)
+        ts0, ts1 = [], []
+        for r in range(5):                       # interleaved: clocks drift over a run
+            hip.enable_splitk("cuda", False)
+            hip.gemm_nt(A, B, m, n, k, hip.EPI_BF16, o0, bias=bias)
+            ts0.append(timeit(lambda: hip.gemm_nt(A, B, m, n, k, hip.EPI_BF16, o0, bias=bias)))
+            hip.enable_splitk("cuda", True)
+            hip.gemm_nt(A, B, m, n, k, hip.EPI_BF16, o1, bias=bias)
+            ts1.append(timeit(lambda: hip.gemm_nt(A, B, m, n, k, hip.EPI_BF16, o1, bias=bias)))
+        t0, t1 = sorted(ts0)[2], sorted(ts1)[2]
+        o2 = torch.full((mp, n), 7.0, device="cuda", dtype=torch.bfloat16)
+        same = True
+        for _ in range(5):
+            hip.gemm_nt(A, B, m, n, k, hip.EPI_BF16, o2, bias=bias)
+            same &= torch.equal(o1, o2)
+        ref = A[:m].float() @ B.float().t() + bias
+        d01 = (o0[:m].float() - o1[:m].float()).abs().max().item()
+        e1 = (o1[:m].float() - ref).abs().max().item()
+        e0 = (o0[:m].float() - ref).abs().max().item()
+        ndiff = (o0[:m] != o1[:m]).float().mean().item()
+        good = same and bool((o1[m:] == 7.0).all()) and e1 <= e0 * 1.5 + 1e-3 and d01 <= 2 ** -7 * ref.abs().max().item()
+        print(f"M={m} N={n} K={k}: split-K {2*m*n*k/t1/1e12:7.1f} TF/s ({t1*1e6:6.1f} us) vs {2*m*n*k/t0/1e12:7.1f} ({t0*1e6:6.1f} us)  "
+              f"max|d| {d01:.4f} differing {ndiff:.2e}  err vs fp32 {e1:.4f} / {e0:.4f}  deterministic {same} -> {'ok' if good else 'BAD'}")
+        ok &= good
+    print("SPLITK", "PASSED" if ok else "FAILED")
+    return ok
+
+
 if __name__ == "__main__":
+    if os.environ.get("SPLITK"):
+        sys.exit(0 if splitk() else 1)
     ok = check()
     if ok or os.environ.get("FORCE_BENCH"):
         bench()
