@@ -172,6 +172,15 @@ int oat_attn_text_bwd(const void* qkv, int ldqkv, const void* mask, const void* 
                       const float* lse, float* delta_scratch, const void* dout, int lddo, void* dqkv,
                       int lddqkv, int B, int L, int H, int D, float scale, float drop_p, const void* rng,
                       unsigned drop_site, void* stream);
+/* ---- input pipeline, device side: decoded frames -> clip tensor.  Replaces, per batch and in one launch,
+ * frames.float() / 255 (base/base_dataset.py:519,533,544) and the tensor transforms of data_loader/transforms.py:4-31 /
+ * base_dataset_global_local.py:251-257: crop box + bilinear resize (= torchvision Resize on tensors =
+ * F.interpolate(bilinear, align_corners=False)) + horizontal flip + Normalize.  frames: uint8 [F, H, W, 3] or float
+ * [F, 3, H, W]; crop = {x0, y0, w, h} in source pixels or NULL; out [F, 3, OH, OW] bf16 / fp32; mean / std: 3 floats
+ * (host pointers) or NULL. */
+int oat_frames_resize(const void* frames, int in_u8_hwc, int F, int H, int W, const float* crop_xywh_or_null, int flip,
+                      void* out, int out_bf16, int OH, int OW, float scale, const float* mean3, const float* std3, void* stream);
+
 /* ---- launch tape: record the launches of a schedule once, replay them from C (csrc/tape.hip).  Stands where the reference
  * relies on PyTorch's eager dispatcher for every op of the step (model/video_transformer.py:303-351 forward, autograd for
  * backward).  Between oat_tape_begin and oat_tape_end (same thread) every oat_* launch is executed AND recorded with its

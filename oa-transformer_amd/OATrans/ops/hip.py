@@ -359,6 +359,31 @@ def attn_text_fwd_dual(qkv, qkv32, mask, out, out32, lse, B, L, H, D, scale, dro
                                         _f(drop_p), _ptr(rng), ctypes.c_uint(site), _stream()), "oat_attn_text_fwd_dual")
 
 
+IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+
+
+def frames_resize(frames, out_hw, crop=None, flip=False, mean=IMAGENET_MEAN, std=IMAGENET_STD, out=None, dtype=torch.bfloat16):
+    """Decoded frames -> normalised clip: uint8 [F, H, W, 3] (or float [F, 3, H, W]) -> [F, 3, OH, OW].  crop = (x0, y0, w, h)
+    in source pixels.  One launch for all frames (see oat_frames_resize)."""
+    u8 = frames.dtype == torch.uint8
+    frames = frames.contiguous()
+    if u8:
+        F, H, W, _ = frames.shape
+    else:
+        frames = frames.float()
+        F, _, H, W = frames.shape
+    OH, OW = out_hw
+    if out is None:
+        out = torch.empty(F, 3, OH, OW, dtype=dtype, device=frames.device)
+    arr3 = ctypes.c_float * 3
+    arr4 = ctypes.c_float * 4
+    _check(lib().oat_frames_resize(_ptr(frames), int(u8), F, H, W, arr4(*[float(v) for v in crop]) if crop is not None else None,
+                                   int(flip), _ptr(out), int(out.dtype == torch.bfloat16), OH, OW, _f(1.0 / 255.0 if u8 else 1.0),
+                                   arr3(*mean) if mean is not None else None, arr3(*std) if std is not None else None, _stream()),
+           "oat_frames_resize")
+    return out
+
+
 # ---- launch tape ----------------------------------------------------------------------------------------------------
 def tape_begin():
     _check(lib().oat_tape_begin(), "oat_tape_begin")

@@ -204,3 +204,24 @@ def test_reference_shipped_configs_parse_and_build(tmp_path, monkeypatch, rel):
         assert not unknown, (rel, unknown)                      # every kwarg the reference passes is accepted
     vp = config["arch"]["args"]["video_params"]
     assert vp["model"] == "SpaceTimeTransformer" and vp["arch_config"] == "base_patch16_224"
+
+
+def test_frame_transform_host_logic_and_oracle_identities():
+    """data_loader/frames.py host side (crop-box sampling, shorter-side resize arithmetic) and oracle/frames_oracle.py
+    identities: resizing to the same size is the identity, the eval pipeline of a 256 x 256 frame is one resize."""
+    import random
+    import torch
+    from OATrans.data_loader import frames as fr
+    from oracle import frames_oracle as forc
+    rng = random.Random(0)
+    for _ in range(200):
+        H, W = rng.randint(32, 720), rng.randint(32, 1280)
+        x0, y0, w, h = fr.random_resized_crop_params(H, W, (0.5, 1.0), rng=rng)
+        assert 0 <= x0 and 0 <= y0 and x0 + w <= W and y0 + h <= H and w > 0 and h > 0
+        assert 0.45 * H * W <= w * h <= H * W
+        assert 3 / 4 - 0.05 <= w / h <= 4 / 3 + 0.05 or (w, h) in ((W, H), (W, int(round(W / 0.75))), (int(round(H * 4 / 3)), H))
+    assert fr.resize_shorter_side(360, 640, 256) == (256, 455) and fr.resize_shorter_side(640, 360, 256) == (455, 256)
+    f = torch.randint(0, 256, (2, 224, 224, 3), dtype=torch.uint8)
+    assert torch.allclose(forc.oa_clip(f, 224), forc.normalize(forc.to_float_chw(f)), atol=1e-6)
+    f = torch.randint(0, 256, (2, 256, 256, 3), dtype=torch.uint8)
+    assert torch.allclose(forc.eval_clip(f, 224), forc.normalize(forc.resize(forc.to_float_chw(f), (224, 224))), atol=1e-6)
