@@ -101,15 +101,25 @@ class FrozenInTime(BaseModel):
         return encode_object_and_video(self, v)
 
     def forward(self, data, return_embeds=True):
-        text_embeddings, text_tokens = self.compute_text(data['text'])
-        pad_text_embeddings, pad_tokens = self.compute_text(data['pad_text'])
+        # everything on the text side (two DistilBERT passes, tag masks, tag pooling, text_local_proj) is independent of the
+        # video side until the losses: it runs on its own HIP stream beneath the video encoder, enqueued first (as in
+        # oa_model.FrozenInTime.forward); autograd replays each side's backward on the stream of its forward
+        main = torch.cuda.current_stream()
+        if getattr(self, "_text_stream", None) is None:
+            self._text_stream = torch.cuda.Stream()
+        side = self._text_stream
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            text_embeddings, text_tokens = self.compute_text(data['text'])
+            pad_text_embeddings, pad_tokens = self.compute_text(data['pad_text'])
+            n_txt = data['text']['attention_mask'].sum(dim=1)
+            tags_masks = hip.tag_masks(data['object_token_masks'].to(torch.int64), n_txt.to(torch.int64), pad_tokens.shape[1])
+            tags_feat = self.text_local_proj(mask_pool(tags_masks, pad_tokens))
         object_image_embeddings, object_region, video_embeddings, video_region = self.encode_clips(data['video'])
-        region_feat = mask_pool(data['patch_masks'].float(), object_region)
-        n_txt = data['text']['attention_mask'].sum(dim=1)
-        tags_masks = hip.tag_masks(data['object_token_masks'].to(torch.int64), n_txt.to(torch.int64), pad_tokens.shape[1])
-        tags_feat = mask_pool(tags_masks, pad_tokens)
-        region_feat = self.vid_local_proj(region_feat)
-        tags_feat = self.text_local_proj(tags_feat)
+        region_feat = self.vid_local_proj(mask_pool(data['patch_masks'].float(), object_region))
+        main.wait_stream(side)
+        for t in (text_embeddings, text_tokens, pad_text_embeddings, pad_tokens, tags_feat):
+            t.record_stream(main)
         return text_embeddings, pad_text_embeddings, video_embeddings, object_image_embeddings, \
             [text_tokens, pad_tokens, video_region, object_region, region_feat, tags_feat]
 

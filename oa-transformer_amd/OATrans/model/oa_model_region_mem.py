@@ -61,12 +61,22 @@ class FrozenInTime(BaseModel):
         self.video_model.begin_step()
 
     def forward(self, data, aug=False, return_embeds=True):
-        text_embeddings = self.compute_text(data['text'])
+        # text side (DistilBERT pass, txt_proj_2 of the class-prompt embeddings) on its own stream beneath the video encoder
+        main = torch.cuda.current_stream()
+        if getattr(self, "_text_stream", None) is None:
+            self._text_stream = torch.cuda.Stream()
+        side = self._text_stream
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            text_embeddings = self.compute_text(data['text'])
+            text_region = self.txt_proj_2(data['text_region_embedding'].float())
         # clip layouts ('interleaved' = the reference's view(2B, F/2), 'native' = object frame + T-frame video):
         # oa_model_global_local.encode_object_and_video
         _, object_region, video_embeddings, video_region = encode_object_and_video(self, data['video'])
-        text_region = self.txt_proj_2(data['text_region_embedding'].float())
         video_embeddings = mix(video_embeddings, mean_rows(video_region), 0.5, 0.5)
+        main.wait_stream(side)
+        text_embeddings.record_stream(main)
+        text_region.record_stream(main)
         return text_embeddings, video_embeddings, self.compute_region_sim(object_region, text_region)
 
     def compute_text(self, text_data, pad=False):
