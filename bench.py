@@ -102,7 +102,9 @@ def _gemm_class(kind, epi, M, N, K):
     if kind == "tn":
         big = M >= 4096 and N % 256 == 0 and K % 256 == 0          # (N, K) = (N1, N2) here
         return "gemm_tn_pp_kernel (+ tn_reduce)" if big else "gemm_tn_kernel<2,2,4,4> (+ tn_reduce)"
-    big = M >= 4096 and N % 256 == 0
+    u8 = bool(epi & 0x100)                     # 8-bit GELU derivative: always the ping-pong kernel
+    epi &= 0xff
+    big = M >= 4096 and N % 256 == 0 and (u8 or ((M + 255) // 256) * (N // 256) * 5 >= 256 * 2)
     nk = K // 64
     if big and epi in (0, 5, 6) and N <= 4096 and nk >= 2 and nk % 2 == 0:
         return f"gemm_nt_pp_kernel<{epis[epi]}>"

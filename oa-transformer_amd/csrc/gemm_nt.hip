@@ -686,7 +686,10 @@ static int launch_big(const GemmArgs& g, hipStream_t s) {
 
 template <int EPI>
 static int launch(const GemmArgs& g, hipStream_t s) {
-  const bool big = g_variant >= 2 || (g_variant == 0 && g.M >= 4096 && g.N % 256 == 0);
+  // 256x256 tiles need enough of them: below ~100 tiles (the object clip of the OA variants, 6304 rows x 768 columns = 75
+  // tiles on 256 CUs) the 128x128 configuration's 300 quarter tiles finish 20-30 % sooner (scripts/dev/small_m_gemm.py)
+  const bool big = g_variant >= 2 || (g_variant == 0 && g.M >= 4096 && g.N % 256 == 0 &&
+                                      ((g.M + 255) / 256) * (g.N / 256) * 5 >= cu_count() * 2);
   if (big && g_variant == 3) return launch_cfg<EPI, 2, 2, 8, 8, 3, false, true>(g, s);   // 4 waves x 128x128, hand-pipelined
   if (big) {
     // Tail split.  256x256 tiles leave the last round of workgroups mostly empty when tiles % CUs is small (N = 768 at
