@@ -45,6 +45,8 @@ def encode_object_and_video(model, v):
         raise ValueError(f"object_clip = {layout!r}: expected 'auto', 'interleaved' or 'native'")
     if F < 2:
         raise ValueError("native object clip layout needs the object frame and at least one video frame")
+    # (Measured: encoding the object clip on its own stream beside the video clip gains nothing - 70.2 vs 69.8 ms; its short
+    # workgroups do not fill the tails of the video clip's launches.  Folding its rows into the same launches is the open step.)
     obj_emb, obj_region = model.compute_video(v[:, :1])
     vid_emb, vid_region = model.compute_video(v[:, 1:])
     return obj_emb, obj_region, vid_emb, vid_region

@@ -100,6 +100,13 @@ class _EncoderFn(torch.autograd.Function):
             d_region = d_region.reshape(-1, D).float()
         accumulate = module._bwd_calls > 0
         module._bwd_calls += 1
+        # autograd runs a backward on the stream of its forward.  Two clips encoded on two streams: the accumulating
+        # backward must not overtake the one that overwrites the gradient buffers
+        cur = torch.cuda.current_stream()
+        prev = module.__dict__.get("_last_bwd_stream")
+        if accumulate and prev is not None and prev != cur:
+            cur.wait_stream(prev)
+        module.__dict__["_last_bwd_stream"] = cur
         # a block's gradients are final - and may go to the all-reduce / eager optimiser - only in the LAST backward of
         # the step (earlier clips have been accumulated by then); if a clip's output never receives a gradient the
         # ranges stay unannounced and are handled after backward (GradSync.all_reduce / AdamW.step)
