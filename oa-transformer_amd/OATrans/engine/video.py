@@ -10,7 +10,12 @@ buffers sized once per shape ("plan"; 288 GB of HBM3E holds every saved activati
 
 HBM layout
   token rows  : patch (b,f,n) -> row (b*T+f)*N + n ; CLS(b) -> row B*T*N + b ; M = B*T*N + B
-                rows, padded with zero rows to a multiple of 256 (GEMM tiles never branch on M)
+                rows, padded with zero rows to a multiple of 256 (GEMM tiles never branch on M).
+                A forward may take SEVERAL clips of different frame counts (the object-aware models: one object frame +
+                a T-frame clip per sample): each clip is a *segment* of the row space laid out as above, one after the
+                other.  Every row-wise kernel (GEMMs, LayerNorm, quantisation, weight gradients) runs once over all
+                segments - a 6304-row object clip alone leaves most CUs idle, as 12 % more rows of the video clip's
+                launches it is free - and only attention, embedding and the CLS rows are handled per segment.
   residuals   : fp32 [Mp, D]          (x, x+time, x+space, block output)
   GEMM inputs : bf16 [Mp, D|3D|4D]    (LN outputs, qkv, attention outputs, MLP hidden)
   weights     : fp32 masters (nn.Parameters, reference state_dict names) + bf16 shadows
@@ -51,23 +56,50 @@ class _BlockActs:
         self.stats = torch.zeros(6, Mp, dtype=torch.float32, device=dev)   # mean/rstd of norm3, norm1, norm2
 
 
-class _Plan:
-    """Activation and gradient buffers of one (B, T, N) shape, allocated once and reused every step."""
+class _Seg:
+    """One clip batch [B, T] inside a plan's row space: rows [row0, row0 + B*T*N) are its patch tokens, the next B its CLS
+    tokens; lane0 = its first row in the (sum of B)-row buffers of the CLS lane."""
 
-    def __init__(self, B, T, N, D, Hd, H, depth, Kp, dev):
+    def __init__(self, B, T, N, row0, lane0, D, H, Kp, dev):
         self.B, self.T, self.N = B, T, N
-        self.M = B * T * N + B
+        self.BTN = B * T * N
+        self.M = self.BTN + B
+        self.row0, self.cls0, self.end = row0, row0 + self.BTN, row0 + self.M
+        self.lane0 = lane0
+        self.cols = torch.zeros(_round_up(self.BTN, 256), Kp, dtype=torch.bfloat16, device=dev)
+        self.table = torch.zeros(T * N, D, dtype=torch.float32, device=dev)
+        self.cls_side = torch.zeros(B, H, 3, 64, dtype=torch.float32, device=dev)
+        self.Gp = torch.zeros(T * N, D, dtype=torch.float32, device=dev)
+        self.video = self.video_buf = None                # static copy of the input clip
+        self.d_region_buf = None
+
+    def rows(self, t):
+        """this segment's rows (patches + CLS) of a [Mp, ...] buffer"""
+        return t[self.row0:self.end]
+
+    def lane(self, t):
+        return t[self.lane0:self.lane0 + self.B]
+
+
+class _Plan:
+    """Activation and gradient buffers of one list of (B, T, N) clip shapes, allocated once and reused every step."""
+
+    def __init__(self, shapes, D, Hd, H, depth, Kp, dev):
+        self.segs, row0, lane0 = [], 0, 0
+        for (B, T, N) in shapes:
+            self.segs.append(_Seg(B, T, N, row0, lane0, D, H, Kp, dev))
+            row0 += self.segs[-1].M
+            lane0 += B
+        self.M, self.Bsum = row0, lane0
         self.Mp = _round_up(self.M, 256)
         Mp = self.Mp
         z16 = lambda c: torch.zeros(Mp, c, dtype=torch.bfloat16, device=dev)
         self.blocks = [_BlockActs(Mp, D, Hd, H, dev) for _ in range(depth)]
         self.x0 = torch.zeros(Mp, D, dtype=torch.float32, device=dev)
-        self.cols = torch.zeros(_round_up(B * T * N, 256), Kp, dtype=torch.bfloat16, device=dev)
-        self.table = torch.zeros(T * N, D, dtype=torch.float32, device=dev)
         self.cls0 = torch.zeros(D, dtype=torch.float32, device=dev)
         self.fstats = torch.zeros(2, Mp, dtype=torch.float32, device=dev)
         self.normed = torch.zeros(Mp, D, dtype=torch.float32, device=dev)
-        self.region = None                      # [B*T*N, D] fp32, allocated on first use (region_mem variant)
+        self.region = None                      # [Mp, D] fp32, allocated on first use (region_mem variant)
         self.rstats = None
         self.branch16 = z16(D)                  # forward: bf16 branch output awaiting its fused add + LayerNorm
         # backward temporaries.  Weight gradients read their dY from small rings so the chain can run ahead:
@@ -78,13 +110,10 @@ class _Plan:
         self.sets = [dict(d_h=z16(Hd), gb=z16(D), d_qkv_s=z16(3 * D), gc=z16(D), d_qkv_t=z16(3 * D)) for _ in range(2)]
         self.d_a = z16(D)
         self.d_o = z16(D)
-        self.cls_side = torch.zeros(B, H, 3, 64, dtype=torch.float32, device=dev)
-        self.Gp = torch.zeros(T * N, D, dtype=torch.float32, device=dev)
-        self.side = self.video = self.x_final = None      # set per call
-        self.video_buf = None                             # static copy of the input clip
+        self.side = self.x_final = None                   # set per call
         self.tape_fwd = self.tape_bwd = None              # (key, tape id, outputs, segments)
         self.dn = torch.zeros(Mp, D, dtype=torch.float32, device=dev)     # static copy of the output gradients
-        self.d_region_buf = None
+        self.d_region = None                              # [Mp, D] static copy of the region-token gradients
         self.lane = None                                  # fp32 buffers of the precise CLS lane (VideoEngine.forward)
 
 
@@ -93,11 +122,16 @@ class _Run:
 
     def __init__(self, pl, need_patches, region_layer):
         self.pl, self.need_patches, self.region_layer = pl, need_patches, region_layer
-        self.B, self.G = pl.B, pl.G
+        self.G = pl.G
+
+    @property
+    def regions(self):
+        """region tokens per segment: [B*T*N, D] views"""
+        return [self.pl.region[sg.row0:sg.cls0] for sg in self.pl.segs]
 
     @property
     def region(self):
-        return self.pl.region
+        return self.regions[0]
 
     @property
     def blocks(self):
@@ -304,12 +338,12 @@ class VideoEngine:
         f8 = self._f8
         hip.fp8_update_scales(f8["amax"], f8["qscale"], f8["dq"], f8["n"], self.fp8_margin)
 
-    def plan(self, B, T, N, dev, call=0):
-        """One plan per clip shape AND per call of a step: the object-aware models encode two clips (object frame,
-        video) through the same weights in one step, and each forward's activations must survive to its backward."""
-        key = (B, T, N, str(dev), call)
+    def plan(self, shapes, dev, call=0):
+        """One plan per list of clip shapes AND per call of a step (each forward's activations must survive to its
+        backward)."""
+        key = (tuple(shapes), str(dev), call)
         if key not in self.plans:
-            self.plans[key] = _Plan(B, T, N, self.D, self.Hd, self.H, self.depth, self.Kp, dev)
+            self.plans[key] = _Plan(shapes, self.D, self.Hd, self.H, self.depth, self.Kp, dev)
         return self.plans[key]
 
     def _get_streams(self, dev):
@@ -322,30 +356,40 @@ class VideoEngine:
     # ------------------------------------------------------------------ forward
     def forward(self, video, params, need_patches=False, sig=None, region_layer=None, call=0):
         """video [B,T,C,R,R] fp32|bf16 -> (cls_normed fp32 [B,D], patches_normed fp32 [B*T*N, D] | None, run).
-        region_layer=K additionally leaves region_norm(x after block K)[patch rows] in run.region
-        (oa_video_transformer_region.py:364-376)."""
-        B, T, C, R, _ = video.shape
-        if T > self.num_frames:
-            raise ValueError(f"{T} frames > num_frames={self.num_frames}")     # video_transformer.py:73
+        region_layer=K additionally leaves region_norm(x after block K)[patch rows] in run.region(s)
+        (oa_video_transformer_region.py:364-376).
+        video may be a LIST of clips (same C, R; any B, T): they are encoded together as segments of one row space and
+        the first two results are lists (one entry per clip)."""
+        many = isinstance(video, (list, tuple))
+        clips = list(video) if many else [video]
+        C, R = clips[0].shape[2], clips[0].shape[3]
         g = R // self.ps
         N = g * g
+        shapes = []
+        for v in clips:
+            if v.shape[1] > self.num_frames:
+                raise ValueError(f"{v.shape[1]} frames > num_frames={self.num_frames}")     # video_transformer.py:73
+            if v.shape[2] != C or v.shape[3] != R:
+                raise ValueError("clips encoded together must share channels and resolution")
+            shapes.append((v.shape[0], v.shape[1], N))
         self.refresh_shadows(params, sig)
-        dev = video.device
+        dev = clips[0].device
         if self.splitk and not self._splitk_set:
             hip.enable_splitk(dev)               # the N = 768 GEMMs run 2.31 rounds of tiles: share the last round's K range
             self._splitk_set = True
         st = self._get_streams(dev)
-        pl = self.plan(B, T, N, dev, call)
+        pl = self.plan(shapes, dev, call)
         pl.side = st["side"]
-        # the clip is copied into a plan-owned buffer: every launch of the schedule then has static arguments and the
+        # the clips are copied into plan-owned buffers: every launch of the schedule then has static arguments and the
         # schedule can be replayed from its tape (csrc/tape.hip)
-        if pl.video_buf is None or pl.video_buf.dtype != video.dtype or pl.video_buf.shape != video.shape:
-            pl.video_buf = torch.empty(video.shape, dtype=video.dtype, device=dev)
-            pl.tape_fwd = None
-        pl.video_buf.copy_(video)
-        pl.video = pl.video_buf
+        for sg, v in zip(pl.segs, clips):
+            if sg.video_buf is None or sg.video_buf.dtype != v.dtype or sg.video_buf.shape != v.shape:
+                sg.video_buf = torch.empty(v.shape, dtype=v.dtype, device=dev)
+                pl.tape_fwd = None
+            sg.video_buf.copy_(v)
+            sg.video = sg.video_buf
         if self.cls_lane and pl.lane is None:
-            z = lambda c: torch.zeros(B, c, dtype=torch.float32, device=dev)
+            z = lambda c: torch.zeros(pl.Bsum, c, dtype=torch.float32, device=dev)
             pl.lane = dict(x=z(self.D), xt=z(self.D), y=z(self.D), out=z(self.D), a32=z(self.D), q32=z(self.D), o32=z(self.D),
                            br32=z(self.D), g32=z(self.Hd))
         elif not self.cls_lane:
@@ -377,7 +421,9 @@ class VideoEngine:
 
         key = self._tape_key(pl, params, None, need_patches, region_layer, C, R)
         out = self._taped(pl, "tape_fwd", key, body)
-        return out[0], out[1], run
+        if many:
+            return out[0], out[1], run
+        return out[0][0], out[1][0], run
 
     # ------------------------------------------------------------------ launch tapes
     def _tape_key(self, pl, params, grads, *flags):
@@ -434,13 +480,13 @@ class VideoEngine:
         return out
 
     def _embed(self, pl, params, C, R):
-        B, T, N, D = pl.B, pl.T, pl.N, self.D
-        BTN = B * T * N
-        hip.im2col(pl.video, pl.cols, B * T, C, R, self.ps)
-        hip.pos_table(params["pos_embed"], params["temporal_embed"], params["cls_token"], pl.table, pl.cls0, T, N, D)
-        hip.gemm_nt(pl.cols, self.shadow["patch_embed.proj.weight"][0], BTN, D, self.Kp, hip.EPI_F32, pl.x0,
-                    bias=params["patch_embed.proj.bias"], resid=pl.table, resid_mod=T * N)
-        hip.broadcast_rows(pl.cls0, pl.x0[BTN:], B, D)
+        D = self.D
+        for sg in pl.segs:
+            hip.im2col(sg.video, sg.cols, sg.B * sg.T, C, R, self.ps)
+            hip.pos_table(params["pos_embed"], params["temporal_embed"], params["cls_token"], sg.table, pl.cls0, sg.T, sg.N, D)
+            hip.gemm_nt(sg.cols, self.shadow["patch_embed.proj.weight"][0], sg.BTN, D, self.Kp, hip.EPI_F32, pl.x0[sg.row0:],
+                        bias=params["patch_embed.proj.bias"], resid=sg.table, resid_mod=sg.T * sg.N)
+            hip.broadcast_rows(pl.cls0, pl.x0[sg.cls0:], sg.B, D)
 
     # ---- the precise CLS lane ------------------------------------------------------------------------------------
     # The cosine-similarity matrix must match the fp32 reference within 1e-3.  Only the CLS row of a clip reaches the
@@ -456,21 +502,20 @@ class VideoEngine:
         """side stream: [sum32 = x + add32 ;] y32 = LayerNorm(.)  on the lane's B fp32 rows"""
         with torch.cuda.stream(pl.side):
             if add32 is None:
-                hip.layernorm_fwd(x, gamma, beta, pl.B, self.D, 1e-6, y32=y32)
+                hip.layernorm_fwd(x, gamma, beta, pl.Bsum, self.D, 1e-6, y32=y32)
             else:
-                hip.add32_layernorm_fwd(x, add32, sum32, gamma, beta, pl.B, self.D, 1e-6, y32=y32)
+                hip.add32_layernorm_fwd(x, add32, sum32, gamma, beta, pl.Bsum, self.D, 1e-6, y32=y32)
 
     def _lane_linear(self, pl, A, W, bias, N, K, out32, act=0):
         with torch.cuda.stream(pl.side):
-            hip.linear_f32(A, W, pl.B, N, K, bias=bias, out32=out32, act=act)
+            hip.linear_f32(A, W, pl.Bsum, N, K, bias=bias, out32=out32, act=act)
 
     def _block_fwd(self, pl, i, params, pend, region_layer):
         """Residual adds are fused into the NEXT LayerNorm (oat_add_layernorm_fwd): the projection / fc2 GEMMs
         write their branch output as bf16 and the streaming LN kernel forms x + branch, stores the new fp32
         stream and the normalised bf16 operand in one pass.  `pend` = the previous block, whose
         out = y + branch is still to be formed."""
-        M, D, Hd, B = pl.M, self.D, self.Hd, pl.B
-        BTN = M - B
+        M, D, Hd = pl.M, self.D, self.Hd
         a, br = pl.blocks[i], pl.branch16
         p = lambda s: params[f"blocks.{i}.{s}"]
         w = lambda s: self.shadow[f"blocks.{i}.{s}.weight"][0]
@@ -486,7 +531,8 @@ class VideoEngine:
             if lane is not None:                         # the lane starts from the embedding's CLS rows
                 hip.stream_edge(torch.cuda.current_stream(), pl.side)
                 with torch.cuda.stream(pl.side):
-                    hip.copy_(lane["x"], x[BTN:M])
+                    for sg in pl.segs:
+                        hip.copy_(sg.lane(lane["x"]), x[sg.cls0:sg.end])
                 self._lane_ln(pl, lane["x"], None, None, p("norm3.weight"), p("norm3.bias"), lane["a32"])
         else:
             if q3:
@@ -559,8 +605,8 @@ class VideoEngine:
         return a                                                                    # out = y + br, formed lazily
 
     def _final_fwd(self, pl, params, need_patches, region_layer):
-        B, M, D = pl.B, pl.M, self.D
-        BTN = M - B
+        """-> ([cls rows per segment], [patch rows per segment] | [None, ...])"""
+        M, D = pl.M, self.D
         last, br = pl.blocks[-1], pl.branch16
         pl.x_final = last.out
         lane = pl.lane
@@ -572,14 +618,16 @@ class VideoEngine:
                 self._region_tap(pl, params, last.out)
         else:
             # contract class: only the CLS rows of the last block's output are ever consumed
-            hip.add_layernorm_fwd(last.y[BTN:], br[BTN:], last.out[BTN:], g, bt, B, D, 1e-6, y32=pl.normed[BTN:],
-                                  mean=pl.fstats[0][BTN:], rstd=pl.fstats[1][BTN:])
-        cls_out = pl.normed[BTN:M]
+            for sg in pl.segs:
+                c0 = sg.cls0
+                hip.add_layernorm_fwd(last.y[c0:], br[c0:], last.out[c0:], g, bt, sg.B, D, 1e-6, y32=pl.normed[c0:],
+                                      mean=pl.fstats[0][c0:], rstd=pl.fstats[1][c0:])
+        cls_out = [pl.normed[sg.cls0:sg.end] for sg in pl.segs]
         if lane is not None:                              # the CLS embedding comes from the lane's fp32 rows
             self._lane_ln(pl, lane["y"], lane["br32"], lane["x"], g, bt, lane["out"])
             hip.stream_edge(pl.side, torch.cuda.current_stream())
-            cls_out = lane["out"]
-        return cls_out, (pl.normed[:BTN] if need_patches else None)
+            cls_out = [sg.lane(lane["out"]) for sg in pl.segs]
+        return cls_out, [pl.normed[sg.row0:sg.cls0] if need_patches else None for sg in pl.segs]
 
     def _attention(self, pl, patch_kernel, qkv, out, lse):
         """Patch attention on the caller's stream, the independent CLS-query attention (it only writes the
@@ -587,20 +635,24 @@ class VideoEngine:
         cur = torch.cuda.current_stream()
         hip.stream_edge(cur, pl.side)                    # qkv is complete
         with torch.cuda.stream(pl.side):
-            if pl.lane is not None:
-                hip.attn_cls_fwd_dual(qkv, out, lse, pl.lane["q32"], pl.lane["o32"], pl.B, pl.T, pl.N, self.H, self.D, self.scale)
-            else:
-                hip.attn_cls_fwd(qkv, out, lse, pl.B, pl.T, pl.N, self.H, self.D, self.scale)
-        patch_kernel(qkv, out, lse, pl.B, pl.T, pl.N, self.H, self.D, self.scale)
+            for sg in pl.segs:                           # attention is per clip: each segment is a self-contained row range
+                q, o, l = sg.rows(qkv), sg.rows(out), sg.rows(lse)
+                if pl.lane is not None:
+                    hip.attn_cls_fwd_dual(q, o, l, sg.lane(pl.lane["q32"]), sg.lane(pl.lane["o32"]), sg.B, sg.T, sg.N, self.H,
+                                          self.D, self.scale)
+                else:
+                    hip.attn_cls_fwd(q, o, l, sg.B, sg.T, sg.N, self.H, self.D, self.scale)
+        for sg in pl.segs:
+            patch_kernel(sg.rows(qkv), sg.rows(out), sg.rows(lse), sg.B, sg.T, sg.N, self.H, self.D, self.scale)
         hip.stream_edge(pl.side, cur)
 
     def _region_tap(self, pl, params, x):
         """region_norm(x after block K)[patch rows] (oa_video_transformer_region.py:364-376)."""
-        BTN, D = pl.M - pl.B, self.D
-        if pl.region is None:
-            pl.region = torch.zeros(BTN, D, dtype=torch.float32, device=x.device)
-            pl.rstats = torch.zeros(2, BTN, dtype=torch.float32, device=x.device)
-        hip.layernorm_fwd(x, params["region_norm.weight"], params["region_norm.bias"], BTN, D, 1e-6, y32=pl.region,
+        M, D = pl.M, self.D
+        if pl.region is None:                      # all rows (row-wise kernel; the few CLS rows in between are never read)
+            pl.region = torch.zeros(pl.Mp, D, dtype=torch.float32, device=x.device)
+            pl.rstats = torch.zeros(2, pl.Mp, dtype=torch.float32, device=x.device)
+        hip.layernorm_fwd(x, params["region_norm.weight"], params["region_norm.bias"], M, D, 1e-6, y32=pl.region,
                           mean=pl.rstats[0], rstd=pl.rstats[1])
 
     # ------------------------------------------------------------------ backward
@@ -622,23 +674,40 @@ class VideoEngine:
         pl.acc = bool(accumulate)
         if run.region_layer is not None:
             ready = None                     # region_norm gradients arrive out of block order: reduce after backward
-        # the incoming gradients go into plan-owned buffers (static launch arguments: the schedule replays from its tape)
-        BTN = pl.M - pl.B
-        pl.dn[BTN:pl.M].copy_(d_cls)
-        have_patches = run.need_patches and d_patches is not None
-        if have_patches:
-            pl.dn[:BTN].copy_(d_patches)
-        if d_region is not None:
-            if pl.d_region_buf is None:
-                pl.d_region_buf = torch.empty(BTN, self.D, dtype=torch.float32, device=run.G.device)
-            pl.d_region_buf.copy_(d_region)
-            d_region = pl.d_region_buf
+        # The incoming gradients go into plan-owned buffers (static launch arguments: the schedule replays from its tape).
+        # One entry per segment (a bare tensor = the only segment's); None = that output received no gradient.
+        as_list = lambda v: list(v) if isinstance(v, (list, tuple)) else [v]
+        d_cls, d_patches, d_region = as_list(d_cls), as_list(d_patches), as_list(d_region)
+        nseg = len(pl.segs)
+        d_patches = d_patches if len(d_patches) == nseg else [None] * nseg
+        d_region = d_region if len(d_region) == nseg else [None] * nseg
+        have_patches = run.need_patches and any(t is not None for t in d_patches)
+        have_region = run.region_layer is not None and any(t is not None for t in d_region)
+        if have_region and pl.d_region is None:
+            pl.d_region = torch.zeros(pl.Mp, self.D, dtype=torch.float32, device=run.G.device)
+        for sg, dc, dp, dr in zip(pl.segs, d_cls, d_patches, d_region):
+            if dc is None:
+                pl.dn[sg.cls0:sg.end].zero_()
+            else:
+                pl.dn[sg.cls0:sg.end].copy_(dc)
+            if have_patches:
+                if dp is None:
+                    pl.dn[sg.row0:sg.cls0].zero_()
+                else:
+                    pl.dn[sg.row0:sg.cls0].copy_(dp)
+            if have_region:
+                if dr is None:
+                    pl.d_region[sg.row0:sg.cls0].zero_()
+                else:
+                    pl.d_region[sg.row0:sg.cls0].copy_(dr)
+        d_region = pl.d_region if have_region else None
         prefixes = [(f"blocks.{i}.", "norm.") if i == self.depth - 1 else (f"blocks.{i}.",) for i in reversed(range(self.depth))]
         prefixes.append(("cls_token", "pos_embed", "temporal_embed", "patch_embed."))
         use_marks = ready is not None
 
         def body():
-            hip.zero_(pl.cls_side)       # once per backward; every attn_cls_finalize leaves it zero for the next one
+            for sg in pl.segs:
+                hip.zero_(sg.cls_side)   # once per backward; every attn_cls_finalize leaves it zero for the next one
             self._final_bwd(pl, run, params, grads, have_patches, d_region)
             hip.gemm_set_tail_split(self.tail_split and not self.bwd_side)
             hip.gemm_tn_set_variant((self.wgrad_cus << 16) if self.bwd_side else 0)
@@ -706,29 +775,36 @@ class VideoEngine:
         hip.gemm_tn(P, Q, rows, n1, n2, w, bias_out=b, ws=self._tn_ws, accumulate=acc)
 
     def _final_bwd(self, pl, run, params, grads, have_patches, d_region):
-        """pl.dn holds dL/d(normed output): rows [:BTN] the patch tokens (when they received a gradient), [BTN:] the CLS rows."""
+        """pl.dn holds dL/d(normed output) in the plan's row layout (patch rows are only valid with have_patches)."""
         D = self.D
-        B, M = pl.B, pl.M
-        BTN = M - B
+        M = pl.M
         G = pl.G
         g16 = pl.ga[(self.depth - 1) % 3]
         if have_patches:
             hip.layernorm_bwd(pl.dn, pl.x_final, pl.fstats[0], pl.fstats[1], params["norm.weight"], M, D, dx=G, dx16=g16,
                               dgamma=grads["norm.weight"], dbeta=grads["norm.bias"], accumulate=pl.acc)
         else:
-            hip.zero_(G[:BTN])
-            hip.zero_(g16[:BTN])
-            hip.layernorm_bwd(pl.dn[BTN:], pl.x_final[BTN:], pl.fstats[0][BTN:], pl.fstats[1][BTN:], params["norm.weight"], B, D,
-                              dx=G[BTN:], dx16=g16[BTN:], dgamma=grads["norm.weight"], dbeta=grads["norm.bias"],
-                              accumulate=pl.acc)
+            hip.zero_(G[:M])
+            hip.zero_(g16[:M])
+            for k, sg in enumerate(pl.segs):
+                c0 = sg.cls0
+                hip.layernorm_bwd(pl.dn[c0:], pl.x_final[c0:], pl.fstats[0][c0:], pl.fstats[1][c0:], params["norm.weight"], sg.B, D,
+                                  dx=G[c0:], dx16=g16[c0:], dgamma=grads["norm.weight"], dbeta=grads["norm.bias"],
+                                  accumulate=pl.acc or k > 0)
         if run.region_layer is not None and d_region is None and not pl.acc:
             for k in ("region_norm.weight", "region_norm.bias"):
                 hip.zero_(grads[k])
 
+    def _attn_bwd(self, pl, kernel, qkv, o, lse, d_o, d_qkv):
+        """attention backward + the CLS-row finalize, per segment (each clip is a self-contained row range)"""
+        for sg in pl.segs:
+            dq = sg.rows(d_qkv)
+            kernel(sg.rows(qkv), sg.rows(o), sg.rows(lse), sg.rows(d_o), dq, sg.cls_side, sg.B, sg.T, sg.N, self.H, self.D, self.scale)
+            hip.attn_cls_finalize(sg.cls_side, dq, sg.B, sg.T, sg.N, self.H, self.D)
+
     def _block_bwd(self, pl, i, run, params, grads, d_region):
-        B, T, N, M = pl.B, pl.T, pl.N, pl.M
+        M = pl.M
         D, Hd, H = self.D, self.Hd, self.H
-        BTN = M - B
         G = pl.G
         a = pl.blocks[i]
         st8 = pl.sets[i % 2]
@@ -736,8 +812,9 @@ class VideoEngine:
         rl = run.region_layer
         if rl is not None and d_region is not None and i + 1 == rl:
             # region tokens branch off the output of block rl-1: add their gradient to the stream
+            # (all M rows: the CLS rows in between carry a zero gradient and come out unchanged)
             hip.layernorm_bwd(d_region, a.out, pl.rstats[0], pl.rstats[1], params["region_norm.weight"],
-                              BTN, D, dx=G, dx16=ga, dres=G, dgamma=grads["region_norm.weight"],
+                              M, D, dx=G, dx16=ga, dres=G, dgamma=grads["region_norm.weight"],
                               dbeta=grads["region_norm.bias"], accumulate=pl.acc)
         x = pl.blocks[i - 1].out if i > 0 else pl.x0
         p = lambda s: params[f"blocks.{i}.{s}"]
@@ -760,8 +837,7 @@ class VideoEngine:
         hip.gemm_nt(gb, wT("attn.proj"), M, D, D, hip.EPI_BF16, pl.d_o)
 
         def space_bwd():
-            hip.attn_space_bwd(a.qkv_s, a.o_s, a.lse_s, pl.d_o, d_qkv_s, pl.cls_side, B, T, N, H, D, self.scale)
-            hip.attn_cls_finalize(pl.cls_side, d_qkv_s, B, T, N, H, D)
+            self._attn_bwd(pl, hip.attn_space_bwd, a.qkv_s, a.o_s, a.lse_s, pl.d_o, d_qkv_s)
         s2 = self._slot(pl, space_bwd,
                         [lambda: self._wgrad(d_h, a.a2, M, Hd, D, gr("mlp.fc1.weight"), gr("mlp.fc1.bias"), pl.acc)])
         self._join(s2)
@@ -776,8 +852,7 @@ class VideoEngine:
         hip.gemm_nt(gc, wT("timeattn.proj"), M, D, D, hip.EPI_BF16, pl.d_o)
 
         def time_bwd():
-            hip.attn_time_bwd(a.qkv_t, a.o_t, a.lse_t, pl.d_o, d_qkv_t, pl.cls_side, B, T, N, H, D, self.scale)
-            hip.attn_cls_finalize(pl.cls_side, d_qkv_t, B, T, N, H, D)
+            self._attn_bwd(pl, hip.attn_time_bwd, a.qkv_t, a.o_t, a.lse_t, pl.d_o, d_qkv_t)
         s4 = self._slot(pl, time_bwd,
                         [lambda: self._wgrad(gb, a.o_s, M, D, D, gr("attn.proj.weight"), gr("attn.proj.bias"), pl.acc),
                          lambda: self._wgrad(gc, a.o_t, M, D, D, gr("timeattn.proj.weight"), gr("timeattn.proj.bias"), pl.acc)])
@@ -794,9 +869,8 @@ class VideoEngine:
         in order on the caller's stream).  Producers of dY write the e5m2 copy themselves once the site has a scale:
         LayerNorm backward (gb, gc, the next block's ga), the fc2 data gradient's epilogue (d_h); the attention
         backward outputs and the top block's ga take one quantisation pass."""
-        B, T, N, M = pl.B, pl.T, pl.N, pl.M
+        M = pl.M
         D, Hd, H = self.D, self.Hd, self.H
-        BTN = M - B
         a = pl.blocks[i]
         st8 = pl.sets[i % 2]
         ga, ga_next = pl.ga[i % 3], pl.ga[(i - 1) % 3]
@@ -804,7 +878,7 @@ class VideoEngine:
         rl = run.region_layer
         if rl is not None and d_region is not None and i + 1 == rl:
             hip.layernorm_bwd(d_region, a.out, pl.rstats[0], pl.rstats[1], params["region_norm.weight"],
-                              BTN, D, dx=pl.G, dx16=ga, dres=pl.G, dgamma=grads["region_norm.weight"],
+                              M, D, dx=pl.G, dx16=ga, dres=pl.G, dgamma=grads["region_norm.weight"],
                               dbeta=grads["region_norm.bias"], accumulate=pl.acc)
             pl.ga8_valid = None                    # ga changed: its e5m2 copy is stale
         x = pl.blocks[i - 1].out if i > 0 else pl.x0
@@ -820,8 +894,7 @@ class VideoEngine:
         self._wgrad(ga, a.g, M, D, Hd, gr("mlp.fc2.weight"), gr("mlp.fc2.bias"), pl.acc)
         # ---- space attention
         self._dgrad_f8(pl, i, 3, gb, D, D, hip.EPI_BF16, pl.d_o, quantised=gb_q)
-        hip.attn_space_bwd(a.qkv_s, a.o_s, a.lse_s, pl.d_o, d_qkv_s, pl.cls_side, B, T, N, H, D, self.scale)
-        hip.attn_cls_finalize(pl.cls_side, d_qkv_s, B, T, N, H, D)
+        self._attn_bwd(pl, hip.attn_space_bwd, a.qkv_s, a.o_s, a.lse_s, pl.d_o, d_qkv_s)
         self._wgrad(d_h, a.a2, M, Hd, D, gr("mlp.fc1.weight"), gr("mlp.fc1.bias"), pl.acc)
         self._dgrad_f8(pl, i, 2, d_qkv_s, 3 * D, D, hip.EPI_BF16, pl.d_a)
         gc_q = self._ln_bwd(pl, i, 1, pl.d_a, a.xt, st[2], st[3], p("norm1.weight"), gc, gr("norm1.weight"), gr("norm1.bias"),
@@ -829,8 +902,7 @@ class VideoEngine:
         self._wgrad(d_qkv_s, a.a1, M, 3 * D, D, gr("attn.qkv.weight"), gr("attn.qkv.bias"), pl.acc)
         # ---- time attention
         self._dgrad_f8(pl, i, 1, gc, D, D, hip.EPI_BF16, pl.d_o, quantised=gc_q)
-        hip.attn_time_bwd(a.qkv_t, a.o_t, a.lse_t, pl.d_o, d_qkv_t, pl.cls_side, B, T, N, H, D, self.scale)
-        hip.attn_cls_finalize(pl.cls_side, d_qkv_t, B, T, N, H, D)
+        self._attn_bwd(pl, hip.attn_time_bwd, a.qkv_t, a.o_t, a.lse_t, pl.d_o, d_qkv_t)
         self._wgrad(gb, a.o_s, M, D, D, gr("attn.proj.weight"), gr("attn.proj.bias"), pl.acc)
         self._wgrad(gc, a.o_t, M, D, D, gr("timeattn.proj.weight"), gr("timeattn.proj.bias"), pl.acc)
         self._dgrad_f8(pl, i, 0, d_qkv_t, 3 * D, D, hip.EPI_BF16, pl.d_a)
@@ -843,19 +915,20 @@ class VideoEngine:
     def _embed_bwd(self, pl, grads):
         """x0[patch] = cols @ Wp^T + b + pos[1+n] + temporal[f] ; x0[cls] = cls + pos[0]"""
         D = self.D
-        B, T, N, M = pl.B, pl.T, pl.N, pl.M
-        BTN = M - B
         G = pl.G
         gw = grads["patch_embed.proj.weight"]
-        self._wgrad(pl.ga[(-1) % 3], pl.cols, BTN, D, self.Kp, gw.view(D, self.Kp), grads["patch_embed.proj.bias"], pl.acc)
-        hip.periodic_rowsum(G, B, T * N, D, pl.Gp)
-        gpos = grads["pos_embed"].view(N + 1, D)
         gt = grads["temporal_embed"].view(-1, D)
         gcls = grads["cls_token"].view(1, D)
-        acc = pl.acc
-        hip.periodic_rowsum(pl.Gp, T, N, D, gpos[1:], accumulate=acc)
-        if T < gt.shape[0] and not acc:
-            hip.zero_(gt[T:])
-        hip.grouped_rowsum(pl.Gp, T, N, D, gt[:T], accumulate=acc)
-        hip.grouped_rowsum(G[BTN:], 1, B, D, gcls, accumulate=acc)
+        g_in = pl.ga[(-1) % 3]                                # dL/dx0 as bf16 (block 0's LayerNorm-3 backward)
+        for k, sg in enumerate(pl.segs):                      # per clip: its own im2col columns, frame count, CLS rows
+            B, T, N = sg.B, sg.T, sg.N
+            acc = pl.acc or k > 0
+            self._wgrad(g_in[sg.row0:], sg.cols, sg.BTN, D, self.Kp, gw.view(D, self.Kp), grads["patch_embed.proj.bias"], acc)
+            hip.periodic_rowsum(G[sg.row0:], B, T * N, D, sg.Gp)
+            gpos = grads["pos_embed"].view(N + 1, D)
+            hip.periodic_rowsum(sg.Gp, T, N, D, gpos[1:], accumulate=acc)
+            if T < gt.shape[0] and not acc:
+                hip.zero_(gt[T:])
+            hip.grouped_rowsum(sg.Gp, T, N, D, gt[:T], accumulate=acc)
+            hip.grouped_rowsum(G[sg.cls0:], 1, B, D, gcls, accumulate=acc)
         hip.copy_(gpos[:1], gcls)        # pos_embed[0] only ever meets the CLS token: its gradient IS cls_token's

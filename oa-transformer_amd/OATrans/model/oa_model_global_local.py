@@ -45,8 +45,12 @@ def encode_object_and_video(model, v):
         raise ValueError(f"object_clip = {layout!r}: expected 'auto', 'interleaved' or 'native'")
     if F < 2:
         raise ValueError("native object clip layout needs the object frame and at least one video frame")
-    # (Measured: encoding the object clip on its own stream beside the video clip gains nothing - 70.2 vs 69.8 ms; its short
-    # workgroups do not fill the tails of the video clip's launches.  Folding its rows into the same launches is the open step.)
+    # Both clips go through the encoder as two SEGMENTS of one launch sequence (engine/video.py): alone on the GPU the object
+    # clip's GEMMs are 75-300 tiles wide and leave most CUs idle (it cost 14 ms for 12.5 % of the tokens; a second stream
+    # beside the video clip did not help, 70.2 vs 69.8 ms), as extra rows of the video clip's launches it is nearly free.
+    if os.environ.get("OAT_OBJ_SEGMENTS", "1") != "0" and hasattr(model, "compute_videos"):
+        (obj_emb, obj_region), (vid_emb, vid_region) = model.compute_videos([v[:, :1], v[:, 1:]])
+        return obj_emb, obj_region, vid_emb, vid_region
     obj_emb, obj_region = model.compute_video(v[:, :1])
     vid_emb, vid_region = model.compute_video(v[:, 1:])
     return obj_emb, obj_region, vid_emb, vid_region
@@ -133,3 +137,7 @@ class FrozenInTime(BaseModel):
     def compute_video(self, video_data):
         emb, region = self.video_model(video_data)
         return self.vid_proj(emb), region
+
+    def compute_videos(self, clips):
+        """compute_video for several clips encoded together"""
+        return [(self.vid_proj(emb), region) for emb, region in self.video_model.forward_clips(clips)]

@@ -87,5 +87,9 @@ class FrozenInTime(BaseModel):
         cls, region = self.video_model(video_data)
         return self.vid_proj(cls), self.vid_proj(region)
 
+    def compute_videos(self, clips):
+        """compute_video for several clips encoded together"""
+        return [(self.vid_proj(cls), self.vid_proj(region)) for cls, region in self.video_model.forward_clips(clips)]
+
     def compute_region_sim(self, video_feats, text_feats):
         return region_sim(text_feats, video_feats)

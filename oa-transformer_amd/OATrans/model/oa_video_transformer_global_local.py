@@ -16,3 +16,7 @@ class SpaceTimeTransformer(_Base):
     def forward(self, x):
         cls, patches = self.forward_features(x)
         return mix(cls, mean_rows(patches), 0.5, 0.5), patches
+
+    def forward_clips(self, clips):
+        """several clips in one launch sequence -> [(0.5 cls + 0.5 mean patches, patches), ...]"""
+        return [(mix(cls, mean_rows(patches), 0.5, 0.5), patches) for cls, patches in self.forward_features_clips(clips)]

@@ -21,3 +21,7 @@ class SpaceTimeTransformer(_Base):
     def forward(self, x):
         cls, _, region = self.forward_features(x)
         return cls, region
+
+    def forward_clips(self, clips):
+        """several clips in one launch sequence -> [(cls, region), ...]"""
+        return [(cls, region) for cls, _, region in self.forward_features_clips(clips)]

@@ -73,31 +73,35 @@ class _EncoderFn(torch.autograd.Function):
     models) accumulate; `begin_step()` of the owning model resets the call counters."""
 
     @staticmethod
-    def forward(ctx, module, video, need_patches, region_layer, *params):
-        eng = module._engine
+    def forward(ctx, module, n_clips, need_patches, region_layer, *rest):
+        """rest = n_clips clip tensors (encoded together as segments of one launch sequence, engine/video.py), then the
+        parameters.  Returns (cls, patches | None, region | None) per clip, flattened."""
+        clips, eng = list(rest[:n_clips]), module._engine
         pd = module._param_data()
         call = 0
         if module._track_calls:              # a forward that will be differentiated keeps its own activation plan
             call = module._fwd_calls
             module._fwd_calls += 1
-        cls, patches, plan = eng.forward(video, pd, need_patches, module._weights_signature(), region_layer, call=call)
-        ctx.module, ctx.plan = module, plan
+        cls, patches, plan = eng.forward(clips, pd, need_patches, module._weights_signature(), region_layer, call=call)
+        ctx.module, ctx.plan, ctx.n_clips = module, plan, n_clips
         ctx.set_materialize_grads(False)
-        B, D = video.shape[0], cls.shape[-1]
-        # outputs are views of plan buffers that the next step overwrites; consumers use them within the step
-        return (cls.clone(), patches.view(B, -1, D) if need_patches else None,
-                plan.region.view(B, -1, D) if region_layer is not None else None)
+        D = cls[0].shape[-1]
+        regions = plan.regions if region_layer is not None else [None] * n_clips
+        outs = []
+        for k, v in enumerate(clips):        # views of plan buffers that the next step overwrites; used within the step
+            B = v.shape[0]
+            outs += [cls[k].clone(), patches[k].view(B, -1, D) if need_patches else None,
+                     regions[k].view(B, -1, D) if region_layer is not None else None]
+        return tuple(outs)
 
     @staticmethod
-    def backward(ctx, d_cls, d_patches, d_region):
-        module, plan = ctx.module, ctx.plan
+    def backward(ctx, *douts):
+        module, plan, n_clips = ctx.module, ctx.plan, ctx.n_clips
         D = module.embed_dim
-        if d_cls is None:
-            d_cls = torch.zeros(plan.B, D, device=plan.G.device)
-        if d_patches is not None:
-            d_patches = d_patches.reshape(-1, D).float()
-        if d_region is not None:
-            d_region = d_region.reshape(-1, D).float()
+        flat = lambda t: None if t is None else t.reshape(-1, D).float()
+        d_cls = [flat(douts[3 * k]) for k in range(n_clips)]
+        d_patches = [flat(douts[3 * k + 1]) for k in range(n_clips)]
+        d_region = [flat(douts[3 * k + 2]) for k in range(n_clips)]
         accumulate = module._bwd_calls > 0
         module._bwd_calls += 1
         # autograd runs a backward on the stream of its forward.  Two clips encoded on two streams: the accumulating
@@ -112,11 +116,11 @@ class _EncoderFn(torch.autograd.Function):
         # ranges stay unannounced and are handled after backward (GradSync.all_reduce / AdamW.step)
         last = module._bwd_calls >= module._fwd_calls
         ready = module._announce if (module.grad_ready_hook is not None and last) else None
-        module._engine.backward(plan, module._param_data(), module._grad_views(), d_cls.float(), d_patches, d_region,
+        module._engine.backward(plan, module._param_data(), module._grad_views(), d_cls, d_patches, d_region,
                                 ready=ready, accumulate=accumulate)
         if last:
             module._fwd_calls = module._bwd_calls = 0        # step complete without begin_step(): start over
-        return (None, None, None, None) + (None,) * module._n_params
+        return (None, None, None, None) + (None,) * (n_clips + module._n_params)
 
 
 class SpaceTimeTransformer(EngineModule):
@@ -186,10 +190,25 @@ class SpaceTimeTransformer(EngineModule):
         hip.lib()
         params = [p for _, p in self._engine_params()]
         self._track_calls = torch.is_grad_enabled()
-        cls, patches, region = _EncoderFn.apply(self, x, bool(self.need_patch_tokens), self.region_layer, *params)
+        cls, patches, region = _EncoderFn.apply(self, 1, bool(self.need_patch_tokens), self.region_layer, x, *params)
         if self.region_layer is not None:
             return cls, patches, region
         return cls, patches
+
+    def forward_features_clips(self, clips):
+        """Several clips of different frame counts (same batch size is not required) through the encoder in ONE launch
+        sequence - the object-aware models' object frame + video clip.  -> list of forward_features() results."""
+        if not clips[0].is_cuda:
+            raise hip.OatError("SpaceTimeTransformer runs on MI355X only (no CPU path); use the oracle for CPU")
+        hip.lib()
+        params = [p for _, p in self._engine_params()]
+        self._track_calls = torch.is_grad_enabled()
+        outs = _EncoderFn.apply(self, len(clips), bool(self.need_patch_tokens), self.region_layer, *clips, *params)
+        res = []
+        for k in range(len(clips)):
+            cls, patches, region = outs[3 * k:3 * k + 3]
+            res.append((cls, patches, region) if self.region_layer is not None else (cls, patches))
+        return res
 
     def forward(self, x, aug=False):
         x = self.forward_features(x, aug=aug)

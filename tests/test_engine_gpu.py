@@ -211,3 +211,44 @@ def test_launch_tape_replays_the_same_training_trajectory():
     for n in p0:
         d = (p0[n] - p1[n]).abs()
         assert d.max().item() <= len(batches) * 2e-4 + 1e-6 and d.mean().item() < 2e-5, (n, d.max().item(), d.mean().item())
+
+
+def test_clips_encoded_together_equal_clips_encoded_alone():
+    """engine/video.py segments: two clips of different frame counts in ONE launch sequence (the object-aware models'
+    object frame + video clip) give the outputs of two separate forwards (row-wise kernels do not see the boundary;
+    attention / embedding run per segment) and the sum of their gradients."""
+    m = small_model()
+    a = si.seeded_tensor(SEED, "seg.a", (3, 1, 3, 48, 48)).cuda()
+    b = si.seeded_tensor(SEED, "seg.b", (2, 3, 3, 48, 48)).cuda()
+    ga = [si.seeded_tensor(SEED, "seg.ga.cls", (3, 128)).cuda(), si.seeded_tensor(SEED, "seg.ga.p", (3, 9, 128), std=0.1).cuda()]
+    gb = [si.seeded_tensor(SEED, "seg.gb.cls", (2, 128)).cuda(), si.seeded_tensor(SEED, "seg.gb.p", (2, 27, 128), std=0.1).cuda()]
+    # separately (two calls in one step: the second backward accumulates)
+    m.begin_step()
+    ca, pa = m(a)
+    cb, pb = m(b)
+    ((ca * ga[0]).sum() + (pa * ga[1]).sum() + (cb * gb[0]).sum() + (pb * gb[1]).sum()).backward()
+    torch.cuda.synchronize()
+    ref_out = [t.detach().clone() for t in (ca, pa, cb, pb)]
+    ref_grad = {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+    # together
+    m.begin_step()
+    (ca2, pa2), (cb2, pb2) = m.forward_features_clips([a, b])
+    ((ca2 * ga[0]).sum() + (pa2 * ga[1]).sum() + (cb2 * gb[0]).sum() + (pb2 * gb[1]).sum()).backward()
+    torch.cuda.synchronize()
+    for got, want in zip((ca2, pa2, cb2, pb2), ref_out):
+        assert got.shape == want.shape and rel(got, want) < 1e-5, rel(got, want)
+    for k, p in m.named_parameters():
+        if k in ref_grad:
+            assert rel(p.grad, ref_grad[k]) < 2e-3 and cosine(p.grad, ref_grad[k]) > 0.9999, (k, rel(p.grad, ref_grad[k]))
+    # a clip whose outputs receive no gradient at all
+    m.begin_step()
+    (ca3, _), (cb3, pb3) = m.forward_features_clips([a, b])
+    ((cb3 * gb[0]).sum() + (pb3 * gb[1]).sum()).backward()
+    m.begin_step()
+    cb4, pb4 = m(b)
+    g_tog = {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+    ((cb4 * gb[0]).sum() + (pb4 * gb[1]).sum()).backward()
+    torch.cuda.synchronize()
+    for k, p in m.named_parameters():
+        if k in g_tog and p.grad.norm() > 1e-6:
+            assert rel(g_tog[k], p.grad) < 2e-3, (k, rel(g_tog[k], p.grad))
