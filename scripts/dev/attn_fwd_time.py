@@ -20,3 +20,16 @@ for name, fn in (("space_fwd", hip.attn_space_fwd), ("time_fwd", hip.attn_time_f
     ts = sorted(timeit(lambda: fn(qkv, out, lse, B, T, N, H, D, 0.125)) for _ in range(5))
     print(f"{name}: {ts[2]:.1f} us (min {ts[0]:.1f})")
 print("checksum", out.float().abs().sum().item())
+q32 = torch.randn(B, D, device="cuda"); o32 = torch.zeros(B, D, device="cuda")
+ts = sorted(timeit(lambda: hip.attn_cls_fwd_dual(qkv, out, lse, q32, o32, B, T, N, H, D, 0.125)) for _ in range(5))
+print(f"cls_fwd_dual: {ts[2]:.1f} us (min {ts[0]:.1f})")
+side = torch.cuda.Stream()
+def both():
+    ev = torch.cuda.Event(); ev.record(); side.wait_event(ev)
+    with torch.cuda.stream(side):
+        hip.attn_cls_fwd_dual(qkv, out, lse, q32, o32, B, T, N, H, D, 0.125)
+        d = torch.cuda.Event(); d.record()
+    hip.attn_space_fwd(qkv, out, lse, B, T, N, H, D, 0.125)
+    torch.cuda.current_stream().wait_event(d)
+ts = sorted(timeit(both) for _ in range(5))
+print(f"space_fwd beside cls_fwd_dual: {ts[2]:.1f} us")
