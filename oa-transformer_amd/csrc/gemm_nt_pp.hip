@@ -63,8 +63,8 @@ OAT_DEV f32x4 hu8_unpack(uint32_t w) {
 
 // PPF_F8: OCP fp8 (e4m3) operands, per-tensor scaled.  A K-tile is still 128 BYTES of every row - now 128 k - so the
 // staging stream, the LDS layout, the swizzle, the region refill and every wait count are those of the bf16 kernel; a
-// lane's MFMA operand becomes the 32 consecutive k of its row group (chunks 2 fk, 2 fk + 1: lane l of
-// v_mfma_f32_16x16x128_f8f6f4 holds row l & 15, k = 32 (l >> 4) .. + 31; scripts/dev/fp8_probe) and one MFMA does the
+// lane's MFMA operand is 32 bytes of its row (lane l of v_mfma_f32_16x16x128_f8f6f4 holds row l & 15 and the k block
+// l >> 4; scripts/dev/fp8_probe - WHICH 32 k a block holds is free as long as A and B agree) and one MFMA does the
 // work of four bf16 ones in twice the time.  The accumulators hold the product of the QUANTISED operands; the epilogue
 // multiplies by the two dequantisation scales (device scalars, GemmArgs::dq_a / dq_b), the bias enters pre-divided.
 typedef __attribute__((ext_vector_type(8))) int i32x8;
@@ -387,7 +387,10 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs g) {
   uint32_t pA[2], pB[2];
 #pragma unroll
   for (int kk = 0; kk < 2; ++kk) {
-    const int ch = ((F8 ? fk * 2 + kk : kk * 4 + fk) ^ sw) << 4;   // bf16: k = 32 kk + 8 fk .. ; fp8: k = 32 fk + 16 kk ..
+    // bf16: k = 32 kk + 8 fk ..  fp8: the SAME chunks - lane group fk then holds bytes [16 fk, 16 fk + 16) and [64 + 16 fk, ..)
+    // of the 128-k tile instead of 32 consecutive k, for A and B alike, so every product still meets its partner (the MFMA
+    // only sums over k); the consecutive assignment (chunks 2 fk, 2 fk + 1) cost 4 LDS bank conflicts per read (PMC)
+    const int ch = ((kk * 4 + fk) ^ sw) << 4;
     pA[kk] = lds0 + (wm * 128 + frow) * 128 + ch;
     pB[kk] = lds0 + PP_B0 + (wn * 64 + frow) * 128 + ch;
   }

@@ -22,4 +22,24 @@ for _ in range(3):
     hip.attn_space_bwd(qkv, out, lse, dout, dqkv, side, B, T, N, H, D, 0.125)
     hip.attn_time_fwd(qkv, out, lse, B, T, N, H, D, 0.125)
     hip.attn_time_bwd(qkv, out, lse, dout, dqkv, side, B, T, N, H, D, 0.125)
+# round 2: fp8 forward GEMM, MLP-pair epilogues, LayerNorm
+st = torch.zeros(2, 3, device="cuda")
+for (n, k) in [(2304, 768), (768, 3072)]:
+    A = rb(Mp, k); W = (torch.randn(n, k, device="cuda") * k ** -0.5).bfloat16(); o = torch.zeros(Mp, n, device="cuda", dtype=torch.bfloat16)
+    A8 = torch.empty(Mp, k, dtype=torch.uint8, device="cuda"); W8 = torch.empty(n, k, dtype=torch.uint8, device="cuda")
+    for x, x8, r in ((A, A8, 0), (W, W8, 1)):
+        st[r].zero_(); hip.fp8_amax(x, x.shape[0], k, st[r, 0:1]); hip.fp8_update_scales(st[r, 0:1], st[r, 1:2], st[r, 2:3], 1)
+        hip.fp8_quant(x, x8, x.shape[0], k, st[r, 1:2])
+    for _ in range(3): hip.gemm_nt_f8(A8, W8, M, n, k, hip.EPI_BF16, o, st[0, 2:3], st[1, 2:3])
+A = rb(Mp, D); W = (torch.randn(4 * D, D, device="cuda") * D ** -0.5).bfloat16(); bias = torch.randn(4 * D, device="cuda")
+h8 = torch.zeros(Mp, 4 * D, dtype=torch.uint8, device="cuda"); g = torch.zeros(Mp, 4 * D, dtype=torch.bfloat16, device="cuda"); dh = torch.zeros_like(g)
+for _ in range(3):
+    hip.gemm_nt(A, W, M, 4 * D, D, hip.EPI_GELU_GRAD | hip.EPI_U8, h8, out2=g, bias=bias)
+    hip.gemm_nt(A, W, M, 4 * D, D, hip.EPI_MUL_AUX | hip.EPI_U8, dh, aux=h8)
+x = torch.randn(Mp, D, device="cuda"); br = rb(Mp, D); s32 = torch.zeros(Mp, D, device="cuda"); y = torch.zeros(Mp, D, dtype=torch.bfloat16, device="cuda")
+gam = torch.ones(D, device="cuda"); bet = torch.zeros(D, device="cuda"); mean = torch.zeros(Mp, device="cuda"); rstd = torch.zeros(Mp, device="cuda")
+G = torch.zeros(Mp, D, device="cuda"); dg = torch.zeros(D, device="cuda"); db = torch.zeros(D, device="cuda")
+for _ in range(3):
+    hip.add_layernorm_fwd(x, br, s32, gam, bet, M, D, 1e-6, y=y, mean=mean, rstd=rstd)
+    hip.layernorm_bwd(br, s32, mean, rstd, gam, M, D, dx=G, dx16=y, dres=G, dgamma=dg, dbeta=db)
 torch.cuda.synchronize()
