@@ -18,7 +18,15 @@ class _MeanRowsFn(torch.autograd.Function):
         x = x.float().contiguous()
         G, R, D = x.shape
         out = torch.empty(G, D, dtype=torch.float32, device=x.device)
-        hip.grouped_rowsum(x.view(G * R, D), G, R, D, out)
+        # one workgroup per group: with few long groups (32 clips x 1568 patch rows) only G CUs would stream the 154 MB.
+        # Two deterministic stages instead: G x S slices of R / S rows, then the S partial rows of every group.
+        S = next((s_ for s_ in range(min(32, R // 16), 1, -1) if R % s_ == 0), 1) if G < 256 and R >= 64 else 1
+        if S > 1:
+            part = torch.empty(G * S, D, dtype=torch.float32, device=x.device)
+            hip.grouped_rowsum(x.view(G * R, D), G * S, R // S, D, part)
+            hip.grouped_rowsum(part, G, S, D, out)
+        else:
+            hip.grouped_rowsum(x.view(G * R, D), G, R, D, out)
         out.mul_(1.0 / R)
         ctx.shape = (G, R, D)
         return out
