@@ -52,6 +52,9 @@ int oat_gemm_nt(const void* A, const void* B, int M, int N, int K, int lda, int 
  * runs the epilogue.  ws: caller-owned device memory (128 MiB covers every launch), 256 zeroed ints; NULL = off.
  * Launches that use it must be ordered on one stream. */
 int oat_gemm_set_splitk_workspace(void* ws, size_t bytes, void* zeroed_256_ints);
+/* 224-row tiles of the ping-pong kernel (epi 0): 0 never, 1 where rounds x tile rows is smaller than with 256-row tiles
+ * (default; e.g. M = 50208, N = 768: 3 rounds of 224 rows instead of 3 rounds of 256), 2 always.  Results are bit-identical. */
+void oat_gemm_set_m224(int mode);
 
 /* tuning hook.  bits 0-7: 0 = auto tile choice, 1 = force 128x128 (4 waves), 2 = force 256x256 (8 waves),
  * 3 = 256x256 with 4 hand-pipelined waves; bits 8-15: flags (ablations: 128 = static tile walk even with counters, 1 = skip the epilogue, 4 = all row panels write the first 1024

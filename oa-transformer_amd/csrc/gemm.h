@@ -56,6 +56,7 @@ int launch_tn_pp(const TnArgs& g, int flags, hipStream_t s);
 // gemm_nt_pp.hip.  pp_supported: does the ping-pong kernel cover this launch (epilogue, shape)?
 bool pp_supported(int epi, const GemmArgs& g);
 int launch_pp(int epi, const GemmArgs& g, int grid_slots, int flags, hipStream_t s);
+void pp_set_m224(int mode);      // 224-row tiles of the ping-pong kernel: 0 never, 1 where they save a round's worth (default), 2 always
 // the same kernel on OCP fp8 (e4m3) operands with per-tensor scales (GemmArgs::dq_a / dq_b)
 bool pp_f8_supported(int epi, const GemmArgs& g);
 int launch_pp_f8(int epi, const GemmArgs& g, int grid_slots, bool a_e5m2, hipStream_t s);

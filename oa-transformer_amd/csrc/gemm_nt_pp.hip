@@ -42,10 +42,12 @@ constexpr int PP_MAXN = 4096;                       // bias vector kept in LDS
 constexpr int PP_FLAG = PP_BIAS + PP_MAXN * 4;      // one word: the split-K arrival count, broadcast to the workgroup
 constexpr int PP_LDS = PP_FLAG + 16;
 
+static int g_pp_m224 = 1;           // 224-row tiles: 0 never, 1 where they save time (default), 2 always (tests); pp_set_m224
 enum : int { PPF_PRIO = 1, PPF_NOSTAGGER = 2, PPF_LGKM = 4, PPF_BONUS = 8, PPF_NOEPI = 16, PPF_PH2 = 32, PPF_WIDE = 64,
              PPF_F8 = 128, PPF_A_BF8 = 256,     // PPF_A_BF8: the A operand is e5m2 (gradients), B stays e4m3
              PPF_HU8 = 512,                     // the saved GELU derivative travels as 8-bit fixed point (see HU8_*)
-             PPF_SPLITK = 1024 };               // split-K of the last, partial round of tiles (see `sk_*` in the kernel)
+             PPF_SPLITK = 1024,                 // split-K of the last, partial round of tiles (see `sk_*` in the kernel)
+             PPF_M224 = 2048 };                 // 224-row tiles (see TM in the kernel)
 
 // gelu'(h) lies in [-0.129, 1.129].  As bf16 it costs 2 bytes per element to write (fc1 forward) and to read back (fc2 data
 // gradient) - 308 MB per launch each way, all of it on top of a GEMM that is otherwise MFMA-bound.  Stored as
@@ -84,8 +86,11 @@ OAT_DEV void mfma_inplace(f32x4& c, const bf16x8 a, const bf16x8 b) {
 // Epilogue of one 256x256 tile (no LDS, no barriers): lane (fk, frow) owns rows 16 i + 4 fk + r and the 4 consecutive
 // columns 4 frow + j of its wave tile, so 16 consecutive lanes store one 128-byte line per row.  Returns whether the
 // tile was an interior one (then exactly NST = 32 (64 for EPI_GELU_GRAD) store instructions were issued per lane).
-template <int EPI, bool WIDE = false, bool F8 = false, bool HU8 = false>
+template <int EPI, bool WIDE = false, bool F8 = false, bool HU8 = false, int TM = 256>
 OAT_DEV bool pp_epilogue(const GemmArgs& g, const f32x4 (&acc)[8][4], int m0, int n0, int wm, int wn, int lane, float dq = 1.f) {
+  // TM: rows of the tile (256, or 224: wave rows of 112 = 7 row groups of 16, acc[7] unused)
+  constexpr int WR = TM / 2, NI = WR / 16;
+  static_assert(!WIDE || TM == 256, "wide stores: 256-row tiles only");
   // HU8: the derivative tensor (out of EPI_GELU_GRAD, aux of EPI_MUL_AUX) is one byte per element, ldc / ldaux in bytes
   constexpr int DSZ = (HU8 && EPI == EPI_GELU_GRAD) ? 1 : 2;      // bytes per element of `out`
   constexpr int ASZ = (HU8 && EPI == EPI_MUL_AUX) ? 1 : 2;        // bytes per element of `aux`
@@ -94,7 +99,7 @@ OAT_DEV bool pp_epilogue(const GemmArgs& g, const f32x4 (&acc)[8][4], int m0, in
   // sit in VGPRs through the K loop, which has none to spare
   asm volatile("" : "+v"(lane));
   const int frow = lane & 15, fk = lane >> 4;
-  const int wrow0 = m0 + wm * 128, wcol00 = n0 + wn * 64;
+  const int wrow0 = m0 + wm * WR, wcol00 = n0 + wn * 64;
   constexpr bool Q8 = F8 && (EPI == EPI_GELU_GRAD || EPI == EPI_MUL_AUX);   // optional fp8 copy for the next GEMM:
                                                        // e4m3 of gelu(h) (-> fc2) or e5m2 of the fc2 data gradient (-> fc1 dgrad)
   uint8_t* const o8 = Q8 ? reinterpret_cast<uint8_t*>(g.out8) : nullptr;
@@ -139,7 +144,7 @@ OAT_DEV bool pp_epilogue(const GemmArgs& g, const f32x4 (&acc)[8][4], int m0, in
       for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
     }
   };
-  const bool interior = m0 + 256 <= g.M;
+  const bool interior = m0 + TM <= g.M;
   if constexpr (WIDE && EPI == EPI_BF16) {
     if (interior) {
       // 16-byte stores: neighbouring lanes (columns 4 frow .. and 4 (frow ^ 1) ..) trade two of their four rows by DPP,
@@ -198,11 +203,11 @@ OAT_DEV bool pp_epilogue(const GemmArgs& g, const f32x4 (&acc)[8][4], int m0, in
       for (int r = 0; r < 4; ++r) an[r] = load_aux(ab + (size_t)(uint32_t)(r * g.ldaux * ASZ) + la);
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NI; ++i) {
       if constexpr (EPI == EPI_MUL_AUX) {        // the saved derivative of row group i + 1 is requested one group ahead
 #pragma unroll
         for (int r = 0; r < 4; ++r) ac[r] = an[r];
-        if (i + 1 < 8) {
+        if (i + 1 < NI) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) an[r] = load_aux(ab + (size_t)(uint32_t)(((i + 1) * 16 + r) * g.ldaux * ASZ) + la);
         }
@@ -224,7 +229,7 @@ OAT_DEV bool pp_epilogue(const GemmArgs& g, const f32x4 (&acc)[8][4], int m0, in
   } else {
     const int col = wcol00 + frow * 4;
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = wrow0 + i * 16 + fk * 4 + r;
@@ -262,13 +267,19 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs g) {
   constexpr bool F8 = FL & PPF_F8;
   constexpr int CBSZ = (FL & PPF_A_BF8) ? 1 : 0;                // MFMA format code of A: 0 = e4m3, 1 = e5m2
   constexpr int ESH = F8 ? 0 : 1;                               // log2(bytes per operand element)
-  constexpr int NST = EPI == EPI_GELU_GRAD ? 64 : 32;           // stores per lane of an interior epilogue
+  // PPF_M224: 224-row tiles.  A persistent launch takes ceil(tiles / CUs) rounds of one tile time each; at M = 50208, N = 768
+  // 256-row tiles are 591 tiles = 2.31 -> 3 rounds, 224-row tiles 675 tiles = 2.64 -> 3 rounds of a tile that is 12.5 %
+  // smaller.  The LDS layout stays that of the 256-row tile (wave row wm at LDS rows wm * 128 ..): the second half of a wave
+  // row simply has 3 row groups of 16 instead of 4 - 12 MFMAs in two of the four intervals - and the 16 unused LDS rows of
+  // each wave row are staged from the wave row's last real row.  Same K order per element: results are bit-identical.
+  constexpr int TM = (FL & PPF_M224) ? 224 : 256, WR = TM / 2, NI = WR / 16, NI1 = NI - 4;
+  constexpr int NST = (EPI == EPI_GELU_GRAD ? 8 : 4) * NI;       // stores per lane of an interior epilogue
   constexpr int WB = 12 + NST > 63 ? 63 : 12 + NST;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;                      // wave tile: rows wm*128.., columns wn*64..
-  const int ntn = g.N >> 8, ntm = (g.M + 255) >> 8, nwg = ntm * ntn;
+  const int ntn = g.N >> 8, ntm = (g.M + TM - 1) / TM, nwg = ntm * ntn;
   const int nk = g.K >> (7 - ESH);                                      // K-tiles of 128 bytes per row
   // Split-K of the last round.  A persistent launch walks nwg tiles in rounds of gridDim.x; when the last round is less
   // than half full (N = 768 at M = 50208: 591 tiles on 256 CUs = 2.31 rounds, the third one 79 tiles wide) most CUs
@@ -304,7 +315,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs g) {
     const int q = nwg >> 3, r = nwg & 7, xcd = w & 7, idx = w >> 3;
     const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;   // XCD-contiguous, bijective
     const int tm = bid / ntn;
-    return Tile{tm << 8, (bid - tm * ntn) << 8};
+    return Tile{tm * TM, (bid - tm * ntn) << 8};
   };
 
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
@@ -369,7 +380,9 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs g) {
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const int p = pa[e] + cls * 8;
-      const uint32_t r = (uint32_t)min(p * 8 + srow, crmax);                    // ragged M: re-read a valid row
+      const int lr = p * 8 + srow;                                              // LDS row; tile row = wave row * WR + row in it
+      const int tr = TM == 256 ? lr : (lr >> 7) * WR + min(lr & 127, WR - 1);
+      const uint32_t r = (uint32_t)min(tr, crmax);                              // ragged M: re-read a valid row
       const uint32_t off = __umul24(r, lda2c) + (c16_0 ^ (e << 6));
       glds16_asm_lds(ca, off, lds0 + buf * PP_A1 + p * 1024);
     }
@@ -400,8 +413,10 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs g) {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i) {
+        if (half == 1 && i >= NI1) continue;              // 224-row tiles: the second half of a wave row has 3 row groups
         f[kk][i] = *(lds_frag)(uintptr_t)(pA[kk] + buf * PP_A1 + (half * 64 + i * 16) * 128);
+      }
   };
   auto readB = [&](bf16x8 (&f)[2][2], int half, int buf) __attribute__((always_inline)) {
 #pragma unroll
@@ -428,20 +443,24 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs g) {
     if constexpr (F8) {
       // constant zero scale operands select the UNSCALED v_mfma_f32_16x16x128_f8f6f4 (cbsz = blgp = 0: e4m3 x e4m3)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i) {
+        if (ah == 1 && i >= NI1) continue;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           acc[ah * 4 + i][bh * 2 + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
               f8_operand(fa[0][i], fa[1][i]), f8_operand(fb[0][j], fb[1][j]), acc[ah * 4 + i][bh * 2 + j], CBSZ, 0, 0, 0, 0, 0);
+      }
     } else {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) {
+          if (ah == 1 && i >= NI1) continue;
 #pragma unroll
           for (int j = 0; j < 2; ++j)
             acc[ah * 4 + i][bh * 2 + j] =
                 __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kk][i], fb[kk][j], acc[ah * 4 + i][bh * 2 + j], 0, 0, 0);
+        }
     }
     if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
@@ -511,7 +530,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs g) {
       prev_interior = false;
       continue;
     }
-    prev_interior = pp_epilogue<EPI, false, F8, (FL & PPF_HU8) != 0>(g, acc, m0, n0, wm, wn, lane, dq);
+    prev_interior = pp_epilogue<EPI, false, F8, (FL & PPF_HU8) != 0, TM>(g, acc, m0, n0, wm, wn, lane, dq);
     __builtin_amdgcn_sched_barrier(0);
   }
   if (STAGGER && wm == 0) __builtin_amdgcn_s_barrier();  // pairs with group 1's extra barrier
@@ -562,7 +581,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs g) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[i][j] += f32x4{b[j], b[j], b[j], b[j]};
         if (tid == 0) g.sk_ctr[sk_tile] = 0;             // ready for the next launch (stream-ordered after this one)
-        pp_epilogue<EPI, false, F8, (FL & PPF_HU8) != 0>(g, acc, tile.m0, tile.n0, wm, wn, lane, dq);
+        pp_epilogue<EPI, false, F8, (FL & PPF_HU8) != 0, TM>(g, acc, tile.m0, tile.n0, wm, wn, lane, dq);
       }
     }
   }
@@ -780,7 +799,8 @@ int launch_pp_cfg(const GemmArgs& g, int grid_slots, hipStream_t s) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
     attr_set = true;
   }
-  const int nwg = ((g.M + 255) / 256) * (g.N / 256);
+  constexpr int TMH = (FL & PPF_M224) ? 224 : 256;
+  const int nwg = ((g.M + TMH - 1) / TMH) * (g.N / 256);
   const int grid = nwg < grid_slots ? nwg : grid_slots;
   if constexpr (FL & PPF_PH2) OAT_LAUNCH((gemm_nt_pp2_kernel<EPI, FL>), dim3(grid), dim3(512), PP_LDS, s, g);
   else OAT_LAUNCH((gemm_nt_pp_kernel<EPI, FL>), dim3(grid), dim3(512), PP_LDS, s, g);
@@ -788,6 +808,18 @@ int launch_pp_cfg(const GemmArgs& g, int grid_slots, hipStream_t s) {
 }
 
 }  // namespace
+
+// 224- or 256-row tiles?  Time of a persistent launch ~ rounds x tile rows; 224 wins where it saves a whole round's worth.
+static bool pp_prefers_224(const GemmArgs& g, int slots) {
+  if (g_pp_m224 == 0) return false;
+  if (g_pp_m224 == 2) return g.M >= 224;
+  const long long ntn = g.N / 256;
+  auto cost = [&](int tm) {
+    const long long tiles = ((g.M + tm - 1) / tm) * ntn, grid = tiles < slots ? tiles : slots;
+    return ((tiles + grid - 1) / grid) * tm;
+  };
+  return g.M >= 224 && cost(224) * 100 < cost(256) * 97;
+}
 
 bool pp_f8_supported(int epi, const GemmArgs& g) {
   if (epi != EPI_BF16 && epi != EPI_GELU_GRAD && epi != EPI_MUL_AUX) return false;
@@ -806,8 +838,12 @@ int launch_pp_f8(int epi, const GemmArgs& g, int grid_slots, bool a_e5m2, hipStr
     if (g.h_u8) return a_e5m2 ? launch_pp_cfg<EPI_MUL_AUX, FLG | PPF_HU8>(g, grid_slots, s) : launch_pp_cfg<EPI_MUL_AUX, FL | PPF_HU8>(g, grid_slots, s);
     return a_e5m2 ? launch_pp_cfg<EPI_MUL_AUX, FLG>(g, grid_slots, s) : launch_pp_cfg<EPI_MUL_AUX, FL>(g, grid_slots, s);
   }
+  if (pp_prefers_224(g, grid_slots))
+    return a_e5m2 ? launch_pp_cfg<EPI_BF16, FLG | PPF_M224>(g, grid_slots, s) : launch_pp_cfg<EPI_BF16, FL | PPF_M224>(g, grid_slots, s);
   return a_e5m2 ? launch_pp_cfg<EPI_BF16, FLG>(g, grid_slots, s) : launch_pp_cfg<EPI_BF16, FL>(g, grid_slots, s);
 }
+
+void pp_set_m224(int mode) { g_pp_m224 = mode; }
 
 bool pp_supported(int epi, const GemmArgs& g) {
   if (epi != EPI_BF16 && epi != EPI_GELU_GRAD && epi != EPI_MUL_AUX) return false;
@@ -820,9 +856,19 @@ bool pp_supported(int epi, const GemmArgs& g) {
 int launch_pp(int epi, const GemmArgs& g, int grid_slots, int flags, hipStream_t s) {
   constexpr int DEF = PPF_PRIO | PPF_BONUS | PPF_LGKM;   // LGKM: measured free, and it makes the WAR spacing strict
   const int fl = DEF ^ flags;                    // a set bit toggles the default
-  if (epi == EPI_GELU_GRAD) return g.h_u8 ? launch_pp_cfg<EPI_GELU_GRAD, DEF | PPF_HU8>(g, grid_slots, s) : launch_pp_cfg<EPI_GELU_GRAD, DEF>(g, grid_slots, s);
-  if (epi == EPI_MUL_AUX) return g.h_u8 ? launch_pp_cfg<EPI_MUL_AUX, DEF | PPF_HU8>(g, grid_slots, s) : launch_pp_cfg<EPI_MUL_AUX, DEF>(g, grid_slots, s);
+  if (epi == EPI_GELU_GRAD) {
+    if (g.h_u8) return pp_prefers_224(g, grid_slots) ? launch_pp_cfg<EPI_GELU_GRAD, DEF | PPF_HU8 | PPF_M224>(g, grid_slots, s)
+                                                     : launch_pp_cfg<EPI_GELU_GRAD, DEF | PPF_HU8>(g, grid_slots, s);
+    return launch_pp_cfg<EPI_GELU_GRAD, DEF>(g, grid_slots, s);
+  }
+  if (epi == EPI_MUL_AUX) {
+    if (g.h_u8) return pp_prefers_224(g, grid_slots) ? launch_pp_cfg<EPI_MUL_AUX, DEF | PPF_HU8 | PPF_M224>(g, grid_slots, s)
+                                                     : launch_pp_cfg<EPI_MUL_AUX, DEF | PPF_HU8>(g, grid_slots, s);
+    return launch_pp_cfg<EPI_MUL_AUX, DEF>(g, grid_slots, s);
+  }
   if (fl == DEF && g.sk_ws != nullptr) return launch_pp_cfg<EPI_BF16, DEF | PPF_SPLITK>(g, grid_slots, s);
+  if (fl == DEF && pp_prefers_224(g, grid_slots)) return launch_pp_cfg<EPI_BF16, DEF | PPF_M224>(g, grid_slots, s);
+  if (fl == (DEF | PPF_M224)) return launch_pp_cfg<EPI_BF16, DEF | PPF_M224>(g, grid_slots, s);      // forced (tests)
   switch (fl) {
     case DEF: return launch_pp_cfg<EPI_BF16, DEF>(g, grid_slots, s);
     case DEF ^ PPF_PRIO: return launch_pp_cfg<EPI_BF16, DEF ^ PPF_PRIO>(g, grid_slots, s);

@@ -165,7 +165,41 @@ def splitk():
     return ok
 
 
+def m224():
+    """224-row tiles vs 256-row tiles: bit-identical outputs (ragged M, rows beyond M untouched), interleaved timing."""
+    torch.manual_seed(2)
+    lib = hip.lib()
+    ok = True
+    for (m, n, k) in SHAPES + [(224, 256, 128), (225, 256, 256), (1000, 768, 128), (4096 + 17, 512, 256), (100416, 768, 768)]:
+        mp = (m + 255) // 256 * 256
+        A = torch.randn(mp, k, device="cuda").bfloat16(); B = (torch.randn(n, k, device="cuda") * k ** -0.5).bfloat16()
+        bias = torch.randn(n, device="cuda")
+        outs, ts = {}, {0: [], 2: [], 1: []}
+        for mode in (0, 2):
+            lib.oat_gemm_set_m224(mode)
+            hip.gemm_set_variant(4)
+            o = torch.full((mp, n), 7.0, device="cuda", dtype=torch.bfloat16)
+            hip.gemm_nt(A, B, m, n, k, hip.EPI_BF16, o, bias=bias)
+            outs[mode] = o
+        for r in range(5):
+            for mode in (0, 2, 1):
+                lib.oat_gemm_set_m224(mode)
+                o = outs[0] if mode == 0 else outs[2]
+                ts[mode].append(timeit(lambda: hip.gemm_nt(A, B, m, n, k, hip.EPI_BF16, o, bias=bias)))
+        same = torch.equal(outs[0], outs[2])
+        t = {mode: sorted(v)[2] for mode, v in ts.items()}
+        print(f"M={m} N={n} K={k}: identical={same}  256-row {2*m*n*k/t[0]/1e12:7.1f} TF/s ({t[0]*1e6:6.1f} us)  224-row {2*m*n*k/t[2]/1e12:7.1f} ({t[2]*1e6:6.1f} us)  "
+              f"auto {t[1]*1e6:6.1f} us")
+        ok &= same
+    lib.oat_gemm_set_m224(1)
+    hip.gemm_set_variant(0)
+    print("M224", "PASSED" if ok else "FAILED")
+    return ok
+
+
 if __name__ == "__main__":
+    if os.environ.get("M224"):
+        sys.exit(0 if m224() else 1)
     if os.environ.get("SPLITK"):
         sys.exit(0 if splitk() else 1)
     ok = check()
