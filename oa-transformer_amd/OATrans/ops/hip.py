@@ -44,6 +44,8 @@ def lib():
         for name in declared_symbols():
             if not hasattr(_lib, name):
                 raise OatError(f"liboatrans_hip.so lacks symbol {name}")
+        if os.environ.get("OAT_GEMM_M224"):              # 0 never / 1 auto (default) / 2 always: 224-row tiles of the ping-pong gemm_nt
+            _lib.oat_gemm_set_m224(int(os.environ["OAT_GEMM_M224"]))
         if os.environ.get("OAT_GEMM_VARIANT"):           # tuning hooks (see oat_gemm_set_variant / oat_gemm_tn_set_variant)
             _lib.oat_gemm_set_variant(int(os.environ["OAT_GEMM_VARIANT"], 0))
             _gemm_variant[0] = int(os.environ["OAT_GEMM_VARIANT"], 0)
