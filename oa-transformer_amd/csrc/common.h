@@ -67,19 +67,22 @@ OAT_DEV float dgelu_f(float x) {
   const float cdf = 0.5f * (1.0f + erf_as(x * 0.70710678118f));
   return cdf + x * 0.3989422804f * __expf(-0.5f * x * x);
 }
-// gelu(x) and gelu'(x) from ONE erf / exp evaluation (exp(-x^2/2) is both the A-S tail and the normal density)
+// gelu(x) and gelu'(x) from ONE erf / exp evaluation (exp(-x^2/2) is both the A-S tail and the normal density).
+// The GEMM epilogues that call this are VALU-bound (ISA count: 26 issue slots per element, 8 of them the two quarter-rate
+// transcendentals), so the constants are folded: m = |x| sqrt(log2(e)/2) makes exp(-x^2/2) = exp2(-m^2) (v_exp_f32 IS
+// exp2) and 0.3275911 |x|/sqrt(2) = C m; the A-S coefficients are halved so that 0.5 (1 - p t e) is one fma.
 OAT_DEV void gelu_both(float x, float& gl, float& dg) {
-  const float ax = fabsf(x) * 0.70710678118f;
-  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);      // v_rcp_f32 (1 ulp); __frcp_rn expands to the 12-instruction IEEE division
-  float p = 1.061405429f;
-  p = p * t - 1.453152027f;
-  p = p * t + 1.421413741f;
-  p = p * t - 0.284496736f;
-  p = p * t + 0.254829592f;
-  const float e = __expf(-ax * ax);
-  const float cdf = 0.5f + 0.5f * copysignf(1.0f - p * t * e, x);
+  const float m = fabsf(x) * 0.8493218002880191f;
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(m, 0.2727374808792225f, 1.0f));   // v_rcp_f32 (1 ulp)
+  float p = 0.5307027145f;
+  p = __builtin_fmaf(p, t, -0.7265760135f);
+  p = __builtin_fmaf(p, t, 0.7107068705f);
+  p = __builtin_fmaf(p, t, -0.142248368f);
+  p = __builtin_fmaf(p, t, 0.127414796f);
+  const float e = __builtin_amdgcn_exp2f(-m * m);
+  const float cdf = 0.5f + copysignf(__builtin_fmaf(-(p * t), e, 0.5f), x);
   gl = x * cdf;
-  dg = cdf + x * 0.3989422804f * e;
+  dg = __builtin_fmaf(x * 0.3989422804f, e, cdf);
 }
 
 // 16-byte async global -> LDS copy: lane i's 16 B land at lds_base + 16 * i.
