@@ -394,34 +394,48 @@ __global__ __launch_bounds__(256) void attn_cls_fwd_dual_kernel(TimeArgs a, cons
   const float c2 = a.scale * T_LOG2E;
   float m = -INFINITY, l = 0.f, o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   float m2 = -INFINITY, l2 = 0.f, o2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int j = grp; j <= S1; j += 32) {
-    const size_t r = j < S1 ? row0 + j : cls_row;
-    const bf16x8 kk = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + a.D + col);
-    const bf16x8 vv = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + 2 * a.D + col);
-    float kf[8], vf[8];
+  // Four keys per 8-lane group and iteration: their eight 16-byte loads are in flight together (one key per iteration left
+  // the kernel latency-bound: 49 dependent round trips, 92 us - longer than the time-attention kernel it runs beside), and
+  // the online softmax rescales once per four keys.  The first iteration of every group holds a real key (grp <= 31 < S1).
+  for (int j0 = grp; j0 <= S1; j0 += 128) {
+    bf16x8 kk[4], vv[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { kf[e] = bf2f(kk[e]); vf[e] = bf2f(vv[e]); }
+    for (int u = 0; u < 4; ++u) {
+      const int j = j0 + 32 * u;
+      const size_t r = j < S1 ? row0 + j : cls_row;           // beyond the last key: any valid row, its score is -inf below
+      kk[u] = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + a.D + col);
+      vv[u] = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + 2 * a.D + col);
+    }
+    float s1[4], s2[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float d = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d += qa[e] * bf2f(kk[u][e]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d += qb[e] * bf2f(kk[u][4 + e]);
+      const bool valid = j0 + 32 * u <= S1;
+      s1[u] = valid ? red8(dot8x(q, kk[u])) * c2 : -INFINITY;
+      s2[u] = valid ? red8(d) * c2 : -INFINITY;
+    }
     {
-      const float s = red8(dot8x(q, kk)) * c2;
-      const float mn = fmaxf(m, s);
-      const float alpha = exp2f(m - mn), p = exp2f(s - mn);
-      l = l * alpha + p;
+      const float mn = fmaxf(fmaxf(fmaxf(m, s1[0]), fmaxf(s1[1], s1[2])), s1[3]);
+      const float alpha = exp2f(m - mn);
+      const float p0 = exp2f(s1[0] - mn), p1 = exp2f(s1[1] - mn), p2 = exp2f(s1[2] - mn), p3 = exp2f(s1[3] - mn);
+      l = l * alpha + ((p0 + p1) + (p2 + p3));
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = o[e] * alpha + p * vf[e];
+      for (int e = 0; e < 8; ++e)
+        o[e] = o[e] * alpha + ((p0 * bf2f(vv[0][e]) + p1 * bf2f(vv[1][e])) + (p2 * bf2f(vv[2][e]) + p3 * bf2f(vv[3][e])));
       m = mn;
     }
     {
-      float d = 0.f;
+      const float mn = fmaxf(fmaxf(fmaxf(m2, s2[0]), fmaxf(s2[1], s2[2])), s2[3]);
+      const float alpha = exp2f(m2 - mn);
+      const float p0 = exp2f(s2[0] - mn), p1 = exp2f(s2[1] - mn), p2 = exp2f(s2[2] - mn), p3 = exp2f(s2[3] - mn);
+      l2 = l2 * alpha + ((p0 + p1) + (p2 + p3));
 #pragma unroll
-      for (int e = 0; e < 4; ++e) d += qa[e] * kf[e];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) d += qb[e] * kf[4 + e];
-      const float s = red8(d) * c2;
-      const float mn = fmaxf(m2, s);
-      const float alpha = exp2f(m2 - mn), p = exp2f(s - mn);
-      l2 = l2 * alpha + p;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) o2[e] = o2[e] * alpha + p * vf[e];
+      for (int e = 0; e < 8; ++e)
+        o2[e] = o2[e] * alpha + ((p0 * bf2f(vv[0][e]) + p1 * bf2f(vv[1][e])) + (p2 * bf2f(vv[2][e]) + p3 * bf2f(vv[3][e])));
       m2 = mn;
     }
   }

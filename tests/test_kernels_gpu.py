@@ -367,6 +367,36 @@ def test_attention_time_bwd_tuning_variants(B, T, N, H, variant):
         hip.lib().oat_attn_time_set_variant(0)
 
 
+@pytest.mark.parametrize("B,T,N,H", [(2, 8, 196, 12), (3, 1, 196, 2), (2, 2, 5, 1), (1, 4, 31, 3), (2, 16, 441, 2)])
+def test_attention_cls_dual_query(B, T, N, H):
+    """oat_attn_cls_fwd_dual: the CLS query over all 1 + T*N keys, once as the bf16 row of qkv (out, lse) and once as a
+    precise fp32 query (o32), against an fp64 softmax; must agree with the single-query kernel on the bf16 lane.
+    Key counts that are no multiple of the 128 keys an iteration covers, and fewer keys than the 32 lane groups."""
+    hip = _hip()
+    D = H * 64
+    M = B * T * N + B
+    qkv = rnd(M, 3 * D, scale=1.5, dtype=torch.bfloat16, seed=40)
+    q32 = rnd(B, D, scale=1.5, seed=41)
+    out = torch.zeros(M, D, dtype=torch.bfloat16, device=DEV); out1 = torch.zeros_like(out)
+    lse = torch.zeros(M, H, device=DEV); lse1 = torch.zeros_like(lse)
+    o32 = torch.zeros(B, D, device=DEV)
+    scale = 64 ** -0.5
+    hip.attn_cls_fwd_dual(qkv, out, lse, q32, o32, B, T, N, H, D, scale)
+    hip.attn_cls_fwd(qkv, out1, lse1, B, T, N, H, D, scale)
+    S1 = T * N
+    for b in range(B):
+        rows = torch.cat([qkv[b * S1:(b + 1) * S1], qkv[B * S1 + b:B * S1 + b + 1]]).double()
+        k = rows[:, D:2 * D].view(S1 + 1, H, 64); v = rows[:, 2 * D:].view(S1 + 1, H, 64)
+        for q, got, tol in ((rows[-1, :D], out[B * S1 + b].double(), 1e-2), (q32[b].double(), o32[b].double(), 2e-5)):
+            sc = torch.einsum("hd,khd->hk", q.view(H, 64), k) * scale
+            ref = torch.einsum("hk,khd->hd", sc.softmax(-1), v).reshape(D)
+            assert (got - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item()), (b, tol)
+        sc = torch.einsum("hd,khd->hk", rows[-1, :D].view(H, 64), k) * scale
+        assert (lse[B * S1 + b].double() - sc.logsumexp(-1)).abs().max().item() < 1e-4
+    assert (out.float() - out1.float()).abs().max().item() <= 2 ** -7 * max(1.0, out1.float().abs().max().item())
+    assert (lse - lse1).abs().max().item() < 1e-4
+
+
 def _attention_case(mode, B, T, N, H):
     hip = _hip()
     D = H * 64
