@@ -480,6 +480,40 @@ def test_linear_f32_matches_fp64(M, N, K, act):
     assert torch.equal(out16, out32.bfloat16())
 
 
+@pytest.mark.parametrize("M,N,K", [(5000, 768, 256), (256, 256, 128), (257, 256, 256), (481, 256, 128), (4113, 512, 256), (25120, 768, 768)])
+def test_gemm_nt_224_row_tiles_bit_identical(M, N, K):
+    """gemm_nt_pp.hip PPF_M224: 224-row tiles (chosen where rounds x tile rows is smaller) must give the bits of the
+    256-row tiles for every epilogue that has the variant - same K order per element - and leave rows >= M untouched."""
+    hip = _hip()
+    lib = hip.lib()
+    mp = (M + 255) // 256 * 256
+    A = rnd(mp, K, dtype=torch.bfloat16, seed=50)
+    W = rnd(N, K, scale=K ** -0.5, dtype=torch.bfloat16, seed=51)
+    bias = rnd(N, seed=52)
+    res = {}
+    try:
+        hip.gemm_set_variant(4)                            # the ping-pong kernel also for small M
+        for mode in (0, 2):                                # never / always
+            lib.oat_gemm_set_m224(mode)
+            o = torch.full((mp, N), 7.0, device=DEV, dtype=torch.bfloat16)
+            hip.gemm_nt(A, W, M, N, K, hip.EPI_BF16, o, bias=bias)
+            d8 = torch.full((mp, N), 9, device=DEV, dtype=torch.uint8)
+            g = torch.full((mp, N), 7.0, device=DEV, dtype=torch.bfloat16)
+            hip.gemm_nt(A, W, M, N, K, hip.EPI_GELU_GRAD | hip.EPI_U8, d8, out2=g, bias=bias)
+            m = torch.full((mp, N), 7.0, device=DEV, dtype=torch.bfloat16)
+            hip.gemm_nt(A, W, M, N, K, hip.EPI_MUL_AUX | hip.EPI_U8, m, aux=d8)
+            res[mode] = (o, d8, g, m)
+    finally:
+        lib.oat_gemm_set_m224(1)
+        hip.gemm_set_variant(0)
+    for a, b in zip(res[0], res[2]):
+        assert torch.equal(a, b)
+    o, d8, g, m = res[2]
+    assert bool((o[M:] == 7.0).all()) and bool((d8[M:] == 9).all()) and bool((g[M:] == 7.0).all()) and bool((m[M:] == 7.0).all())
+    ref = A[:M].float() @ W.float().t() + bias
+    assert (o[:M].float() - ref).abs().max().item() <= 2 ** -7 * max(1.0, ref.abs().max().item())
+
+
 def test_gemm_mlp_pair_with_8bit_derivative():
     """EPI_GELU_GRAD | EPI_U8 / EPI_MUL_AUX | EPI_U8 (gemm_nt_pp.hip HU8_*): the saved GELU derivative as one byte per
     element.  gelu(h) is unchanged bit for bit, the derivative is within 0.0025 + bf16 rounding of the fp32 value,
