@@ -250,13 +250,38 @@ __global__ void periodic_rowsum_kernel(const float* in, int ld, int R, int P, in
   }
 }
 // out[g][:] = sum_r in[(g * R + r)][:]
-__global__ void grouped_rowsum_kernel(const float* in, int ld, int G, int R, int D, float* out, int accumulate) {
+// Few groups (the T frames of temporal_embed's gradient, ONE group for cls_token's) over many rows: one thread per four
+// columns walking all R rows was a chain of R dependent-latency loads on 1..8 workgroups (94 us at R = 196 on the
+// backward chain).  Now RG row lanes per column group, four independent loads in flight per lane, fixed-order LDS sum.
+constexpr int GRS_RG = 4, GRS_THREADS = 1024;
+__global__ __launch_bounds__(GRS_THREADS) void grouped_rowsum_kernel(const float* in, int ld, int G, int R, int D, float* out, int accumulate) {
+  __shared__ f32x4 red[GRS_RG][GRS_THREADS / GRS_RG];
   const int g = blockIdx.x;
-  for (int c = threadIdx.x * 4; c < D; c += blockDim.x * 4) {
-    f32x4 s = {0, 0, 0, 0};
-    for (int r = 0; r < R; ++r) s += *reinterpret_cast<const f32x4*>(in + (size_t)(g * R + r) * ld + c);
-    f32x4* o = reinterpret_cast<f32x4*>(out + (size_t)g * D + c);
-    *o = accumulate ? *o + s : s;
+  const int cl = threadIdx.x % (GRS_THREADS / GRS_RG), rg = threadIdx.x / (GRS_THREADS / GRS_RG);
+  for (int c0 = 0; c0 < D; c0 += GRS_THREADS / GRS_RG * 4) {                 // D = 768: one pass of 256 column lanes (192 used)
+    const int c = c0 + cl * 4;
+    f32x4 s0 = {0, 0, 0, 0}, s1 = s0, s2 = s0, s3 = s0;
+    if (c < D) {
+      const float* base = in + (size_t)g * R * ld + c;
+      int r = rg;
+      for (; r + 3 * GRS_RG < R; r += 4 * GRS_RG) {
+        s0 += *reinterpret_cast<const f32x4*>(base + (size_t)r * ld);
+        s1 += *reinterpret_cast<const f32x4*>(base + (size_t)(r + GRS_RG) * ld);
+        s2 += *reinterpret_cast<const f32x4*>(base + (size_t)(r + 2 * GRS_RG) * ld);
+        s3 += *reinterpret_cast<const f32x4*>(base + (size_t)(r + 3 * GRS_RG) * ld);
+      }
+      for (; r < R; r += GRS_RG) s0 += *reinterpret_cast<const f32x4*>(base + (size_t)r * ld);
+    }
+    red[rg][cl] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (rg == 0 && c < D) {
+      f32x4 s = red[0][cl];
+#pragma unroll
+      for (int q = 1; q < GRS_RG; ++q) s += red[q][cl];
+      f32x4* o = reinterpret_cast<f32x4*>(out + (size_t)g * D + c);
+      *o = accumulate ? *o + s : s;
+    }
+    __syncthreads();
   }
 }
 
@@ -540,7 +565,7 @@ extern "C" int oat_periodic_rowsum(const float* in, int ld, int R, int P, int D,
 extern "C" int oat_grouped_rowsum(const float* in, int ld, int G, int R, int D, float* out, int accumulate, void* stream) {
   if (D % 4 || ld % 4) { set_error("grouped_rowsum: D%4 required"); return -3; }
   if (G <= 0) return 0;
-  OAT_LAUNCH(grouped_rowsum_kernel, dim3(G), dim3(256), 0, (hipStream_t)stream, in, ld, G, R, D, out, accumulate);
+  OAT_LAUNCH(grouped_rowsum_kernel, dim3(G), dim3(GRS_THREADS), 0, (hipStream_t)stream, in, ld, G, R, D, out, accumulate);
   return check_launch("grouped_rowsum");
 }
 

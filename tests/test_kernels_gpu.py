@@ -273,6 +273,11 @@ def test_reductions_and_misc():
     o2 = torch.zeros(R, D, device=DEV)
     hip.grouped_rowsum(x, R, P, D, o2)
     close(o2, x.view(R, P, D).sum(1), atol=1e-4, rtol=1e-5, what="grouped")
+    for (G_, R_, D_) in ((8, 196, 768), (1, 32, 768), (3, 7, 1280), (1, 441, 768)):      # temporal_embed / cls_token gradient shapes; D past one pass
+        x = rnd(G_ * R_, D_, seed=25)
+        o3 = torch.ones(G_, D_, device=DEV)
+        hip.grouped_rowsum(x, G_, R_, D_, o3, accumulate=True)
+        close(o3, x.view(G_, R_, D_).double().sum(1).float() + 1, atol=1e-4, rtol=1e-5, what=f"grouped {G_}x{R_}x{D_}")
     # cast + transpose
     W = rnd(300, 130, seed=24)
     w16 = torch.zeros(300, 130, dtype=torch.bfloat16, device=DEV)
