@@ -142,30 +142,42 @@ __global__ __launch_bounds__(FWD_THREADS, NKT <= 14 ? 4 : 2) void attn_space_fwd
     const int qi = qt * 16 + (lane & 15);
     bf16x8 qf[2] = {qnext[0], qnext[1]};
     if (qt + FWD_THREADS / 64 < nqt) load_q(qt + FWD_THREADS / 64, qnext);     // prefetch the next tile's Q
+    // raw scores: the softmax scale goes into the exponent's fma (max commutes with a positive scale), and only the key
+    // tiles that reach past key N are masked per element - the kernel is VALU-bound in this stretch (10 -> 7.5 issue
+    // slots per score); a key tile that is pure padding (NKT is even: 14 tiles for 197 keys) skips its MFMAs as well
     f32x4 st[NKT];
     float m = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
       f32x4 acc = {0, 0, 0, 0};
+      if (kt * 16 <= N) {                                  // wave-uniform
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Kt, kt * 16, ks, lane), qf[ks], acc, 0, 0, 0);
+        for (int ks = 0; ks < 2; ++ks)
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Kt, kt * 16, ks, lane), qf[ks], acc, 0, 0, 0);
+      }
+      if (kt * 16 + 15 <= N) {                             // every key of the tile is real
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = kt * 16 + g * 4 + r;
-        acc[r] = key <= N ? acc[r] * c2 : -INFINITY;
-        m = fmaxf(m, acc[r]);
+        for (int r = 0; r < 4; ++r) m = fmaxf(m, acc[r]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kt * 16 + g * 4 + r;
+          acc[r] = key <= N ? acc[r] : -INFINITY;
+          m = fmaxf(m, acc[r]);
+        }
       }
       st[kt] = acc;
       if (kt & 1) __builtin_amdgcn_sched_barrier(0);     // keeps the K fragments of at most two tiles live (3 waves/SIMD)
     }
     m = fmaxf(m, __shfl_xor(m, 16, 64));
     m = fmaxf(m, __shfl_xor(m, 32, 64));
+    const float mc = m * c2;
+    m = mc;                                                // log2-domain maximum, as the LSE below expects
     float l = 0.f;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { st[kt][r] = exp2f(st[kt][r] - m); l += st[kt][r]; }
+      for (int r = 0; r < 4; ++r) { st[kt][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kt][r], c2, -mc)); l += st[kt][r]; }
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
     f32x4 ot[4];
