@@ -95,6 +95,46 @@ def synthetic_batch(args, rank, device):
     return batch
 
 
+def other_config_line(base_args, variant, device, steps=5, warmup=2):
+    """Config 3 as BASELINE.json words it ("8-frame 224^2 + 10 object regions/frame, bs 32"): the object-aware model
+    classes on one object frame + the clip.  Run AFTER the headline's timed region and reported under `other_configs`,
+    outside `value`: a short (warmup + steps) single-GPU measurement with the same step function, optimiser and timing
+    brackets as the headline."""
+    import copy
+    import gc
+    from OATrans.trainer.step import global_local_step, region_mem_step
+    args = copy.copy(base_args)
+    args.variant = variant
+    step_impl = {"region_mem": region_mem_step, "global_local": global_local_step}[variant]
+    dp, opt, loss_fn = build(args, device)
+    if args.dtype == "fp8":
+        dp.module.video_model._engine.fp8 = True
+    data = synthetic_batch(args, 0, device)
+    step_args = argparse.Namespace(world_size=1, rank=0, local_rank=device.index or 0)
+    for _ in range(warmup):
+        step_impl(dp, loss_fn, opt, data, step_args)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step_impl(dp, loss_fn, opt, data, step_args)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    value = args.batch * steps / elapsed
+    gf_pair = flops_per_pair(args.frames, N=(args.res // 16) ** 2, clips=(1, args.frames),
+                             text_passes=2 if variant == "global_local" else 1) / 1e9
+    n_obj = {"region_mem": 5, "global_local": 10}[variant]
+    line = {"workload": f"[{variant}] {args.frames}-frame + {n_obj} obj (one object frame with {n_obj} box masks + the {args.frames}-frame "
+                        f"clip, same encoder) {args.res}^2 ViT-B/16 + DistilBERT-base (oa_model_{variant}.FrozenInTime), bs {args.batch}, "
+                        f"fwd+bwd+AdamW",
+            "value": round(value, 2), "unit": "pairs/s", "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps, "warmup": warmup,
+            "gflop_per_pair": round(gf_pair, 1), "step_mfma_frac": round(value * gf_pair / 1e3 / BF16_DENSE_PEAK_TFLOPS, 4),
+            "final_loss": round(float(loss.item()), 4)}
+    del dp, opt, data, loss
+    gc.collect()
+    torch.cuda.empty_cache()
+    return line
+
+
 def _gemm_class(kind, epi, M, N, K):
     """Name of the kernel that serves a launch (the dispatch rules of csrc/gemm_nt.hip / gemm_tn.hip), used to group
     the instrumented launches exactly as rocprofv3 --stats groups them."""
@@ -183,7 +223,7 @@ def instrumented_gemm_profile(step_fn):
     return by
 
 
-def _cpu_sample(frames, threads, budget, max_iters):
+def _cpu_sample(frames, threads, budget, max_iters, min_iters=1):
     """fp32 CPU oracle (port of the reference arithmetic): bs 2, fwd+bwd, `frames` frames; seconds per iteration."""
     from OATrans.utils import seeded_init as si
     from oracle import oatrans_oracle as orc
@@ -205,7 +245,7 @@ def _cpu_sample(frames, threads, budget, max_iters):
     warm = time.time() - tw
     t0 = time.time()
     n = 0
-    while n < 1 or (n < max_iters and (time.time() - t0) + warm < budget):
+    while n < min_iters or (n < max_iters and (time.time() - t0) + warm < budget):
         one()
         n += 1
     return (time.time() - t0) / n, n
@@ -228,7 +268,7 @@ def cpu_baseline(frames):
                       sample=f"{n1} iterations, {dt1:.2f} s/iter"))
     wide = max(t8, min(64, ncpu // 4))
     if wide > t8:
-        dtw, nw = _cpu_sample(frames, wide, 6.0, 2)
+        dtw, nw = _cpu_sample(frames, wide, 8.0, 3, min_iters=2)       # at least two timed iterations after the warm-up
         extra.append(dict(workload=f"{frames} frames 224^2, bs 2", cores=wide, value=round(2 / dtw, 4), unit="pairs/s",
                           sample=f"{nw} iterations, {dtw:.2f} s/iter ({ncpu} logical CPUs on this host)"))
     out["extra"] = extra
@@ -247,6 +287,10 @@ def main():
                     help="AdamW step size (the reference config uses 2e-4 on PRETRAINED towers; random-init towers on one repeated "
                          "synthetic batch spike at that value, which says nothing about throughput but makes final_loss useless)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--other-configs", action="store_true",
+                    help="append the `other_configs` runs at any --frames / --res (default: only at the headline geometry, 8 x 224^2)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short config-3 runs (object-aware variants) that a default 1-GPU run appends under `other_configs`")
     ap.add_argument("--dtype", choices=["bf16", "fp8"], default="bf16",
                     help="fp8 (BASELINE config 5): the six forward linears of every ViT block on OCP e4m3 MFMA with per-tensor "
                          "delayed scaling; attention, LayerNorm, loss and the whole backward stay bf16 / fp32")
@@ -386,6 +430,19 @@ def main():
                                "ms_per_step": top["ms_per_step"], "gflop_per_launch": top["gflop_per_launch"],
                                "traffic_profile": "profiles/ (rocprofv3 --pmc passes of this command, per round)",
                                "other_gemm_kernels": [entry(n, d) for n, d in ranked[1:] if d["ms"] > 0.2]}
+        if world == 1 and not args.no_other_configs and args.variant == "frozen" and \
+                (args.other_configs or (args.frames == 8 and args.res == 224)):
+            # config 3 as worded (object regions on): outside the timed region and outside `value`
+            import gc
+            del dp, opt, data, step, eager_step, engines, by
+            gc.collect()
+            torch.cuda.empty_cache()
+            out["other_configs"] = []
+            for variant in ("global_local", "region_mem"):
+                try:
+                    out["other_configs"].append(other_config_line(args, variant, device))
+                except Exception as exc:              # the headline line must still be printed
+                    out["other_configs"].append({"workload": f"[{variant}]", "error": f"{type(exc).__name__}: {exc}"})
         if world == 1 and not args.no_cpu_baseline and args.variant == "frozen":
             out["cpu_baseline"] = cpu_baseline(args.frames)
         print(json.dumps(out), flush=True)

@@ -18,6 +18,22 @@ def bump_weights_epoch():
 class EngineModule(nn.Module):
     _skip_prefixes = ()
 
+    def _new_step_guard(self):
+        """Self-healing for the forward / backward call counters (`_fwd_calls`, `_bwd_calls`: which activation plan a
+        differentiated forward takes, whether a backward overwrites or accumulates).  `begin_step()` of the owning model
+        resets them; a loop that never calls it, or a grad-enabled forward whose output never receives a gradient,
+        would otherwise leave `_fwd_calls > _bwd_calls` for good - every later step allocating one more plan and
+        ACCUMULATING into the previous step's gradient buffers.  An optimiser step (it bumps the weights epoch) ends a
+        step by definition: the first forward after one starts from zero."""
+        ep = _WEIGHTS_EPOCH[0]
+        if self.__dict__.get("_calls_epoch") != ep:
+            self.__dict__["_calls_epoch"] = ep
+            if getattr(self, "_fwd_calls", 0) or getattr(self, "_bwd_calls", 0):
+                self._fwd_calls = self._bwd_calls = 0
+        if getattr(self, "_fwd_calls", 0) >= 64:
+            raise RuntimeError(f"{type(self).__name__}: {self._fwd_calls} differentiated forwards without a backward or an "
+                               "optimiser step - call model.begin_step() at the start of every step")
+
     def _weights_signature(self):
         pairs = self._engine_params()
         return (_WEIGHTS_EPOCH[0], sum(p._version for _, p in pairs), pairs[0][1].data_ptr(), pairs[-1][1].data_ptr())

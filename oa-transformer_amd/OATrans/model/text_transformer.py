@@ -137,7 +137,11 @@ class DistilBertHIP(EngineModule):
         if attention_mask is None:
             attention_mask = torch.ones_like(input_ids)
         params = [p for _, p in self._engine_params()]
-        idx = self._fwd_calls
-        self._fwd_calls += 1
+        if torch.is_grad_enabled():
+            self._new_step_guard()
+            idx = self._fwd_calls
+            self._fwd_calls += 1
+        else:
+            idx = -1                 # no backward will follow (validation): one dedicated plan, reused by every such call
         hidden = _HiddenFn.apply(self, input_ids, attention_mask, idx, *params)
         return SimpleNamespace(last_hidden_state=hidden)

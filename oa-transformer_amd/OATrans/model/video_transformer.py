@@ -80,6 +80,7 @@ class _EncoderFn(torch.autograd.Function):
         pd = module._param_data()
         call = 0
         if module._track_calls:              # a forward that will be differentiated keeps its own activation plan
+            module._new_step_guard()
             call = module._fwd_calls
             module._fwd_calls += 1
         cls, patches, plan = eng.forward(clips, pd, need_patches, module._weights_signature(), region_layer, call=call)

@@ -188,9 +188,40 @@ class AdamW(torch.optim.Optimizer):
         return loss
 
     def load_state_dict(self, state_dict):
-        """Resume: the loaded per-parameter moments are copied into the flat buffers when the runs are next built."""
+        """Resume.  Without flat buffers yet (or after the parameters moved) the loaded per-parameter moments are copied
+        into them when the runs are next built.  With valid runs - in particular after enable_capture(), when captured
+        graphs hold the addresses of the flat moment buffers and of the device-side step / lr scalars - the loaded
+        state is copied INTO the existing buffers and the device scalars are re-synchronised, so the next (captured or
+        eager) step continues from the loaded step count."""
+        runs = self._runs if self._runs_valid() else None
         super().load_state_dict(state_dict)
-        self._runs = None
+        if runs is None:
+            if self._dev is not None:
+                raise hip.OatError("AdamW.load_state_dict: parameter / gradient buffers moved after enable_capture()")
+            self._runs = None
+            return
+        with torch.no_grad():
+            for r in runs:
+                off = 0
+                for p in r['params']:
+                    st, n = self.state[p], p.numel()
+                    m_view, v_view = r['m'][off:off + n].view_as(p), r['v'][off:off + n].view_as(p)
+                    for key, view in (('exp_avg', m_view), ('exp_avg_sq', v_view)):
+                        t = st.get(key)
+                        if torch.is_tensor(t) and t.shape == p.shape:
+                            if t.data_ptr() != view.data_ptr():
+                                view.copy_(t)
+                        else:
+                            view.zero_()
+                        st[key] = view
+                    st['step'] = int(st.get('step', 0))
+                    off += n
+                r['done'] = []
+            for gi, (g, d) in enumerate(zip(self.param_groups, self._dev or [])):
+                own = [r for r in runs if r['group'] == gi]
+                d['step'].fill_(int(self.state[own[0]['params'][0]]['step']) if own else 0)
+                d['lr'].fill_(float(g['lr']))
+                d['lr_host'] = float(g['lr'])
 
     def zero_grad(self, set_to_none=False):
         """Engine parameters keep their gradients in persistent flat buffers that every backward OVERWRITES (marked

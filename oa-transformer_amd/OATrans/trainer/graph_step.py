@@ -17,13 +17,18 @@ issued eagerly (trainer/step.py), where RCCL overlaps them with backward.
 """
 import torch
 
+from ..engine.module import bump_weights_epoch
+
 
 def _signature(data):
+    """Shapes / dtypes / devices of the TENSOR leaves only.  Everything else in a batch (`meta`: paths and raw captions,
+    lists, strings) differs on every batch and is never read by the step, so it must not key - or defeat - the capture."""
     if isinstance(data, dict):
-        return tuple((k, _signature(v)) for k, v in sorted(data.items()))
+        sub = ((k, _signature(v)) for k, v in sorted(data.items()))
+        return tuple((k, s) for k, s in sub if s is not None)
     if torch.is_tensor(data):
         return (tuple(data.shape), str(data.dtype), str(data.device))
-    return ("const", repr(data))
+    return None
 
 
 def _clone(data):
@@ -35,16 +40,19 @@ def _clone(data):
 def _copy_into(dst, src):
     if isinstance(dst, dict):
         for k in dst:
-            _copy_into(dst[k], src[k])
+            if isinstance(dst[k], dict) or torch.is_tensor(dst[k]):
+                _copy_into(dst[k], src[k])
     elif torch.is_tensor(dst):
         dst.copy_(src, non_blocking=True)
 
 
 class GraphedStep:
+    MAX_SIGNATURES = 16              # distinct input signatures tracked; past that, new ones simply stay eager
+
     def __init__(self, step_fn, model_dp, loss_fn, optimizer, args, warmup=3):
         self.step_fn, self.model_dp, self.loss_fn, self.optimizer, self.args = step_fn, model_dp, loss_fn, optimizer, args
         self.warmup = max(1, int(warmup))
-        self._seen = {}              # signature -> eager steps taken so far
+        self._seen = {}              # signature -> eager steps taken so far (bounded: MAX_SIGNATURES)
         self._graphs = {}            # signature -> (graph, static data, static loss)
         self.replays = 0
         self.failed = False
@@ -57,6 +65,8 @@ class GraphedStep:
         ent = self._graphs.get(sig)
         if ent is None:
             n = self._seen.get(sig, 0)
+            if sig not in self._seen and len(self._seen) >= self.MAX_SIGNATURES:
+                return self._eager(data)
             if n < self.warmup or n < 0:                       # warm-up: plans, workspaces, kernel attributes, optimiser state
                 self._seen[sig] = n + 1
                 return self._eager(data)
@@ -76,6 +86,9 @@ class GraphedStep:
         graph.replay()
         if not first:                                 # the capture pass already advanced the host-side counters once
             self.optimizer.note_replayed_step()
+        # the replayed AdamW wrote the fp32 masters through raw pointers: an eager forward that follows (validation)
+        # must re-cast the bf16 shadows, exactly as after an eager optimizer.step()
+        bump_weights_epoch()
         self.replays += 1
         return loss
 

@@ -8,7 +8,7 @@ OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 F="$OUT/${TAG}_other_config_bench_lines.jsonl"
 : > "$F"
-run() { timeout 600 python bench.py --no-cpu-baseline "$@" 2>> "$OUT/other_configs.err" | tail -1 >> "$F"; }
+run() { timeout 600 python bench.py --no-cpu-baseline --no-other-configs "$@" 2>> "$OUT/other_configs.err" | tail -1 >> "$F"; }
 run --frames 4                                                        # config 2
 run --variant global_local --frames 8                                 # config 3 as worded (8-frame + 10 obj)
 run --variant region_mem --frames 8

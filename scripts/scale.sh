@@ -20,10 +20,10 @@ for N in 1 2 4 8; do
   [ "$N" -gt "$MAX" ] && break
   LOG="$OUT/n$N.log"
   if [ "$N" -eq 1 ]; then
-    OAT_BENCH_RANK_TIMES=1 timeout 900 python bench.py --gpus 1 --steps "$STEPS" --warmup "$WARMUP" --no-cpu-baseline > "$LOG" 2> "$OUT/n$N.err"
+    OAT_BENCH_RANK_TIMES=1 timeout 900 python bench.py --gpus 1 --steps "$STEPS" --warmup "$WARMUP" --no-cpu-baseline --no-other-configs > "$LOG" 2> "$OUT/n$N.err"
   else
     OAT_BENCH_RANK_TIMES=1 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node "$N" --master-addr 127.0.0.1 \
-      --master-port $((29500 + N)) bench.py --gpus "$N" --steps "$STEPS" --warmup "$WARMUP" --no-cpu-baseline > "$LOG" 2> "$OUT/n$N.err"
+      --master-port $((29500 + N)) bench.py --gpus "$N" --steps "$STEPS" --warmup "$WARMUP" --no-cpu-baseline --no-other-configs > "$LOG" 2> "$OUT/n$N.err"
   fi
   python - "$LOG" "$N" "${BASE:-0}" <<'PY'
 import json, sys

@@ -41,11 +41,17 @@ def _check(rec, n):
 
 
 def test_bench_single_rank_line():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "4", "--frames", "2"],
-                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "4", "--frames", "2",
+                        "--other-configs"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     rec = _line(r.stdout)
     _check(rec, 1)
+    # config 3 as worded (object-aware variants) rides along outside `value`
+    oc = rec["other_configs"]
+    assert [o["workload"].split("]")[0] for o in oc] == ["[global_local", "[region_mem"], oc
+    for o in oc:
+        assert "error" not in o, o
+        assert o["value"] > 0 and o["ms_per_step"] > 0 and 0 < o["step_mfma_frac"] < 1 and o["unit"] == "pairs/s"
     cb = rec["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "pairs/s" and cb["sample"]
 

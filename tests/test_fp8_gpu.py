@@ -136,3 +136,92 @@ def test_config5_geometry_fp8_forward_vs_oracle():
     cos = torch.nn.functional.cosine_similarity(cls, ocls, dim=1).min().item()
     print(f"config-5 geometry (16 x 336^2, fp8 forward): CLS rel-L2 {e:.4f}, min cosine {cos:.5f}")
     assert e < 5e-2 and cos > 0.998
+
+
+def test_config5_composed_global_local_16f_336_fp8_vs_oracle():
+    """BASELINE config 5 COMPOSED, the form `bench.py --variant global_local --frames 16 --res 336 --dtype fp8` measures:
+    oa_model_global_local.FrozenInTime (train_dist_multi_global_local.py) on one object frame + a 16-frame clip of
+    336^2 per sample (441 patches per frame, native clip layout: two segments of one launch sequence), two DistilBERT
+    passes, fp8 (e4m3) forward linears in the video tower.  B = 2 against the fp32 CPU oracle's run of the same graph:
+    every embedding the trainer's three losses consume, and the loss itself (oa_model_global_local.py:149-208,
+    trainer_global_local.py:187-211).  Then one backward: the fp8-forward step's parameter gradients against the bf16
+    step's on the same weights and inputs (the oracle's backward at this size needs tens of GB).
+    Stated tolerance for fp8: embeddings rel-L2 <= 5e-2, sim matrices <= 3e-2 max-abs, loss <= 5e-2; the text side and
+    the CLS path of the video side stay fp32 (CLS lane), so what moves is the patch keys / values the CLS attends."""
+    from OATrans.data_loader.data_loader import MultiDistTextObjectVideoDataLoader
+    from OATrans.model import NormSoftmaxLoss, sim_matrix
+    from OATrans.model.oa_layers import mean_rows
+    from OATrans.model.oa_model_global_local import FrozenInTime
+    from oracle import oatrans_oracle as orc
+    torch.set_num_threads(min(16, max(8, torch.get_num_threads())))
+    B, T, R, L, O = 2, 16, 336, 32, 10
+    p = si.frozen_state_dict(SEED, dict(num_frames=T, patches_per_frame=441), {})
+    p.update(si.seeded_state_dict({"video_model.object_embed.weight": (768, 2054), "video_model.object_embed.bias": (768,),
+                                   "text_local_proj.1.weight": (256, 768), "text_local_proj.1.bias": (256,),
+                                   "vid_local_proj.0.weight": (256, 768), "vid_local_proj.0.bias": (256,)}, SEED))
+    dl = MultiDistTextObjectVideoDataLoader("Synthetic", {"max_length": L}, {"input_res": R, "num_frames": 1}, "",
+                                            batch_size=B, object_params={"input_objects": True, "num_objects": O})
+    ex = dl.make_batch(55)
+    video = si.seeded_tensor(SEED, "c5.gl.video", (B, T + 1, 3, R, R))
+    ids = si.seeded_ints(SEED, "c5.ids", (B, L), 1000, 30000)
+    ids[:, 0] = 101
+    mask = torch.ones(B, L, dtype=torch.int64)
+    mask[1, 20:] = 0
+    pids, pmask, otm, pm = ex["pad_text"]["input_ids"], ex["pad_text"]["attention_mask"], ex["object_token_masks"], ex["patch_masks"]
+    assert pm.shape == (B, O, 441)
+    data = {"video": video.cuda(), "text": {"input_ids": ids.cuda(), "attention_mask": mask.cuda()},
+            "pad_text": {"input_ids": pids.cuda(), "attention_mask": pmask.cuda()}, "patch_masks": pm.cuda(),
+            "object_token_masks": otm.cuda(), "object_token_len": otm[:, -1].cuda()}
+    Lf = NormSoftmaxLoss()
+    runs = {}
+    for fp8 in (True, False):
+        m = FrozenInTime(dict(model="SpaceTimeTransformer", arch_config="base_patch16_224", num_frames=T, pretrained=True,
+                              time_init="rand", two_outputs=False, object_clip="native", arch_kwargs=dict(img_size=R)),
+                         dict(model="", input_objects=False),
+                         dict(model="pretrained/distilbert-base-uncased", pretrained=True, input="text"))
+        m.text_model.eval()
+        r = m.load_state_dict(p, strict=False)
+        assert not r.unexpected_keys and not r.missing_keys, r
+        m = m.cuda()
+        m.set_device(torch.device("cuda"))
+        m.video_model._engine.fp8 = fp8
+        for step in range(2 if fp8 else 1):       # fp8: the second step runs on delayed scales, producers quantise
+            m.begin_step()
+            for prm in m.parameters():
+                if not getattr(prm, "_oat_engine_grad", False):
+                    prm.grad = None
+            t, pt, v, ov, extra = m(data)
+            rf, tf = extra[4], extra[5]
+            loss = Lf(sim_matrix(t, v)) + Lf(sim_matrix(pt, v)) + Lf(sim_matrix(mean_rows(rf), mean_rows(tf)))
+            loss.backward()
+        torch.cuda.synchronize()
+        runs[fp8] = dict(out=[x.detach().float().cpu() for x in (t, pt, v, ov, rf, tf)], loss=loss.item(),
+                         grads={k: prm.grad.detach().float().cpu().clone() for k, prm in m.named_parameters() if prm.grad is not None})
+        if fp8:
+            assert len(m.video_model._engine._f8["primed"]) == 6 * 12
+        del m
+        torch.cuda.empty_cache()
+    with torch.no_grad():
+        o = orc.gl_forward(p, video, (ids, mask), (pids, pmask), pm, otm, object_clip="native")
+        oloss = orc.gl_loss(o[0], o[1], o[2], o[4], o[5]).item()
+    names = ("text", "tagged text", "video", "object clip", "region_feat", "tags_feat")
+    rel = lambda a, b: ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
+    for fp8 in (True, False):
+        out = runs[fp8]["out"]
+        rels = {n: rel(a, b) for n, a, b in zip(names, out, o)}
+        sims = {"text x video": (orc.sim_matrix(out[0], out[2]) - orc.sim_matrix(o[0], o[2])).abs().max().item(),
+                "tagged x video": (orc.sim_matrix(out[1], out[2]) - orc.sim_matrix(o[1], o[2])).abs().max().item(),
+                "region x tags": (orc.sim_matrix(out[4].mean(1), out[5].mean(1)) - orc.sim_matrix(o[4].mean(1), o[5].mean(1))).abs().max().item()}
+        print(f"config 5 composed (global_local 1+16 x 336^2, {'fp8' if fp8 else 'bf16'} forward): rel-L2 {rels}; sim errs {sims}; "
+              f"loss {runs[fp8]['loss']:.4f} vs oracle {oloss:.4f}")
+        tol_rel, tol_sim, tol_loss = (5e-2, 3e-2, 5e-2) if fp8 else (1e-2, 1e-3, 2e-2)
+        assert all(e < tol_rel for e in rels.values()), rels
+        assert all(e <= tol_sim for e in sims.values()), sims
+        assert abs(runs[fp8]["loss"] - oloss) < tol_loss * max(1.0, abs(oloss))
+    # backward of the fp8-forward step vs the bf16 step: same weights, same inputs
+    g8, g16 = runs[True]["grads"], runs[False]["grads"]
+    errs = {k: abs(g8[k].norm().item() - g16[k].norm().item()) / g16[k].norm().item() for k in g16 if g16[k].norm() > 1e-6 and "object_embed" not in k}
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:4]
+    print("fp8-forward vs bf16 step, worst gradient-norm differences:", worst)
+    assert all(torch.isfinite(x).all() for x in g8.values())
+    assert sum(e > 0.1 for e in errs.values()) <= 2, worst

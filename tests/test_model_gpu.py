@@ -386,6 +386,49 @@ def test_optimizer_resume_continues_the_trajectory():
     assert exp_avg.abs().max().item() > 0
 
 
+def test_optimizer_load_state_dict_in_capture_mode():
+    """AdamW.load_state_dict after enable_capture(): the loaded moments go INTO the existing flat buffers (captured
+    graphs hold their addresses) and the device-side step / lr scalars are re-synchronised, so the next step carries
+    the loaded step count's bias corrections - it used to raise 'buffers moved after enable_capture'."""
+    import copy
+    from OATrans.optim import AdamW
+    torch.manual_seed(3)
+    ps = [torch.nn.Parameter(torch.randn(257, device="cuda")), torch.nn.Parameter(torch.randn(33, 5, device="cuda"))]
+    gs = [[torch.randn_like(p) for p in ps] for _ in range(4)]
+
+    def run(opt, k):
+        for p, g in zip(ps_of[opt], gs[k]):
+            p.grad = g.clone() if p.grad is None else p.grad.copy_(g)
+        opt.step()
+
+    ps_of = {}
+    a_params = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    a = AdamW(a_params, lr=1e-2)
+    ps_of[a] = a_params
+    for k in range(3):
+        run(a, k)
+    sd = copy.deepcopy(a.state_dict())
+    saved = [p.detach().clone() for p in a_params]
+    run(a, 3)                                            # fourth step, uninterrupted, host scalars
+    b_params = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    b = AdamW(b_params, lr=1e-2)
+    ps_of[b] = b_params
+    run(b, 0)                                            # builds the runs
+    b.enable_capture()
+    m_ptr = b._runs[0]['m'].data_ptr()
+    with torch.no_grad():
+        for p, s in zip(b_params, saved):
+            p.copy_(s)
+    b.load_state_dict(sd)
+    assert b._runs[0]['m'].data_ptr() == m_ptr           # same flat buffers: captured graphs stay valid
+    assert int(b._dev[0]['step'].item()) == 3
+    run(b, 3)                                            # fourth step through the device-scalar path
+    torch.cuda.synchronize()
+    assert all(int(st["step"]) == 4 for st in b.state.values())
+    for pa, pb in zip(a_params, b_params):
+        assert torch.allclose(pa, pb, atol=2e-6, rtol=1e-5), (pa - pb).abs().max()
+
+
 @pytest.mark.parametrize("B", [32, 64])
 def test_headline_batch_sim_matrix_vs_oracle_rows(B):
     """The benchmarked shapes themselves - bs 32 (configs 2 / 3) and bs 64 per GPU (config 4), 8 frames, ViT-B/16 +

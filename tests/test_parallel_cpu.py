@@ -215,6 +215,56 @@ def test_four_rank_gradient_sync_with_ragged_buckets(grad_dtype):
     assert got == [0, 1, 2, 3]
 
 
+def _eight_rank_worker(rank, world, port, q):
+    """W = 8 (config 4's rank count): the engine's announcement order - top block (+ final norm) first, then the block
+    below it, each announced range all-reduced asynchronously in 5-element buckets whose last one is ragged - then the
+    final sync for the loose parameters; three steps so that the per-step reset of the pending / covered state is seen."""
+    from OATrans.parallel import GradSync
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    torch.manual_seed(1)
+    toy = _FlatToy()
+    loose = torch.nn.Parameter(torch.zeros(13))
+    model = torch.nn.ModuleDict({"toy": toy})
+    model.register_parameter("loose", loose)
+    sync = GradSync(model, overlap=True, bucket_elems=5)
+    views = toy._grad_views()
+    loose.grad = torch.zeros(13)
+    g = torch.Generator().manual_seed(11)
+    for step in range(3):
+        per_rank = [{n: torch.randn(v.shape, generator=g) for n, v in views.items()} for _ in range(world)]
+        loose_rank = [torch.randn(13, generator=g) for _ in range(world)]
+        for n, v in views.items():
+            v.copy_(per_rank[rank][n])
+        loose.grad.copy_(loose_rank[rank])
+        toy._announce(("blocks.1.", "norm."))               # backward runs top to bottom: the same order on every rank
+        n_first = len(sync._pending)
+        toy._announce(("blocks.0.",))
+        assert n_first >= 1 and len(sync._pending) > n_first
+        sync.all_reduce(average=True)
+        assert not sync._pending and not sync._covered
+        for n, v in views.items():
+            want = sum(per_rank[r][n] for r in range(world)) / world
+            assert torch.allclose(v, want, atol=1e-6, rtol=1e-6), (n, (v - want).abs().max())      # averaged exactly once
+        assert torch.allclose(loose.grad, sum(loose_rank) / world, atol=1e-6, rtol=1e-6)
+    q.put(rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_rank_gradient_sync_in_announcement_order():
+    world, port = 8, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_eight_rank_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert got == list(range(8))
+
+
 def _broadcast_worker(rank, world, port, q):
     from OATrans.parallel import HipDataParallel
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
