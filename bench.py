@@ -205,12 +205,24 @@ def instrumented_gemm_profile(step_fn):
         e.record()
         records.append((_gemm_class("tn", 0, M, N1, N2), 2.0 * M * N1 * N2, s, e))
 
-    hip.gemm_nt, hip.gemm_tn, hip.gemm_nt_f8 = timed_nt, timed_tn, timed_f8
+    orig_grp = hip.TnGroup.run
+
+    def timed_grp(self):
+        # grouped weight gradients (csrc/gemm_tn_sk.hip): one GEMM launch + its fix-up for several problems
+        s, e = Ev(), Ev()
+        s.record()
+        orig_grp(self)
+        e.record()
+        fl = sum(2.0 * (r[4] & 0xffffffff) * (r[4] >> 32) * (r[5] & 0xffffffff) for r in self.table.tolist())
+        big = (self.table[0, 4].item() & 0xffffffff) >= 4096
+        records.append(("gemm_tn_sk_kernel (+ tn_sk_fix)" if big else "gemm_tn_sk_kernel [DistilBERT, 36 problems]", fl, s, e))
+
+    hip.gemm_nt, hip.gemm_tn, hip.gemm_nt_f8, hip.TnGroup.run = timed_nt, timed_tn, timed_f8, timed_grp
     try:
         step_fn()
         torch.cuda.synchronize()
     finally:
-        hip.gemm_nt, hip.gemm_tn, hip.gemm_nt_f8 = orig_nt, orig_tn, orig_f8
+        hip.gemm_nt, hip.gemm_tn, hip.gemm_nt_f8, hip.TnGroup.run = orig_nt, orig_tn, orig_f8, orig_grp
     by = {}
     for name, fl, s, e in records:
         d = by.setdefault(name, dict(flops=0.0, ms=0.0, n=0))

@@ -55,6 +55,11 @@ int oat_gemm_set_splitk_workspace(void* ws, size_t bytes, void* zeroed_256_ints)
 /* 224-row tiles of the ping-pong kernel (epi 0): 0 never, 1 where rounds x tile rows is smaller than with 256-row tiles
  * (default; e.g. M = 50208, N = 768: 3 rounds of 224 rows instead of 3 rounds of 256), 2 always.  Results are bit-identical. */
 void oat_gemm_set_m224(int mode);
+/* Band-grouped tile walk of the ping-pong kernel: inside an XCD's chunk of tiles the whole row panels are walked in groups
+ * of `tiles` column tiles, so that a round of 32 tiles needs `tiles` column bands of B and 32 / tiles row panels of A instead
+ * of all of B (which overflows the 4 MB L2 at N >= 2304).  0 = off (row-major walk), -1 = auto, > 0 = group width.
+ * Results are bit-identical. */
+void oat_gemm_set_band(int tiles);
 
 /* tuning hook.  bits 0-7: 0 = auto tile choice, 1 = force 128x128 (4 waves), 2 = force 256x256 (8 waves),
  * 3 = 256x256 with 4 hand-pipelined waves; bits 8-15: flags (ablations: 128 = static tile walk even with counters, 1 = skip the epilogue, 4 = all row panels write the first 1024
@@ -77,6 +82,26 @@ size_t oat_gemm_tn_workspace_bytes(int M, int N1, int N2);
 int oat_gemm_tn(const void* P, const void* Q, int M, int N1, int N2, int ldp, int ldq, float* out,
                 float* bias_out /* [N1] column sums of P, or NULL */, int accumulate, void* workspace,
                 size_t workspace_bytes, void* stream);
+/* ---- grouped weight gradients (csrc/gemm_tn_sk.hip): out_p (+)= P_p^T Q_p, bias_p (+)= colsum(P_p) for a LIST of
+ * problems in ONE persistent launch + one fix-up launch.  Replaces the per-layer `dW = dY^T X` of autograd for the six
+ * nn.Linear of a SpaceTimeBlock (/root/reference/OATrans/model/video_transformer.py:46-50,102,133) and the 36 of a
+ * DistilBERT pass (HF DistilBertModel, call site model/oa_model.py:113).
+ * Tables (same layout on host and device, little endian):
+ *   OatTnProblem (64 B): const void* P, Q; float* out; float* bias_out (NULL: none); int M, N1, N2, ldp, ldq, accumulate, 0, 0
+ *                        (N1, N2 multiples of 256; rows [M, round_up(M, 64)) of P and Q readable)
+ *   OatTnSeg (32 B):     int prob, c1, c2, t2, kt0, n, slot (-1: whole tile, direct store), last
+ *   OatTnFix (32 B):     int prob, c1, c2, t2, slot0, nslots, 0, 0
+ * oat_tn_group_plan (host only, no GPU) -> segments, seg_off[blocks + 1], fix records; counts = {segments, fix records,
+ * slabs, blocks}.  splits == 0: the sequence of K-tile pairs of all output tiles (tile-major) is cut into `grid` contiguous
+ * shares (blocks = grid; for many small tiles).  splits >= 1: every tile is split that many ways over M (same M in every
+ * problem), one segment per workgroup, blocks = tiles x splits in split-major, XCD-contiguous order (a row range of the
+ * operands is fetched once per XCD); splits == 1 writes the gradients directly.  The plan depends on the shapes only.  The
+ * caller copies the tables to device memory and provides oat_tn_group_slab_bytes(counts[2]) bytes; launch with grid = blocks. */
+int oat_tn_group_plan(const void* problems, int n, int grid, int splits, void* segs_out, int seg_cap, int* seg_off,
+                      void* fix_out, int fix_cap, int* counts);
+size_t oat_tn_group_slab_bytes(int nslots);
+int oat_tn_group_run(const void* d_problems, const void* d_segs, const void* d_seg_off, int grid,
+                     const void* d_fixes, int nfix, void* d_slabs, void* stream);
 void oat_gemm_tn_set_variant(int v);   /* bits 0-7: 0 auto, 1 force 128x128, 2 force 256x256 tiles; bits 8-15: ablations (1 = no
                                           * global loads after the ring fill, 2 = no slab store); bits 16-31: workgroup budget of the
                                           * 256x256 launch (0 = 256): the caller's share of the CUs when another stream needs the rest */

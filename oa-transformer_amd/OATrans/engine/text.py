@@ -36,6 +36,9 @@ class _LayerActs:
         self.x1_16, self.x2_16 = z16(D), z16(D)
         self.h, self.g = z16(Hd), z16(Hd)
         self.stats = torch.zeros(4, Mp, dtype=torch.float32, device=dev)
+        # backward: the incoming gradients of this layer's four linears stay until the END of the tower's backward, when
+        # all 36 weight gradients run as ONE grouped launch (csrc/gemm_tn_sk.hip): 14 MB per layer at B = 32, L = 32
+        self.dy_lin2, self.d_h, self.dy_out, self.d_qkv = z16(D), z16(Hd), z16(D), z16(3 * D)
 
 
 class _TextPlan:
@@ -59,6 +62,7 @@ class _TextPlan:
         self.ids = torch.zeros(B, L, dtype=torch.int64, device=dev)
         self.mask = torch.zeros(B, L, dtype=torch.int64, device=dev)
         self.tape_fwd = self.tape_bwd = None
+        self.tn_group = None                                           # (key, hip.TnGroup) of the tower's weight gradients
 
 
 class TextEngine:
@@ -71,6 +75,8 @@ class TextEngine:
         self.scale = 64 ** -0.5
         self.plans, self.shadow, self.versions = {}, {}, None
         self.use_tape = os.environ.get("OAT_TAPE", "1") != "0"
+        # 1 (default): the 36 weight gradients of a backward pass as one grouped launch at its end; 0: 36 gemm_tn + tn_reduce pairs
+        self.group_wgrads = os.environ.get("OAT_GROUP_WGRADS", "1") != "0"
 
     def refresh_shadows(self, params, sig=None):
         names = []
@@ -149,7 +155,7 @@ class TextEngine:
             return None
         ptrs = tuple(t.data_ptr() for t in params.values())
         gptr = next(iter(grads.values())).data_ptr() if grads else 0
-        return (torch.cuda.current_stream().cuda_stream, ptrs, gptr, flags)
+        return (torch.cuda.current_stream().cuda_stream, ptrs, gptr, self.group_wgrads, flags)
 
     @staticmethod
     def _taped(pl, slot, key, body):
@@ -221,7 +227,16 @@ class TextEngine:
     def _backward_body(self, pl, params, grads, acc, ph, pa):
         B, L, M = pl.B, pl.L, pl.M
         D, Hd, H = self.D, self.Hd, self.H
-        G, g16 = pl.G, pl.g16
+        G = pl.G
+        grouped = self.group_wgrads and D % 256 == 0 and Hd % 256 == 0
+        wq = []                                   # (P, Q, M, N1, N2, dW, db, accumulate): launched together after the last layer
+
+        def wgrad(P, Q, n1, n2, w, bias):
+            if grouped:
+                wq.append((P, Q, M, n1, n2, w, bias, acc))
+            else:
+                hip.gemm_tn(P, Q, M, n1, n2, w, accumulate=acc, bias_out=bias)
+
         for i in reversed(range(self.n_layers)):
             a = pl.layers[i]
             x16 = pl.layers[i - 1].x2_16 if i > 0 else pl.x0_16
@@ -229,28 +244,34 @@ class TextEngine:
             p = lambda s: params[b + s]
             gr = lambda s: grads[b + s]
             wT = lambda s: self.shadow[b + s][1]
+            dy_lin2, d_h, dy_out, d_qkv = (a.dy_lin2, a.d_h, a.dy_out, a.d_qkv) if grouped else (pl.g16, pl.d_h, pl.g16, pl.d_qkv)
             # x2 = LN(f), f = x1 + lin2(gelu(lin1(x1)))
-            hip.layernorm_bwd(G, a.f, a.stats[2], a.stats[3], p("output_layer_norm.weight"), M, D, dx=G, dx16=g16,
+            hip.layernorm_bwd(G, a.f, a.stats[2], a.stats[3], p("output_layer_norm.weight"), M, D, dx=G, dx16=dy_lin2,
                               dgamma=gr("output_layer_norm.weight"), dbeta=gr("output_layer_norm.bias"),
                               accumulate=acc)                                              # G = dL/df
             if ph > 0:                       # lin2's output met the mask; the residual path (G) did not
-                hip.dropout(G, M, D, ph, pl.rng, self.site(i, "ffn"), out16=g16)
-            hip.gemm_tn(g16, a.g, M, D, Hd, gr("ffn.lin2.weight"), accumulate=acc, bias_out=gr("ffn.lin2.bias"))
-            hip.gemm_nt(g16, wT("ffn.lin2"), M, Hd, D, hip.EPI_MUL_AUX, pl.d_h, aux=a.h)
-            hip.gemm_tn(pl.d_h, a.x1_16, M, Hd, D, gr("ffn.lin1.weight"), accumulate=acc, bias_out=gr("ffn.lin1.bias"))
-            hip.gemm_nt(pl.d_h, wT("ffn.lin1"), M, D, Hd, hip.EPI_F32, G, resid=G)          # G = dL/dx1
+                hip.dropout(G, M, D, ph, pl.rng, self.site(i, "ffn"), out16=dy_lin2)
+            wgrad(dy_lin2, a.g, D, Hd, gr("ffn.lin2.weight"), gr("ffn.lin2.bias"))
+            hip.gemm_nt(dy_lin2, wT("ffn.lin2"), M, Hd, D, hip.EPI_MUL_AUX, d_h, aux=a.h)
+            wgrad(d_h, a.x1_16, Hd, D, gr("ffn.lin1.weight"), gr("ffn.lin1.bias"))
+            hip.gemm_nt(d_h, wT("ffn.lin1"), M, D, Hd, hip.EPI_F32, G, resid=G)             # G = dL/dx1
             # x1 = LN(s), s = x + out_lin(attn(qkv(x)))
-            hip.layernorm_bwd(G, a.s, a.stats[0], a.stats[1], p("sa_layer_norm.weight"), M, D, dx=G, dx16=g16,
+            hip.layernorm_bwd(G, a.s, a.stats[0], a.stats[1], p("sa_layer_norm.weight"), M, D, dx=G, dx16=dy_out,
                               dgamma=gr("sa_layer_norm.weight"), dbeta=gr("sa_layer_norm.bias"), accumulate=acc)
-            hip.gemm_tn(g16, a.ctx, M, D, D, gr("attention.out_lin.weight"), accumulate=acc,
-                        bias_out=gr("attention.out_lin.bias"))
-            hip.gemm_nt(g16, wT("attention.out_lin"), M, D, D, hip.EPI_BF16, pl.d_ctx)
-            hip.attn_text_bwd(a.qkv, pl.mask, a.ctx, a.lse, pl.delta, pl.d_ctx, pl.d_qkv, B, L, H, D, self.scale,
+            wgrad(dy_out, a.ctx, D, D, gr("attention.out_lin.weight"), gr("attention.out_lin.bias"))
+            hip.gemm_nt(dy_out, wT("attention.out_lin"), M, D, D, hip.EPI_BF16, pl.d_ctx)
+            hip.attn_text_bwd(a.qkv, pl.mask, a.ctx, a.lse, pl.delta, pl.d_ctx, d_qkv, B, L, H, D, self.scale,
                               drop_p=pa, rng=pl.rng if pa > 0 else None, site=self.site(i, "attn"))
-            for k, l in enumerate(("q_lin", "k_lin", "v_lin")):      # q | k | v gradients are separate tensors: three GEMMs
-                hip.gemm_tn(pl.d_qkv[:, k * D:(k + 1) * D], x16, M, D, D, gr(f"attention.{l}.weight"), accumulate=acc,
-                            bias_out=gr(f"attention.{l}.bias"))
-            hip.gemm_nt(pl.d_qkv, wT("qkv"), M, D, 3 * D, hip.EPI_F32, G, resid=G)          # G = dL/dx
+            for k, l in enumerate(("q_lin", "k_lin", "v_lin")):      # q | k | v gradients are separate tensors: three problems
+                wgrad(d_qkv[:, k * D:(k + 1) * D], x16, D, D, gr(f"attention.{l}.weight"), gr(f"attention.{l}.bias"))
+            hip.gemm_nt(d_qkv, wT("qkv"), M, D, 3 * D, hip.EPI_F32, G, resid=G)              # G = dL/dx
+        if wq:
+            # all 36 weight gradients: 648 output tiles of 256 x 256 over M = B L rows, whole tiles per workgroup (stream
+            # mode: nothing is split, no partial tiles) - one launch instead of 36 gemm_tn + 36 tn_reduce
+            key = tuple((P.data_ptr(), Q.data_ptr(), w.data_ptr(), bias.data_ptr(), acc) for P, Q, _, _, _, w, bias, acc in wq)
+            if pl.tn_group is None or pl.tn_group[0] != key:
+                pl.tn_group = (key, hip.TnGroup(wq, splits=0))
+            pl.tn_group[1].run()
         # embeddings: x0 = dropout(LN(word[ids] + pos[l]))
         if ph > 0:
             hip.dropout(G, M, D, ph, pl.rng, self.site(0, "emb"), out32=G)

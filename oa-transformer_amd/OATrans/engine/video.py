@@ -112,6 +112,8 @@ class _Plan:
         self.d_o = z16(D)
         self.side = self.x_final = None                   # set per call
         self.tape_fwd = self.tape_bwd = None              # (key, tape id, outputs, segments)
+        self.wq = None                                    # queue of weight-gradient problems (grouped mode, engine._wgrad)
+        self.tn_groups = {}                               # (block, group) -> (key, hip.TnGroup)
         self.dn = torch.zeros(Mp, D, dtype=torch.float32, device=dev)     # static copy of the output gradients
         self.d_region = None                              # [Mp, D] static copy of the region-token gradients
         self.lane = None                                  # fp32 buffers of the precise CLS lane (VideoEngine.forward)
@@ -195,6 +197,10 @@ class VideoEngine:
         self._streams = None
         self._tn_ws = None
         self._tn_retired = []
+        self._tn_slabs = None               # fp32 partial-tile workspace shared by every grouped weight-gradient launch
+        # 1 (default): the six weight gradients of a block are queued and launched together at the block's end
+        # (csrc/gemm_tn_sk.hip); 0: one gemm_tn + tn_reduce pair per weight, where its dY becomes available
+        self.group_wgrads = os.environ.get("OAT_GROUP_WGRADS", "1") != "0"
 
     # ------------------------------------------------------------------ weights / plans / streams
     def refresh_shadows(self, params, sig=None):
@@ -435,7 +441,7 @@ class VideoEngine:
         gptr = next(iter(grads.values())).data_ptr() if grads else 0
         f8 = (len(self._f8["primed"]), self._f8["key"]) if (self.fp8 and self._f8) else None
         return (torch.cuda.current_stream().cuda_stream, pl.side.cuda_stream, ptrs, gptr, self.fp8, self.fp8_bwd, f8, self.cls_lane, self.h_u8,
-                self.tail_split, self.bwd_side, self.bwd_nt_grid, hip.gemm_get_variant(), flags)
+                self.tail_split, self.bwd_side, self.bwd_nt_grid, self.group_wgrads, hip.gemm_get_variant(), flags)
 
     @staticmethod
     def _announce_segment(ready, prefixes, recording):
@@ -717,7 +723,11 @@ class VideoEngine:
             f8b = self.fp8 and self.fp8_bwd and not self.bwd_side
             pl.ga8_valid = None              # the top block's dL/d(out) comes from the final LayerNorm: quantised in a pass
             for k, i in enumerate(reversed(range(self.depth))):
+                pl.wq = [] if (self.group_wgrads and not self.bwd_side) else None
                 (self._block_bwd_f8 if f8b else self._block_bwd)(pl, i, run, params, grads, d_region)
+                if pl.wq is not None:
+                    self._flush_wgrads(pl, i)
+                    pl.wq = None
                 if use_marks:
                     self._announce_segment(ready, prefixes[k], recording)
             if f8b:
@@ -766,13 +776,59 @@ class VideoEngine:
         if done is not None:
             torch.cuda.current_stream().wait_event(done)
 
-    def _wgrad(self, P, Q, rows, n1, n2, w, b, acc=False):
+    def _wgrad(self, P, Q, rows, n1, n2, w, b, acc=False, pl=None):
+        """One weight gradient w (+)= P[:rows]^T Q[:rows], b (+)= colsum(P).  With a plan whose queue is open (`pl.wq`,
+        grouped mode) the problem is only QUEUED: _flush_wgrads launches a block's six together (csrc/gemm_tn_sk.hip)."""
+        if pl is not None and pl.wq is not None and n1 % 256 == 0 and n2 % 256 == 0:
+            pl.wq.append((P, Q, rows, n1, n2, w, b, bool(acc)))
+            return
         need = hip.lib().oat_gemm_tn_workspace_bytes(rows, n1, n2) // 4     # exact for this (rows, shape)
         if self._tn_ws is None or self._tn_ws.numel() < need:
             if self._tn_ws is not None:
                 self._tn_retired.append(self._tn_ws)       # launch tapes recorded so far still point at it
             self._tn_ws = torch.empty(need, dtype=torch.float32, device=P.device)   # one slab workspace, grown on demand
         hip.gemm_tn(P, Q, rows, n1, n2, w, bias_out=b, ws=self._tn_ws, accumulate=acc)
+
+    def _flush_wgrads(self, pl, tag):
+        """Launch the queued weight gradients of one block.  Big problems share a launch as long as their output tiles
+        leave every tile >= 2 splits over M on the CUs (ViT-B: {fc2, fc1, qkv, qkv} = 126 tiles, 2 splits), the small ones
+        form a second group ({proj, proj}: 18 tiles, 14 splits): 2 GEMM launches + 2 fix-ups and 126 MB of fp32 partial
+        tiles per block instead of 6 + 6 and 387 MB.  Groups are cached per (plan, block): their tables hold raw pointers
+        of plan-owned buffers and of the flat gradient buffer."""
+        items, pl.wq = pl.wq, []
+        if not items:
+            return
+        grid = torch.cuda.get_device_properties(items[0][0].device).multi_processor_count
+        order = sorted(range(len(items)), key=lambda k: -(items[k][3] // 256) * (items[k][4] // 256))
+        groups, cur, cur_tiles = [], [], 0
+        for k in order:
+            t = (items[k][3] // 256) * (items[k][4] // 256)
+            if cur and cur_tiles + t > grid // 2:
+                groups.append(cur)
+                cur, cur_tiles = [], 0
+            cur.append(k)
+            cur_tiles += t
+        if cur:
+            groups.append(cur)
+        for gi, ks in enumerate(groups):
+            probs = [items[k] for k in ks]
+            key = tuple((P.data_ptr(), Q.data_ptr(), w.data_ptr(), b.data_ptr() if b is not None else 0, rows, acc)
+                        for P, Q, rows, n1, n2, w, b, acc in probs)
+            held = pl.tn_groups.get((tag, gi))
+            if held is None or held[0] != key:
+                meta = [(rows, n1, n2) for _, _, rows, n1, n2, _, _, _ in probs]
+                need = hip.lib().oat_tn_group_slab_bytes(
+                    hip.TnGroup.plan(meta, grid, hip.TnGroup.auto_splits(meta, grid))[3]) // 4
+                if self._tn_slabs is None or self._tn_slabs.numel() < need:
+                    if self._tn_slabs is not None:
+                        self._tn_retired.append(self._tn_slabs)       # launch tapes recorded so far still point at it
+                        pl.tn_groups.clear()
+                    self._tn_slabs = torch.empty(need, dtype=torch.float32, device=probs[0][0].device)
+                grp = hip.TnGroup([(P, Q, rows, n1, n2, w, b, acc) for P, Q, rows, n1, n2, w, b, acc in probs], grid=grid,
+                                  slabs=self._tn_slabs)
+                held = (key, grp)
+                pl.tn_groups[(tag, gi)] = held
+            held[1].run()
 
     def _final_bwd(self, pl, run, params, grads, have_patches, d_region):
         """pl.dn holds dL/d(normed output) in the plan's row layout (patch rows are only valid with have_patches)."""
@@ -831,7 +887,7 @@ class VideoEngine:
         s1 = self._slot(pl, lambda: hip.layernorm_bwd(
             pl.d_a, a.y, st[4], st[5], p("norm2.weight"), M, D, dx=G, dx16=gb, dres=G,
             dgamma=gr("norm2.weight"), dbeta=gr("norm2.bias"), accumulate=pl.acc),                               # G = dL/dy
-            [lambda: self._wgrad(ga, a.g, M, D, Hd, gr("mlp.fc2.weight"), gr("mlp.fc2.bias"), pl.acc)])
+            [lambda: self._wgrad(ga, a.g, M, D, Hd, gr("mlp.fc2.weight"), gr("mlp.fc2.bias"), pl.acc, pl=pl)])
         self._join(s1)
         # ---- space attention: y = x + proj(attn(LN1(xt)))
         hip.gemm_nt(gb, wT("attn.proj"), M, D, D, hip.EPI_BF16, pl.d_o)
@@ -839,14 +895,14 @@ class VideoEngine:
         def space_bwd():
             self._attn_bwd(pl, hip.attn_space_bwd, a.qkv_s, a.o_s, a.lse_s, pl.d_o, d_qkv_s)
         s2 = self._slot(pl, space_bwd,
-                        [lambda: self._wgrad(d_h, a.a2, M, Hd, D, gr("mlp.fc1.weight"), gr("mlp.fc1.bias"), pl.acc)])
+                        [lambda: self._wgrad(d_h, a.a2, M, Hd, D, gr("mlp.fc1.weight"), gr("mlp.fc1.bias"), pl.acc, pl=pl)])
         self._join(s2)
         hip.gemm_nt(d_qkv_s, wT("attn.qkv"), M, D, 3 * D, hip.EPI_BF16, pl.d_a)
         # G <- dL/dy + dL/dxt (both reach x directly); gc <- dL/dxt alone (feeds the time branch)
         s3 = self._slot(pl, lambda: hip.layernorm_bwd(
             pl.d_a, a.xt, st[2], st[3], p("norm1.weight"), M, D, dx=G, dx16=gc, dres=G, dx16_excl_res=True,
             dgamma=gr("norm1.weight"), dbeta=gr("norm1.bias"), accumulate=pl.acc),
-            [lambda: self._wgrad(d_qkv_s, a.a1, M, 3 * D, D, gr("attn.qkv.weight"), gr("attn.qkv.bias"), pl.acc)])
+            [lambda: self._wgrad(d_qkv_s, a.a1, M, 3 * D, D, gr("attn.qkv.weight"), gr("attn.qkv.bias"), pl.acc, pl=pl)])
         self._join(s3)
         # ---- time attention: xt = x + proj(attn(LN3(x)))
         hip.gemm_nt(gc, wT("timeattn.proj"), M, D, D, hip.EPI_BF16, pl.d_o)
@@ -854,14 +910,14 @@ class VideoEngine:
         def time_bwd():
             self._attn_bwd(pl, hip.attn_time_bwd, a.qkv_t, a.o_t, a.lse_t, pl.d_o, d_qkv_t)
         s4 = self._slot(pl, time_bwd,
-                        [lambda: self._wgrad(gb, a.o_s, M, D, D, gr("attn.proj.weight"), gr("attn.proj.bias"), pl.acc),
-                         lambda: self._wgrad(gc, a.o_t, M, D, D, gr("timeattn.proj.weight"), gr("timeattn.proj.bias"), pl.acc)])
+                        [lambda: self._wgrad(gb, a.o_s, M, D, D, gr("attn.proj.weight"), gr("attn.proj.bias"), pl.acc, pl=pl),
+                         lambda: self._wgrad(gc, a.o_t, M, D, D, gr("timeattn.proj.weight"), gr("timeattn.proj.bias"), pl.acc, pl=pl)])
         self._join(s4)
         hip.gemm_nt(d_qkv_t, wT("timeattn.qkv"), M, D, 3 * D, hip.EPI_BF16, pl.d_a)
         s5 = self._slot(pl, lambda: hip.layernorm_bwd(
             pl.d_a, x, st[0], st[1], p("norm3.weight"), M, D, dx=G, dx16=ga_next, dres=G,
             dgamma=gr("norm3.weight"), dbeta=gr("norm3.bias"), accumulate=pl.acc),                               # G = dL/dx
-            [lambda: self._wgrad(d_qkv_t, a.a3, M, 3 * D, D, gr("timeattn.qkv.weight"), gr("timeattn.qkv.bias"), pl.acc)])
+            [lambda: self._wgrad(d_qkv_t, a.a3, M, 3 * D, D, gr("timeattn.qkv.weight"), gr("timeattn.qkv.bias"), pl.acc, pl=pl)])
         self._join(s5)
 
     def _block_bwd_f8(self, pl, i, run, params, grads, d_region):
@@ -891,26 +947,26 @@ class VideoEngine:
                               aux=a.h8 if pl.h_u8 else a.h, quantised=pl.ga8_valid == i, dy8=ga8)
         self._dgrad_f8(pl, i, 4, d_h, Hd, D, hip.EPI_BF16, pl.d_a, quantised=dh_q)
         gb_q = self._ln_bwd(pl, i, 3, pl.d_a, a.y, st[4], st[5], p("norm2.weight"), gb, gr("norm2.weight"), gr("norm2.bias"))
-        self._wgrad(ga, a.g, M, D, Hd, gr("mlp.fc2.weight"), gr("mlp.fc2.bias"), pl.acc)
+        self._wgrad(ga, a.g, M, D, Hd, gr("mlp.fc2.weight"), gr("mlp.fc2.bias"), pl.acc, pl=pl)
         # ---- space attention
         self._dgrad_f8(pl, i, 3, gb, D, D, hip.EPI_BF16, pl.d_o, quantised=gb_q)
         self._attn_bwd(pl, hip.attn_space_bwd, a.qkv_s, a.o_s, a.lse_s, pl.d_o, d_qkv_s)
-        self._wgrad(d_h, a.a2, M, Hd, D, gr("mlp.fc1.weight"), gr("mlp.fc1.bias"), pl.acc)
+        self._wgrad(d_h, a.a2, M, Hd, D, gr("mlp.fc1.weight"), gr("mlp.fc1.bias"), pl.acc, pl=pl)
         self._dgrad_f8(pl, i, 2, d_qkv_s, 3 * D, D, hip.EPI_BF16, pl.d_a)
         gc_q = self._ln_bwd(pl, i, 1, pl.d_a, a.xt, st[2], st[3], p("norm1.weight"), gc, gr("norm1.weight"), gr("norm1.bias"),
                             dx16_excl_res=True)
-        self._wgrad(d_qkv_s, a.a1, M, 3 * D, D, gr("attn.qkv.weight"), gr("attn.qkv.bias"), pl.acc)
+        self._wgrad(d_qkv_s, a.a1, M, 3 * D, D, gr("attn.qkv.weight"), gr("attn.qkv.bias"), pl.acc, pl=pl)
         # ---- time attention
         self._dgrad_f8(pl, i, 1, gc, D, D, hip.EPI_BF16, pl.d_o, quantised=gc_q)
         self._attn_bwd(pl, hip.attn_time_bwd, a.qkv_t, a.o_t, a.lse_t, pl.d_o, d_qkv_t)
-        self._wgrad(gb, a.o_s, M, D, D, gr("attn.proj.weight"), gr("attn.proj.bias"), pl.acc)
-        self._wgrad(gc, a.o_t, M, D, D, gr("timeattn.proj.weight"), gr("timeattn.proj.bias"), pl.acc)
+        self._wgrad(gb, a.o_s, M, D, D, gr("attn.proj.weight"), gr("attn.proj.bias"), pl.acc, pl=pl)
+        self._wgrad(gc, a.o_t, M, D, D, gr("timeattn.proj.weight"), gr("timeattn.proj.bias"), pl.acc, pl=pl)
         self._dgrad_f8(pl, i, 0, d_qkv_t, 3 * D, D, hip.EPI_BF16, pl.d_a)
         # LayerNorm-3 backward writes dL/d(output of block i-1): the fc2 data gradient's operand of the NEXT block to run
         nxt_q = self._ln_bwd(pl, i - 1, 5, pl.d_a, x, st[0], st[1], p("norm3.weight"), ga_next, gr("norm3.weight"),
                              gr("norm3.bias"), dx8=ga8_next)
         pl.ga8_valid = i - 1 if nxt_q else None
-        self._wgrad(d_qkv_t, a.a3, M, 3 * D, D, gr("timeattn.qkv.weight"), gr("timeattn.qkv.bias"), pl.acc)
+        self._wgrad(d_qkv_t, a.a3, M, 3 * D, D, gr("timeattn.qkv.weight"), gr("timeattn.qkv.bias"), pl.acc, pl=pl)
 
     def _embed_bwd(self, pl, grads):
         """x0[patch] = cols @ Wp^T + b + pos[1+n] + temporal[f] ; x0[cls] = cls + pos[0]"""

@@ -39,6 +39,7 @@ def lib():
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.oat_last_error.restype = ctypes.c_char_p
         _lib.oat_gemm_tn_workspace_bytes.restype = ctypes.c_size_t
+        _lib.oat_tn_group_slab_bytes.restype = ctypes.c_size_t
         _lib.oat_infonce_workspace_floats.restype = ctypes.c_size_t
         _lib.oat_sim_workspace_floats.restype = ctypes.c_size_t
         for name in declared_symbols():
@@ -46,6 +47,8 @@ def lib():
                 raise OatError(f"liboatrans_hip.so lacks symbol {name}")
         if os.environ.get("OAT_GEMM_M224"):              # 0 never / 1 auto (default) / 2 always: 224-row tiles of the ping-pong gemm_nt
             _lib.oat_gemm_set_m224(int(os.environ["OAT_GEMM_M224"]))
+        if os.environ.get("OAT_GEMM_BAND"):              # band-grouped tile walk of the ping-pong gemm_nt: 0 off / -1 auto / n column tiles per group
+            _lib.oat_gemm_set_band(int(os.environ["OAT_GEMM_BAND"]))
         if os.environ.get("OAT_GEMM_VARIANT"):           # tuning hooks (see oat_gemm_set_variant / oat_gemm_tn_set_variant)
             _lib.oat_gemm_set_variant(int(os.environ["OAT_GEMM_VARIANT"], 0))
             _gemm_variant[0] = int(os.environ["OAT_GEMM_VARIANT"], 0)
@@ -295,6 +298,92 @@ class CastTable:
 
     def run(self):
         _check(lib().oat_cast_bf16_multi(_ptr(self.table), self.n, self.tiles, _ptr(self.owner), _stream()), "oat_cast_bf16_multi")
+
+
+class TnGroup:
+    """Several weight gradients  out_p[N1,N2] (+)= P_p[:M]^T @ Q_p[:M],  bias_p[N1] (+)= colsum(P_p)  in ONE persistent
+    launch + one fix-up launch (csrc/gemm_tn_sk.hip: the K-tile pairs of all output tiles of all problems form one
+    sequence, cut into `grid` equal shares; only the tiles a share boundary cuts leave fp32 partial tiles).
+    problems: (P bf16 [>=M, >=N1], Q bf16 [>=M, >=N2], M, N1, N2, out fp32 [N1, N2] contiguous, bias_out fp32 [N1] | None,
+    accumulate).  N1, N2 multiples of 256.  The tables hold raw pointers: every tensor is plan-owned and static; `key`
+    identifies the set (rebuild when a buffer moved).  The plan itself is computed by the library on the host
+    (oat_tn_group_plan, no GPU needed)."""
+
+    REC = 8       # int32 words per segment / fix record
+
+    @staticmethod
+    def plan(problems_meta, grid, splits=0):
+        """Host-side decomposition: problems_meta = [(M, N1, N2)] -> (segs int32 [nseg, 8], seg_off int32 [blocks + 1],
+        fixes int32 [nfix, 8], nslots).  splits = 0: the unit sequence cut into `grid` shares; splits >= 1: every tile split
+        that many ways over M, split-major and XCD-contiguous (oat_tn_group_plan).  Segment record: prob, c1, c2, t2, kt0,
+        n, slot, last; fix record: prob, c1, c2, t2, slot0, nslots, 0, 0.  CPU-testable."""
+        import numpy as np
+        n = len(problems_meta)
+        tab = np.zeros((n, 8), dtype=np.int64)
+        for i, (M, N1, N2) in enumerate(problems_meta):
+            tab[i, 4] = (M & 0xffffffff) | (N1 << 32)
+            tab[i, 5] = (N2 & 0xffffffff) | (8 << 32)        # ldp (unused by the planner beyond its % 8 check)
+            tab[i, 6] = 8                                      # ldq | accumulate << 32
+        tiles = sum((N1 // 256) * (N2 // 256) for _, N1, N2 in problems_meta)
+        cap = max(tiles + 2 * grid + 8, tiles * max(splits, 1) + 8)
+        segs = np.zeros((cap, TnGroup.REC), dtype=np.int32)
+        seg_off = np.zeros(cap + 1, dtype=np.int32)
+        fcap = max(grid, tiles) + 8
+        fixes = np.zeros((fcap, TnGroup.REC), dtype=np.int32)
+        counts = np.zeros(4, dtype=np.int32)
+        rc = lib().oat_tn_group_plan(tab.ctypes.data_as(ctypes.c_void_p), n, grid, int(splits), segs.ctypes.data_as(ctypes.c_void_p), cap,
+                                     seg_off.ctypes.data_as(ctypes.c_void_p), fixes.ctypes.data_as(ctypes.c_void_p), fcap,
+                                     counts.ctypes.data_as(ctypes.c_void_p))
+        _check(rc, "oat_tn_group_plan")
+        return segs[:counts[0]].copy(), seg_off[:counts[3] + 1].copy(), fixes[:counts[1]].copy(), int(counts[2])
+
+    @staticmethod
+    def auto_splits(problems_meta, grid):
+        """Uniform splits where the problems are big and share one M: the largest split count whose tiles x splits
+        workgroups fit one round of the CUs; 0 (stream mode) for many small tiles."""
+        tiles = sum((N1 // 256) * (N2 // 256) for _, N1, N2 in problems_meta)
+        same_m = len({M for M, _, _ in problems_meta}) == 1
+        if not same_m or tiles > grid:
+            return 0
+        return max(1, grid // tiles)
+
+    def __init__(self, problems, grid=None, splits=None, slabs=None):
+        """slabs: optional caller-owned fp32 workspace shared by several groups that never run concurrently (grown by the
+        caller; must hold oat_tn_group_slab_bytes(self.nslots) bytes - see `slab_floats`)."""
+        import numpy as np
+        dev = problems[0][0].device
+        if grid is None:
+            grid = torch.cuda.get_device_properties(dev).multi_processor_count
+        rows, meta, keep = [], [], []
+        for P, Q, M, N1, N2, out, bias_out, acc in problems:
+            if out.dtype != torch.float32 or not out.is_contiguous() or out.numel() != N1 * N2:
+                raise OatError("TnGroup: out must be a contiguous fp32 [N1, N2] tensor")
+            if P.dtype != torch.bfloat16 or Q.dtype != torch.bfloat16 or P.stride(1) != 1 or Q.stride(1) != 1:
+                raise OatError("TnGroup: P and Q must be bf16 with unit column stride")
+            rows.append([P.data_ptr(), Q.data_ptr(), out.data_ptr(), bias_out.data_ptr() if bias_out is not None else 0,
+                         (M & 0xffffffff) | (N1 << 32), (N2 & 0xffffffff) | (P.stride(0) << 32),
+                         (Q.stride(0) & 0xffffffff) | ((1 if acc else 0) << 32), 0])
+            meta.append((M, N1, N2))
+            keep.append((P, Q, out, bias_out))
+        if splits is None:
+            splits = self.auto_splits(meta, grid)
+        segs, seg_off, fixes, nslots = self.plan(meta, grid, splits)
+        self.splits = splits
+        self.grid, self.nfix, self.nslots, self.n = len(seg_off) - 1, len(fixes), nslots, len(rows)
+        self.key = tuple(tuple(r[:4]) + (r[6] >> 32,) for r in rows)
+        self.table = torch.tensor(rows, dtype=torch.int64).to(dev)
+        self.segs = torch.from_numpy(segs).to(dev)
+        self.seg_off = torch.from_numpy(seg_off).to(dev)
+        self.fixes = torch.from_numpy(fixes if len(fixes) else np.zeros((1, self.REC), dtype=np.int32)).to(dev)
+        self.slab_floats = lib().oat_tn_group_slab_bytes(nslots) // 4
+        if slabs is not None and slabs.numel() < self.slab_floats:
+            raise OatError("TnGroup: the shared slab workspace is too small")
+        self.slabs = slabs if slabs is not None else torch.empty(self.slab_floats, dtype=torch.float32, device=dev)
+        self.keep = keep
+
+    def run(self):
+        _check(lib().oat_tn_group_run(_ptr(self.table), _ptr(self.segs), _ptr(self.seg_off), self.grid, _ptr(self.fixes), self.nfix,
+                                      _ptr(self.slabs), _stream()), "oat_tn_group_run")
 
 
 def _attn_fwd(fn, name, qkv, out, lse, B, T, N, H, D, scale):

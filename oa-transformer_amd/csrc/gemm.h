@@ -35,6 +35,7 @@ struct GemmArgs {
   int h_u8;                // the GELU-derivative tensor (out of EPI_GELU_GRAD / aux of EPI_MUL_AUX) is 8-bit fixed point,
                            // one byte per element, ldc / ldaux in bytes (ping-pong kernel only; gemm_nt_pp.hip HU8_*)
   float* sk_ws; int* sk_ctr;   // split-K of the last round (gemm_nt_pp.hip): partial-tile workspace, zeroed per-tile counters
+  int band;                    // ping-pong kernel, PPF_BAND: column tiles per band group of the per-XCD tile walk (0 = row-major walk)
 };
 
 constexpr int BK = 64;
@@ -56,7 +57,8 @@ int launch_tn_pp(const TnArgs& g, int flags, hipStream_t s);
 // gemm_nt_pp.hip.  pp_supported: does the ping-pong kernel cover this launch (epilogue, shape)?
 bool pp_supported(int epi, const GemmArgs& g);
 int launch_pp(int epi, const GemmArgs& g, int grid_slots, int flags, hipStream_t s);
-void pp_set_m224(int mode);      // 224-row tiles of the ping-pong kernel: 0 never, 1 where they save a round's worth (default), 2 always
+void pp_set_m224(int mode);
+void pp_set_band(int tiles);     // band-grouped tile walk (gemm_nt_pp.hip PPF_BAND): column tiles per group, 0 = off, -1 = auto      // 224-row tiles of the ping-pong kernel: 0 never, 1 where they save a round's worth (default), 2 always
 // the same kernel on OCP fp8 (e4m3) operands with per-tensor scales (GemmArgs::dq_a / dq_b)
 bool pp_f8_supported(int epi, const GemmArgs& g);
 int launch_pp_f8(int epi, const GemmArgs& g, int grid_slots, bool a_e5m2, hipStream_t s);

@@ -745,6 +745,7 @@ extern "C" int oat_gemm_set_splitk_workspace(void* ws, size_t bytes, void* zeroe
   return 0;
 }
 extern "C" void oat_gemm_set_m224(int mode) { oat::pp_set_m224(mode); }
+extern "C" void oat_gemm_set_band(int tiles) { oat::pp_set_band(tiles); }
 extern "C" void oat_gemm_set_variant(int v) { oat::g_variant = v & 0xff; oat::g_dbg = (v >> 8) & 0xff; oat::g_persist = (v >> 16) & 0xffff; }
 
 extern "C" int oat_gemm_nt(const void* A, const void* B, int M, int N, int K, int lda, int ldb,

@@ -47,7 +47,8 @@ enum : int { PPF_PRIO = 1, PPF_NOSTAGGER = 2, PPF_LGKM = 4, PPF_BONUS = 8, PPF_N
              PPF_F8 = 128, PPF_A_BF8 = 256,     // PPF_A_BF8: the A operand is e5m2 (gradients), B stays e4m3
              PPF_HU8 = 512,                     // the saved GELU derivative travels as 8-bit fixed point (see HU8_*)
              PPF_SPLITK = 1024,                 // split-K of the last, partial round of tiles (see `sk_*` in the kernel)
-             PPF_M224 = 2048 };                 // 224-row tiles (see TM in the kernel)
+             PPF_M224 = 2048,                   // 224-row tiles (see TM in the kernel)
+             PPF_BAND = 4096 };                 // band-grouped per-XCD tile walk (see `tile_of` in the kernel)
 
 // gelu'(h) lies in [-0.129, 1.129].  As bf16 it costs 2 bytes per element to write (fc1 forward) and to read back (fc2 data
 // gradient) - 308 MB per launch each way, all of it on top of a GEMM that is otherwise MFMA-bound.  Stored as
@@ -309,21 +310,60 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs g) {
   const bool sk_on = sk_S > 1;
   const int sk_tile = sk_on ? (int)blockIdx.x % sk_r : 0, sk_split = sk_on ? (int)blockIdx.x / sk_r : 0;
   const int sk_nk = sk_on ? nk / sk_S : nk;                             // K-tiles of a split tile
-  const int ntl = sk_on ? full + ((int)blockIdx.x < sk_r * sk_S ? 1 : 0)
-                        : (nwg - 1 - (int)blockIdx.x) / grid + 1;
+  const int ntl_rm = sk_on ? full + ((int)blockIdx.x < sk_r * sk_S ? 1 : 0)
+                           : (nwg - 1 - (int)blockIdx.x) / grid + 1;
   float dq = 1.f, inv_dq = 1.f;
   if constexpr (F8) {
     dq = g.dq_a[0] * g.dq_b[0];
     inv_dq = 1.f / dq;
   }
+  // PPF_BAND: band-grouped walk.  The row-major walk gives an XCD (32 CUs, one 4 MB L2) 32 CONSECUTIVE tiles per round:
+  // 32 / ntn row panels x all ntn column tiles, i.e. the whole of B every round - at N = 3072, K = 768 that is 4.7 MB of
+  // B + 0.9 MB of A per XCD and round, more than the L2 holds, so B is re-fetched from the Infinity Cache / HBM in every
+  // round (PMC: 549 MB read per launch for 82 MB of operands).  Here the XCD's chunk of tiles is the same, but the WHOLE
+  // row panels inside it are walked band group by band group: a round is (32 / GW) panels x GW column tiles, so per round
+  // the XCD needs GW column bands of B (which stay for the next rounds of the same group) and streams 32 / GW row panels of
+  // A, each used by GW tiles at the same time.  The partial panels at the two ends of the chunk keep their row-major
+  // places.  Same tiles, same per-tile arithmetic: results are bit-identical to the row-major walk.
+  // Host guarantees grid % 8 == 0 (a workgroup then stays on one XCD chunk for its whole walk).
+  constexpr bool BAND = (FL & PPF_BAND) != 0;
+  static_assert(!(BAND && SPLITK), "band walk and split-K are separate variants");
+  int bw_s0 = 0, bw_f = 0, bw_mid = 0, bw_pm = 0, bw_P0 = 0, bw_gw = 1;
+  if constexpr (BAND) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = (int)blockIdx.x & 7;
+    bw_s0 = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;     // first tile (row-major id) of this XCD's chunk
+    const int n = q + (xcd < r ? 1 : 0);
+    const int c0 = bw_s0 % ntn;
+    bw_f = min(c0 == 0 ? 0 : ntn - c0, n);                             // tiles of the partial first panel
+    bw_pm = (n - bw_f) / ntn;                                          // whole panels
+    bw_mid = bw_pm * ntn;
+    bw_P0 = (bw_s0 + bw_f) / ntn;
+    bw_gw = g.band;
+  }
   struct Tile { int m0, n0; };
   auto tile_of = [&](int t) __attribute__((always_inline)) {
-    const int w = (sk_on && t == full) ? full * grid + sk_tile : (int)blockIdx.x + t * grid;
-    const int q = nwg >> 3, r = nwg & 7, xcd = w & 7, idx = w >> 3;
-    const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;   // XCD-contiguous, bijective
-    const int tm = bid / ntn;
-    return Tile{tm * TM, (bid - tm * ntn) << 8};
+    if constexpr (BAND) {
+      const int idx = ((int)blockIdx.x >> 3) + t * (grid >> 3);
+      const int L = idx - bw_f;
+      const bool mid = L >= 0 && L < bw_mid;
+      // row-major place (ends of the chunk)
+      const int bid = bw_s0 + idx, tm_r = bid / ntn, tn_r = bid - tm_r * ntn;
+      // band-grouped place (whole panels)
+      const int Lm = mid ? L : 0, gsz = max(bw_pm * bw_gw, 1);
+      const int gi = Lm / gsz, rem = Lm - gi * gsz;
+      const int wg = max(min(bw_gw, ntn - gi * bw_gw), 1);
+      const int pn = rem / wg;
+      const int tm = mid ? bw_P0 + pn : tm_r, tn = mid ? gi * bw_gw + rem - pn * wg : tn_r;
+      return Tile{tm * TM, tn << 8};
+    } else {
+      const int w = (sk_on && t == full) ? full * grid + sk_tile : (int)blockIdx.x + t * grid;
+      const int q = nwg >> 3, r = nwg & 7, xcd = w & 7, idx = w >> 3;
+      const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;   // XCD-contiguous, bijective
+      const int tm = bid / ntn;
+      return Tile{tm * TM, (bid - tm * ntn) << 8};
+    }
   };
+  const int ntl = ntl_rm;
 
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   float* const sbias = reinterpret_cast<float*>(smem + PP_BIAS);
@@ -852,6 +892,23 @@ int launch_pp_f8(int epi, const GemmArgs& g, int grid_slots, bool a_e5m2, hipStr
 
 void pp_set_m224(int mode) { g_pp_m224 = mode; }
 
+// Band-grouped tile walk (PPF_BAND): column tiles per band group.  0 = off (row-major walk), > 0 = that many where the
+// launch qualifies, -1 = auto: only the short-K, wide-N launches whose B operand overflows an XCD's L2 (N >= 2304 with
+// K <= 1024), groups of 3 or 4 column tiles (a divisor of the column-tile count).
+static int g_pp_band = 0;
+void pp_set_band(int tiles) { g_pp_band = tiles; }
+static int pp_band_for(const GemmArgs& g, int slots, int tm) {
+  if (g_pp_band == 0 || g.sk_ws != nullptr) return 0;
+  const long long ntn = g.N / 256, nwg = ((g.M + tm - 1) / tm) * ntn, grid = nwg < slots ? nwg : slots;
+  if (grid % 8 != 0 || nwg < 2 * grid) return 0;           // a workgroup must stay on one XCD chunk; >= 2 rounds to gain anything
+  int gw = g_pp_band;
+  if (gw < 0) {
+    if (ntn < 9 || g.K > 1024) return 0;
+    gw = ntn % 4 == 0 ? 4 : 3;
+  }
+  return gw < ntn ? gw : 0;
+}
+
 bool pp_supported(int epi, const GemmArgs& g) {
   if (epi != EPI_BF16 && epi != EPI_GELU_GRAD && epi != EPI_MUL_AUX) return false;
   const int nk = g.K / 64;
@@ -863,17 +920,32 @@ bool pp_supported(int epi, const GemmArgs& g) {
 int launch_pp(int epi, const GemmArgs& g, int grid_slots, int flags, hipStream_t s) {
   constexpr int DEF = PPF_PRIO | PPF_BONUS | PPF_LGKM;   // LGKM: measured free, and it makes the WAR spacing strict
   const int fl = DEF ^ flags;                    // a set bit toggles the default
-  if (epi == EPI_GELU_GRAD) {
-    if (g.h_u8) return pp_prefers_224(g, grid_slots) ? launch_pp_cfg<EPI_GELU_GRAD, DEF | PPF_HU8 | PPF_M224>(g, grid_slots, s)
-                                                     : launch_pp_cfg<EPI_GELU_GRAD, DEF | PPF_HU8>(g, grid_slots, s);
-    return launch_pp_cfg<EPI_GELU_GRAD, DEF>(g, grid_slots, s);
-  }
-  if (epi == EPI_MUL_AUX) {
-    if (g.h_u8) return pp_prefers_224(g, grid_slots) ? launch_pp_cfg<EPI_MUL_AUX, DEF | PPF_HU8 | PPF_M224>(g, grid_slots, s)
-                                                     : launch_pp_cfg<EPI_MUL_AUX, DEF | PPF_HU8>(g, grid_slots, s);
-    return launch_pp_cfg<EPI_MUL_AUX, DEF>(g, grid_slots, s);
+  if (epi == EPI_GELU_GRAD || epi == EPI_MUL_AUX) {
+    if (g.h_u8) {
+      const bool m224 = pp_prefers_224(g, grid_slots);
+      GemmArgs a = g;
+      a.band = pp_band_for(g, grid_slots, m224 ? 224 : 256);
+      if (epi == EPI_GELU_GRAD) {
+        if (a.band) return m224 ? launch_pp_cfg<EPI_GELU_GRAD, DEF | PPF_HU8 | PPF_M224 | PPF_BAND>(a, grid_slots, s)
+                                : launch_pp_cfg<EPI_GELU_GRAD, DEF | PPF_HU8 | PPF_BAND>(a, grid_slots, s);
+        return m224 ? launch_pp_cfg<EPI_GELU_GRAD, DEF | PPF_HU8 | PPF_M224>(g, grid_slots, s)
+                    : launch_pp_cfg<EPI_GELU_GRAD, DEF | PPF_HU8>(g, grid_slots, s);
+      }
+      if (a.band) return m224 ? launch_pp_cfg<EPI_MUL_AUX, DEF | PPF_HU8 | PPF_M224 | PPF_BAND>(a, grid_slots, s)
+                              : launch_pp_cfg<EPI_MUL_AUX, DEF | PPF_HU8 | PPF_BAND>(a, grid_slots, s);
+      return m224 ? launch_pp_cfg<EPI_MUL_AUX, DEF | PPF_HU8 | PPF_M224>(g, grid_slots, s)
+                  : launch_pp_cfg<EPI_MUL_AUX, DEF | PPF_HU8>(g, grid_slots, s);
+    }
+    return epi == EPI_GELU_GRAD ? launch_pp_cfg<EPI_GELU_GRAD, DEF>(g, grid_slots, s) : launch_pp_cfg<EPI_MUL_AUX, DEF>(g, grid_slots, s);
   }
   if (fl == DEF && g.sk_ws != nullptr) return launch_pp_cfg<EPI_BF16, DEF | PPF_SPLITK>(g, grid_slots, s);
+  if (fl == DEF) {
+    const bool m224 = pp_prefers_224(g, grid_slots);
+    GemmArgs a = g;
+    a.band = pp_band_for(g, grid_slots, m224 ? 224 : 256);
+    if (a.band) return m224 ? launch_pp_cfg<EPI_BF16, DEF | PPF_M224 | PPF_BAND>(a, grid_slots, s)
+                            : launch_pp_cfg<EPI_BF16, DEF | PPF_BAND>(a, grid_slots, s);
+  }
   if (fl == DEF && pp_prefers_224(g, grid_slots)) return launch_pp_cfg<EPI_BF16, DEF | PPF_M224>(g, grid_slots, s);
   if (fl == (DEF | PPF_M224)) return launch_pp_cfg<EPI_BF16, DEF | PPF_M224>(g, grid_slots, s);      // forced (tests)
   switch (fl) {

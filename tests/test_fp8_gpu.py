@@ -2,7 +2,10 @@
 Kernel level: the e4m3 conversion equals torch.float8_e4m3fn bit for bit, oat_gemm_nt_f8 equals an fp32 matmul of the
 SAME quantised operands up to its bf16 output rounding, and stays within 4 % rel-L2 of the unquantised product.
 Model level: the contract class with fp8 forward linears AND fp8 data-gradient GEMMs against the reference golden; stated (looser) tolerance:
-embeddings rel-L2 <= 5e-2, sim matrix <= 3e-2 max-abs, loss <= 5e-2 (bf16 path: 1e-2 / 1e-3 / 2e-2)."""
+embeddings rel-L2 <= 5e-2, sim matrix <= 6e-3 max-abs, loss <= 1e-2 (bf16 path: 1e-2 / 1e-3 / 2e-2).  Measured: video embedding
+1.5-3.7e-2, sim 1.3-3.6e-3, loss 0.1-0.2 %.  The term that breaks the bf16 path's 1e-3: the text tower and the CLS rows of the
+video tower stay fp32 (CLS lane), but the patch keys / values the CLS query attends come out of e4m3 GEMMs (2^-4 relative
+rounding per operand element, per-tensor scale) - their error averages over ~1.5-7 k keys to ~2e-2 of the embedding."""
 import os
 
 import pytest
@@ -91,8 +94,8 @@ def test_frozen_in_time_fp8_forward_vs_reference_golden(golden_dir, frames, fp8_
         sim_err = (sim.detach().cpu() - g["sim"]).abs().max().item()
         print(f"fp8 step {step}: video rel {rel(v.detach(), g['video']):.4f} sim err {sim_err:.4f} loss {loss.item():.4f} vs {g['loss'].item():.4f}")
         assert rel(v.detach(), g["video"]) < 5e-2
-        assert sim_err <= 3e-2
-        assert abs(loss.item() - g["loss"].item()) < 5e-2
+        assert sim_err <= 6e-3
+        assert abs(loss.item() - g["loss"].item()) < 1e-2
     f8 = m.video_model._engine._f8
     # per block: 6 forward inputs (+ 6 incoming gradients with fp8 backward) have a delayed scale; every weight has one
     assert len(f8["primed"]) == (12 if fp8_bwd else 6) * 12
@@ -113,7 +116,7 @@ def test_frozen_in_time_fp8_forward_vs_reference_golden(golden_dir, frames, fp8_
 def test_config5_geometry_fp8_forward_vs_oracle():
     """BASELINE config 5's geometry at full width - ViT-B/16, 16 frames of 336^2 (441 patches per frame, 7057 tokens per
     clip), fp8 forward linears - against the fp32 CPU oracle (pinned at 224^2 by the reference goldens; the 336^2 run is
-    the oracle's own).  Two clips; stated tolerance as above: video embedding rel-L2 <= 5e-2, CLS cosine >= 0.998."""
+    the oracle's own).  Two clips; stated tolerance as above: video embedding rel-L2 <= 5e-2, CLS cosine >= 0.9995."""
     from OATrans.model.video_transformer import SpaceTimeTransformer
     from oracle import oatrans_oracle as orc
     geo = dict(num_frames=16, patches_per_frame=441)
@@ -135,7 +138,7 @@ def test_config5_geometry_fp8_forward_vs_oracle():
     e = ((cls - ocls).norm() / ocls.norm()).item()
     cos = torch.nn.functional.cosine_similarity(cls, ocls, dim=1).min().item()
     print(f"config-5 geometry (16 x 336^2, fp8 forward): CLS rel-L2 {e:.4f}, min cosine {cos:.5f}")
-    assert e < 5e-2 and cos > 0.998
+    assert e < 5e-2 and cos > 0.9995
 
 
 def test_config5_composed_global_local_16f_336_fp8_vs_oracle():
@@ -146,8 +149,10 @@ def test_config5_composed_global_local_16f_336_fp8_vs_oracle():
     every embedding the trainer's three losses consume, and the loss itself (oa_model_global_local.py:149-208,
     trainer_global_local.py:187-211).  Then one backward: the fp8-forward step's parameter gradients against the bf16
     step's on the same weights and inputs (the oracle's backward at this size needs tens of GB).
-    Stated tolerance for fp8: embeddings rel-L2 <= 5e-2, sim matrices <= 3e-2 max-abs, loss <= 5e-2; the text side and
-    the CLS path of the video side stay fp32 (CLS lane), so what moves is the patch keys / values the CLS attends."""
+    Stated tolerance for fp8: embeddings rel-L2 <= 5e-2, sim matrices <= 1e-2 max-abs (region x tags: mean over 10 region
+    features of ONE object frame, 442 keys - the least averaging; measured 3.6e-3, text x video 1.3e-3), loss <= 1e-2; the text
+    side and the CLS path of the video side stay fp32 (CLS lane), so what moves is the patch keys / values the CLS attends.
+    The bf16 run of the same model is held to the bf16 bounds (1e-2 / 1e-3 / 2e-2; measured 2.4e-3 / 3e-4 / 0.05 %)."""
     from OATrans.data_loader.data_loader import MultiDistTextObjectVideoDataLoader
     from OATrans.model import NormSoftmaxLoss, sim_matrix
     from OATrans.model.oa_layers import mean_rows
@@ -214,7 +219,7 @@ def test_config5_composed_global_local_16f_336_fp8_vs_oracle():
                 "region x tags": (orc.sim_matrix(out[4].mean(1), out[5].mean(1)) - orc.sim_matrix(o[4].mean(1), o[5].mean(1))).abs().max().item()}
         print(f"config 5 composed (global_local 1+16 x 336^2, {'fp8' if fp8 else 'bf16'} forward): rel-L2 {rels}; sim errs {sims}; "
               f"loss {runs[fp8]['loss']:.4f} vs oracle {oloss:.4f}")
-        tol_rel, tol_sim, tol_loss = (5e-2, 3e-2, 5e-2) if fp8 else (1e-2, 1e-3, 2e-2)
+        tol_rel, tol_sim, tol_loss = (5e-2, 1e-2, 1e-2) if fp8 else (1e-2, 1e-3, 2e-2)
         assert all(e < tol_rel for e in rels.values()), rels
         assert all(e <= tol_sim for e in sims.values()), sims
         assert abs(runs[fp8]["loss"] - oloss) < tol_loss * max(1.0, abs(oloss))

@@ -206,6 +206,87 @@ def test_gemm_tn(M, N1, N2):
     close(bias, 2 * bref, atol=4e-3 * math.sqrt(M), rtol=2e-3, what="gemm_tn bias accumulate")
 
 
+@pytest.mark.parametrize("mode", ["stream", "uniform", "uniform1"])
+def test_gemm_tn_grouped(mode):
+    """oat_tn_group_plan / oat_tn_group_run (csrc/gemm_tn_sk.hip): several weight gradients in one launch + one fix-up,
+    against fp32 torch math.  Problems of different shapes (one with a strided P view - the q | k | v slices of DistilBERT's
+    d_qkv - one without a bias, one that ACCUMULATES into existing values), ragged M (rows beyond M are readable garbage),
+    stream mode (unit sequence cut into shares: split AND whole tiles) and uniform split-major mode (with 1 split: direct
+    stores, no fix-up).  Repeat-run determinism: bit-identical."""
+    hip = _hip()
+    M = 1000 if mode == "stream" else 2500                     # 15.6 / 39.06 K-tiles: ragged last tile
+    Mp = (M + 255) // 256 * 256
+    g = torch.Generator(device="cpu").manual_seed(7)
+    shapes = [(768, 256, True, False), (256, 512, True, True), (512, 256, False, False), (256, 256, True, False)]
+    wide = torch.full((Mp, 1024), 3.0, dtype=torch.bfloat16, device=DEV)     # problem 3 reads columns 512..767 of this buffer
+    wide[:M] = (torch.randn(M, 1024, generator=g)).to(DEV).to(torch.bfloat16)
+    probs, refs = [], []
+    for k, (N1, N2, has_bias, acc) in enumerate(shapes):
+        if k == 3:
+            P = wide[:, 512:768]
+        else:
+            P = torch.full((Mp, N1), 3.0, dtype=torch.bfloat16, device=DEV)
+            P[:M] = torch.randn(M, N1, generator=g).to(DEV).to(torch.bfloat16)
+        Q = torch.full((Mp, N2), -5.0, dtype=torch.bfloat16, device=DEV)
+        Q[:M] = torch.randn(M, N2, generator=g).to(DEV).to(torch.bfloat16)
+        out = torch.full((N1, N2), 7.0, device=DEV)
+        bias = torch.full((N1,), 9.0, device=DEV) if has_bias else None
+        ref = P[:M].float().t() @ Q[:M].float() + (7.0 if acc else 0.0)
+        bref = P[:M].float().sum(0) + (9.0 if acc else 0.0)
+        probs.append((P, Q, M, N1, N2, out, bias, acc))
+        refs.append((ref, bref))
+    grid, splits = {"stream": (5, 0), "uniform": (256, 3), "uniform1": (256, 1)}[mode]
+    grp = hip.TnGroup(probs, grid=grid, splits=splits)
+    if mode == "stream":
+        assert grp.nfix > 0 and any(int(s[6]) < 0 for s in grp.segs.cpu())      # both kinds of tiles are exercised
+    if mode == "uniform1":
+        assert grp.nfix == 0 and grp.nslots == 0
+    grp.run()
+    torch.cuda.synchronize()
+    first = [(p[5].clone(), p[6].clone() if p[6] is not None else None) for p in probs]
+    for (P, Q, _, N1, N2, out, bias, acc), (ref, bref) in zip(probs, refs):
+        close(out, ref, atol=2e-3 * math.sqrt(M), rtol=2e-3, what=f"grouped tn {mode} {N1}x{N2}")
+        if bias is not None:
+            close(bias, bref, atol=2e-3 * math.sqrt(M), rtol=2e-3, what=f"grouped tn bias {mode} {N1}x{N2}")
+    # determinism: reset the outputs and run again -> bit-identical
+    for (_, _, _, N1, N2, out, bias, acc) in probs:
+        out.fill_(7.0)
+        if bias is not None:
+            bias.fill_(9.0)
+    grp.run()
+    torch.cuda.synchronize()
+    for (p, (o1, b1)) in zip(probs, first):
+        assert torch.equal(p[5], o1) and (b1 is None or torch.equal(p[6], b1))
+
+
+def test_gemm_tn_grouped_matches_single_launches_at_block_shapes():
+    """The grouping engine/video.py uses per ViT block - {fc2, fc1, qkv, qkv} 2-way split and {proj, proj} 14-way split at
+    M = 50208 rows - against the per-problem oat_gemm_tn launches on the same operands (same MFMA products, another
+    summation tree over M: equal within fp32 accumulation noise)."""
+    hip = _hip()
+    M, D = 50208, 768
+    Mp = (M + 255) // 256 * 256
+    torch.manual_seed(3)
+    mk = lambda c: (torch.randn(Mp, c, device=DEV) * 0.5).to(torch.bfloat16)
+    dY = {"fc2": mk(D), "fc1": mk(4 * D), "qkv_s": mk(3 * D), "qkv_t": mk(3 * D), "proj_s": mk(D), "proj_t": mk(D)}
+    X = {"fc2": mk(4 * D), "fc1": mk(D), "qkv_s": mk(D), "qkv_t": mk(D), "proj_s": mk(D), "proj_t": mk(D)}
+    outs, refs = {}, {}
+    for k in dY:
+        n1, n2 = dY[k].shape[1], X[k].shape[1]
+        outs[k] = (torch.zeros(n1, n2, device=DEV), torch.zeros(n1, device=DEV))
+        refs[k] = (torch.zeros(n1, n2, device=DEV), torch.zeros(n1, device=DEV))
+        hip.gemm_tn(dY[k], X[k], M, n1, n2, refs[k][0], bias_out=refs[k][1])
+    for names in (("fc2", "fc1", "qkv_s", "qkv_t"), ("proj_s", "proj_t")):
+        grp = hip.TnGroup([(dY[k], X[k], M, dY[k].shape[1], X[k].shape[1], outs[k][0], outs[k][1], False) for k in names])
+        assert grp.grid == 252 and grp.splits == (2 if len(names) == 4 else 14)
+        grp.run()
+    torch.cuda.synchronize()
+    for k in dY:
+        scale = refs[k][0].abs().max().item()
+        assert (outs[k][0] - refs[k][0]).abs().max().item() <= 2e-5 * scale + 1e-3, k
+        assert (outs[k][1] - refs[k][1]).abs().max().item() <= 2e-5 * refs[k][1].abs().max().item() + 1e-3, k
+
+
 def test_gemm_tn_asymmetric():
     hip = _hip()
     M, N1, N2 = 64, 128, 128
