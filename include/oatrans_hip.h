@@ -57,7 +57,8 @@ int oat_gemm_set_splitk_workspace(void* ws, size_t bytes, void* zeroed_256_ints)
 void oat_gemm_set_m224(int mode);
 /* Band-grouped tile walk of the ping-pong kernel: inside an XCD's chunk of tiles the whole row panels are walked in groups
  * of `tiles` column tiles, so that a round of 32 tiles needs `tiles` column bands of B and 32 / tiles row panels of A instead
- * of all of B (which overflows the 4 MB L2 at N >= 2304).  0 = off (row-major walk), -1 = auto, > 0 = group width.
+ * of all of B (which overflows the 4 MB L2 at N >= 2304).  0 = off (row-major walk), -1 = auto (default: the fc1 forward
+ * launch only, where it measures faster), > 0 = group width.
  * Results are bit-identical. */
 void oat_gemm_set_band(int tiles);
 
@@ -138,13 +139,34 @@ int oat_pos_table(const float* pos, const float* temporal, const float* cls_toke
                   float* cls0, int T, int N, int D, void* stream);
 int oat_broadcast_rows(const float* src, float* dst, int ld, int R, int D, void* stream);
 int oat_cast_bf16(const float* src, void* dst_bf16, void* dstT_bf16, int R, int C, void* stream);
-/* All weight shadows of a module in one launch.  desc: device array of n_matrices records of eight int64
- * {src f32*, dst bf16* | 0, dstT bf16* | 0, R, C, ldd, ldT, first_tile}; matrix m owns the T x T tiles (T = oat_cast_bf16_tile())
+/* All weight shadows of a module in one launch.  desc: device array of n_matrices records of NINE int64
+ * {src f32*, dst bf16* | 0, dstT bf16* | 0, R, C, ldd, ldT, first_tile, colscale f32* | 0}; colscale[c] multiplies column c
+ * before the cast (the LayerNorm scale folded into the following linear layer, W' = W diag(gamma)); matrix m owns the T x T tiles (T = oat_cast_bf16_tile())
  * [first_tile[m], first_tile[m+1]) of the grid, total_tiles blocks in all (the per-weight `.to(bfloat16)` /
  * `.t().contiguous()` / `torch.cat` ATen work a mixed-precision port of video_transformer.py:102,133,46-50 performs). */
 int oat_cast_bf16_tile(void);   /* edge of the square tiles oat_cast_bf16_multi counts in (first_tile, total_tiles) */
 int oat_cast_bf16_multi(const void* desc, int n_matrices, int total_tiles, const int* tile_matrix /* device int32[total_tiles]: matrix of each tile, or NULL (binary search per block) */,
                         void* stream);
+
+/* ---- folded LayerNorm (norm1 / norm2 / norm3 of a SpaceTimeBlock, video_transformer.py:161-176) -------------------------
+ * z = W (gamma * xhat + beta) + b  is executed as  z = W' xhat + b'  with W' = W diag(gamma) (colscale of
+ * oat_cast_bf16_multi) and b' = b + W beta (oat_fold_bias_multi): oat_layernorm_fwd with gamma = beta = NULL then writes the
+ * plain normalised row, the data-gradient GEMM of W'^T delivers d(xhat), and oat_layernorm_bwd_xhat needs the saved bf16 xhat
+ * and rstd only (539 instead of 616 MB per call at M = 50208, no (dgamma, dbeta) partial sums).  The weight-gradient GEMM
+ * on xhat gives dW' and db'; oat_ln_fold_grads turns them into dW = dW' diag(gamma) + db' beta^T, dgamma[k] =
+ * sum_n W[n,k] dW'[n,k], dbeta[k] = sum_n W[n,k] db'[n].  Same function, same gradients as autograd of nn.LayerNorm + nn.Linear.
+ *   oat_fold_bias_multi: desc = device array of {W, beta, b | 0, out, N, K, first_row, 0} (8 x 8 B); 4 rows per block;
+ *                        block_desc[i] = descriptor of block i; first_row = 4 x the descriptor's first block
+ *   oat_ln_fold_grads:   desc = device array of {dWp, dbp, W, gamma, beta, dW, db, dgamma, dbeta, N, K, first_block,
+ *                        accumulate} (13 x 8 B); a layer owns oat_ln_fold_blocks(K) consecutive blocks; dW may alias dWp
+ *                        (in place), db may alias dbp; work = total_blocks * 128 floats + total_blocks ints, the ints ZERO
+ *                        before the first launch (ticket counters; every launch leaves them zero); deterministic */
+int oat_layernorm_bwd_xhat(const void* dxh_bf16, int lddxh, const void* xhat_bf16, int ldxh, const float* rstd,
+                           const float* dres, int lddres, float* dx, int lddx, void* dx16, int lddx16,
+                           int dx16_excl_res, int M, int D, void* stream);
+int oat_fold_bias_multi(const void* desc, const int* block_desc, int total_blocks, void* stream);
+int oat_ln_fold_blocks(int K);
+int oat_ln_fold_grads(const void* desc, int n_desc, int total_blocks, void* work, void* stream);
 
 /* ---- divided space-time attention (video_transformer.py:99-135, :28-32) ------------------
  * qkv: bf16 [M, 3*D] (q | k | v, heads contiguous); out: bf16 [M, D]; lse: fp32 [M, H].

@@ -114,6 +114,8 @@ class _Plan:
         self.tape_fwd = self.tape_bwd = None              # (key, tape id, outputs, segments)
         self.wq = None                                    # queue of weight-gradient problems (grouped mode, engine._wgrad)
         self.tn_groups = {}                               # (block, group) -> (key, hip.TnGroup)
+        self.fold_tabs = {}                               # block -> (key, hip.FoldGradTable)
+        self.fold_pending = None
         self.dn = torch.zeros(Mp, D, dtype=torch.float32, device=dev)     # static copy of the output gradients
         self.d_region = None                              # [Mp, D] static copy of the region-token gradients
         self.lane = None                                  # fp32 buffers of the precise CLS lane (VideoEngine.forward)
@@ -148,6 +150,11 @@ class VideoEngine:
     (overwrite semantics: the reference zeroes grads every step, trainer_dist.py:156)."""
 
     LINEARS = ("attn.qkv", "attn.proj", "timeattn.qkv", "timeattn.proj", "mlp.fc1", "mlp.fc2")
+    FOLDED = {"timeattn.qkv": "norm3", "attn.qkv": "norm1", "mlp.fc1": "norm2"}     # linear <- the LayerNorm folded into it
+
+    def fold_active(self):
+        """LayerNorm folding runs on the bf16 in-order path (the fp8 kernels quantise gamma * xhat + beta themselves)."""
+        return self.fold_ln and not self.fp8 and not self.bwd_side
 
     def __init__(self, depth, embed_dim, num_heads, mlp_ratio, patch_size, in_chans, num_frames):
         self.depth, self.D, self.H = depth, embed_dim, num_heads
@@ -201,6 +208,15 @@ class VideoEngine:
         # 1 (default): the six weight gradients of a block are queued and launched together at the block's end
         # (csrc/gemm_tn_sk.hip); 0: one gemm_tn + tn_reduce pair per weight, where its dY becomes available
         self.group_wgrads = os.environ.get("OAT_GROUP_WGRADS", "1") != "0"
+        # 1 (default, bf16 path): norm3 / norm1 / norm2 are FOLDED into the linear layer that follows them (timeattn.qkv /
+        # attn.qkv / mlp.fc1): the shadows are W' = W diag(gamma), the bias b' = b + W beta, LayerNorm forward writes the plain
+        # normalised row xhat, LayerNorm backward reads the saved bf16 xhat + rstd instead of the fp32 input (no fp32 copy of
+        # x + time is kept at all), and (dW, dgamma, dbeta) come out of dW' by oat_ln_fold_grads: the same function and
+        # the same gradients with 77 MB less per LayerNorm backward and 154 MB less in norm1's forward (rowops.hip)
+        self.fold_ln = os.environ.get("OAT_FOLD_LN", "1") != "0"
+        self.fbias = {}                     # folded biases b' (fp32), per folded linear
+        self._fold_bias = None
+        self._fold_tmp = {}                 # accumulate mode: scratch (dW', db') of the folded linears
 
     # ------------------------------------------------------------------ weights / plans / streams
     def refresh_shadows(self, params, sig=None):
@@ -208,18 +224,33 @@ class VideoEngine:
         (`sig` = EngineModule._weights_signature())."""
         names = [f"blocks.{i}.{l}.weight" for i in range(self.depth) for l in self.LINEARS]
         names.append("patch_embed.proj.weight")
+        fold = self.fold_active()
+        sig = (sig, fold) if sig is not None else None
         if sig is not None and sig == self.shadow_versions:
             return
         srcs = [params[n].detach().reshape(params[n].shape[0], -1) for n in names]
-        key = tuple(w.data_ptr() for w in srcs)
-        if self._cast is None or self._cast.key != key:           # masters moved (first call, .to(), flatten)
-            entries = []
+        key = tuple(w.data_ptr() for w in srcs) + (fold,)
+        if self._cast is None or self._cast.key != key:           # masters moved (first call, .to(), flatten) or the fold flag changed
+            entries, fb = [], []
             for n, w in zip(names, srcs):
                 self.shadow[n] = (torch.empty_like(w, dtype=torch.bfloat16),
                                   torch.empty(w.shape[1], w.shape[0], dtype=torch.bfloat16, device=w.device))
-                entries.append((w, self.shadow[n][0], self.shadow[n][1], w.shape[1], w.shape[0]))
+                norm = self.FOLDED.get(n.split(".", 2)[2][:-len(".weight")]) if (fold and n.startswith("blocks.")) else None
+                if norm is None:
+                    entries.append((w, self.shadow[n][0], self.shadow[n][1], w.shape[1], w.shape[0]))
+                else:                                             # W' = W diag(gamma of the LayerNorm in front), b' = b + W beta
+                    blk = ".".join(n.split(".")[:2])                  # "blocks.<i>"
+                    gamma, beta = params[f"{blk}.{norm}.weight"].detach(), params[f"{blk}.{norm}.bias"].detach()
+                    entries.append((w, self.shadow[n][0], self.shadow[n][1], w.shape[1], w.shape[0], gamma))
+                    bname = n[:-len("weight")] + "bias"
+                    self.fbias[bname] = torch.empty(w.shape[0], dtype=torch.float32, device=w.device)
+                    fb.append((w, beta, params[bname].detach(), self.fbias[bname]))
             self._cast = hip.CastTable(entries)
+            self._cast.key = key
+            self._fold_bias = hip.FoldBiasTable(fb) if fb else None
         self._cast.run()                                          # all 73 W / W^T shadows in one launch
+        if self._fold_bias is not None:
+            self._fold_bias.run()                                 # the 36 folded biases in one launch
         self.shadow_versions = sig
         if self.fp8:
             self._refresh_fp8_weights()
@@ -441,7 +472,7 @@ class VideoEngine:
         gptr = next(iter(grads.values())).data_ptr() if grads else 0
         f8 = (len(self._f8["primed"]), self._f8["key"]) if (self.fp8 and self._f8) else None
         return (torch.cuda.current_stream().cuda_stream, pl.side.cuda_stream, ptrs, gptr, self.fp8, self.fp8_bwd, f8, self.cls_lane, self.h_u8,
-                self.tail_split, self.bwd_side, self.bwd_nt_grid, self.group_wgrads, hip.gemm_get_variant(), flags)
+                self.tail_split, self.bwd_side, self.bwd_nt_grid, self.group_wgrads, self.fold_active(), hip.gemm_get_variant(), flags)
 
     @staticmethod
     def _announce_segment(ready, prefixes, recording):
@@ -527,13 +558,17 @@ class VideoEngine:
         w = lambda s: self.shadow[f"blocks.{i}.{s}.weight"][0]
         st = a.stats
         lane = pl.lane
+        fold = self.fold_active()
+        # folded LayerNorms write the plain normalised row (gamma = beta = None); their linear layers take the folded bias
+        ln_gb = lambda n: (None, None) if fold else (p(n + ".weight"), p(n + ".bias"))
+        lin_b = lambda n: self.fbias[f"blocks.{i}.{n}.bias"] if fold else p(n + ".bias")
         q3 = self._f8_primed(i, 0)          # fp8: LayerNorm outputs are quantised by the LayerNorm kernel itself
         if pend is None:
             x = pl.x0
             if q3:
                 self._ln_f8(pl, i, 0, x, p("norm3.weight"), p("norm3.bias"), a.a3, st[0], st[1])
             else:
-                hip.layernorm_fwd(x, p("norm3.weight"), p("norm3.bias"), M, D, 1e-6, y=a.a3, mean=st[0], rstd=st[1])
+                hip.layernorm_fwd(x, *ln_gb("norm3"), M, D, 1e-6, y=a.a3, mean=st[0], rstd=st[1])
             if lane is not None:                         # the lane starts from the embedding's CLS rows
                 hip.stream_edge(torch.cuda.current_stream(), pl.side)
                 with torch.cuda.stream(pl.side):
@@ -544,8 +579,7 @@ class VideoEngine:
             if q3:
                 self._ln_f8(pl, i, 0, pend.y, p("norm3.weight"), p("norm3.bias"), a.a3, st[0], st[1], add16=br, sum32=pend.out)
             else:
-                hip.add_layernorm_fwd(pend.y, br, pend.out, p("norm3.weight"), p("norm3.bias"), M, D, 1e-6, y=a.a3,
-                                      mean=st[0], rstd=st[1])
+                hip.add_layernorm_fwd(pend.y, br, pend.out, *ln_gb("norm3"), M, D, 1e-6, y=a.a3, mean=st[0], rstd=st[1])
             x = pend.out
             if lane is not None:                         # x = y + mlp of the previous block
                 self._lane_ln(pl, lane["y"], lane["br32"], lane["x"], p("norm3.weight"), p("norm3.bias"), lane["a32"])
@@ -558,7 +592,7 @@ class VideoEngine:
         if f8:
             self._linear_f8(pl, i, 0, a.a3, D, 3 * D, hip.EPI_BF16, a.qkv_t, p("timeattn.qkv.bias"), quantised=q3)
         else:
-            hip.gemm_nt(a.a3, w("timeattn.qkv"), M, 3 * D, D, hip.EPI_BF16, a.qkv_t, bias=p("timeattn.qkv.bias"))
+            hip.gemm_nt(a.a3, w("timeattn.qkv"), M, 3 * D, D, hip.EPI_BF16, a.qkv_t, bias=lin_b("timeattn.qkv"))
         self._attention(pl, hip.attn_time_fwd, a.qkv_t, a.o_t, a.lse_t)
         if lane is not None:
             self._lane_linear(pl, lane["o32"], p("timeattn.proj.weight"), p("timeattn.proj.bias"), D, D, lane["br32"])
@@ -572,13 +606,14 @@ class VideoEngine:
         if q1:
             self._ln_f8(pl, i, 2, x, p("norm1.weight"), p("norm1.bias"), a.a1, st[2], st[3], add16=br, sum32=a.xt)
         else:
-            hip.add_layernorm_fwd(x, br, a.xt, p("norm1.weight"), p("norm1.bias"), M, D, 1e-6, y=a.a1, mean=st[2],
+            # xt = x + time feeds norm1 only (the space residual comes from x): folded, its fp32 copy is never stored
+            hip.add_layernorm_fwd(x, br, None if fold else a.xt, *ln_gb("norm1"), M, D, 1e-6, y=a.a1, mean=st[2],
                                   rstd=st[3])                                       # xt = x + time
         # ---- space attention
         if f8:
             self._linear_f8(pl, i, 2, a.a1, D, 3 * D, hip.EPI_BF16, a.qkv_s, p("attn.qkv.bias"), quantised=q1)
         else:
-            hip.gemm_nt(a.a1, w("attn.qkv"), M, 3 * D, D, hip.EPI_BF16, a.qkv_s, bias=p("attn.qkv.bias"))
+            hip.gemm_nt(a.a1, w("attn.qkv"), M, 3 * D, D, hip.EPI_BF16, a.qkv_s, bias=lin_b("attn.qkv"))
         self._attention(pl, hip.attn_space_fwd, a.qkv_s, a.o_s, a.lse_s)
         if lane is not None:
             self._lane_linear(pl, lane["o32"], p("attn.proj.weight"), p("attn.proj.bias"), D, D, lane["br32"])
@@ -595,7 +630,7 @@ class VideoEngine:
         if q2:
             self._ln_f8(pl, i, 4, x, p("norm2.weight"), p("norm2.bias"), a.a2, st[4], st[5], add16=br, sum32=a.y)
         else:
-            hip.add_layernorm_fwd(x, br, a.y, p("norm2.weight"), p("norm2.bias"), M, D, 1e-6, y=a.a2, mean=st[4],
+            hip.add_layernorm_fwd(x, br, a.y, *ln_gb("norm2"), M, D, 1e-6, y=a.a2, mean=st[4],
                                   rstd=st[5])                                       # y = x + space
         # ---- MLP
         if f8:
@@ -604,9 +639,9 @@ class VideoEngine:
             self._linear_f8(pl, i, 5, a.g, Hd, D, hip.EPI_BF16, br, p("mlp.fc2.bias"), quantised=gq)
         else:
             if pl.h_u8:
-                hip.gemm_nt(a.a2, w("mlp.fc1"), M, Hd, D, hip.EPI_GELU_GRAD | hip.EPI_U8, a.h8, out2=a.g, bias=p("mlp.fc1.bias"))
+                hip.gemm_nt(a.a2, w("mlp.fc1"), M, Hd, D, hip.EPI_GELU_GRAD | hip.EPI_U8, a.h8, out2=a.g, bias=lin_b("mlp.fc1"))
             else:
-                hip.gemm_nt(a.a2, w("mlp.fc1"), M, Hd, D, hip.EPI_GELU_GRAD, a.h, out2=a.g, bias=p("mlp.fc1.bias"))
+                hip.gemm_nt(a.a2, w("mlp.fc1"), M, Hd, D, hip.EPI_GELU_GRAD, a.h, out2=a.g, bias=lin_b("mlp.fc1"))
             hip.gemm_nt(a.g, w("mlp.fc2"), M, D, Hd, hip.EPI_BF16, br, bias=p("mlp.fc2.bias"))
         return a                                                                    # out = y + br, formed lazily
 
@@ -728,6 +763,9 @@ class VideoEngine:
                 if pl.wq is not None:
                     self._flush_wgrads(pl, i)
                     pl.wq = None
+                if getattr(pl, "fold_pending", None) == i:
+                    self._fold_grads(pl, i, params, grads)
+                    pl.fold_pending = None
                 if use_marks:
                     self._announce_segment(ready, prefixes[k], recording)
             if f8b:
@@ -790,45 +828,62 @@ class VideoEngine:
         hip.gemm_tn(P, Q, rows, n1, n2, w, bias_out=b, ws=self._tn_ws, accumulate=acc)
 
     def _flush_wgrads(self, pl, tag):
-        """Launch the queued weight gradients of one block.  Big problems share a launch as long as their output tiles
-        leave every tile >= 2 splits over M on the CUs (ViT-B: {fc2, fc1, qkv, qkv} = 126 tiles, 2 splits), the small ones
-        form a second group ({proj, proj}: 18 tiles, 14 splits): 2 GEMM launches + 2 fix-ups and 126 MB of fp32 partial
-        tiles per block instead of 6 + 6 and 387 MB.  Groups are cached per (plan, block): their tables hold raw pointers
-        of plan-owned buffers and of the flat gradient buffer."""
+        """Launch the queued weight gradients of one block as ONE grouped launch + one fix-up (csrc/gemm_tn_sk.hip).
+        The problems are layered by size: big ones share a layer as long as their output tiles leave every tile >= 2 splits
+        over M on the CUs (ViT-B: {fc2, fc1, qkv, qkv} = 126 tiles x 2 splits), the small ones form the next layer
+        ({proj, proj}: 18 tiles x 14 splits); every workgroup walks one segment of each layer.  Per block: 1 + 1 launches
+        and 126 MB of fp32 partial tiles instead of 6 + 6 and 387 MB.  The group is cached per (plan, block): its tables
+        hold raw pointers of plan-owned buffers and of the flat gradient buffer."""
         items, pl.wq = pl.wq, []
         if not items:
             return
         grid = torch.cuda.get_device_properties(items[0][0].device).multi_processor_count
         order = sorted(range(len(items)), key=lambda k: -(items[k][3] // 256) * (items[k][4] // 256))
-        groups, cur, cur_tiles = [], [], 0
+        layers, cur, cur_tiles = [], [], 0
         for k in order:
             t = (items[k][3] // 256) * (items[k][4] // 256)
             if cur and cur_tiles + t > grid // 2:
-                groups.append(cur)
+                layers.append(cur)
                 cur, cur_tiles = [], 0
             cur.append(k)
             cur_tiles += t
         if cur:
-            groups.append(cur)
-        for gi, ks in enumerate(groups):
-            probs = [items[k] for k in ks]
-            key = tuple((P.data_ptr(), Q.data_ptr(), w.data_ptr(), b.data_ptr() if b is not None else 0, rows, acc)
-                        for P, Q, rows, n1, n2, w, b, acc in probs)
-            held = pl.tn_groups.get((tag, gi))
-            if held is None or held[0] != key:
-                meta = [(rows, n1, n2) for _, _, rows, n1, n2, _, _, _ in probs]
-                need = hip.lib().oat_tn_group_slab_bytes(
-                    hip.TnGroup.plan(meta, grid, hip.TnGroup.auto_splits(meta, grid))[3]) // 4
-                if self._tn_slabs is None or self._tn_slabs.numel() < need:
-                    if self._tn_slabs is not None:
-                        self._tn_retired.append(self._tn_slabs)       # launch tapes recorded so far still point at it
-                        pl.tn_groups.clear()
-                    self._tn_slabs = torch.empty(need, dtype=torch.float32, device=probs[0][0].device)
-                grp = hip.TnGroup([(P, Q, rows, n1, n2, w, b, acc) for P, Q, rows, n1, n2, w, b, acc in probs], grid=grid,
-                                  slabs=self._tn_slabs)
-                held = (key, grp)
-                pl.tn_groups[(tag, gi)] = held
-            held[1].run()
+            layers.append(cur)
+        probs = [items[k] for ks in layers for k in ks]
+        key = tuple((P.data_ptr(), Q.data_ptr(), w.data_ptr(), b.data_ptr() if b is not None else 0, rows, acc)
+                    for P, Q, rows, n1, n2, w, b, acc in probs)
+        held = pl.tn_groups.get(tag)
+        if held is None or held[0] != key:
+            idx, pos = [], 0
+            for ks in layers:
+                idx.append(list(range(pos, pos + len(ks))))
+                pos += len(ks)
+            meta = [(rows, n1, n2) for _, _, rows, n1, n2, _, _, _ in probs]
+            need = hip.lib().oat_tn_group_slab_bytes(hip.TnGroup.plan_layers([[meta[k] for k in ks] for ks in idx], grid)[3]) // 4
+            if self._tn_slabs is None or self._tn_slabs.numel() < need:
+                if self._tn_slabs is not None:
+                    self._tn_retired.append(self._tn_slabs)       # launch tapes recorded so far still point at it
+                    pl.tn_groups.clear()
+                self._tn_slabs = torch.empty(need, dtype=torch.float32, device=probs[0][0].device)
+            held = (key, hip.TnGroup(probs, grid=grid, slabs=self._tn_slabs, layers=idx))
+            pl.tn_groups[tag] = held
+        held[1].run()
+
+    def _fold_grads(self, pl, i, params, grads):
+        """dW' / db' of the three folded linear layers of block i -> dW, db, dgamma, dbeta (one launch, oat_ln_fold_grads)."""
+        ents = []
+        for lin, norm in self.FOLDED.items():
+            gw, gb = grads[f"blocks.{i}.{lin}.weight"], grads[f"blocks.{i}.{lin}.bias"]
+            src_w, src_b = self._fold_tmp[lin] if pl.acc else (gw, gb)
+            ents.append((src_w, src_b, params[f"blocks.{i}.{lin}.weight"], params[f"blocks.{i}.{norm}.weight"],
+                         params[f"blocks.{i}.{norm}.bias"], gw, gb, grads[f"blocks.{i}.{norm}.weight"],
+                         grads[f"blocks.{i}.{norm}.bias"], pl.acc))
+        key = tuple(t.data_ptr() for e in ents for t in e[:9]) + (pl.acc,)
+        held = pl.fold_tabs.get(i)
+        if held is None or held[0] != key:
+            held = (key, hip.FoldGradTable(ents))
+            pl.fold_tabs[i] = held
+        held[1].run()
 
     def _final_bwd(self, pl, run, params, grads, have_patches, d_region):
         """pl.dn holds dL/d(normed output) in the plan's row layout (patch rows are only valid with have_patches)."""
@@ -878,15 +933,36 @@ class VideoEngine:
         wT = lambda s: self.shadow[f"blocks.{i}.{s}.weight"][1]
         st = a.stats
         d_h, gb, d_qkv_s, gc, d_qkv_t = st8["d_h"], st8["gb"], st8["d_qkv_s"], st8["gc"], st8["d_qkv_t"]
+        fold = self.fold_active()
+
+        def ln_bwd(norm, k, xin, xhat, dx16, **kw):
+            """backward of norm3 / norm1 / norm2 (stats rows 2k, 2k + 1): folded -> from the saved bf16 xhat and rstd"""
+            if fold:
+                hip.layernorm_bwd_xhat(pl.d_a, xhat, st[2 * k + 1], M, D, dx=G, dx16=dx16, dres=G, **kw)
+            else:
+                hip.layernorm_bwd(pl.d_a, xin, st[2 * k], st[2 * k + 1], p(norm + ".weight"), M, D, dx=G, dx16=dx16, dres=G,
+                                  dgamma=gr(norm + ".weight"), dbeta=gr(norm + ".bias"), accumulate=pl.acc, **kw)
+
+        def wgrad_folded(P, Q, n1, n2, lin):
+            """weight gradient of a linear layer that may carry a folded LayerNorm: dW' (and db') then go to the gradient
+            buffers (in place; oat_ln_fold_grads finishes them at the block's end) or - when this backward ACCUMULATES into
+            gradients an earlier backward of the step already finished - to scratch buffers the fold kernel adds from."""
+            if fold and pl.acc:
+                if lin not in self._fold_tmp:
+                    self._fold_tmp[lin] = (torch.empty(n1, n2, dtype=torch.float32, device=P.device),
+                                           torch.empty(n1, dtype=torch.float32, device=P.device))
+                tw, tb = self._fold_tmp[lin]
+                self._wgrad(P, Q, M, n1, n2, tw, tb, False, pl=pl)
+            else:
+                self._wgrad(P, Q, M, n1, n2, gr(lin + ".weight"), gr(lin + ".bias"), pl.acc, pl=pl)
+
         # ---- MLP: out = y + fc2(gelu(fc1(LN2(y))))
         if pl.h_u8:
             hip.gemm_nt(ga, wT("mlp.fc2"), M, Hd, D, hip.EPI_MUL_AUX | hip.EPI_U8, d_h, aux=a.h8)
         else:
             hip.gemm_nt(ga, wT("mlp.fc2"), M, Hd, D, hip.EPI_MUL_AUX, d_h, aux=a.h)
         hip.gemm_nt(d_h, wT("mlp.fc1"), M, D, Hd, hip.EPI_BF16, pl.d_a)
-        s1 = self._slot(pl, lambda: hip.layernorm_bwd(
-            pl.d_a, a.y, st[4], st[5], p("norm2.weight"), M, D, dx=G, dx16=gb, dres=G,
-            dgamma=gr("norm2.weight"), dbeta=gr("norm2.bias"), accumulate=pl.acc),                               # G = dL/dy
+        s1 = self._slot(pl, lambda: ln_bwd("norm2", 2, a.y, a.a2, gb),                                          # G = dL/dy
             [lambda: self._wgrad(ga, a.g, M, D, Hd, gr("mlp.fc2.weight"), gr("mlp.fc2.bias"), pl.acc, pl=pl)])
         self._join(s1)
         # ---- space attention: y = x + proj(attn(LN1(xt)))
@@ -895,14 +971,12 @@ class VideoEngine:
         def space_bwd():
             self._attn_bwd(pl, hip.attn_space_bwd, a.qkv_s, a.o_s, a.lse_s, pl.d_o, d_qkv_s)
         s2 = self._slot(pl, space_bwd,
-                        [lambda: self._wgrad(d_h, a.a2, M, Hd, D, gr("mlp.fc1.weight"), gr("mlp.fc1.bias"), pl.acc, pl=pl)])
+                        [lambda: wgrad_folded(d_h, a.a2, Hd, D, "mlp.fc1")])
         self._join(s2)
         hip.gemm_nt(d_qkv_s, wT("attn.qkv"), M, D, 3 * D, hip.EPI_BF16, pl.d_a)
         # G <- dL/dy + dL/dxt (both reach x directly); gc <- dL/dxt alone (feeds the time branch)
-        s3 = self._slot(pl, lambda: hip.layernorm_bwd(
-            pl.d_a, a.xt, st[2], st[3], p("norm1.weight"), M, D, dx=G, dx16=gc, dres=G, dx16_excl_res=True,
-            dgamma=gr("norm1.weight"), dbeta=gr("norm1.bias"), accumulate=pl.acc),
-            [lambda: self._wgrad(d_qkv_s, a.a1, M, 3 * D, D, gr("attn.qkv.weight"), gr("attn.qkv.bias"), pl.acc, pl=pl)])
+        s3 = self._slot(pl, lambda: ln_bwd("norm1", 1, a.xt, a.a1, gc, dx16_excl_res=True),
+            [lambda: wgrad_folded(d_qkv_s, a.a1, 3 * D, D, "attn.qkv")])
         self._join(s3)
         # ---- time attention: xt = x + proj(attn(LN3(x)))
         hip.gemm_nt(gc, wT("timeattn.proj"), M, D, D, hip.EPI_BF16, pl.d_o)
@@ -914,11 +988,11 @@ class VideoEngine:
                          lambda: self._wgrad(gc, a.o_t, M, D, D, gr("timeattn.proj.weight"), gr("timeattn.proj.bias"), pl.acc, pl=pl)])
         self._join(s4)
         hip.gemm_nt(d_qkv_t, wT("timeattn.qkv"), M, D, 3 * D, hip.EPI_BF16, pl.d_a)
-        s5 = self._slot(pl, lambda: hip.layernorm_bwd(
-            pl.d_a, x, st[0], st[1], p("norm3.weight"), M, D, dx=G, dx16=ga_next, dres=G,
-            dgamma=gr("norm3.weight"), dbeta=gr("norm3.bias"), accumulate=pl.acc),                               # G = dL/dx
-            [lambda: self._wgrad(d_qkv_t, a.a3, M, 3 * D, D, gr("timeattn.qkv.weight"), gr("timeattn.qkv.bias"), pl.acc, pl=pl)])
+        s5 = self._slot(pl, lambda: ln_bwd("norm3", 0, x, a.a3, ga_next),                                       # G = dL/dx
+            [lambda: wgrad_folded(d_qkv_t, a.a3, 3 * D, D, "timeattn.qkv")])
         self._join(s5)
+        if fold:
+            pl.fold_pending = i            # finished after the block's weight gradients have run (_flush_wgrads)
 
     def _block_bwd_f8(self, pl, i, run, params, grads, d_region):
         """_block_bwd with the six data-gradient GEMMs on fp8 operands (dY e5m2, W^T e4m3; weight gradients stay bf16,

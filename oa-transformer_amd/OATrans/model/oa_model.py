@@ -90,7 +90,7 @@ class FrozenInTime(BaseModel):
         main = torch.cuda.current_stream()
         if getattr(self, "_text_stream", None) is None:
             self._text_stream = torch.cuda.Stream()
-        side = self._text_stream
+        side = self._text_stream if os.environ.get("OAT_TEXT_STREAM", "1") != "0" else main     # 0: both towers on one stream (measurement)
         side.wait_stream(main)           # the text stream starts after what is on `main` NOW (the optimiser step)
         # host enqueue order: the text tower first.  Its ~80 launches are queued in about a millisecond and then run
         # beneath the first blocks of the video tower; queued behind the video tower's ~450 launches they started only

@@ -240,6 +240,61 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, M, D, dx=None, dx16=None, dres=None,
     _check(rc, "oat_layernorm_bwd")
 
 
+def layernorm_bwd_xhat(dxh, xhat, rstd, M, D, dx=None, dx16=None, dres=None, dx16_excl_res=False):
+    """LayerNorm backward, folded form: dxh / xhat bf16 (gradient w.r.t. the normalised row, the saved normalised row)."""
+    s0 = lambda t: t.stride(0) if t is not None else 0
+    _check(lib().oat_layernorm_bwd_xhat(_ptr(dxh), dxh.stride(0), _ptr(xhat), xhat.stride(0), _ptr(rstd), _ptr(dres), s0(dres),
+                                        _ptr(dx), s0(dx), _ptr(dx16), s0(dx16), int(dx16_excl_res), M, D, _stream()),
+           "oat_layernorm_bwd_xhat")
+
+
+class FoldBiasTable:
+    """b' = b + W beta for every folded linear layer of a module in one launch.  entries: (W fp32 [N, K], beta fp32 [K],
+    b fp32 [N] | None, out fp32 [N])."""
+
+    def __init__(self, entries):
+        rows, owner, blocks = [], [], 0
+        for W, beta, b, out in entries:
+            N, K = W.shape
+            rows.append([W.data_ptr(), beta.data_ptr(), b.data_ptr() if b is not None else 0, out.data_ptr(), N, K, blocks * 4, 0])
+            nb = (N + 3) // 4
+            owner.append(torch.full((nb,), len(rows) - 1, dtype=torch.int32))
+            blocks += nb
+        dev = entries[0][0].device
+        self.table = torch.tensor(rows, dtype=torch.int64).to(dev)
+        self.owner = torch.cat(owner).to(dev)
+        self.blocks = blocks
+        self.keep = entries
+
+    def run(self):
+        _check(lib().oat_fold_bias_multi(_ptr(self.table), _ptr(self.owner), self.blocks, _stream()), "oat_fold_bias_multi")
+
+
+class FoldGradTable:
+    """dW' / db' -> dW, db, dgamma, dbeta of folded LayerNorm + linear pairs (oat_ln_fold_grads).  entries: (dWp, dbp, W,
+    gamma, beta, dW, db, dgamma, dbeta, accumulate) - fp32 tensors; dW may be dWp and db may be dbp (in place)."""
+
+    def __init__(self, entries):
+        rows, blocks = [], 0
+        for dWp, dbp, W, gamma, beta, dW, db, dgamma, dbeta, acc in entries:
+            N, K = W.shape
+            rows.append([dWp.data_ptr(), dbp.data_ptr(), W.data_ptr(), gamma.data_ptr(), beta.data_ptr(), dW.data_ptr(),
+                         db.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), N, K, blocks, 1 if acc else 0])
+            if K % 4:
+                raise OatError("FoldGradTable: K must be a multiple of 4")
+            blocks += lib().oat_ln_fold_blocks(K)
+        dev = entries[0][0].device
+        self.table = torch.tensor(rows, dtype=torch.int64).to(dev)
+        self.n, self.blocks = len(rows), blocks
+        self.key = tuple(tuple(r) for r in rows)
+        self.keep = entries
+        # partial (dgamma, dbeta) sums per block, then the ticket counters (zero now; every launch leaves them zero)
+        self.work = torch.zeros(blocks * 128 + blocks, dtype=torch.float32, device=dev)
+
+    def run(self):
+        _check(lib().oat_ln_fold_grads(_ptr(self.table), self.n, self.blocks, _ptr(self.work), _stream()), "oat_ln_fold_grads")
+
+
 def colsum(A, M, N, out, accumulate=False):
     part = _partials(A.device, lib().oat_colsum_rows(M) * N)
     rc = lib().oat_colsum(_ptr(A), int(A.dtype == torch.bfloat16), A.stride(0), M, N, _ptr(out), int(accumulate),
@@ -278,15 +333,18 @@ def cast_bf16(src, dst=None, dstT=None):
 
 class CastTable:
     """Device descriptor table for oat_cast_bf16_multi, built once per set of (master, shadow) buffers.
-    entries: (src fp32 [R, C] contiguous, dst bf16 | None, dstT bf16 | None, ldd, ldT) - dst / dstT may be row or
-    column slices of larger shadows (ldd / ldT = their leading dimensions)."""
+    entries: (src fp32 [R, C] contiguous, dst bf16 | None, dstT bf16 | None, ldd, ldT[, colscale fp32 [C] | None]) - dst /
+    dstT may be row or column slices of larger shadows (ldd / ldT = their leading dimensions)."""
 
     def __init__(self, entries):
         rows, tiles, T, owner = [], 0, lib().oat_cast_bf16_tile(), []
-        for src, dst, dstT, ldd, ldT in entries:
+        for ent in entries:
+            src, dst, dstT, ldd, ldT = ent[:5]
+            colscale = ent[5] if len(ent) > 5 else None         # fp32 [C]: column scale applied before the cast (folded LayerNorm)
             R, C = src.shape
             rows.append([src.data_ptr(), dst.data_ptr() if dst is not None else 0,
-                         dstT.data_ptr() if dstT is not None else 0, R, C, ldd, ldT, tiles])
+                         dstT.data_ptr() if dstT is not None else 0, R, C, ldd, ldT, tiles,
+                         colscale.data_ptr() if colscale is not None else 0])
             nt = ((R + T - 1) // T) * ((C + T - 1) // T)
             owner.append(torch.full((nt,), len(rows) - 1, dtype=torch.int32))
             tiles += nt
@@ -347,9 +405,43 @@ class TnGroup:
             return 0
         return max(1, grid // tiles)
 
-    def __init__(self, problems, grid=None, splits=None, slabs=None):
+    @staticmethod
+    def plan_layers(layers, grid):
+        """Several uniform-split groups STACKED in one launch: `layers` = [[(M, N1, N2), ...], ...]; every layer is planned
+        on its own (largest split count that fits `grid` workgroups) and workgroup b walks its segment of layer 0, then of
+        layer 1, ...  ViT-B: layer 0 = {fc2, fc1, qkv, qkv} (126 tiles x 2 splits = 252 workgroups), layer 1 = {proj, proj}
+        (18 tiles x 14 splits = 252): one GEMM launch + one fix-up per block instead of two each, every workgroup equally
+        loaded.  Problem indices, slab slots and fix records of later layers are offset behind the earlier ones'.
+        -> (segs, seg_off, fixes, nslots)"""
+        import numpy as np
+        parts, pbase, sbase = [], 0, 0
+        for meta in layers:
+            segs, off, fixes, nslots = TnGroup.plan(meta, grid, TnGroup.auto_splits(meta, grid) or 1)
+            segs, fixes = segs.copy(), fixes.copy()
+            segs[:, 0] += pbase
+            segs[:, 6] = np.where(segs[:, 6] >= 0, segs[:, 6] + sbase, -1)
+            if len(fixes):
+                fixes[:, 0] += pbase
+                fixes[:, 4] += sbase
+            parts.append((segs, off, fixes))
+            pbase += len(meta)
+            sbase += nslots
+        blocks = max(len(off) - 1 for _, off, _ in parts)
+        out, seg_off = [], [0]
+        for b in range(blocks):
+            for segs, off, _ in parts:
+                if b < len(off) - 1:
+                    out.append(segs[off[b]:off[b + 1]])
+            seg_off.append(sum(len(x) for x in out))
+        fixes = [f for _, _, f in parts if len(f)]
+        return (np.concatenate(out), np.asarray(seg_off, dtype=np.int32),
+                np.concatenate(fixes) if fixes else np.zeros((0, TnGroup.REC), dtype=np.int32), sbase)
+
+    def __init__(self, problems, grid=None, splits=None, slabs=None, layers=None):
         """slabs: optional caller-owned fp32 workspace shared by several groups that never run concurrently (grown by the
-        caller; must hold oat_tn_group_slab_bytes(self.nslots) bytes - see `slab_floats`)."""
+        caller; must hold oat_tn_group_slab_bytes(self.nslots) bytes - see `slab_floats`).
+        layers: optional partition of `problems` (list of index lists, together covering range(len(problems)) in order):
+        uniform-split groups stacked in one launch (plan_layers)."""
         import numpy as np
         dev = problems[0][0].device
         if grid is None:
@@ -365,9 +457,15 @@ class TnGroup:
                          (Q.stride(0) & 0xffffffff) | ((1 if acc else 0) << 32), 0])
             meta.append((M, N1, N2))
             keep.append((P, Q, out, bias_out))
-        if splits is None:
-            splits = self.auto_splits(meta, grid)
-        segs, seg_off, fixes, nslots = self.plan(meta, grid, splits)
+        if layers is not None:
+            if [k for ks in layers for k in ks] != list(range(len(meta))):
+                raise OatError("TnGroup: layers must partition the problems in order")
+            segs, seg_off, fixes, nslots = self.plan_layers([[meta[k] for k in ks] for ks in layers], grid)
+            splits = -1
+        else:
+            if splits is None:
+                splits = self.auto_splits(meta, grid)
+            segs, seg_off, fixes, nslots = self.plan(meta, grid, splits)
         self.splits = splits
         self.grid, self.nfix, self.nslots, self.n = len(seg_off) - 1, len(fixes), nslots, len(rows)
         self.key = tuple(tuple(r[:4]) + (r[6] >> 32,) for r in rows)

@@ -893,18 +893,21 @@ int launch_pp_f8(int epi, const GemmArgs& g, int grid_slots, bool a_e5m2, hipStr
 void pp_set_m224(int mode) { g_pp_m224 = mode; }
 
 // Band-grouped tile walk (PPF_BAND): column tiles per band group.  0 = off (row-major walk), > 0 = that many where the
-// launch qualifies, -1 = auto: only the short-K, wide-N launches whose B operand overflows an XCD's L2 (N >= 2304 with
-// K <= 1024), groups of 3 or 4 column tiles (a divisor of the column-tile count).
-static int g_pp_band = 0;
+// launch qualifies, -1 = auto (default).  Measured at M = 50208 (scripts/dev/band_probe.py, us per launch, row-major ->
+// groups of 4): N 3072 / K 768 plain bf16 217 -> 202, GELU epilogue (fc1 forward) 287 -> 277, x derivative epilogue (fc2
+// data gradient, which also streams the 154 MB derivative tensor) 249 -> 256; N 2304 / K 768 161 -> 163; N 768 shapes
+// slower.  The kernel tolerates the L2 misses of the row-major walk well (its LDS-DMA runs 14 intervals ahead), so auto
+// only takes the one case that pays: the fc1 forward launch (EPI_GELU_GRAD, N >= 3072, K <= 1024), groups of 4.
+static int g_pp_band = -1;
 void pp_set_band(int tiles) { g_pp_band = tiles; }
-static int pp_band_for(const GemmArgs& g, int slots, int tm) {
+static int pp_band_for(const GemmArgs& g, int slots, int tm, int epi = EPI_BF16) {
   if (g_pp_band == 0 || g.sk_ws != nullptr) return 0;
   const long long ntn = g.N / 256, nwg = ((g.M + tm - 1) / tm) * ntn, grid = nwg < slots ? nwg : slots;
   if (grid % 8 != 0 || nwg < 2 * grid) return 0;           // a workgroup must stay on one XCD chunk; >= 2 rounds to gain anything
   int gw = g_pp_band;
   if (gw < 0) {
-    if (ntn < 9 || g.K > 1024) return 0;
-    gw = ntn % 4 == 0 ? 4 : 3;
+    if (epi != EPI_GELU_GRAD || ntn < 12 || ntn % 4 != 0 || g.K > 1024) return 0;
+    gw = 4;
   }
   return gw < ntn ? gw : 0;
 }
@@ -924,7 +927,7 @@ int launch_pp(int epi, const GemmArgs& g, int grid_slots, int flags, hipStream_t
     if (g.h_u8) {
       const bool m224 = pp_prefers_224(g, grid_slots);
       GemmArgs a = g;
-      a.band = pp_band_for(g, grid_slots, m224 ? 224 : 256);
+      a.band = pp_band_for(g, grid_slots, m224 ? 224 : 256, epi);
       if (epi == EPI_GELU_GRAD) {
         if (a.band) return m224 ? launch_pp_cfg<EPI_GELU_GRAD, DEF | PPF_HU8 | PPF_M224 | PPF_BAND>(a, grid_slots, s)
                                 : launch_pp_cfg<EPI_GELU_GRAD, DEF | PPF_HU8 | PPF_BAND>(a, grid_slots, s);

@@ -69,8 +69,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     for (int i = 0; i < LN_MAXV; ++i) {
       const int c = (i * 64 + lane) * 4;
       if (c < D) {
-        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c);
+        // gamma == nullptr: the plain normalised row xhat (the affine map is folded into the next linear layer's weights)
+        const f32x4 g = gamma ? *reinterpret_cast<const f32x4*>(gamma + c) : f32x4{1.f, 1.f, 1.f, 1.f};
+        const f32x4 b = beta ? *reinterpret_cast<const f32x4*>(beta + c) : f32x4{0.f, 0.f, 0.f, 0.f};
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mu) * rs * g[e] + b[e];
@@ -171,6 +172,173 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* dy_, int lddy, 
   for (int c = threadIdx.x; c < D; c += 256) {
     part[((size_t)blockIdx.x * 2 + 0) * D + c] = red[0][0][c] + red[1][0][c] + red[2][0][c] + red[3][0][c];
     part[((size_t)blockIdx.x * 2 + 1) * D + c] = red[0][1][c] + red[1][1][c] + red[2][1][c] + red[3][1][c];
+  }
+}
+
+// LayerNorm backward in "folded" form: the layer's affine map lives in the next linear layer's weights (W' = W diag(gamma),
+// b' = b + W beta, see oat_fold_bias_multi / oat_ln_fold_grads), so the data-gradient GEMM delivers d(xhat) directly and the
+// saved GEMM operand IS xhat (bf16):   dx = rstd * (dxh - mean(dxh) - xhat * mean(dxh * xhat)).
+// Against ln_bwd_kernel: reads 2 B instead of 4 B per element of the forward input and produces no (dgamma, dbeta)
+// partials - 539 instead of 616 MB per call at M = 50208, D = 768.
+__global__ __launch_bounds__(256) void ln_bwd_xhat_kernel(const bf16* __restrict__ dxh, int lddxh, const bf16* __restrict__ xh16,
+                                                          int ldxh, const float* __restrict__ rstd, const float* dres,
+                                                          int lddres, float* dx, int lddx, bf16* dx16, int lddx16,
+                                                          int dx16_excl_res, int M, int D) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    const float rs = rstd[row];
+    f32x4 xh[LN_MAXV], g[LN_MAXV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < D) {
+        const bf16x4 xv = *reinterpret_cast<const bf16x4*>(xh16 + (size_t)row * ldxh + c);
+        const bf16x4 t = *reinterpret_cast<const bf16x4*>(dxh + (size_t)row * lddxh + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          xh[i][e] = bf2f(xv[e]);
+          g[i][e] = bf2f(t[e]);
+          s1 += g[i][e];
+          s2 += g[i][e] * xh[i][e];
+        }
+      }
+    }
+    const float c1 = wave_sum(s1) / D, c2 = wave_sum(s2) / D;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < D) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = rs * (g[i][e] - c1 - xh[i][e] * c2);
+        const f32x4 o_nores = o;
+        if (dres) o += *reinterpret_cast<const f32x4*>(dres + (size_t)row * lddres + c);
+        if (dx) *reinterpret_cast<f32x4*>(dx + (size_t)row * lddx + c) = o;
+        if (dx16) {
+          const f32x4 w = dx16_excl_res ? o_nores : o;
+          *reinterpret_cast<bf16x4*>(dx16 + (size_t)row * lddx16 + c) = bf16x4{f2bf(w[0]), f2bf(w[1]), f2bf(w[2]), f2bf(w[3])};
+        }
+      }
+    }
+  }
+}
+
+// Folded LayerNorm, weights side.  A linear layer z = W (gamma * xhat + beta) + b is run as z = W' xhat + b' with
+// W' = W diag(gamma) (cast_bf16_multi's column scale) and b' = b + W beta:
+//   fold_bias: out[n] = b[n] + sum_k W[n, k] beta[k]     one wave per output row; table-driven (all folded layers in one launch)
+struct FoldBiasDesc { const float* W; const float* beta; const float* b; float* out; long long N, K, first_row, pad; };
+__global__ __launch_bounds__(256) void fold_bias_multi_kernel(const FoldBiasDesc* desc, const int* block_desc) {
+  const FoldBiasDesc d = desc[block_desc[blockIdx.x]];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = (int)(blockIdx.x * 4 + wave - d.first_row);
+  if (n >= (int)d.N) return;
+  const float* w = d.W + (size_t)n * d.K;
+  float s = 0.f;
+  for (int k = lane * 4; k < (int)d.K; k += 256) {
+    const f32x4 wv = *reinterpret_cast<const f32x4*>(w + k), bv = *reinterpret_cast<const f32x4*>(d.beta + k);
+    s += wv[0] * bv[0] + wv[1] * bv[1] + wv[2] * bv[2] + wv[3] * bv[3];
+  }
+  s = wave_sum(s);
+  if (lane == 0) d.out[n] = s + (d.b ? d.b[n] : 0.f);
+}
+// ... and the gradients.  The weight-gradient GEMM on xhat yields dW' = dz^T xhat and db' = colsum(dz); then
+//   dW[n, k]   (+)= dW'[n, k] gamma[k] + db'[n] beta[k]        db (+)= db'   (only when db != db': accumulate mode)
+//   dgamma[k]  (+)= sum_n W[n, k] dW'[n, k]                      dbeta[k] (+)= sum_n W[n, k] db'[n]
+// Grid: (64-column strip, row slice) per layer - FG_SPLIT row slices per strip so that ~300 workgroups stream the 70 MB of
+// a block's three layers (one workgroup per strip took 107 us: 190 dependent iterations per thread).  A workgroup is 16
+// float4 column lanes x 16 row lanes, 4 rows in flight per thread; its (dgamma, dbeta) partial sums go to `part`, and the
+// LAST slice of a strip to arrive (ticket counter, agent-scope release / acquire as in cdna_hip_programming.md G16) adds
+// the FG_SPLIT partials in slice order - a fixed order whoever comes last: deterministic.  The counter resets itself.
+constexpr int FG_SPLIT = 8, FG_COLS = 64;
+struct FoldGradDesc {
+  const float* dWp; const float* dbp; const float* W; const float* gamma; const float* beta;
+  float* dW; float* db; float* dgamma; float* dbeta;
+  long long N, K, first_block, accumulate;
+};
+__global__ __launch_bounds__(256) void ln_fold_grads_kernel(const FoldGradDesc* desc, int n_desc, float* part, int* ticket) {
+  __shared__ float red[2][16][FG_COLS + 4];
+  __shared__ int s_last;
+  int di = 0;
+  while (di + 1 < n_desc && desc[di + 1].first_block <= (long long)blockIdx.x) ++di;
+  const FoldGradDesc d = desc[di];
+  const int local = (int)(blockIdx.x - d.first_block), strip = local / FG_SPLIT, slice = local - strip * FG_SPLIT;
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = strip * FG_COLS + cl * 4;
+  const int N = (int)d.N, K = (int)d.K;
+  const bool acc = d.accumulate != 0;
+  const int rows = (N + FG_SPLIT - 1) / FG_SPLIT, n0 = slice * rows, n1 = min(n0 + rows, N);
+  f32x4 sg = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
+  if (c < K) {
+    const f32x4 gm = *reinterpret_cast<const f32x4*>(d.gamma + c), bt = *reinterpret_cast<const f32x4*>(d.beta + c);
+    for (int n = n0 + rl; n < n1; n += 64) {
+      f32x4 w[4], gw[4];
+      float gb[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int nn = n + u * 16;
+        const bool ok = nn < n1;
+        const size_t o = (size_t)(ok ? nn : n) * K + c;
+        w[u] = *reinterpret_cast<const f32x4*>(d.W + o);
+        gw[u] = *reinterpret_cast<const f32x4*>(d.dWp + o);
+        gb[u] = d.dbp[ok ? nn : n];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int nn = n + u * 16;
+        if (nn < n1) {
+          sg += w[u] * gw[u];
+          sb += w[u] * gb[u];
+          f32x4 v = gw[u] * gm + bt * gb[u];
+          f32x4* dst = reinterpret_cast<f32x4*>(d.dW + (size_t)nn * K + c);
+          if (acc) v += *dst;
+          *dst = v;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { red[0][rl][cl * 4 + e] = sg[e]; red[1][rl][cl * 4 + e] = sb[e]; }
+  __syncthreads();
+  // this slice's partial sums of the strip: part[(block) * 2 * FG_COLS + {0: dgamma, 1: dbeta} * FG_COLS + column]
+  float* mine = part + (size_t)blockIdx.x * 2 * FG_COLS;
+  if (threadIdx.x < 2 * FG_COLS) {
+    const int which = threadIdx.x / FG_COLS, col = threadIdx.x % FG_COLS;
+    float a = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a += red[which][r][col];
+    mine[threadIdx.x] = a;
+  }
+  if (d.db != d.dbp && local == 0) {                            // accumulate mode: the bias gradient arrived in a scratch vector
+    for (int n = threadIdx.x; n < N; n += 256) d.db[n] = acc ? d.db[n] + d.dbp[n] : d.dbp[n];
+  }
+  // publish the partials, take a ticket; the last slice of the strip finishes it
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int t = __hip_atomic_fetch_add(ticket + (blockIdx.x - slice), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = t == FG_SPLIT - 1;
+    if (s_last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      ticket[blockIdx.x - slice] = 0;                           // ready for the next launch (stream-ordered after this one)
+    }
+  }
+  __syncthreads();
+  if (!s_last) return;
+  if (threadIdx.x < 2 * FG_COLS) {
+    const int which = threadIdx.x / FG_COLS, col = threadIdx.x % FG_COLS, cc = strip * FG_COLS + col;
+    if (cc < K) {
+      const float* base = part + (size_t)(blockIdx.x - slice) * 2 * FG_COLS + threadIdx.x;
+      float a = 0.f;
+#pragma unroll
+      for (int sl = 0; sl < FG_SPLIT; ++sl)
+        a += __hip_atomic_load(base + (size_t)sl * 2 * FG_COLS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1: not from a stale L1 line
+      float* o = (which == 0 ? d.dgamma : d.dbeta) + cc;
+      *o = acc ? *o + a : a;
+    }
   }
 }
 
@@ -352,7 +520,9 @@ __global__ void cast_bf16_kernel(const float* src, bf16* dst, bf16* dstT, int R,
 // 64x64 tiles, 16-byte loads, 8-byte stores for both copies (the transposed one through a bf16 LDS tile): the first
 // version moved one element per thread through 32x32 tiles and ran at 2 TB/s.
 constexpr int CAST_TILE = 64;
-struct CastDesc { const float* src; bf16* dst; bf16* dstT; long long R, C, ldd, ldT, first_tile; };
+struct CastDesc { const float* src; bf16* dst; bf16* dstT; long long R, C, ldd, ldT, first_tile; const float* colscale; };
+// colscale (or nullptr): column c of src is multiplied by colscale[c] before the cast - the LayerNorm scale folded into the
+// weight of the linear layer that follows it (W' = W diag(gamma))
 __global__ __launch_bounds__(256) void cast_bf16_multi_kernel(const CastDesc* desc, int n, const int* tile_matrix) {
   __shared__ __attribute__((aligned(8))) bf16 tile[CAST_TILE][CAST_TILE + 4];     // 136-byte pitch: rows stay 8-byte aligned
   int lo = 0, hi = n - 1;                               // last matrix whose first_tile <= blockIdx.x
@@ -370,7 +540,7 @@ __global__ __launch_bounds__(256) void cast_bf16_multi_kernel(const CastDesc* de
   const int c0 = (t % tpr) * CAST_TILE, r0 = (t / tpr) * CAST_TILE;
   const bool vec = C % 4 == 0 && R % 4 == 0 && d.ldd % 4 == 0 && d.ldT % 4 == 0 &&
                    (reinterpret_cast<uintptr_t>(d.src) & 15) == 0 && (reinterpret_cast<uintptr_t>(d.dst) & 7) == 0 &&
-                   (reinterpret_cast<uintptr_t>(d.dstT) & 7) == 0;
+                   (reinterpret_cast<uintptr_t>(d.dstT) & 7) == 0 && (reinterpret_cast<uintptr_t>(d.colscale) & 15) == 0;
   const int q = threadIdx.x >> 4, e4 = (threadIdx.x & 15) * 4;       // 16 rows x 16 groups of 4 elements per pass
   if (vec) {
 #pragma unroll
@@ -378,7 +548,8 @@ __global__ __launch_bounds__(256) void cast_bf16_multi_kernel(const CastDesc* de
       const int r = r0 + p * 16 + q, c = c0 + e4;
       bf16x4 o = {f2bf(0.f), f2bf(0.f), f2bf(0.f), f2bf(0.f)};
       if (r < R && c < C) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(d.src + (size_t)r * C + c);
+        f32x4 v = *reinterpret_cast<const f32x4*>(d.src + (size_t)r * C + c);
+        if (d.colscale) v *= *reinterpret_cast<const f32x4*>(d.colscale + c);
         o = bf16x4{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
         if (d.dst) *reinterpret_cast<bf16x4*>(d.dst + (size_t)r * d.ldd + c) = o;
       }
@@ -398,7 +569,7 @@ __global__ __launch_bounds__(256) void cast_bf16_multi_kernel(const CastDesc* de
     for (int i = threadIdx.x; i < CAST_TILE * CAST_TILE; i += 256) {
       const int lr = i / CAST_TILE, lc = i % CAST_TILE, r = r0 + lr, c = c0 + lc;
       bf16 o = f2bf(0.f);
-      if (r < R && c < C) { o = f2bf(d.src[(size_t)r * C + c]); if (d.dst) d.dst[(size_t)r * d.ldd + c] = o; }
+      if (r < R && c < C) { o = f2bf(d.src[(size_t)r * C + c] * (d.colscale ? d.colscale[c] : 1.f)); if (d.dst) d.dst[(size_t)r * d.ldd + c] = o; }
       tile[lr][lc] = o;
     }
     if (!d.dstT) return;
@@ -537,6 +708,42 @@ static int ln_bwd_launch(const void* dy, int dy_is_bf16, int lddy, const float* 
     OAT_LAUNCH(reduce_partials_kernel, dim3((D + 31) / 32), dim3(1024), 0, s, part + D, blocks, (size_t)2 * D, dbeta, D,
                        accumulate, (float*)nullptr, D);
   return check_launch("layernorm_bwd_finish");
+}
+
+// LayerNorm backward, folded form (ln_bwd_xhat_kernel): dxh = bf16 gradient w.r.t. the normalised row (what the data-
+// gradient GEMM of the folded weights delivers), xhat = the saved bf16 normalised row, rstd fp32 per row.
+// dx (fp32, optional) = result (+ dres); dx16 (bf16, optional) = the same, or without dres when dx16_excl_res.
+extern "C" int oat_layernorm_bwd_xhat(const void* dxh, int lddxh, const void* xhat, int ldxh, const float* rstd,
+                                      const float* dres, int lddres, float* dx, int lddx, void* dx16, int lddx16,
+                                      int dx16_excl_res, int M, int D, void* stream) {
+  if (M <= 0) return 0;
+  if (D % 4 || D > LN_MAXV * 256 || lddxh % 4 || ldxh % 4) { set_error("layernorm_bwd_xhat: D%4==0, D<=1024, ld%4==0 required"); return -3; }
+  if (!dxh || !xhat || !rstd || (!dx && !dx16)) { set_error("layernorm_bwd_xhat: null pointer"); return -4; }
+  OAT_LAUNCH(ln_bwd_xhat_kernel, dim3(oat_ln_bwd_blocks(M)), dim3(256), 0, (hipStream_t)stream, (const bf16*)dxh, lddxh,
+             (const bf16*)xhat, ldxh, rstd, dres, lddres, dx, lddx, (bf16*)dx16, lddx16, dx16_excl_res, M, D);
+  return check_launch("layernorm_bwd_xhat");
+}
+// desc: device array of {W, beta, b, out, N, K, first_row, 0} (8 x 8 bytes); block_desc[i] = descriptor of block i (4 rows
+// per block; first_row = 4 x the descriptor's first block)
+extern "C" int oat_fold_bias_multi(const void* desc, const int* block_desc, int total_blocks, void* stream) {
+  if (total_blocks <= 0) return 0;
+  if (!desc || !block_desc) { set_error("fold_bias_multi: null pointer"); return -4; }
+  OAT_LAUNCH(fold_bias_multi_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, (const FoldBiasDesc*)desc, block_desc);
+  return check_launch("fold_bias_multi");
+}
+// desc: device array of {dWp, dbp, W, gamma, beta, dW, db, dgamma, dbeta, N, K, first_block, accumulate} (13 x 8 bytes);
+// a layer owns oat_ln_fold_blocks(K) consecutive blocks from first_block.  work: caller-owned device memory,
+// total_blocks * 128 floats of partial sums followed by total_blocks ints of ticket counters that must be ZERO at the first
+// launch (every launch leaves them zero); K % 4 == 0.
+extern "C" int oat_ln_fold_blocks(int K) { return ((K + FG_COLS - 1) / FG_COLS) * FG_SPLIT; }
+extern "C" int oat_ln_fold_grads(const void* desc, int n_desc, int total_blocks, void* work, void* stream) {
+  if (n_desc <= 0 || total_blocks <= 0) return 0;
+  if (!desc || !work) { set_error("ln_fold_grads: null pointer"); return -4; }
+  float* part = static_cast<float*>(work);
+  int* ticket = reinterpret_cast<int*>(part + (size_t)total_blocks * 2 * FG_COLS);
+  OAT_LAUNCH(ln_fold_grads_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, (const FoldGradDesc*)desc, n_desc,
+             part, ticket);
+  return check_launch("ln_fold_grads");
 }
 
 extern "C" int oat_colsum_rows(int M) { int r = (M + 7) / 8; return r > 256 ? 256 : (r < 1 ? 1 : r); }

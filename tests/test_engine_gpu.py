@@ -129,6 +129,10 @@ def test_slot_schedule_matches_serial_schedule():
         m = small_model()
         m.need_patch_tokens = False
         m._engine.bwd_side = side
+        # the slot schedule runs the per-weight gemm_tn launches and the unfolded LayerNorms: give the serial schedule the
+        # same kernels (its defaults - grouped weight gradients, folded LayerNorms - are other summation orders)
+        m._engine.group_wgrads = False
+        m._engine.fold_ln = False
         for _ in range(2):
             cls, _ = m(video)
             (cls * gc).sum().backward()

@@ -300,6 +300,67 @@ def test_gemm_tn_asymmetric():
     assert torch.equal(out, ref)
 
 
+def test_folded_layernorm_linear_pair_matches_autograd():
+    """LayerNorm folded into the linear layer behind it (rowops.hip: colscale of oat_cast_bf16_multi, oat_fold_bias_multi,
+    oat_layernorm_fwd with gamma = beta = NULL, oat_layernorm_bwd_xhat, oat_ln_fold_grads) against torch autograd of
+    nn.LayerNorm -> nn.Linear in fp32: forward output, dx, dW, db, dgamma, dbeta - in place and in accumulate mode.
+    Tolerances: what the bf16 storage of xhat / W' / d(xhat) costs (2^-8 relative per element)."""
+    hip = _hip()
+    torch.manual_seed(5)
+    M, D, N = 600, 256, 512
+    x = (torch.randn(M, D, device=DEV) * 2 + 0.3).requires_grad_(True)
+    gamma = (torch.rand(D, device=DEV) * 1.5 + 0.05).requires_grad_(True)      # includes small scales
+    beta = (torch.randn(D, device=DEV) * 0.5).requires_grad_(True)
+    W = (torch.randn(N, D, device=DEV) * D ** -0.5).requires_grad_(True)
+    b = torch.randn(N, device=DEV).requires_grad_(True)
+    dz = torch.randn(M, N, device=DEV).bfloat16()
+    dres = torch.randn(M, D, device=DEV)
+    z = torch.nn.functional.linear(torch.nn.functional.layer_norm(x, (D,), gamma, beta, 1e-6), W, b)
+    (z * dz.float()).sum().backward()
+    # ---- folded forward pieces
+    xh16 = torch.empty(M, D, dtype=torch.bfloat16, device=DEV)
+    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    hip.layernorm_fwd(x.detach(), None, None, M, D, 1e-6, y=xh16, mean=mean, rstd=rstd)
+    xh_ref = torch.nn.functional.layer_norm(x.detach(), (D,), None, None, 1e-6)
+    close(xh16, xh_ref, atol=1e-2, rtol=1e-2, what="plain normalised row")
+    Wf = torch.empty(N, D, dtype=torch.bfloat16, device=DEV)
+    WfT = torch.empty(D, N, dtype=torch.bfloat16, device=DEV)
+    hip.CastTable([(W.detach(), Wf, WfT, D, N, gamma.detach())]).run()
+    assert torch.equal(Wf, (W.detach() * gamma.detach()).bfloat16()) and torch.equal(WfT, Wf.t().contiguous())
+    bf = torch.empty(N, device=DEV)
+    hip.FoldBiasTable([(W.detach(), beta.detach(), b.detach(), bf)]).run()
+    close(bf, b.detach() + W.detach() @ beta.detach(), atol=1e-5, rtol=1e-5, what="folded bias")
+    zf = xh16.float() @ Wf.float().t() + bf
+    assert ((zf - z.detach()).norm() / z.detach().norm()).item() < 6e-3          # same function up to bf16 operand rounding
+    # ---- backward: d(xhat) = dz W', LayerNorm backward from xhat
+    dxh16 = (dz.float() @ Wf.float()).bfloat16()
+    dx = torch.empty(M, D, device=DEV)
+    dx16 = torch.empty(M, D, dtype=torch.bfloat16, device=DEV)
+    hip.layernorm_bwd_xhat(dxh16, xh16, rstd, M, D, dx=dx, dx16=dx16, dres=dres, dx16_excl_res=True)
+    want = x.grad + dres
+    assert ((dx - want).norm() / want.norm()).item() < 6e-3
+    assert ((dx16.float() - x.grad).norm() / x.grad.norm()).item() < 8e-3       # dx16 excludes the residual addend
+    # ---- weights side: dW' = dz^T xhat, db' = colsum(dz) -> dW, dgamma, dbeta
+    dWp = dz.float().t() @ xh16.float()
+    dbp = dz.float().sum(0)
+    rel = lambda a, r: ((a - r).norm() / r.norm()).item()
+    for acc in (False, True):
+        if acc:                                     # accumulate mode: scratch inputs, outputs pre-filled
+            dW, db = torch.full((N, D), 2.0, device=DEV), torch.full((N,), 3.0, device=DEV)
+            dg, dbt = torch.full((D,), 4.0, device=DEV), torch.full((D,), 5.0, device=DEV)
+            src_w, src_b = dWp.clone(), dbp.clone()
+            off = (2.0, 3.0, 4.0, 5.0)
+        else:                                       # in place: dW == dW', db == db'
+            dW, db = dWp.clone(), dbp.clone()
+            dg, dbt = torch.empty(D, device=DEV), torch.empty(D, device=DEV)
+            src_w, src_b = dW, db
+            off = (0.0, 0.0, 0.0, 0.0)
+        hip.FoldGradTable([(src_w, src_b, W.detach(), gamma.detach(), beta.detach(), dW, db, dg, dbt, acc)]).run()
+        assert rel(dW - off[0], W.grad) < 6e-3, rel(dW - off[0], W.grad)
+        assert rel(db - off[1], b.grad) < 1e-5
+        assert rel(dg - off[2], gamma.grad) < 6e-3 and rel(dbt - off[3], beta.grad) < 1e-4
+
+
 # ----------------------------------------------------------------------------- LayerNorm / reductions
 @pytest.mark.parametrize("M,D", [(1000, 768), (37, 128), (5, 1024)])
 def test_layernorm_fwd_bwd(M, D):
@@ -538,7 +599,9 @@ def test_cast_bf16_multi_assembles_concatenated_shadows():
 
 
 @pytest.mark.parametrize("M,N,K,act", [(32, 768, 768, 0), (32, 3072, 768, 1), (32, 768, 3072, 0), (1024, 2304, 768, 0),
-                                       (5, 256, 768, 2), (77, 192, 48, 1)])
+                                       (5, 256, 768, 2), (77, 192, 48, 1),
+                                       # the text tower's own shapes (B L = 1024 / 1984 rows), ragged M and N
+                                       (1024, 768, 768, 0), (1024, 3072, 768, 1), (1984, 768, 3072, 0), (1000, 200, 2048, 1), (333, 72, 128, 2)])
 def test_linear_f32_matches_fp64(M, N, K, act):
     """oat_linear_f32 (exact-f32 MFMA on fp32 master weights: text tower, CLS lane, projections) against an fp64
     product: fp32-roundoff accuracy (1e-6 relative), the bf16 side outputs are the roundings of the fp32 result, the
