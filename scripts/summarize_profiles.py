@@ -73,8 +73,9 @@ with open(os.path.join(dst, f"{tag}_pmc_hbm_traffic.md"), "w") as fh:
         fh.write(f"| `{k[:84]}` | {n} | {r / 1e6:.1f} | {w / 1e6:.1f} | {(r + w) / 1e6:.1f} |\n")
 out = []
 for k, n, r, w in rows:
-    if "gemm_nt_pp_kernel<0" in k.replace(" ", "") or "gemm_tn_pp_kernel" in k:
-        out.append({"kernel": "gemm_nt_pp_kernel<EPI_BF16>" if "gemm_nt" in k else "gemm_tn_pp_kernel", "rocprof_name": k, "read_bytes_per_launch": r,
+    if "gemm_nt_pp_kernel<0" in k.replace(" ", "") or "gemm_tn_pp_kernel" in k or "gemm_tn_sk_kernel" in k:
+        out.append({"kernel": "gemm_nt_pp_kernel<EPI_BF16>" if "gemm_nt" in k else ("gemm_tn_sk_kernel" if "_sk_" in k else "gemm_tn_pp_kernel"),
+                    "rocprof_name": k, "read_bytes_per_launch": r,
                    "write_bytes_per_launch": w, "bytes_per_launch": r + w, "launches": n,
                    "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, bench.py --steps 1 --warmup 1; "
                              "reads = 2*FETCH_SIZE KiB (gfx950 correction), writes = WRITE_SIZE KiB",
