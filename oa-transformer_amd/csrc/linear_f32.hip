@@ -34,16 +34,28 @@ struct LinArgs {
 // The LDS-tiled kernel (many rows):
 //   large (the text tower, M = B * L)              128 x 128 x 16, waves 2 x 2, 4 x 4 MFMA tiles per wave (8 LDS reads
 //       per 16 MFMAs); 64 x 64 x 16 when that would give fewer than 128 workgroups
-template <int ACT, int BM, int BN, int BK, int WM, int WN>
-__global__ __launch_bounds__(256) void linear_f32_kernel(LinArgs g) {
+// KG = 2: the workgroup is TWO such wave quartets (512 threads) that split K between them - each with its own LDS tiles,
+// the same barriers - and add their partial tiles through LDS at the end (quartet 1 hands over, quartet 0 finishes: a
+// fixed order).  The 64 x 64 configuration runs ONE workgroup per CU (192 workgroups for the text tower's N = 768), i.e. one
+// wave per SIMD with nothing to hide its global -> LDS -> MFMA round trips behind; two waves per SIMD do.
+template <int ACT, int BM, int BN, int BK, int WM, int WN, int KG = 1>
+__global__ __launch_bounds__(256 * KG) void linear_f32_kernel(LinArgs g) {
   constexpr int PITCH = BK + 1, FM = BM / WM / 16, FN = BN / WN / 16, KQ = BK / 4;
   constexpr int LA = BM * KQ / 256, LB = BN * KQ / 256;
-  static_assert(WM * WN == 4 && LA >= 1 && LB >= 1, "256 threads, at least one float4 per thread and operand");
-  __shared__ float sA[BM * PITCH], sB[BN * PITCH];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  static_assert(WM * WN == 4 && LA >= 1 && LB >= 1, "256 threads per quartet, at least one float4 per thread and operand");
+  __shared__ float sAB[KG][(BM + BN) * PITCH];
+  __shared__ float sX[KG == 2 ? BM * BN : 1];               // quartet 1's partial tile
+  const int kg = KG == 2 ? (int)(threadIdx.x >> 8) : 0;
+  float* const sA = sAB[kg];
+  float* const sB = sAB[kg] + BM * PITCH;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  // K range of this quartet: whole BK steps, the first quartet takes the odd one
+  const int nsteps = g.K / BK, my_steps = KG == 2 ? (kg == 0 ? (nsteps + 1) / 2 : nsteps / 2) : nsteps;
+  const int kbeg = KG == 2 && kg == 1 ? ((nsteps + 1) / 2) * BK : 0, kend = kbeg + my_steps * BK;
+  const int loop_steps = KG == 2 ? (nsteps + 1) / 2 : nsteps;   // both quartets run the same number of barrier pairs
   f32x4 ra[LA], rb[LB];
   auto load = [&](int k0) {
 #pragma unroll
@@ -68,8 +80,10 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(LinArgs g) {
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = zero;
   const int fr = lane & 15, fk = lane >> 4;
-  load(0);
-  for (int k0 = 0; k0 < g.K; k0 += BK) {
+  if (my_steps > 0) load(kbeg);
+  for (int st = 0; st < loop_steps; ++st) {
+    const int k0 = kbeg + st * BK;
+    const bool live = k0 < kend;                               // the second quartet may run one (empty) step more
 #pragma unroll
     for (int l = 0; l < LA; ++l) {
       const int idx = tid + l * 256, row = idx / KQ, kq = (idx % KQ) * 4;
@@ -83,7 +97,8 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(LinArgs g) {
       for (int e = 0; e < 4; ++e) sB[row * PITCH + kq + e] = rb[l][e];
     }
     __syncthreads();
-    if (k0 + BK < g.K) load(k0 + BK);
+    if (k0 + BK < kend) load(k0 + BK);
+    if (live) {
 #pragma unroll
     for (int ks = 0; ks < BK / 4; ++ks) {
       float fa[FM], fb[FN];
@@ -96,7 +111,23 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(LinArgs g) {
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
+    }
     __syncthreads();
+  }
+  if constexpr (KG == 2) {
+    if (kg == 1) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          *reinterpret_cast<f32x4*>(sX + ((wave * FM + i) * FN + j) * 256 + lane * 4) = acc[i][j];
+    }
+    __syncthreads();
+    if (kg == 1) return;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[i][j] += *reinterpret_cast<const f32x4*>(sX + ((wave * FM + i) * FN + j) * 256 + lane * 4);
   }
   // D[row = 4 * (lane >> 4) + r][col = lane & 15]
 #pragma unroll
@@ -199,13 +230,19 @@ __global__ __launch_bounds__(256) void linear_f32_small_kernel(LinArgs g) {
   }
 }
 
+static int g_lin_kg2 = 1;          // 0: one wave quartet per 64 x 64 workgroup (OAT_LIN_KG2=0, A/B measurements)
 template <int ACT>
 static void launch_linear(const LinArgs& g, hipStream_t s) {
+  static bool env = false;
+  if (!env) { const char* e = getenv("OAT_LIN_KG2"); if (e) g_lin_kg2 = atoi(e); env = true; }
   if (g.M <= 64 && g.K % 64 == 0) {
     OAT_LAUNCH(linear_f32_small_kernel<ACT>, dim3((g.N + 15) / 16, (g.M + 31) / 32), dim3(256), 0, s, g);
   } else if (((g.N + 127) / 128) * ((g.M + 127) / 128) >= 128) {
     OAT_LAUNCH((linear_f32_kernel<ACT, 128, 128, 16, 2, 2>), dim3((g.N + 127) / 128, (g.M + 127) / 128), dim3(256), 0, s, g);
-  } else {     // too few 128 x 128 tiles to occupy the GPU (text tower, N = 768: 48): quarter tiles
+  } else if (g_lin_kg2 && g.K >= 256) {   // too few 128 x 128 tiles to occupy the GPU (text tower, N = 768: 48): quarter tiles,
+    // two wave quartets per workgroup splitting K (two waves per SIMD)
+    OAT_LAUNCH((linear_f32_kernel<ACT, 64, 64, 16, 2, 2, 2>), dim3((g.N + 63) / 64, (g.M + 63) / 64), dim3(512), 0, s, g);
+  } else {
     OAT_LAUNCH((linear_f32_kernel<ACT, 64, 64, 16, 2, 2>), dim3((g.N + 63) / 64, (g.M + 63) / 64), dim3(256), 0, s, g);
   }
 }
