@@ -153,8 +153,10 @@ class VideoEngine:
     FOLDED = {"timeattn.qkv": "norm3", "attn.qkv": "norm1", "mlp.fc1": "norm2"}     # linear <- the LayerNorm folded into it
 
     def fold_active(self):
-        """LayerNorm folding runs on the bf16 in-order path (the fp8 kernels quantise gamma * xhat + beta themselves)."""
-        return self.fold_ln and not self.fp8 and not self.bwd_side
+        """LayerNorm folding runs on the in-order path with a bf16 backward (fp8 FORWARD linears included: their e4m3 weights
+        are quantised from the folded bf16 shadows, their LayerNorm kernels quantise the plain normalised row); the fp8
+        data-gradient path (OAT_FP8_BWD) keeps the unfolded kernels."""
+        return self.fold_ln and not self.bwd_side and not (self.fp8 and self.fp8_bwd)
 
     def __init__(self, depth, embed_dim, num_heads, mlp_ratio, patch_size, in_chans, num_frames):
         self.depth, self.D, self.H = depth, embed_dim, num_heads
@@ -566,7 +568,7 @@ class VideoEngine:
         if pend is None:
             x = pl.x0
             if q3:
-                self._ln_f8(pl, i, 0, x, p("norm3.weight"), p("norm3.bias"), a.a3, st[0], st[1])
+                self._ln_f8(pl, i, 0, x, *ln_gb("norm3"), a.a3, st[0], st[1])
             else:
                 hip.layernorm_fwd(x, *ln_gb("norm3"), M, D, 1e-6, y=a.a3, mean=st[0], rstd=st[1])
             if lane is not None:                         # the lane starts from the embedding's CLS rows
@@ -577,7 +579,7 @@ class VideoEngine:
                 self._lane_ln(pl, lane["x"], None, None, p("norm3.weight"), p("norm3.bias"), lane["a32"])
         else:
             if q3:
-                self._ln_f8(pl, i, 0, pend.y, p("norm3.weight"), p("norm3.bias"), a.a3, st[0], st[1], add16=br, sum32=pend.out)
+                self._ln_f8(pl, i, 0, pend.y, *ln_gb("norm3"), a.a3, st[0], st[1], add16=br, sum32=pend.out)
             else:
                 hip.add_layernorm_fwd(pend.y, br, pend.out, *ln_gb("norm3"), M, D, 1e-6, y=a.a3, mean=st[0], rstd=st[1])
             x = pend.out
@@ -590,7 +592,7 @@ class VideoEngine:
             self._lane_linear(pl, lane["a32"], p("timeattn.qkv.weight")[:D], p("timeattn.qkv.bias")[:D], D, D, lane["q32"])
         f8 = self.fp8
         if f8:
-            self._linear_f8(pl, i, 0, a.a3, D, 3 * D, hip.EPI_BF16, a.qkv_t, p("timeattn.qkv.bias"), quantised=q3)
+            self._linear_f8(pl, i, 0, a.a3, D, 3 * D, hip.EPI_BF16, a.qkv_t, lin_b("timeattn.qkv"), quantised=q3)
         else:
             hip.gemm_nt(a.a3, w("timeattn.qkv"), M, 3 * D, D, hip.EPI_BF16, a.qkv_t, bias=lin_b("timeattn.qkv"))
         self._attention(pl, hip.attn_time_fwd, a.qkv_t, a.o_t, a.lse_t)
@@ -604,14 +606,14 @@ class VideoEngine:
             hip.gemm_nt(a.o_t, w("timeattn.proj"), M, D, D, hip.EPI_BF16, br, bias=p("timeattn.proj.bias"))
         q1 = self._f8_primed(i, 2)
         if q1:
-            self._ln_f8(pl, i, 2, x, p("norm1.weight"), p("norm1.bias"), a.a1, st[2], st[3], add16=br, sum32=a.xt)
+            self._ln_f8(pl, i, 2, x, *ln_gb("norm1"), a.a1, st[2], st[3], add16=br, sum32=None if fold else a.xt)
         else:
             # xt = x + time feeds norm1 only (the space residual comes from x): folded, its fp32 copy is never stored
             hip.add_layernorm_fwd(x, br, None if fold else a.xt, *ln_gb("norm1"), M, D, 1e-6, y=a.a1, mean=st[2],
                                   rstd=st[3])                                       # xt = x + time
         # ---- space attention
         if f8:
-            self._linear_f8(pl, i, 2, a.a1, D, 3 * D, hip.EPI_BF16, a.qkv_s, p("attn.qkv.bias"), quantised=q1)
+            self._linear_f8(pl, i, 2, a.a1, D, 3 * D, hip.EPI_BF16, a.qkv_s, lin_b("attn.qkv"), quantised=q1)
         else:
             hip.gemm_nt(a.a1, w("attn.qkv"), M, 3 * D, D, hip.EPI_BF16, a.qkv_s, bias=lin_b("attn.qkv"))
         self._attention(pl, hip.attn_space_fwd, a.qkv_s, a.o_s, a.lse_s)
@@ -628,14 +630,14 @@ class VideoEngine:
         # space residual comes from x, NOT from x + time (video_transformer.py:170)
         q2 = self._f8_primed(i, 4)
         if q2:
-            self._ln_f8(pl, i, 4, x, p("norm2.weight"), p("norm2.bias"), a.a2, st[4], st[5], add16=br, sum32=a.y)
+            self._ln_f8(pl, i, 4, x, *ln_gb("norm2"), a.a2, st[4], st[5], add16=br, sum32=a.y)
         else:
             hip.add_layernorm_fwd(x, br, a.y, *ln_gb("norm2"), M, D, 1e-6, y=a.a2, mean=st[4],
                                   rstd=st[5])                                       # y = x + space
         # ---- MLP
         if f8:
             gq = self._linear_f8(pl, i, 4, a.a2, D, Hd, hip.EPI_GELU_GRAD | (hip.EPI_U8 if pl.h_u8 else 0), a.h8 if pl.h_u8 else a.h,
-                                 p("mlp.fc1.bias"), out2=a.g, quantised=q2)
+                                 lin_b("mlp.fc1"), out2=a.g, quantised=q2)
             self._linear_f8(pl, i, 5, a.g, Hd, D, hip.EPI_BF16, br, p("mlp.fc2.bias"), quantised=gq)
         else:
             if pl.h_u8:
