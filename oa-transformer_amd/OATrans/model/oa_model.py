@@ -96,13 +96,7 @@ class FrozenInTime(BaseModel):
         # beneath the first blocks of the video tower; queued behind the video tower's ~450 launches they started only
         # when the video forward was nearly over and added their whole length (fp32 forward: ~5 ms) to the step
         with torch.cuda.stream(side):
-            if os.environ.get("OAT_SKIP_TEXT", "0") == "1":      # measurement hook: what does the step cost WITHOUT a text tower?
-                if getattr(self, "_fake_text", None) is None or self._fake_text.shape[0] != data['text']['input_ids'].shape[0]:
-                    self._fake_text = torch.randn(data['text']['input_ids'].shape[0], 256,
-                                                  device=data['video'].device, requires_grad=True)
-                text_embeddings = self._fake_text * 1.0
-            else:
-                text_embeddings = self.compute_text(data['text'])
+            text_embeddings = self.compute_text(data['text'])
         video_embeddings = self.compute_video(data['video'], aug=aug)
         main.wait_stream(side)
         text_embeddings.record_stream(main)
