@@ -161,9 +161,12 @@ int oat_cast_bf16_multi(const void* desc, int n_matrices, int total_tiles, const
  *                        accumulate} (13 x 8 B); a layer owns oat_ln_fold_blocks(K) consecutive blocks; dW may alias dWp
  *                        (in place), db may alias dbp; work = total_blocks * 128 floats + total_blocks ints, the ints ZERO
  *                        before the first launch (ticket counters; every launch leaves them zero); deterministic */
+/* add_a / add_b (bf16 | NULL): further addends of dx / dx16; dxp16 (bf16 | NULL): the plain result before any addend - so that
+ * the fp32 residual-gradient stream is read by norm2's and read + written by norm3's backward only (norm1's touches none) */
 int oat_layernorm_bwd_xhat(const void* dxh_bf16, int lddxh, const void* xhat_bf16, int ldxh, const float* rstd,
                            const float* dres, int lddres, float* dx, int lddx, void* dx16, int lddx16,
-                           int dx16_excl_res, int M, int D, void* stream);
+                           int dx16_excl_res, const void* add_a, int ldadd_a, const void* add_b, int ldadd_b,
+                           void* dxp16, int lddxp, int M, int D, void* stream);
 int oat_fold_bias_multi(const void* desc, const int* block_desc, int total_blocks, void* stream);
 int oat_ln_fold_blocks(int K);
 int oat_ln_fold_grads(const void* desc, int n_desc, int total_blocks, void* work, void* stream);

@@ -110,6 +110,7 @@ class _Plan:
         self.sets = [dict(d_h=z16(Hd), gb=z16(D), d_qkv_s=z16(3 * D), gc=z16(D), d_qkv_t=z16(3 * D)) for _ in range(2)]
         self.d_a = z16(D)
         self.d_o = z16(D)
+        self.dx2_16 = z16(D)                    # folded LayerNorms: norm2's dx of the current block (added to G by norm3's backward)
         self.side = self.x_final = None                   # set per call
         self.tape_fwd = self.tape_bwd = None              # (key, tape id, outputs, segments)
         self.wq = None                                    # queue of weight-gradient problems (grouped mode, engine._wgrad)
@@ -216,6 +217,9 @@ class VideoEngine:
         # x + time is kept at all), and (dW, dgamma, dbeta) come out of dW' by oat_ln_fold_grads: the same function and
         # the same gradients with 77 MB less per LayerNorm backward and 154 MB less in norm1's forward (rowops.hip)
         self.fold_ln = os.environ.get("OAT_FOLD_LN", "1") != "0"
+        # 1 (default): with folded LayerNorms the fp32 residual-gradient stream is read by norm2's backward, skipped by norm1's
+        # and read + written once by norm3's (ln_bwd_xhat_kernel); 0: every LayerNorm backward reads and re-writes it
+        self.fold_gstream = os.environ.get("OAT_FOLD_GSTREAM", "1") != "0"
         self.fbias = {}                     # folded biases b' (fp32), per folded linear
         self._fold_bias = None
         self._fold_tmp = {}                 # accumulate mode: scratch (dW', db') of the folded linears
@@ -474,7 +478,7 @@ class VideoEngine:
         gptr = next(iter(grads.values())).data_ptr() if grads else 0
         f8 = (len(self._f8["primed"]), self._f8["key"]) if (self.fp8 and self._f8) else None
         return (torch.cuda.current_stream().cuda_stream, pl.side.cuda_stream, ptrs, gptr, self.fp8, self.fp8_bwd, f8, self.cls_lane, self.h_u8,
-                self.tail_split, self.bwd_side, self.bwd_nt_grid, self.group_wgrads, self.fold_active(), hip.gemm_get_variant(), flags)
+                self.tail_split, self.bwd_side, self.bwd_nt_grid, self.group_wgrads, self.fold_active(), self.fold_gstream, hip.gemm_get_variant(), flags)
 
     @staticmethod
     def _announce_segment(ready, prefixes, recording):
@@ -938,9 +942,17 @@ class VideoEngine:
         fold = self.fold_active()
 
         def ln_bwd(norm, k, xin, xhat, dx16, **kw):
-            """backward of norm3 / norm1 / norm2 (stats rows 2k, 2k + 1): folded -> from the saved bf16 xhat and rstd"""
-            if fold:
+            """backward of norm3 / norm1 / norm2 (stats rows 2k, 2k + 1): folded -> from the saved bf16 xhat and rstd.  Folded,
+            the fp32 stream G is only read by norm2 (its own dx stays bf16 in pl.dx2_16), untouched by norm1 (gc = its dx)
+            and read + written once by norm3, which adds the two bf16 increments: G_out = G_in + dx2 + dx1 + dx3."""
+            if fold and not self.fold_gstream:
                 hip.layernorm_bwd_xhat(pl.d_a, xhat, st[2 * k + 1], M, D, dx=G, dx16=dx16, dres=G, **kw)
+            elif fold and norm == "norm2":
+                hip.layernorm_bwd_xhat(pl.d_a, xhat, st[2 * k + 1], M, D, dx16=dx16, dres=G, dxp16=pl.dx2_16)
+            elif fold and norm == "norm1":
+                hip.layernorm_bwd_xhat(pl.d_a, xhat, st[2 * k + 1], M, D, dx16=dx16)
+            elif fold:
+                hip.layernorm_bwd_xhat(pl.d_a, xhat, st[2 * k + 1], M, D, dx=G, dx16=dx16, dres=G, add_a=pl.dx2_16, add_b=gc)
             else:
                 hip.layernorm_bwd(pl.d_a, xin, st[2 * k], st[2 * k + 1], p(norm + ".weight"), M, D, dx=G, dx16=dx16, dres=G,
                                   dgamma=gr(norm + ".weight"), dbeta=gr(norm + ".bias"), accumulate=pl.acc, **kw)

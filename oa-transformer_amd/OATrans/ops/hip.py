@@ -240,11 +240,14 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, M, D, dx=None, dx16=None, dres=None,
     _check(rc, "oat_layernorm_bwd")
 
 
-def layernorm_bwd_xhat(dxh, xhat, rstd, M, D, dx=None, dx16=None, dres=None, dx16_excl_res=False):
-    """LayerNorm backward, folded form: dxh / xhat bf16 (gradient w.r.t. the normalised row, the saved normalised row)."""
+def layernorm_bwd_xhat(dxh, xhat, rstd, M, D, dx=None, dx16=None, dres=None, dx16_excl_res=False, add_a=None, add_b=None,
+                       dxp16=None):
+    """LayerNorm backward, folded form: dxh / xhat bf16 (gradient w.r.t. the normalised row, the saved normalised row).
+    dx (fp32) / dx16 (bf16) = result + dres + add_a + add_b (dx16 without them when dx16_excl_res); dxp16 = plain result."""
     s0 = lambda t: t.stride(0) if t is not None else 0
     _check(lib().oat_layernorm_bwd_xhat(_ptr(dxh), dxh.stride(0), _ptr(xhat), xhat.stride(0), _ptr(rstd), _ptr(dres), s0(dres),
-                                        _ptr(dx), s0(dx), _ptr(dx16), s0(dx16), int(dx16_excl_res), M, D, _stream()),
+                                        _ptr(dx), s0(dx), _ptr(dx16), s0(dx16), int(dx16_excl_res), _ptr(add_a), s0(add_a),
+                                        _ptr(add_b), s0(add_b), _ptr(dxp16), s0(dxp16), M, D, _stream()),
            "oat_layernorm_bwd_xhat")
 
 

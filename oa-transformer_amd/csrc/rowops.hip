@@ -180,10 +180,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* dy_, int lddy, 
 // saved GEMM operand IS xhat (bf16):   dx = rstd * (dxh - mean(dxh) - xhat * mean(dxh * xhat)).
 // Against ln_bwd_kernel: reads 2 B instead of 4 B per element of the forward input and produces no (dgamma, dbeta)
 // partials - 539 instead of 616 MB per call at M = 50208, D = 768.
+// The residual-gradient stream G (fp32) need not be read and re-written by every LayerNorm of a block: norm2's backward
+// only READS it (for the bf16 sum the space branch's data gradient needs) and leaves its own dx as bf16 (`dxp16`), norm1's
+// touches neither, and norm3's adds both bf16 increments (`add_a`, `add_b`) when it forms the block's outgoing G - the
+// increments, not the stream, are rounded to bf16.  1386 instead of 1617 MB per block.
 __global__ __launch_bounds__(256) void ln_bwd_xhat_kernel(const bf16* __restrict__ dxh, int lddxh, const bf16* __restrict__ xh16,
                                                           int ldxh, const float* __restrict__ rstd, const float* dres,
                                                           int lddres, float* dx, int lddx, bf16* dx16, int lddx16,
-                                                          int dx16_excl_res, int M, int D) {
+                                                          int dx16_excl_res, int M, int D, const bf16* add_a, int ldadd_a,
+                                                          const bf16* add_b, int ldadd_b, bf16* dxp16, int lddxp) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
@@ -214,7 +219,16 @@ __global__ __launch_bounds__(256) void ln_bwd_xhat_kernel(const bf16* __restrict
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = rs * (g[i][e] - c1 - xh[i][e] * c2);
         const f32x4 o_nores = o;
+        if (dxp16) *reinterpret_cast<bf16x4*>(dxp16 + (size_t)row * lddxp + c) = bf16x4{f2bf(o[0]), f2bf(o[1]), f2bf(o[2]), f2bf(o[3])};
         if (dres) o += *reinterpret_cast<const f32x4*>(dres + (size_t)row * lddres + c);
+        if (add_a) {
+          const bf16x4 t = *reinterpret_cast<const bf16x4*>(add_a + (size_t)row * ldadd_a + c);
+          o += f32x4{bf2f(t[0]), bf2f(t[1]), bf2f(t[2]), bf2f(t[3])};
+        }
+        if (add_b) {
+          const bf16x4 t = *reinterpret_cast<const bf16x4*>(add_b + (size_t)row * ldadd_b + c);
+          o += f32x4{bf2f(t[0]), bf2f(t[1]), bf2f(t[2]), bf2f(t[3])};
+        }
         if (dx) *reinterpret_cast<f32x4*>(dx + (size_t)row * lddx + c) = o;
         if (dx16) {
           const f32x4 w = dx16_excl_res ? o_nores : o;
@@ -251,7 +265,7 @@ __global__ __launch_bounds__(256) void fold_bias_multi_kernel(const FoldBiasDesc
 // float4 column lanes x 16 row lanes, 4 rows in flight per thread; its (dgamma, dbeta) partial sums go to `part`, and the
 // LAST slice of a strip to arrive (ticket counter, agent-scope release / acquire as in cdna_hip_programming.md G16) adds
 // the FG_SPLIT partials in slice order - a fixed order whoever comes last: deterministic.  The counter resets itself.
-constexpr int FG_SPLIT = 8, FG_COLS = 64;
+constexpr int FG_SPLIT = 16, FG_COLS = 64;
 struct FoldGradDesc {
   const float* dWp; const float* dbp; const float* W; const float* gamma; const float* beta;
   float* dW; float* db; float* dgamma; float* dbeta;
@@ -713,14 +727,20 @@ static int ln_bwd_launch(const void* dy, int dy_is_bf16, int lddy, const float* 
 // LayerNorm backward, folded form (ln_bwd_xhat_kernel): dxh = bf16 gradient w.r.t. the normalised row (what the data-
 // gradient GEMM of the folded weights delivers), xhat = the saved bf16 normalised row, rstd fp32 per row.
 // dx (fp32, optional) = result (+ dres); dx16 (bf16, optional) = the same, or without dres when dx16_excl_res.
+// add_a / add_b (bf16, optional): further addends of dx / dx16 (earlier LayerNorms' increments of the residual gradient);
+// dxp16 (bf16, optional): the plain result, before any addend.
 extern "C" int oat_layernorm_bwd_xhat(const void* dxh, int lddxh, const void* xhat, int ldxh, const float* rstd,
                                       const float* dres, int lddres, float* dx, int lddx, void* dx16, int lddx16,
-                                      int dx16_excl_res, int M, int D, void* stream) {
+                                      int dx16_excl_res, const void* add_a, int ldadd_a, const void* add_b, int ldadd_b,
+                                      void* dxp16, int lddxp, int M, int D, void* stream) {
   if (M <= 0) return 0;
-  if (D % 4 || D > LN_MAXV * 256 || lddxh % 4 || ldxh % 4) { set_error("layernorm_bwd_xhat: D%4==0, D<=1024, ld%4==0 required"); return -3; }
-  if (!dxh || !xhat || !rstd || (!dx && !dx16)) { set_error("layernorm_bwd_xhat: null pointer"); return -4; }
+  if (D % 4 || D > LN_MAXV * 256 || lddxh % 4 || ldxh % 4 || ldadd_a % 4 || ldadd_b % 4 || lddxp % 4) {
+    set_error("layernorm_bwd_xhat: D%4==0, D<=1024, ld%4==0 required"); return -3;
+  }
+  if (!dxh || !xhat || !rstd || (!dx && !dx16 && !dxp16)) { set_error("layernorm_bwd_xhat: null pointer"); return -4; }
   OAT_LAUNCH(ln_bwd_xhat_kernel, dim3(oat_ln_bwd_blocks(M)), dim3(256), 0, (hipStream_t)stream, (const bf16*)dxh, lddxh,
-             (const bf16*)xhat, ldxh, rstd, dres, lddres, dx, lddx, (bf16*)dx16, lddx16, dx16_excl_res, M, D);
+             (const bf16*)xhat, ldxh, rstd, dres, lddres, dx, lddx, (bf16*)dx16, lddx16, dx16_excl_res, M, D,
+             (const bf16*)add_a, ldadd_a, (const bf16*)add_b, ldadd_b, (bf16*)dxp16, lddxp);
   return check_launch("layernorm_bwd_xhat");
 }
 // desc: device array of {W, beta, b, out, N, K, first_row, 0} (8 x 8 bytes); block_desc[i] = descriptor of block i (4 rows

@@ -340,6 +340,16 @@ def test_folded_layernorm_linear_pair_matches_autograd():
     want = x.grad + dres
     assert ((dx - want).norm() / want.norm()).item() < 6e-3
     assert ((dx16.float() - x.grad).norm() / x.grad.norm()).item() < 8e-3       # dx16 excludes the residual addend
+    # the three-LayerNorm form of a block: bf16 addends (earlier LayerNorms' increments) and the plain bf16 result
+    add_a, add_b = torch.randn(M, D, device=DEV).bfloat16(), torch.randn(M, D, device=DEV).bfloat16()
+    dx2 = torch.empty(M, D, device=DEV)
+    dx2_16 = torch.empty(M, D, dtype=torch.bfloat16, device=DEV)
+    dxp = torch.empty(M, D, dtype=torch.bfloat16, device=DEV)
+    hip.layernorm_bwd_xhat(dxh16, xh16, rstd, M, D, dx=dx2, dx16=dx2_16, dres=dres, add_a=add_a, add_b=add_b, dxp16=dxp)
+    assert torch.equal(dxp, dx16)                                               # plain result: what dx16_excl_res delivered
+    want2 = (dx - dres) + dres + add_a.float() + add_b.float()
+    assert (dx2 - want2).abs().max().item() < 1e-5 * max(1.0, want2.abs().max().item())
+    assert torch.equal(dx2_16, dx2.bfloat16())
     # ---- weights side: dW' = dz^T xhat, db' = colsum(dz) -> dW, dgamma, dbeta
     dWp = dz.float().t() @ xh16.float()
     dbp = dz.float().sum(0)
