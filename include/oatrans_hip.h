@@ -115,6 +115,11 @@ int oat_layernorm_fwd(const float* x, int ldx, const float* gamma, const float* 
 int oat_add_layernorm_fwd(const float* x, int ldx, const void* add16, int ldadd, float* sum32, int ldsum,
                           const float* gamma, const float* beta, void* y_bf16, int ldy, float* y_f32, int ldy32,
                           float* mean, float* rstd, int M, int D, float eps, void* stream);
+/* the same with TWO bf16 addends: sum32 = x + add16 + add16b (out = x + space + mlp of a SpaceTimeBlock, video_transformer.py:170,175,
+ * formed by the next block's first LayerNorm so that y = x + space is never stored) */
+int oat_add2_layernorm_fwd(const float* x, int ldx, const void* add16, int ldadd, const void* add16b, int ldaddb,
+                           float* sum32, int ldsum, const float* gamma, const float* beta, void* y, int ldy,
+                           float* y32, int ldy32, float* mean, float* rstd, int M, int D, float eps, void* stream);
 /* the same with an fp32 addend: s = x + add32 (the precise CLS lane of the video tower) */
 int oat_add32_layernorm_fwd(const float* x, int ldx, const float* add32, int ldadd, float* sum32, int ldsum,
                             const float* gamma, const float* beta, void* y, int ldy, float* y32, int ldy32,

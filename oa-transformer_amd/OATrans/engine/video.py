@@ -445,6 +445,10 @@ class VideoEngine:
             pl.x8_qkv = torch.zeros(pl.Mp, 3 * self.D, dtype=torch.uint8, device=dev)      # e5m2 d_qkv (backward)
             pl.ga8 = [torch.zeros(pl.Mp, self.D, dtype=torch.uint8, device=dev) for _ in range(3)]   # e5m2 copies of the ga ring
         run = _Run(pl, need_patches, region_layer)
+        # folded LayerNorms + bf16 forward: y = x + space is never stored (the next block's norm3 adds both branch outputs)
+        pl.skip_y = self.fold_active() and not self.fp8 and os.environ.get("OAT_SKIP_Y", "1") != "0"
+        if pl.skip_y and getattr(pl, "branch16s", None) is None:
+            pl.branch16s = torch.zeros(pl.Mp, self.D, dtype=torch.bfloat16, device=dev)
         pl.h_u8 = (self.h_u8 and pl.M >= 256 and self.Hd % 256 == 0 and self.Hd <= 4096 and self.D % 128 == 0 and self.D >= 128)
         if pl.h_u8 and pl.blocks[0].h8 is None:
             for a in pl.blocks:              # the bf16 buffer's first half, viewed as [Mp, Hd] bytes
@@ -478,7 +482,7 @@ class VideoEngine:
         gptr = next(iter(grads.values())).data_ptr() if grads else 0
         f8 = (len(self._f8["primed"]), self._f8["key"]) if (self.fp8 and self._f8) else None
         return (torch.cuda.current_stream().cuda_stream, pl.side.cuda_stream, ptrs, gptr, self.fp8, self.fp8_bwd, f8, self.cls_lane, self.h_u8,
-                self.tail_split, self.bwd_side, self.bwd_nt_grid, self.group_wgrads, self.fold_active(), self.fold_gstream, hip.gemm_get_variant(), flags)
+                self.tail_split, self.bwd_side, self.bwd_nt_grid, self.group_wgrads, self.fold_active(), self.fold_gstream, os.environ.get("OAT_SKIP_Y", "1"), hip.gemm_get_variant(), flags)
 
     @staticmethod
     def _announce_segment(ready, prefixes, recording):
@@ -584,6 +588,9 @@ class VideoEngine:
         else:
             if q3:
                 self._ln_f8(pl, i, 0, pend.y, *ln_gb("norm3"), a.a3, st[0], st[1], add16=br, sum32=pend.out)
+            elif pl.skip_y:          # out = x + space + mlp of the previous block in one pass (its y = x + space was never stored)
+                hip.add2_layernorm_fwd(pend.xin, pl.branch16s, br, pend.out, *ln_gb("norm3"), M, D, 1e-6, y=a.a3, mean=st[0],
+                                       rstd=st[1])
             else:
                 hip.add_layernorm_fwd(pend.y, br, pend.out, *ln_gb("norm3"), M, D, 1e-6, y=a.a3, mean=st[0], rstd=st[1])
             x = pend.out
@@ -627,16 +634,18 @@ class VideoEngine:
             self._lane_ln(pl, lane["x"], lane["br32"], lane["y"], p("norm2.weight"), p("norm2.bias"), lane["a32"])
             self._lane_linear(pl, lane["a32"], p("mlp.fc1.weight"), p("mlp.fc1.bias"), Hd, D, lane["g32"], act=hip.LIN_GELU)
             self._lane_linear(pl, lane["g32"], p("mlp.fc2.weight"), p("mlp.fc2.bias"), D, Hd, lane["br32"])
+        brs = pl.branch16s if pl.skip_y else br      # skip_y: the space branch keeps its own buffer until the next block's norm3
+        a.xin = x
         if f8:
             self._linear_f8(pl, i, 3, a.o_s, D, D, hip.EPI_BF16, br, p("attn.proj.bias"))
         else:
-            hip.gemm_nt(a.o_s, w("attn.proj"), M, D, D, hip.EPI_BF16, br, bias=p("attn.proj.bias"))
+            hip.gemm_nt(a.o_s, w("attn.proj"), M, D, D, hip.EPI_BF16, brs, bias=p("attn.proj.bias"))
         # space residual comes from x, NOT from x + time (video_transformer.py:170)
         q2 = self._f8_primed(i, 4)
         if q2:
             self._ln_f8(pl, i, 4, x, *ln_gb("norm2"), a.a2, st[4], st[5], add16=br, sum32=a.y)
         else:
-            hip.add_layernorm_fwd(x, br, a.y, *ln_gb("norm2"), M, D, 1e-6, y=a.a2, mean=st[4],
+            hip.add_layernorm_fwd(x, brs, None if pl.skip_y else a.y, *ln_gb("norm2"), M, D, 1e-6, y=a.a2, mean=st[4],
                                   rstd=st[5])                                       # y = x + space
         # ---- MLP
         if f8:
@@ -659,16 +668,21 @@ class VideoEngine:
         lane = pl.lane
         g, bt = params["norm.weight"], params["norm.bias"]
         tap_last = region_layer is not None and region_layer == self.depth
+        def final_ln(r0, rows):
+            kw = dict(y32=pl.normed[r0:], mean=pl.fstats[0][r0:], rstd=pl.fstats[1][r0:])
+            if pl.skip_y:
+                hip.add2_layernorm_fwd(last.xin[r0:], pl.branch16s[r0:], br[r0:], last.out[r0:], g, bt, rows, D, 1e-6, **kw)
+            else:
+                hip.add_layernorm_fwd(last.y[r0:], br[r0:], last.out[r0:], g, bt, rows, D, 1e-6, **kw)
+
         if need_patches or tap_last:
-            hip.add_layernorm_fwd(last.y, br, last.out, g, bt, M, D, 1e-6, y32=pl.normed, mean=pl.fstats[0], rstd=pl.fstats[1])
+            final_ln(0, M)
             if tap_last:
                 self._region_tap(pl, params, last.out)
         else:
             # contract class: only the CLS rows of the last block's output are ever consumed
             for sg in pl.segs:
-                c0 = sg.cls0
-                hip.add_layernorm_fwd(last.y[c0:], br[c0:], last.out[c0:], g, bt, sg.B, D, 1e-6, y32=pl.normed[c0:],
-                                      mean=pl.fstats[0][c0:], rstd=pl.fstats[1][c0:])
+                final_ln(sg.cls0, sg.B)
         cls_out = [pl.normed[sg.cls0:sg.end] for sg in pl.segs]
         if lane is not None:                              # the CLS embedding comes from the lane's fp32 rows
             self._lane_ln(pl, lane["y"], lane["br32"], lane["x"], g, bt, lane["out"])

@@ -200,6 +200,15 @@ def add_layernorm_fwd(x, add16, sum32, gamma, beta, M, D, eps, y=None, y32=None,
     _check(rc, "oat_add_layernorm_fwd")
 
 
+def add2_layernorm_fwd(x, add16, add16b, sum32, gamma, beta, M, D, eps, y=None, y32=None, mean=None, rstd=None):
+    """sum32 = x + add16 + add16b ; y = LN(sum32)  (two bf16 branch outputs added in one pass)."""
+    s0 = lambda t: t.stride(0) if t is not None else 0
+    rc = lib().oat_add2_layernorm_fwd(_ptr(x), x.stride(0), _ptr(add16), add16.stride(0), _ptr(add16b), add16b.stride(0),
+                                      _ptr(sum32), s0(sum32), _ptr(gamma), _ptr(beta), _ptr(y), s0(y), _ptr(y32), s0(y32),
+                                      _ptr(mean), _ptr(rstd), M, D, _f(eps), _stream())
+    _check(rc, "oat_add2_layernorm_fwd")
+
+
 def add32_layernorm_fwd(x, add32, sum32, gamma, beta, M, D, eps, y=None, y32=None, mean=None, rstd=None):
     """sum32 = x + add32 (fp32) ; y / y32 = LN(sum32)."""
     rc = lib().oat_add32_layernorm_fwd(_ptr(x), x.stride(0), _ptr(add32), add32.stride(0), _ptr(sum32),

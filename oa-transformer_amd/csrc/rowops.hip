@@ -28,7 +28,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                                                      const float* __restrict__ beta, bf16* y, int ldy,
                                                      float* y32, int ldy32, float* mean, float* rstd,
                                                      int M, int D, float eps, const bf16* add16, int ldadd,
-                                                     float* sum32, int ldsum, const float* add32, int ldadd32, LnF8 f8) {
+                                                     float* sum32, int ldsum, const float* add32, int ldadd32, LnF8 f8,
+                                                     const bf16* add16b, int ldaddb) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const float qs = f8.y8 ? f8.qscale[0] : 0.f;
@@ -45,6 +46,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         if (add16) {
           const bf16x4 t = *reinterpret_cast<const bf16x4*>(add16 + (size_t)row * ldadd + c);
           v[i] += f32x4{bf2f(t[0]), bf2f(t[1]), bf2f(t[2]), bf2f(t[3])};
+          if (add16b) {                            // second bf16 branch output (x + space + mlp formed in one pass)
+            const bf16x4 u = *reinterpret_cast<const bf16x4*>(add16b + (size_t)row * ldaddb + c);
+            v[i] += f32x4{bf2f(u[0]), bf2f(u[1]), bf2f(u[2]), bf2f(u[3])};
+          }
           if (sum32) *reinterpret_cast<f32x4*>(sum32 + (size_t)row * ldsum + c) = v[i];
         } else if (add32) {                        // fp32 addend (the precise CLS lane of the video tower)
           v[i] += *reinterpret_cast<const f32x4*>(add32 + (size_t)row * ldadd32 + c);
@@ -612,7 +617,7 @@ static int ln_fwd_launch(const float* x, int ldx, const float* gamma, const floa
   int blocks = (M + 3) / 4; if (blocks > cap) blocks = cap;
   OAT_LAUNCH(ln_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta,
              (bf16*)y, ldy, y32, ldy32, mean, rstd, M, D, eps, (const bf16*)add16, ldadd, sum32, ldsum, (const float*)nullptr, 0,
-             oat::LnF8{nullptr, 0, nullptr, nullptr});
+             oat::LnF8{nullptr, 0, nullptr, nullptr}, (const bf16*)nullptr, 0);
   return check_launch("layernorm_fwd");
 }
 extern "C" int oat_layernorm_fwd(const float* x, int ldx, const float* gamma, const float* beta, void* y,
@@ -628,6 +633,22 @@ extern "C" int oat_add_layernorm_fwd(const float* x, int ldx, const void* add16,
   return ln_fwd_launch(x, ldx, gamma, beta, y, ldy, y32, ldy32, mean, rstd, M, D, eps, add16, ldadd, sum32, ldsum, stream);
 }
 
+// s = x + add16 + add16b (both bf16) ; sum32 = s (may alias x) ; y = LN(s).  With folded LayerNorms a block never stores
+// y = x + space: the next block's first LayerNorm forms out = x + space + mlp from the block's input and its two bf16
+// branch outputs (154 MB written less, 77 MB read more per block).
+extern "C" int oat_add2_layernorm_fwd(const float* x, int ldx, const void* add16, int ldadd, const void* add16b, int ldaddb,
+                                      float* sum32, int ldsum, const float* gamma, const float* beta, void* y, int ldy,
+                                      float* y32, int ldy32, float* mean, float* rstd, int M, int D, float eps, void* stream) {
+  if (!add16 || !add16b) { set_error("add2_layernorm_fwd: both addends are required"); return -4; }
+  if (M <= 0) return 0;
+  if (D % 4 || D > LN_MAXV * 256 || ldx % 4 || ldadd % 4 || ldaddb % 4 || (y && ldy % 4)) { set_error("layernorm_fwd: D%4==0, D<=1024 required"); return -3; }
+  int blocks = (M + 3) / 4; if (blocks > 4096) blocks = 4096;
+  OAT_LAUNCH(ln_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta, (bf16*)y, ldy, y32, ldy32,
+             mean, rstd, M, D, eps, (const bf16*)add16, ldadd, sum32, ldsum, (const float*)nullptr, 0,
+             oat::LnF8{nullptr, 0, nullptr, nullptr}, (const bf16*)add16b, ldaddb);
+  return check_launch("add2_layernorm_fwd");
+}
+
 // LayerNorm with the fp8 copy of its output for an fp8 GEMM: y (bf16, kept for backward) and y8 = e4m3(y * *qscale),
 // amax of y recorded.  add16 optional (then sum32 = x + add16 as in oat_add_layernorm_fwd).
 static int ln_fwd_launch_f8(const float* x, int ldx, const float* gamma, const float* beta, void* y, int ldy, float* mean,
@@ -638,7 +659,8 @@ static int ln_fwd_launch_f8(const float* x, int ldx, const float* gamma, const f
   if (!f8.y8 || !f8.qscale || !f8.amax) { set_error("layernorm_fwd_f8: null pointer"); return -4; }
   int blocks = (M + 3) / 4; if (blocks > 4096) blocks = 4096;
   OAT_LAUNCH(ln_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta, (bf16*)y, ldy,
-                     (float*)nullptr, 0, mean, rstd, M, D, eps, (const bf16*)add16, ldadd, sum32, ldsum, (const float*)nullptr, 0, f8);
+                     (float*)nullptr, 0, mean, rstd, M, D, eps, (const bf16*)add16, ldadd, sum32, ldsum, (const float*)nullptr, 0, f8,
+                     (const bf16*)nullptr, 0);
   return check_launch("layernorm_fwd_f8");
 }
 extern "C" int oat_layernorm_fwd_f8(const float* x, int ldx, const void* add16_or_null, int ldadd, float* sum32, int ldsum,
@@ -658,7 +680,8 @@ extern "C" int oat_add32_layernorm_fwd(const float* x, int ldx, const float* add
   if (D % 4 || D > LN_MAXV * 256 || ldx % 4 || ldadd % 4 || (y && ldy % 4)) { set_error("layernorm_fwd: D%4==0, D<=1024 required"); return -3; }
   const int blocks = (M + 3) / 4;
   OAT_LAUNCH(ln_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta, (bf16*)y, ldy, y32,
-                     ldy32, mean, rstd, M, D, eps, (const bf16*)nullptr, 0, sum32, ldsum, add32, ldadd, oat::LnF8{nullptr, 0, nullptr, nullptr});
+                     ldy32, mean, rstd, M, D, eps, (const bf16*)nullptr, 0, sum32, ldsum, add32, ldadd, oat::LnF8{nullptr, 0, nullptr, nullptr},
+                     (const bf16*)nullptr, 0);
   return check_launch("add32_layernorm_fwd");
 }
 
