@@ -613,7 +613,7 @@ static int ln_fwd_launch(const float* x, int ldx, const float* gamma, const floa
   if (M <= 0) return 0;
   if (D % 4 || D > LN_MAXV * 256 || ldx % 4 || (y && ldy % 4)) { set_error("layernorm_fwd: D%4==0, D<=1024 required"); return -3; }
   static int cap = 0;
-  if (cap == 0) { const char* e = getenv("OAT_LN_FWD_BLOCKS"); cap = e ? atoi(e) : 4096; if (cap < 1) cap = 4096; }
+  if (cap == 0) { const char* e = getenv("OAT_LN_FWD_BLOCKS"); cap = e ? atoi(e) : 8192; if (cap < 1) cap = 8192; }
   int blocks = (M + 3) / 4; if (blocks > cap) blocks = cap;
   OAT_LAUNCH(ln_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta,
              (bf16*)y, ldy, y32, ldy32, mean, rstd, M, D, eps, (const bf16*)add16, ldadd, sum32, ldsum, (const float*)nullptr, 0,
@@ -642,7 +642,7 @@ extern "C" int oat_add2_layernorm_fwd(const float* x, int ldx, const void* add16
   if (!add16 || !add16b) { set_error("add2_layernorm_fwd: both addends are required"); return -4; }
   if (M <= 0) return 0;
   if (D % 4 || D > LN_MAXV * 256 || ldx % 4 || ldadd % 4 || ldaddb % 4 || (y && ldy % 4)) { set_error("layernorm_fwd: D%4==0, D<=1024 required"); return -3; }
-  int blocks = (M + 3) / 4; if (blocks > 4096) blocks = 4096;
+  int blocks = (M + 3) / 4; if (blocks > 8192) blocks = 8192;
   OAT_LAUNCH(ln_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta, (bf16*)y, ldy, y32, ldy32,
              mean, rstd, M, D, eps, (const bf16*)add16, ldadd, sum32, ldsum, (const float*)nullptr, 0,
              oat::LnF8{nullptr, 0, nullptr, nullptr}, (const bf16*)add16b, ldaddb);
@@ -761,7 +761,13 @@ extern "C" int oat_layernorm_bwd_xhat(const void* dxh, int lddxh, const void* xh
     set_error("layernorm_bwd_xhat: D%4==0, D<=1024, ld%4==0 required"); return -3;
   }
   if (!dxh || !xhat || !rstd || (!dx && !dx16 && !dxp16)) { set_error("layernorm_bwd_xhat: null pointer"); return -4; }
-  OAT_LAUNCH(ln_bwd_xhat_kernel, dim3(oat_ln_bwd_blocks(M)), dim3(256), 0, (hipStream_t)stream, (const bf16*)dxh, lddxh,
+  // no partial-sum rows hang on the grid here (ln_bwd_kernel's cap of 1024 blocks keeps its (dgamma, dbeta) partials small):
+  // 4096 blocks measure 90 / 40 / 128 us for the three forms of a block at M = 50208 against 102 / 48 / 151 at 1024; in the
+  // step 1024 -> 4096 -> 8192: 48.42 -> 47.97 -> 47.88 ms
+  static int cap = 0;
+  if (cap == 0) { const char* e = getenv("OAT_LN_BWDX_BLOCKS"); cap = e ? atoi(e) : 8192; if (cap < 1) cap = 8192; }
+  int blocks = (M + 3) / 4; if (blocks > cap) blocks = cap;
+  OAT_LAUNCH(ln_bwd_xhat_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)dxh, lddxh,
              (const bf16*)xhat, ldxh, rstd, dres, lddres, dx, lddx, (bf16*)dx16, lddx16, dx16_excl_res, M, D,
              (const bf16*)add_a, ldadd_a, (const bf16*)add_b, ldadd_b, (bf16*)dxp16, lddxp);
   return check_launch("layernorm_bwd_xhat");
