@@ -326,6 +326,10 @@ __global__ __launch_bounds__(WIDE == 1 ? 1024 : WIDE == 3 ? 64 : 512, WIDE == 2 
     return bf16x8{f2bf(a[0]), f2bf(a[1]), f2bf(a[2]), f2bf(a[3]), f2bf(b[0]), f2bf(b[1]), f2bf(b[2]), f2bf(b[3])};
   };
   const int ntile = N / 16 + 1;                         // tiles that contain a real row (index <= N)
+  // 32-row key (phase A) / query (phase B) pairs that contain a real row.  The pair loops below run this trip count and have
+  // NO early exit: with `if (u * 32 > N) break;` hipcc kept the loop-carried accumulators in a second register block and
+  // copied all 16 (dQ) / 32 (dK, dV) of them at every loop end - a quarter of the loop's VALU instructions (ISA count).
+  const int nu = min(NKT / 2, N / 32 + 1);
 
   // ------------------------------------------------ phase A: lane = query column, produces dQ
   // streamed over key pairs: dS of keys [32u, 32u+32) is consumed by the dQ MFMAs right away
@@ -349,14 +353,14 @@ __global__ __launch_bounds__(WIDE == 1 ? 1024 : WIDE == 3 ? 64 : 512, WIDE == 2 
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) { dqA[dt] = f32x4{0, 0, 0, 0}; dqB[dt] = f32x4{0, 0, 0, 0}; }
 #pragma unroll 1
-    for (int u = 0; u < NKT / 2; ++u) {
-      if (u * 32 > N) break;
+    for (int u = 0; u < nu; ++u) {
       f32x4 dsA[2], dsB[2];
       const bool plain = !TIME && (qt0 + (two ? 2 : 1)) * 16 <= N && u * 32 + 32 <= N;      // wave-uniform
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         const int kt = 2 * u + hf;
-        f32x4 sA = {0, 0, 0, 0}, pA = {0, 0, 0, 0}, sB = {0, 0, 0, 0}, pB = {0, 0, 0, 0};
+        // dP - delta comes out of the matrix pipe: the accumulator starts at -delta (this lane's query) instead of zero
+        f32x4 sA = {0, 0, 0, 0}, pA = {-dlA, -dlA, -dlA, -dlA}, sB = {0, 0, 0, 0}, pB = {-dlB, -dlB, -dlB, -dlB};
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
           const bf16x8 kf = row_frag(Kt, kt * 16, ks, lane, RMAX), vf = row_frag(Vt, kt * 16, ks, lane, RMAX);
@@ -370,8 +374,8 @@ __global__ __launch_bounds__(WIDE == 1 ? 1024 : WIDE == 3 ? 64 : 512, WIDE == 2 
         if (plain) {          // every query and key of this pass is an ordinary patch row: no masks (the kernel is issue-bound)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            dsA[hf][r] = __builtin_amdgcn_exp2f(sA[r] * c2 - lqA) * (pA[r] - dlA);
-            dsB[hf][r] = two ? __builtin_amdgcn_exp2f(sB[r] * c2 - lqB) * (pB[r] - dlB) : 0.f;
+            dsA[hf][r] = __builtin_amdgcn_exp2f(sA[r] * c2 - lqA) * pA[r];
+            dsB[hf][r] = two ? __builtin_amdgcn_exp2f(sB[r] * c2 - lqB) * pB[r] : 0.f;
           }
         } else {
 #pragma unroll
@@ -380,8 +384,8 @@ __global__ __launch_bounds__(WIDE == 1 ? 1024 : WIDE == 3 ? 64 : 512, WIDE == 2 
             const bool clsdup = key == N && f != 0;       // CLS->CLS pair is counted once (frame 0)
             const bool okA = key <= N && qiA <= N && !(qiA == N && clsdup) && rm.sees<TIME>(qiA, key);
             const bool okB = key <= N && qiB <= N && !(qiB == N && clsdup) && rm.sees<TIME>(qiB, key);
-            dsA[hf][r] = okA ? __builtin_amdgcn_exp2f(sA[r] * c2 - lqA) * (pA[r] - dlA) : 0.f;
-            dsB[hf][r] = (two && okB) ? __builtin_amdgcn_exp2f(sB[r] * c2 - lqB) * (pB[r] - dlB) : 0.f;
+            dsA[hf][r] = okA ? __builtin_amdgcn_exp2f(sA[r] * c2 - lqA) * pA[r] : 0.f;
+            dsB[hf][r] = (two && okB) ? __builtin_amdgcn_exp2f(sB[r] * c2 - lqB) * pB[r] : 0.f;
           }
         }
       }
@@ -447,14 +451,15 @@ __global__ __launch_bounds__(WIDE == 1 ? 1024 : WIDE == 3 ? 64 : 512, WIDE == 2 
       dkA[dt] = f32x4{0, 0, 0, 0}; dvA[dt] = f32x4{0, 0, 0, 0}; dkB[dt] = f32x4{0, 0, 0, 0}; dvB[dt] = f32x4{0, 0, 0, 0};
     }
 #pragma unroll 1
-    for (int u = 0; u < NKT / 2; ++u) {
-      if (u * 32 > N) break;
+    for (int u = 0; u < nu; ++u) {
       f32x4 pvA[2], svA[2], pvB[2], svB[2];
       const bool plain = !TIME && (kt0 + (two ? 2 : 1)) * 16 <= N && u * 32 + 32 <= N;      // wave-uniform
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         const int q0 = u * 32 + hf * 16;
-        f32x4 sA = {0, 0, 0, 0}, pA = {0, 0, 0, 0}, sB = {0, 0, 0, 0}, pB = {0, 0, 0, 0};
+        // this lane's four query rows q0 + 4g .. + 3 are contiguous: one 16-byte read each for lse and delta
+        const f32x4 lq4 = *reinterpret_cast<const f32x4*>(lse_s + q0 + g * 4), dl4 = *reinterpret_cast<const f32x4*>(del_s + q0 + g * 4);
+        f32x4 sA = {0, 0, 0, 0}, pA = -dl4, sB = {0, 0, 0, 0}, pB = -dl4;      // accumulators start at -delta (row r = query q0 + 4g + r)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
           const bf16x8 qf = row_frag(Qt, q0, ks, lane, RMAX), df = row_frag(Dt, q0, ks, lane, RMAX);
@@ -465,29 +470,27 @@ __global__ __launch_bounds__(WIDE == 1 ? 1024 : WIDE == 3 ? 64 : 512, WIDE == 2 
             pB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, vfB[ks], pB, 0, 0, 0);
           }
         }
-        // this lane's four query rows q0 + 4g .. + 3 are contiguous: one 16-byte read each for lse and delta
-        const f32x4 lq4 = *reinterpret_cast<const f32x4*>(lse_s + q0 + g * 4), dl4 = *reinterpret_cast<const f32x4*>(del_s + q0 + g * 4);
         if (plain) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float lq = lq4[r], dl = dl4[r];
+            const float lq = lq4[r];
             const float a_ = __builtin_amdgcn_exp2f(sA[r] * c2 - lq);
             const float b_ = two ? __builtin_amdgcn_exp2f(sB[r] * c2 - lq) : 0.f;
-            pvA[hf][r] = a_; svA[hf][r] = a_ * (pA[r] - dl);
-            pvB[hf][r] = b_; svB[hf][r] = b_ * (pB[r] - dl);
+            pvA[hf][r] = a_; svA[hf][r] = a_ * pA[r];
+            pvB[hf][r] = b_; svB[hf][r] = b_ * pB[r];
           }
         } else {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int qi = q0 + g * 4 + r;
-            const float lq = lq4[r], dl = dl4[r];
+            const float lq = lq4[r];
             const bool clsq = qi == N && f != 0;
             const bool okA = keyA <= N && qi <= N && !(clsq && keyA == N) && rm.sees<TIME>(qi, keyA);
             const bool okB = two && keyB <= N && qi <= N && !(clsq && keyB == N) && rm.sees<TIME>(qi, keyB);
             const float a_ = okA ? __builtin_amdgcn_exp2f(sA[r] * c2 - lq) : 0.f;
             const float b_ = okB ? __builtin_amdgcn_exp2f(sB[r] * c2 - lq) : 0.f;
-            pvA[hf][r] = a_; svA[hf][r] = a_ * (pA[r] - dl);
-            pvB[hf][r] = b_; svB[hf][r] = b_ * (pB[r] - dl);
+            pvA[hf][r] = a_; svA[hf][r] = a_ * pA[r];
+            pvB[hf][r] = b_; svB[hf][r] = b_ * pB[r];
           }
         }
       }

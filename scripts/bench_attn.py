@@ -35,12 +35,17 @@ for rep in range(2):
         print(f"time bwd variant {var} ({['mfma', 'two-pass', 'single-read LDS'][var]}): {t:.1f} us  checksum {dqkv.float().abs().sum().item():.6e}")
 hip.lib().oat_attn_time_set_variant(0)
 hip.attn_space_fwd(qkv, out, lse, B, T, N, H, D, sc)
-for rep in range(2):
-    for var in (1, 2, 0):
+ref_dq = None
+for rep in range(3):
+    for var in (0, 1, 2):
         hip.lib().oat_attn_space_set_variant(var)
         side.zero_(); dqkv.zero_()
-        t = timeit(lambda: hip.attn_space_bwd(qkv, out, lse, dout, dqkv, side, B, T, N, H, D, sc))
-        print(f"space bwd variant {var}: {t:.1f} us  checksum {dqkv[:M - B].float().abs().sum().item():.6e}")
+        hip.attn_space_bwd(qkv, out, lse, dout, dqkv, side, B, T, N, H, D, sc)
+        torch.cuda.synchronize()
+        if ref_dq is None: ref_dq, ref_side = dqkv.clone(), side.clone()
+        err = (dqkv.float() - ref_dq.float()).abs().max().item(); serr = ((side - ref_side).abs().max() / ref_side.abs().max()).item()
+        t = timeit(lambda: hip.attn_space_bwd(qkv, out, lse, dout, dqkv, side, B, T, N, H, D, sc), n=20)
+        print(f"space bwd variant {var}: {t:.1f} us  checksum {dqkv[:M - B].float().abs().sum().item():.6e}  max|dqkv - v0| {err:.3e}  side rel {serr:.3e}")
 hip.lib().oat_attn_space_set_variant(0)
 for gpw in (1, 2, 4, 7, 14, 25):
     hip.lib().oat_attn_time_set_variant(gpw << 8)

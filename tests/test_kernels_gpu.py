@@ -512,6 +512,13 @@ def test_attention_space_bwd_tuning_variants(B, T, N, H, variant):
         hip.lib().oat_attn_space_set_variant(0)
 
 
+@pytest.mark.parametrize("B,T,N,H", [(40, 8, 196, 12), (1, 2, 199, 2), (3, 5, 160, 7), (1, 2, 207, 2), (1, 3, 208, 2)])
+def test_attention_space_more_shapes(B, T, N, H):
+    """space attention at more 14-key-tile shapes: more problems than two rounds of workgroups, patch counts off the 16-row
+    grid (the key-pair loops of the backward run a trip count computed from N), a last key pair that holds only padding"""
+    _attention_case("space", B, T, N, H)
+
+
 @pytest.mark.parametrize("variant", [1, 2])
 @pytest.mark.parametrize("B,T,N,H", [(2, 8, 196, 12), (2, 3, 9, 2), (1, 16, 441, 2), (1, 12, 16, 1)])
 def test_attention_time_bwd_tuning_variants(B, T, N, H, variant):
