@@ -73,37 +73,114 @@ struct TextArgs {
   float* out32; int ldo32;          // forward only: precise context
   DropSite drop;                    // drop.rng == nullptr: no dropout (eval mode)
 };
-OAT_DEV float attn_drop(const TextArgs& a, int b, int h, int i, int j) {
-  if (a.drop.rng == nullptr) return 1.f;
-  return drop_mult(a.drop, (((unsigned long long)b * a.H + h) * a.L + i) * a.L + j);
+
+// One workgroup = (b, h, 32 consecutive queries [forward, backward pass A] or keys [pass B]); 8 lanes per row, lane p
+// holding dims [8p, 8p + 8).  The rows of the OTHER side (keys / queries) are staged through the LDS in chunks of 64,
+// together with their mask flags and - in training mode - the chunk's tile of dropout decisions: the first form of
+// these kernels walked the keys with two dependent global loads per step (89 us for an L = 32 attention) and evaluated
+// Philox4x32-10 once per (query, key) element in EVERY one of the 8 lanes, twice in the dual forward (80 VALU
+// instructions per element against ~30 for the attention itself); now a draw of 4 elements is made once per workgroup.
+constexpr int TX_KC = 64;
+
+// dm[r * pitch + jj] = 1 if element (row i0 + r, column j0 + jj) of the [L, L] probability matrix of (b, h) is KEPT
+// (same element numbering as attn_drop: ((b H + h) L + i) L + j, four consecutive indices per Philox draw)
+OAT_DEV void stage_drop_tile(unsigned char* dm, const DropSite& d, unsigned long long bh, int L, int i0, int nr, int j0,
+                             int nk, int pitch) {
+  const int nq = (nk + 3) / 4 + 1;                          // quads a row of nk elements can touch
+  for (int t = threadIdx.x; t < nr * nq; t += blockDim.x) {
+    const int r = t / nq, qi = t % nq;
+    const unsigned long long idx0 = (bh * L + i0 + r) * (unsigned long long)L + j0;
+    const unsigned long long q = (idx0 >> 2) + qi;
+    if (q > ((idx0 + nk - 1) >> 2)) continue;
+    const u32x4 dr = drop_draw4(d, q);
+    const uint32_t v[4] = {dr.x, dr.y, dr.z, dr.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const long long jj = (long long)(q * 4 + e) - (long long)idx0;
+      if (jj >= 0 && jj < nk) dm[r * pitch + jj] = v[e] >= d.thresh;
+    }
+  }
 }
 
-// one 8-lane group per (b, h, i); groups laid out i-fastest
 __global__ __launch_bounds__(256) void attn_text_fwd_kernel(TextArgs a) {
-  const int gid = blockIdx.x * 32 + (threadIdx.x >> 3);
-  const int pl = threadIdx.x & 7;
-  const int total = a.B * a.H * a.L;
-  const bool valid = gid < total;
-  const int gg = valid ? gid : total - 1;
-  const int i = gg % a.L, h = (gg / a.L) % a.H, b = gg / (a.L * a.H);
-  const size_t row = (size_t)b * a.L + i;
+  __shared__ __attribute__((aligned(16))) bf16 k16[TX_KC * 64], v16[TX_KC * 64];
+  __shared__ __attribute__((aligned(16))) float k32[TX_KC * 64], v32[TX_KC * 64];
+  __shared__ unsigned char keep[TX_KC], dm[32 * TX_KC];
+  const int nqc = (a.L + 31) / 32;
+  const int qc = blockIdx.x % nqc, h = (blockIdx.x / nqc) % a.H, b = blockIdx.x / (nqc * a.H);
+  const int grp = threadIdx.x >> 3, pl = threadIdx.x & 7;
+  const int i = qc * 32 + grp;
+  const bool valid = i < a.L;
+  const size_t row = (size_t)b * a.L + (valid ? i : a.L - 1);
   const int col = h * 64 + pl * 8;
+  const bool dual = a.qkv32 != nullptr, drop = a.drop.rng != nullptr;
   const bf16x8 q = *reinterpret_cast<const bf16x8*>(a.qkv + row * a.ldqkv + col);
+  f32x4 q0 = {0, 0, 0, 0}, q1 = {0, 0, 0, 0};
+  if (dual) {
+    const float* qp = a.qkv32 + row * a.ldqkv32 + col;
+    q0 = *reinterpret_cast<const f32x4*>(qp); q1 = *reinterpret_cast<const f32x4*>(qp + 4);
+  }
   const float c2 = a.scale * X_LOG2E;
   float m = -INFINITY, l = 0.f, o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int j = 0; j < a.L; ++j) {
-    if (a.mask[(size_t)b * a.L + j] == 0) continue;          // uniform across the 8 lanes
-    const size_t r = (size_t)b * a.L + j;
-    const bf16x8 kk = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + a.D + col);
-    const bf16x8 vv = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + 2 * a.D + col);
-    const float s = xred8(xdot8x(q, kk)) * c2;
-    const float mn = fmaxf(m, s);
-    const float alpha = exp2f(m - mn), p = exp2f(s - mn);
-    l = l * alpha + p;
-    const float pd = p * attn_drop(a, b, h, i, j);
+  float m2 = -INFINITY, l2 = 0.f, o2[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // precise path (fp32 q | k | v)
+  for (int j0 = 0; j0 < a.L; j0 += TX_KC) {
+    const int nk = min(TX_KC, a.L - j0);
+    if (j0) __syncthreads();
+    for (int t = threadIdx.x; t < nk * 8; t += 256) {
+      const int j = t >> 3, c = t & 7;
+      const bf16* src = a.qkv + ((size_t)b * a.L + j0 + j) * a.ldqkv + h * 64 + c * 8;
+      *reinterpret_cast<bf16x8*>(k16 + j * 64 + c * 8) = *reinterpret_cast<const bf16x8*>(src + a.D);
+      *reinterpret_cast<bf16x8*>(v16 + j * 64 + c * 8) = *reinterpret_cast<const bf16x8*>(src + 2 * a.D);
+    }
+    if (dual) {
+      for (int t = threadIdx.x; t < nk * 16; t += 256) {
+        const int j = t >> 4, c = t & 15;
+        const float* src = a.qkv32 + ((size_t)b * a.L + j0 + j) * a.ldqkv32 + h * 64 + c * 4;
+        *reinterpret_cast<f32x4*>(k32 + j * 64 + c * 4) = *reinterpret_cast<const f32x4*>(src + a.D);
+        *reinterpret_cast<f32x4*>(v32 + j * 64 + c * 4) = *reinterpret_cast<const f32x4*>(src + 2 * a.D);
+      }
+    }
+    if (threadIdx.x < nk) keep[threadIdx.x] = a.mask[(size_t)b * a.L + j0 + threadIdx.x] != 0;
+    if (drop) stage_drop_tile(dm, a.drop, (unsigned long long)b * a.H + h, a.L, qc * 32, min(32, a.L - qc * 32), j0, nk, TX_KC);
+    __syncthreads();
+    for (int jj = 0; jj < nk; ++jj) {
+      if (!keep[jj]) continue;                               // uniform across the workgroup
+      const float mult = !drop ? 1.f : (dm[grp * TX_KC + jj] ? a.drop.keep_scale : 0.f);
+      {
+        const bf16x8 kk = *reinterpret_cast<const bf16x8*>(k16 + jj * 64 + pl * 8);
+        const bf16x8 vv = *reinterpret_cast<const bf16x8*>(v16 + jj * 64 + pl * 8);
+        const float s = xred8(xdot8x(q, kk)) * c2;
+        const float mn = fmaxf(m, s);
+        const float alpha = exp2f(m - mn), p = exp2f(s - mn);
+        l = l * alpha + p;
+        const float pd = p * mult;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = o[e] * alpha + pd * bf2f(vv[e]);
-    m = mn;
+        for (int e = 0; e < 8; ++e) o[e] = o[e] * alpha + pd * bf2f(vv[e]);
+        m = mn;
+      }
+      // Precise path (forward value of the layer): the same attention on the fp32 q | k | v.  The bf16 results above -
+      // what backward differentiates and recomputes its probabilities from - stay exactly self-consistent.
+      if (dual) {
+        const f32x4 k0 = *reinterpret_cast<const f32x4*>(k32 + jj * 64 + pl * 8), k1 = *reinterpret_cast<const f32x4*>(k32 + jj * 64 + pl * 8 + 4);
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(v32 + jj * 64 + pl * 8), v1 = *reinterpret_cast<const f32x4*>(v32 + jj * 64 + pl * 8 + 4);
+        float d = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d += q0[e] * k0[e];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d += q1[e] * k1[e];
+        const float s = xred8(d) * c2;
+        const float mn = fmaxf(m2, s);
+        const float alpha = exp2f(m2 - mn), p = exp2f(s - mn);
+        l2 = l2 * alpha + p;
+        const float pd = p * mult;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o2[e] = o2[e] * alpha + pd * v0[e];
+          o2[4 + e] = o2[4 + e] * alpha + pd * v1[e];
+        }
+        m2 = mn;
+      }
+    }
   }
   if (valid) {
     const float inv = 1.0f / l;
@@ -111,54 +188,27 @@ __global__ __launch_bounds__(256) void attn_text_fwd_kernel(TextArgs a) {
                        f2bf(o[4] * inv), f2bf(o[5] * inv), f2bf(o[6] * inv), f2bf(o[7] * inv)};
     *reinterpret_cast<bf16x8*>(a.out + row * a.ldo + col) = ob;
     if (pl == 0) a.lse[row * a.H + h] = (m + log2f(l)) * X_LN2;
-  }
-  // Precise path (forward value of the layer): the same attention on the fp32 q | k | v.  The bf16 results above - what
-  // backward differentiates and recomputes its probabilities from - stay exactly self-consistent.
-  if (a.qkv32 != nullptr) {
-    const float* qp = a.qkv32 + row * a.ldqkv32 + col;
-    const f32x4 q0 = *reinterpret_cast<const f32x4*>(qp), q1 = *reinterpret_cast<const f32x4*>(qp + 4);
-    float m2 = -INFINITY, l2 = 0.f, o2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int j = 0; j < a.L; ++j) {
-      if (a.mask[(size_t)b * a.L + j] == 0) continue;
-      const float* kp = a.qkv32 + ((size_t)b * a.L + j) * a.ldqkv32 + a.D + col;
-      const f32x4 k0 = *reinterpret_cast<const f32x4*>(kp), k1 = *reinterpret_cast<const f32x4*>(kp + 4);
-      const f32x4 v0 = *reinterpret_cast<const f32x4*>(kp + a.D), v1 = *reinterpret_cast<const f32x4*>(kp + a.D + 4);
-      float d = 0.f;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) d += q0[e] * k0[e];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) d += q1[e] * k1[e];
-      const float s = xred8(d) * c2;
-      const float mn = fmaxf(m2, s);
-      const float alpha = exp2f(m2 - mn), p = exp2f(s - mn);
-      l2 = l2 * alpha + p;
-      const float pd = p * attn_drop(a, b, h, i, j);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        o2[e] = o2[e] * alpha + pd * v0[e];
-        o2[4 + e] = o2[4 + e] * alpha + pd * v1[e];
-      }
-      m2 = mn;
-    }
-    if (valid) {
-      const float inv = 1.0f / l2;
+    if (dual) {
+      const float inv2 = 1.0f / l2;
       float* op = a.out32 + row * a.ldo32 + col;
-      *reinterpret_cast<f32x4*>(op) = f32x4{o2[0] * inv, o2[1] * inv, o2[2] * inv, o2[3] * inv};
-      *reinterpret_cast<f32x4*>(op + 4) = f32x4{o2[4] * inv, o2[5] * inv, o2[6] * inv, o2[7] * inv};
+      *reinterpret_cast<f32x4*>(op) = f32x4{o2[0] * inv2, o2[1] * inv2, o2[2] * inv2, o2[3] * inv2};
+      *reinterpret_cast<f32x4*>(op + 4) = f32x4{o2[4] * inv2, o2[5] * inv2, o2[6] * inv2, o2[7] * inv2};
     }
   }
 }
 
 // pass A: per query -> delta, dq
 __global__ __launch_bounds__(256) void attn_text_bwd_q_kernel(TextArgs a) {
-  const int gid = blockIdx.x * 32 + (threadIdx.x >> 3);
-  const int pl = threadIdx.x & 7;
-  const int total = a.B * a.H * a.L;
-  const bool valid = gid < total;
-  const int gg = valid ? gid : total - 1;
-  const int i = gg % a.L, h = (gg / a.L) % a.H, b = gg / (a.L * a.H);
-  const size_t row = (size_t)b * a.L + i;
+  __shared__ __attribute__((aligned(16))) bf16 k16[TX_KC * 64], v16[TX_KC * 64];
+  __shared__ unsigned char keep[TX_KC], dm[32 * TX_KC];
+  const int nqc = (a.L + 31) / 32;
+  const int qc = blockIdx.x % nqc, h = (blockIdx.x / nqc) % a.H, b = blockIdx.x / (nqc * a.H);
+  const int grp = threadIdx.x >> 3, pl = threadIdx.x & 7;
+  const int i = qc * 32 + grp;
+  const bool valid = i < a.L;
+  const size_t row = (size_t)b * a.L + (valid ? i : a.L - 1);
   const int col = h * 64 + pl * 8;
+  const bool drop = a.drop.rng != nullptr;
   const bf16x8 q = *reinterpret_cast<const bf16x8*>(a.qkv + row * a.ldqkv + col);
   const bf16x8 go = *reinterpret_cast<const bf16x8*>(a.dout + row * a.lddo + col);
   const bf16x8 oo = *reinterpret_cast<const bf16x8*>(a.out + row * a.ldo + col);
@@ -166,15 +216,28 @@ __global__ __launch_bounds__(256) void attn_text_bwd_q_kernel(TextArgs a) {
   const float lse2 = a.lse[row * a.H + h] * X_LOG2E;
   const float c2 = a.scale * X_LOG2E;
   float dq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int j = 0; j < a.L; ++j) {
-    if (a.mask[(size_t)b * a.L + j] == 0) continue;
-    const size_t r = (size_t)b * a.L + j;
-    const bf16x8 kk = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + a.D + col);
-    const bf16x8 vv = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + 2 * a.D + col);
-    const float p = exp2f(xred8(xdot8(q, kk)) * c2 - lse2);
-    const float ds = p * (xred8(xdot8(go, vv)) * attn_drop(a, b, h, i, j) - delta) * a.scale;
+  for (int j0 = 0; j0 < a.L; j0 += TX_KC) {
+    const int nk = min(TX_KC, a.L - j0);
+    if (j0) __syncthreads();
+    for (int t = threadIdx.x; t < nk * 8; t += 256) {
+      const int j = t >> 3, c = t & 7;
+      const bf16* src = a.qkv + ((size_t)b * a.L + j0 + j) * a.ldqkv + h * 64 + c * 8;
+      *reinterpret_cast<bf16x8*>(k16 + j * 64 + c * 8) = *reinterpret_cast<const bf16x8*>(src + a.D);
+      *reinterpret_cast<bf16x8*>(v16 + j * 64 + c * 8) = *reinterpret_cast<const bf16x8*>(src + 2 * a.D);
+    }
+    if (threadIdx.x < nk) keep[threadIdx.x] = a.mask[(size_t)b * a.L + j0 + threadIdx.x] != 0;
+    if (drop) stage_drop_tile(dm, a.drop, (unsigned long long)b * a.H + h, a.L, qc * 32, min(32, a.L - qc * 32), j0, nk, TX_KC);
+    __syncthreads();
+    for (int jj = 0; jj < nk; ++jj) {
+      if (!keep[jj]) continue;
+      const float mult = !drop ? 1.f : (dm[grp * TX_KC + jj] ? a.drop.keep_scale : 0.f);
+      const bf16x8 kk = *reinterpret_cast<const bf16x8*>(k16 + jj * 64 + pl * 8);
+      const bf16x8 vv = *reinterpret_cast<const bf16x8*>(v16 + jj * 64 + pl * 8);
+      const float p = exp2f(xred8(xdot8(q, kk)) * c2 - lse2);
+      const float ds = p * (xred8(xdot8(go, vv)) * mult - delta) * a.scale;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) dq[e] += ds * bf2f(kk[e]);
+      for (int e = 0; e < 8; ++e) dq[e] += ds * bf2f(kk[e]);
+    }
   }
   if (valid) {
     const bf16x8 ob = {f2bf(dq[0]), f2bf(dq[1]), f2bf(dq[2]), f2bf(dq[3]), f2bf(dq[4]), f2bf(dq[5]), f2bf(dq[6]), f2bf(dq[7])};
@@ -183,32 +246,51 @@ __global__ __launch_bounds__(256) void attn_text_bwd_q_kernel(TextArgs a) {
   }
 }
 
-// pass B: per key -> dk, dv (masked keys receive exact zeros)
+// pass B: per key -> dk, dv (masked keys receive exact zeros); queries staged in chunks with their lse / delta
 __global__ __launch_bounds__(256) void attn_text_bwd_kv_kernel(TextArgs a) {
-  const int gid = blockIdx.x * 32 + (threadIdx.x >> 3);
-  const int pl = threadIdx.x & 7;
-  const int total = a.B * a.H * a.L;
-  const bool valid = gid < total;
-  const int gg = valid ? gid : total - 1;
-  const int j = gg % a.L, h = (gg / a.L) % a.H, b = gg / (a.L * a.H);
-  const size_t row = (size_t)b * a.L + j;
+  __shared__ __attribute__((aligned(16))) bf16 q16[TX_KC * 64], g16[TX_KC * 64];
+  __shared__ float lse_s[TX_KC], del_s[TX_KC];
+  __shared__ unsigned char dm[TX_KC * 32];
+  const int nkc = (a.L + 31) / 32;
+  const int kc = blockIdx.x % nkc, h = (blockIdx.x / nkc) % a.H, b = blockIdx.x / (nkc * a.H);
+  const int grp = threadIdx.x >> 3, pl = threadIdx.x & 7;
+  const int j = kc * 32 + grp;
+  const bool valid = j < a.L;
+  const size_t row = (size_t)b * a.L + (valid ? j : a.L - 1);
   const int col = h * 64 + pl * 8;
+  const bool drop = a.drop.rng != nullptr;
   const bf16x8 kk = *reinterpret_cast<const bf16x8*>(a.qkv + row * a.ldqkv + a.D + col);
   const bf16x8 vv = *reinterpret_cast<const bf16x8*>(a.qkv + row * a.ldqkv + 2 * a.D + col);
-  const bool keep = a.mask[(size_t)b * a.L + j] != 0;
+  const bool keepk = valid && a.mask[(size_t)b * a.L + (valid ? j : a.L - 1)] != 0;
   const float c2 = a.scale * X_LOG2E;
   float dk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (keep) {
-    for (int i = 0; i < a.L; ++i) {
-      const size_t r = (size_t)b * a.L + i;
-      const bf16x8 q = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + col);
-      const bf16x8 go = *reinterpret_cast<const bf16x8*>(a.dout + r * a.lddo + col);
-      const float p = exp2f(xred8(xdot8(q, kk)) * c2 - a.lse[r * a.H + h] * X_LOG2E);
-      const float mij = attn_drop(a, b, h, i, j);
-      const float ds = p * (xred8(xdot8(go, vv)) * mij - a.delta[r * a.H + h]) * a.scale;
-      const float pd = p * mij;
+  for (int i0 = 0; i0 < a.L; i0 += TX_KC) {
+    const int nq = min(TX_KC, a.L - i0);
+    if (i0) __syncthreads();
+    for (int t = threadIdx.x; t < nq * 8; t += 256) {
+      const int i = t >> 3, c = t & 7;
+      const size_t r = (size_t)b * a.L + i0 + i;
+      *reinterpret_cast<bf16x8*>(q16 + i * 64 + c * 8) = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + h * 64 + c * 8);
+      *reinterpret_cast<bf16x8*>(g16 + i * 64 + c * 8) = *reinterpret_cast<const bf16x8*>(a.dout + r * a.lddo + h * 64 + c * 8);
+    }
+    if (threadIdx.x < nq) {
+      const size_t r = (size_t)b * a.L + i0 + threadIdx.x;
+      lse_s[threadIdx.x] = a.lse[r * a.H + h] * X_LOG2E;
+      del_s[threadIdx.x] = a.delta[r * a.H + h];
+    }
+    if (drop) stage_drop_tile(dm, a.drop, (unsigned long long)b * a.H + h, a.L, i0, nq, kc * 32, min(32, a.L - kc * 32), 32);
+    __syncthreads();
+    if (keepk) {
+      for (int ii = 0; ii < nq; ++ii) {
+        const bf16x8 q = *reinterpret_cast<const bf16x8*>(q16 + ii * 64 + pl * 8);
+        const bf16x8 go = *reinterpret_cast<const bf16x8*>(g16 + ii * 64 + pl * 8);
+        const float p = exp2f(xred8(xdot8(q, kk)) * c2 - lse_s[ii]);
+        const float mij = !drop ? 1.f : (dm[ii * 32 + grp] ? a.drop.keep_scale : 0.f);
+        const float ds = p * (xred8(xdot8(go, vv)) * mij - del_s[ii]) * a.scale;
+        const float pd = p * mij;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { dk[e] += ds * bf2f(q[e]); dv[e] += pd * bf2f(go[e]); }
+        for (int e = 0; e < 8; ++e) { dk[e] += ds * bf2f(q[e]); dv[e] += pd * bf2f(go[e]); }
+      }
     }
   }
   if (valid) {
@@ -251,8 +333,7 @@ extern "C" int oat_embed_bwd(const void* ids, const float* g, int ld, float* dwo
 static int attn_text_fwd_launch(oat::TextArgs a, void* stream) {
   using namespace oat;
   if (a.D != a.H * 64) { set_error("attn_text: head_dim must be 64"); return -3; }
-  const int groups = a.B * a.H * a.L;
-  OAT_LAUNCH(attn_text_fwd_kernel, dim3((groups + 31) / 32), dim3(256), 0, (hipStream_t)stream, a);
+  OAT_LAUNCH(attn_text_fwd_kernel, dim3(a.B * a.H * ((a.L + 31) / 32)), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("attn_text_fwd");
 }
 extern "C" int oat_attn_text_fwd(const void* qkv, int ldqkv, const void* mask, void* out, int ldo, float* lse, int B,
@@ -284,10 +365,10 @@ extern "C" int oat_attn_text_bwd(const void* qkv, int ldqkv, const void* mask, c
   TextArgs a{(const bf16*)qkv, ldqkv, (const long long*)mask, (bf16*)out, ldo, (float*)lse, delta, (const bf16*)dout, lddo,
              (bf16*)dqkv, lddqkv, B, L, H, D, scale, nullptr, 0, nullptr, 0,
              drop_p > 0.f ? make_drop_site(rng, drop_site, drop_p) : DropSite{nullptr, 0, 0, 1.f}};
-  const int groups = B * H * L;
+  const int blocks = B * H * ((L + 31) / 32);
   hipStream_t s = (hipStream_t)stream;
-  OAT_LAUNCH(attn_text_bwd_q_kernel, dim3((groups + 31) / 32), dim3(256), 0, s, a);
-  OAT_LAUNCH(attn_text_bwd_kv_kernel, dim3((groups + 31) / 32), dim3(256), 0, s, a);
+  OAT_LAUNCH(attn_text_bwd_q_kernel, dim3(blocks), dim3(256), 0, s, a);
+  OAT_LAUNCH(attn_text_bwd_kv_kernel, dim3(blocks), dim3(256), 0, s, a);
   return check_launch("attn_text_bwd");
 }
 
