@@ -201,6 +201,16 @@ int oat_attn_time_bwd(const void* qkv, int ldqkv, const void* out, int ldo, cons
                       int N, int H, int D, float scale, void* stream);
 int oat_attn_cls_finalize(float* cls_side, void* dqkv, int lddqkv, int B, int T, int N, int H, int D,
                           void* stream);
+/* The two steps above in ONE launch (replaces the same ATen work, video_transformer.py:99-135 backward): `done` = int [B,H]
+ * tickets, zero on entry and on exit; the last workgroup that feeds cls_side[b][h] swaps the sums out (atomic exchange: cls_side
+ * is left zero), writes the CLS row of dqkv and resets its ticket.  The VALU tuning variants of the time backward
+ * (oat_attn_time_set_variant 1 / 2, T > 16) run the finalize as a second launch. */
+int oat_attn_space_bwd_fin(const void* qkv, int ldqkv, const void* out, int ldo, const float* lse,
+                           const void* dout, int lddo, void* dqkv, int lddqkv, float* cls_side, int* done, int B, int T,
+                           int N, int H, int D, float scale, void* stream);
+int oat_attn_time_bwd_fin(const void* qkv, int ldqkv, const void* out, int ldo, const float* lse,
+                          const void* dout, int lddo, void* dqkv, int lddqkv, float* cls_side, int* done, int B, int T,
+                          int N, int H, int D, float scale, void* stream);
 
 /* ---- fp32 linear layer for small row counts (exact-f32 MFMA 16x16x4; fp32 master weights, no bf16 shadow) ---------
  * out = act(in(A)[M,K] * W[N,K]^T + bias) (+ resid).  Carries the two places where bf16 operand rounding would break

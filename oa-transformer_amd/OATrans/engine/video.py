@@ -69,6 +69,7 @@ class _Seg:
         self.cols = torch.zeros(_round_up(self.BTN, 256), Kp, dtype=torch.bfloat16, device=dev)
         self.table = torch.zeros(T * N, D, dtype=torch.float32, device=dev)
         self.cls_side = torch.zeros(B, H, 3, 64, dtype=torch.float32, device=dev)
+        self.cls_done = torch.zeros(B, H, dtype=torch.int32, device=dev)       # tickets of the fused CLS-row finalize
         self.Gp = torch.zeros(T * N, D, dtype=torch.float32, device=dev)
         self.video = self.video_buf = None                # static copy of the input clip
         self.d_region_buf = None
@@ -186,6 +187,9 @@ class VideoEngine:
         # fp8 forward (BASELINE.json config 5): the six linears of every block run on OCP e4m3 operands with per-tensor
         # delayed scaling (csrc/fp8.hip, gemm_nt_pp.hip PPF_F8); attention, LayerNorm, the CLS lane, the loss and the
         # whole backward stay bf16 / fp32.  Set by OAT_FP8=1 or by the caller (bench.py --dtype fp8).
+        # CLS-row gradients of the attention backward written by the attention kernel itself (oat_attn_*_bwd_fin); 0: separate
+        # oat_attn_cls_finalize launches (A/B measurements)
+        self.fused_finalize = os.environ.get("OAT_FUSED_FINALIZE", "1") != "0"
         self.fp8 = os.environ.get("OAT_FP8", "0") != "0"
         self.fp8_margin = float(os.environ.get("OAT_FP8_MARGIN", "1.0"))
         # OAT_FP8_BWD=1 (with fp8 on): the data-gradient GEMMs as well (dY as e5m2, W^T as e4m3; weight gradients stay
@@ -928,8 +932,12 @@ class VideoEngine:
 
     def _attn_bwd(self, pl, kernel, qkv, o, lse, d_o, d_qkv):
         """attention backward + the CLS-row finalize, per segment (each clip is a self-contained row range)"""
+        fin = {hip.attn_space_bwd: hip.attn_space_bwd_fin, hip.attn_time_bwd: hip.attn_time_bwd_fin}[kernel] if self.fused_finalize else None
         for sg in pl.segs:
             dq = sg.rows(d_qkv)
+            if fin is not None:      # one launch: the last workgroup per (sample, head) writes the CLS row (24 launches per step less)
+                fin(sg.rows(qkv), sg.rows(o), sg.rows(lse), sg.rows(d_o), dq, sg.cls_side, sg.cls_done, sg.B, sg.T, sg.N, self.H, self.D, self.scale)
+                continue
             kernel(sg.rows(qkv), sg.rows(o), sg.rows(lse), sg.rows(d_o), dq, sg.cls_side, sg.B, sg.T, sg.N, self.H, self.D, self.scale)
             hip.attn_cls_finalize(sg.cls_side, dq, sg.B, sg.T, sg.N, self.H, self.D)
 

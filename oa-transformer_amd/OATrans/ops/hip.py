@@ -536,6 +536,22 @@ def attn_time_bwd(qkv, out, lse, dout, dqkv, cls_side, B, T, N, H, D, scale):
               scale)
 
 
+def _attn_bwd_fin(fn, name, qkv, out, lse, dout, dqkv, cls_side, done, B, T, N, H, D, scale):
+    _check(fn(_ptr(qkv), qkv.stride(0), _ptr(out), out.stride(0), _ptr(lse), _ptr(dout), dout.stride(0),
+              _ptr(dqkv), dqkv.stride(0), _ptr(cls_side), _ptr(done), B, T, N, H, D, _f(scale), _stream()), name)
+
+
+def attn_space_bwd_fin(qkv, out, lse, dout, dqkv, cls_side, done, B, T, N, H, D, scale):
+    """attn_space_bwd + attn_cls_finalize in one launch; done: int32 [B, H] tickets, zero on entry and on exit"""
+    _attn_bwd_fin(lib().oat_attn_space_bwd_fin, "oat_attn_space_bwd_fin", qkv, out, lse, dout, dqkv, cls_side, done, B, T,
+                  N, H, D, scale)
+
+
+def attn_time_bwd_fin(qkv, out, lse, dout, dqkv, cls_side, done, B, T, N, H, D, scale):
+    _attn_bwd_fin(lib().oat_attn_time_bwd_fin, "oat_attn_time_bwd_fin", qkv, out, lse, dout, dqkv, cls_side, done, B, T,
+                  N, H, D, scale)
+
+
 def attn_cls_finalize(cls_side, dqkv, B, T, N, H, D):
     _check(lib().oat_attn_cls_finalize(_ptr(cls_side), _ptr(dqkv), dqkv.stride(0), B, T, N, H, D, _stream()),
            "oat_attn_cls_finalize")

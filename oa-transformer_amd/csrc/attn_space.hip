@@ -55,6 +55,8 @@ struct SpaceArgs {
   int B, T, N, H, D;
   float scale;
   int gpw;                         // TIME backward: position groups per workgroup (0 = 1)
+  int* done;                       // bwd, optional: [B, H] tickets (zero on entry, left zero) - the LAST workgroup that feeds
+                                   // cls_side[b][h] writes the CLS row of dqkv itself (no oat_attn_cls_finalize launch)
 };
 
 // forward: 4 waves, 56 KB LDS -> two workgroups per CU overlap each other's prologue;
@@ -550,6 +552,33 @@ __global__ __launch_bounds__(WIDE == 1 ? 1024 : WIDE == 3 ? 64 : 512, WIDE == 2 
         }
     }
   }
+  // Fused finalize: the CLS row's three gradients are complete once every workgroup that feeds side[b][h] has had its
+  // atomics acknowledged (vmcnt(0): they are performed at the memory side, where all XCDs meet).  Each workgroup then
+  // draws a ticket; the last one swaps the 192 sums out (atomic exchange: a coherent read that also leaves the buffer
+  // zero for the next launch), writes the bf16 row and resets the ticket.  No release fence is needed - nothing but
+  // atomics carries data between the workgroups - so no L2 write-back is paid per workgroup.
+  if (a.done != nullptr) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int last;
+    if constexpr (THR > 64) {
+      __syncthreads();
+      int* flag = reinterpret_cast<int*>(smem);             // every wave is done with the tiles
+      if (threadIdx.x == 0) *flag = atomicAdd(a.done + b * a.H + h, 1) == (TIME ? nchunk : a.T) - 1;
+      __syncthreads();
+      last = *flag;
+    } else {
+      int t = 0;
+      if (threadIdx.x == 0) t = atomicAdd(a.done + b * a.H + h, 1) == (TIME ? nchunk : a.T) - 1;
+      last = __shfl(t, 0, 64);
+    }
+    if (last) {
+      for (int t = threadIdx.x; t < 192; t += THR) {
+        const float v = atomicExch(side + t, 0.f);
+        a.dqkv[cls_row * a.lddqkv + (t >> 6) * a.D + h * 64 + (t & 63)] = f2bf(v);
+      }
+      if (threadIdx.x == 0) atomicExch(a.done + b * a.H + h, 0);
+    }
+  }
 }
 
 // dqkv[cls row(b)][which*D + h*64 + d] = bf16(side[b][h][which][d]); side is left ZERO again, ready for the next
@@ -591,9 +620,10 @@ static int launch_time_bwd(const SpaceArgs& a, int blocks, int lds, hipStream_t 
 }
 int g_time_gpw = 4;        // position groups per workgroup (tuning: oat_attn_time_set_variant bits 8-15)
 int attn_time_bwd_mfma(const void* qkv, int ldqkv, const void* out, int ldo, const float* lse, const void* dout, int lddo,
-                       void* dqkv, int lddqkv, float* cls_side, int B, int T, int N, int H, int D, float scale, hipStream_t s) {
+                       void* dqkv, int lddqkv, float* cls_side, int B, int T, int N, int H, int D, float scale, hipStream_t s,
+                       int* done) {
   SpaceArgs a{(const bf16*)qkv, ldqkv, (bf16*)out, ldo, (float*)lse, (const bf16*)dout, lddo, (bf16*)dqkv, lddqkv,
-              cls_side, B, T, N, H, D, scale, g_time_gpw > 0 ? g_time_gpw : 4};
+              cls_side, B, T, N, H, D, scale, g_time_gpw > 0 ? g_time_gpw : 4, done};
   const int G = 16 / T, ngrp = (N + G - 1) / G, nchunk = (ngrp + a.gpw - 1) / a.gpw;
   const int lds = 2 * (4 * 17 * 128 + 2 * 32 * 4), blocks = B * nchunk * H;      // two problem buffers
   switch (T) {
@@ -635,14 +665,14 @@ extern "C" int oat_attn_space_fwd(const void* qkv, int ldqkv, void* out, int ldo
 
 // cls_side: fp32 [B, H, 3, 64], must be ZERO on entry (caller memsets); it receives the CLS row's
 // dq/dk/dv partial sums.  Call oat_attn_cls_finalize afterwards to write them into dqkv (it zeroes cls_side again).
-extern "C" int oat_attn_space_bwd(const void* qkv, int ldqkv, const void* out, int ldo, const float* lse,
-                                  const void* dout, int lddo, void* dqkv, int lddqkv, float* cls_side, int B, int T,
-                                  int N, int H, int D, float scale, void* stream) {
+static int space_bwd(const void* qkv, int ldqkv, const void* out, int ldo, const float* lse, const void* dout, int lddo,
+                     void* dqkv, int lddqkv, float* cls_side, int* done, int B, int T, int N, int H, int D, float scale,
+                     void* stream) {
   if (D != H * 64) { set_error("attn_space: head_dim must be 64"); return -3; }
   const int nkt = pick_nkt(N);
   if (nkt < 0) { set_error("attn_space: patches per frame > 447 not supported by this build"); return -3; }
   SpaceArgs a{(const bf16*)qkv, ldqkv, (bf16*)out, ldo, (float*)lse, (const bf16*)dout, lddo, (bf16*)dqkv, lddqkv,
-              cls_side, B, T, N, H, D, scale};
+              cls_side, B, T, N, H, D, scale, 0, done};
   hipStream_t s = (hipStream_t)stream;
   switch (nkt) {
     case 2: return launch_bwd<2>(a, s);
@@ -651,6 +681,18 @@ extern "C" int oat_attn_space_bwd(const void* qkv, int ldqkv, const void* out, i
     case 14: return g_space_variant == 1 ? launch_bwd<14>(a, s) : g_space_variant == 2 ? launch_bwd<14, false, 1>(a, s) : launch_bwd<14, true, 2>(a, s);
     default: return g_space_variant == 1 ? launch_bwd<28, true>(a, s) : launch_bwd<28, true, 1>(a, s);
   }
+}
+extern "C" int oat_attn_space_bwd(const void* qkv, int ldqkv, const void* out, int ldo, const float* lse,
+                                  const void* dout, int lddo, void* dqkv, int lddqkv, float* cls_side, int B, int T,
+                                  int N, int H, int D, float scale, void* stream) {
+  return space_bwd(qkv, ldqkv, out, ldo, lse, dout, lddo, dqkv, lddqkv, cls_side, nullptr, B, T, N, H, D, scale, stream);
+}
+// As oat_attn_space_bwd followed by oat_attn_cls_finalize, in ONE launch: `done` = int [B, H], zero on entry, zero on exit.
+extern "C" int oat_attn_space_bwd_fin(const void* qkv, int ldqkv, const void* out, int ldo, const float* lse,
+                                      const void* dout, int lddo, void* dqkv, int lddqkv, float* cls_side, int* done,
+                                      int B, int T, int N, int H, int D, float scale, void* stream) {
+  if (!done) { set_error("attn_space_bwd_fin: null ticket buffer"); return -4; }
+  return space_bwd(qkv, ldqkv, out, ldo, lse, dout, lddo, dqkv, lddqkv, cls_side, done, B, T, N, H, D, scale, stream);
 }
 
 extern "C" int oat_attn_space_set_variant(int v) { g_space_variant = v; return 0; }

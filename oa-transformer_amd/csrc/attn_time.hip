@@ -56,7 +56,8 @@ struct TimeArgs {
 
 // defined in attn_space.hip (the space backward kernel in its block-diagonal TIME mode)
 int attn_time_bwd_mfma(const void* qkv, int ldqkv, const void* out, int ldo, const float* lse, const void* dout, int lddo,
-                       void* dqkv, int lddqkv, float* cls_side, int B, int T, int N, int H, int D, float scale, hipStream_t s);
+                       void* dqkv, int lddqkv, float* cls_side, int B, int T, int N, int H, int D, float scale, hipStream_t s,
+                       int* done);
 
 // grid: B*H*ceil(N/8) waves (4 per block); wave -> (b, h, n0), 8-lane group gq -> n = n0 + gq
 template <int TT>
@@ -497,15 +498,33 @@ extern "C" int oat_attn_time_fwd(const void* qkv, int ldqkv, void* out, int ldo,
   return check_launch("attn_time_fwd");
 }
 
+static int time_bwd(const void* qkv, int ldqkv, const void* out, int ldo, const float* lse, const void* dout, int lddo,
+                    void* dqkv, int lddqkv, float* cls_side, int* done, int B, int T, int N, int H, int D, float scale,
+                    void* stream);
+extern "C" int oat_attn_cls_finalize(float* cls_side, void* dqkv, int lddqkv, int B, int T, int N, int H, int D, void* stream);
 extern "C" int oat_attn_time_bwd(const void* qkv, int ldqkv, const void* out, int ldo, const float* lse,
                                  const void* dout, int lddo, void* dqkv, int lddqkv, float* cls_side, int B, int T,
                                  int N, int H, int D, float scale, void* stream) {
+  return time_bwd(qkv, ldqkv, out, ldo, lse, dout, lddo, dqkv, lddqkv, cls_side, nullptr, B, T, N, H, D, scale, stream);
+}
+// As oat_attn_time_bwd followed by oat_attn_cls_finalize: one launch on the default (MFMA) kernel - the last workgroup
+// that feeds cls_side[b][h] writes the CLS row itself (`done` = int [B, H], zero on entry and on exit) - two launches on
+// the VALU tuning variants.
+extern "C" int oat_attn_time_bwd_fin(const void* qkv, int ldqkv, const void* out, int ldo, const float* lse,
+                                     const void* dout, int lddo, void* dqkv, int lddqkv, float* cls_side, int* done,
+                                     int B, int T, int N, int H, int D, float scale, void* stream) {
+  if (!done) { set_error("attn_time_bwd_fin: null ticket buffer"); return -4; }
+  return time_bwd(qkv, ldqkv, out, ldo, lse, dout, lddo, dqkv, lddqkv, cls_side, done, B, T, N, H, D, scale, stream);
+}
+static int time_bwd(const void* qkv, int ldqkv, const void* out, int ldo, const float* lse, const void* dout, int lddo,
+                    void* dqkv, int lddqkv, float* cls_side, int* done, int B, int T, int N, int H, int D, float scale,
+                    void* stream) {
   if (D != H * 64) { set_error("attn_time: head_dim must be 64"); return -3; }
   TimeArgs a{(const bf16*)qkv, ldqkv, (bf16*)out, ldo, (float*)lse, (const bf16*)dout, lddo, (bf16*)dqkv, lddqkv,
              cls_side, B, T, N, H, D, scale};
   hipStream_t s = (hipStream_t)stream;
   if (g_time_two_pass == 0 && T <= 16)        // default: the MFMA kernel of attn_space.hip on 16-row mini problems
-    return attn_time_bwd_mfma(qkv, ldqkv, out, ldo, lse, dout, lddo, dqkv, lddqkv, cls_side, B, T, N, H, D, scale, s);
+    return attn_time_bwd_mfma(qkv, ldqkv, out, ldo, lse, dout, lddo, dqkv, lddqkv, cls_side, B, T, N, H, D, scale, s, done);
   const int waves = B * H * ((N + 7) / 8);
   const int blocks = (waves + 3) / 4;
   if (T <= 8 && g_time_two_pass != 1) {
@@ -522,10 +541,12 @@ extern "C" int oat_attn_time_bwd(const void* qkv, int ldqkv, const void* out, in
       default: set_error("attn_time: supported frame counts are 1-8, 12, 16"); return -3;
     }
 #undef OAT_TIME_LDS
-    return check_launch("attn_time_bwd");
+    const int rc = check_launch("attn_time_bwd");
+    return rc == 0 && done ? oat_attn_cls_finalize(cls_side, dqkv, lddqkv, B, T, N, H, D, stream) : rc;
   }
   OAT_TIME_DISPATCH(attn_time_bwd_kernel)
-  return check_launch("attn_time_bwd");
+  const int rc = check_launch("attn_time_bwd");
+  return rc == 0 && done ? oat_attn_cls_finalize(cls_side, dqkv, lddqkv, B, T, N, H, D, stream) : rc;
 }
 
 extern "C" int oat_attn_cls_fwd(const void* qkv, int ldqkv, void* out, int ldo, float* lse, int B, int T, int N, int H,

@@ -591,6 +591,17 @@ def _attention_case(mode, B, T, N, H):
     gs = gref.abs().max().item()
     close(dqkv[:M], gref, atol=2e-2 * gs, rtol=3e-2, what=f"{mode} attention bwd")
     assert torch.count_nonzero(dqkv[M:]) == 0
+    assert torch.count_nonzero(side) == 0                  # the finalize leaves the side buffer ready for the next launch
+    # the same backward with the CLS-row finalize fused into the launch (last workgroup per (sample, head) writes the row):
+    # patch rows bit-identical, the CLS rows equal up to the order of their fp32 atomics; twice, to see the tickets reset
+    fin = hip.attn_space_bwd_fin if mode == "space" else hip.attn_time_bwd_fin
+    done = torch.zeros(B, H, dtype=torch.int32, device=DEV)
+    for _ in range(2):
+        dq2 = torch.zeros_like(dqkv)
+        fin(qkv, out, lse, dout, dq2, side, done, B, T, N, H, D, scale)
+        assert torch.equal(dq2[:M - B], dqkv[:M - B])
+        close(dq2[M - B:M], dqkv[M - B:M].float(), atol=1e-2 * gs, rtol=2e-2, what=f"{mode} attention bwd, fused CLS-row finalize")
+        assert torch.count_nonzero(dq2[M:]) == 0 and torch.count_nonzero(side) == 0 and torch.count_nonzero(done) == 0
 
 
 def test_cast_bf16_multi_assembles_concatenated_shadows():
