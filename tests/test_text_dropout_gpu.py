@@ -56,7 +56,7 @@ def test_masks_equal_the_oracle_and_are_bernoulli(p):
 def _text_tower(n_layers=2):
     from OATrans.model.text_transformer import DistilBertHIP
     torch.manual_seed(0)
-    txt = DistilBertHIP(dict(vocab_size=1000, max_position_embeddings=64, n_layers=n_layers, n_heads=12, dim=768, hidden_dim=3072))
+    txt = DistilBertHIP(dict(vocab_size=1000, max_position_embeddings=128, n_layers=n_layers, n_heads=12, dim=768, hidden_dim=3072))
     with torch.no_grad():
         for n, prm in txt.named_parameters():
             if "LayerNorm.weight" in n or "layer_norm.weight" in n:
@@ -66,17 +66,19 @@ def _text_tower(n_layers=2):
     return txt.cuda()
 
 
-def test_training_mode_tower_matches_oracle_given_the_same_masks():
+@pytest.mark.parametrize("B,L,pad", [(4, 9, 6), (2, 70, 41), (3, 33, 32)])
+def test_training_mode_tower_matches_oracle_given_the_same_masks(B, L, pad):
+    """L = 9: one workgroup per (b, h), a sequence length that is no multiple of the four elements a Philox draw covers;
+    L = 70: three 32-row workgroups per (b, h) and two LDS chunks of keys / queries (64 + 6); L = 33: a one-row last chunk"""
     txt = _text_tower()
     txt.train()
     txt.set_dropout_seed(777)
-    B, L = 4, 9
     g = torch.Generator().manual_seed(1)
     ids = torch.randint(1, 1000, (B, L), generator=g)
     mask = torch.ones(B, L, dtype=torch.int64)
-    mask[1, 6:] = 0
+    mask[1, pad:] = 0
     dout = torch.randn(B, L, 768, generator=g)
-    dout[1, 6:] = 0                                       # padded positions: don't-care rows
+    dout[1, pad:] = 0                                     # padded positions: don't-care rows
     txt.begin_step()
     h = txt(input_ids=ids.cuda(), attention_mask=mask.cuda()).last_hidden_state
     (h * dout.cuda()).sum().backward()
