@@ -60,8 +60,13 @@ int attn_time_bwd_mfma(const void* qkv, int ldqkv, const void* out, int ldo, con
                        int* done);
 
 // grid: B*H*ceil(N/8) waves (4 per block); wave -> (b, h, n0), 8-lane group gq -> n = n0 + gq
+// The kernel is VALU-bound, not memory-bound (ISA count: ~450 VALU instructions per query frame and wave with packed K / V,
+// i.e. 9600 waves x 3.6 K x 4 clk over 1024 SIMDs = 66 us of issue time in an 82 us launch; occupancy 2 -> 4 waves per SIMD
+// had changed nothing): every one of the T queries of a position re-converted the SAME T + 1 keys and values from bf16.
+// UNPACKED (T <= 8): K and V are converted once into fp32 registers (16 (T + 1) of them) and reused by all T queries -
+// the fp32 fma chains are the same, the results bit-identical, the instruction count less than half.
 template <int TT>
-__global__ __launch_bounds__(256, TT <= 8 ? 4 : 2) void attn_time_fwd_kernel(TimeArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_time_fwd_kernel(TimeArgs a) {
   const int lane = threadIdx.x & 63;
   const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int ng = (a.N + 7) / 8;
@@ -73,6 +78,7 @@ __global__ __launch_bounds__(256, TT <= 8 ? 4 : 2) void attn_time_fwd_kernel(Tim
   const int nn = valid ? n : a.N - 1;
   const size_t cls_row = (size_t)a.B * a.T * a.N + b;
   const int col = h * 64 + pl * 8;
+  constexpr bool UNPACKED = TT <= 8;
   bf16x8 k[TT + 1], v[TT + 1];
 #pragma unroll
   for (int j = 0; j <= TT; ++j) {
@@ -81,26 +87,47 @@ __global__ __launch_bounds__(256, TT <= 8 ? 4 : 2) void attn_time_fwd_kernel(Tim
     v[j] = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + 2 * a.D + col);
   }
   const float c2 = a.scale * T_LOG2E;
-  // rolled frame loop with the next query requested one iteration ahead: K and V (72 registers) stay resident and the
-  // kernel fits 4 waves per SIMD (the unrolled loop hoisted all T query loads and ran at 2)
   bf16x8 qn = *reinterpret_cast<const bf16x8*>(a.qkv + (((size_t)b * TT) * a.N + nn) * a.ldqkv + col);
+  float kf[UNPACKED ? TT + 1 : 1][8], vf[UNPACKED ? TT + 1 : 1][8];
+  if constexpr (UNPACKED) {
+#pragma unroll
+    for (int j = 0; j <= TT; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { kf[j][e] = bf2f(k[j][e]); vf[j][e] = bf2f(v[j][e]); }
+  }
+  // rolled frame loop with the next query requested one iteration ahead
 #pragma unroll 1
   for (int f = 0; f < TT; ++f) {
     const size_t r = ((size_t)b * TT + f) * a.N + nn;
+    if constexpr (!UNPACKED) {
 #pragma unroll
-    for (int j = 0; j <= TT; ++j) { asm volatile("" : "+v"(k[j])); asm volatile("" : "+v"(v[j])); }   // keep K, V packed (no hoisted fp32 copies)
+      for (int j = 0; j <= TT; ++j) { asm volatile("" : "+v"(k[j])); asm volatile("" : "+v"(v[j])); }   // keep K, V packed (no hoisted fp32 copies)
+    }
     const bf16x8 q = qn;
     if (f + 1 < TT) qn = *reinterpret_cast<const bf16x8*>(a.qkv + (r + a.N) * a.ldqkv + col);
     float s[TT + 1], m = -INFINITY;
+    if constexpr (UNPACKED) {
+      float qf[8];
 #pragma unroll
-    for (int j = 0; j <= TT; ++j) { s[j] = red8(dot8x(q, k[j])) * c2; m = fmaxf(m, s[j]); }
+      for (int e = 0; e < 8; ++e) qf[e] = bf2f(q[e]);
+#pragma unroll
+      for (int j = 0; j <= TT; ++j) {
+        float d = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d += qf[e] * kf[j][e];            // same chain as dot8x
+        s[j] = red8(d) * c2; m = fmaxf(m, s[j]);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j <= TT; ++j) { s[j] = red8(dot8x(q, k[j])) * c2; m = fmaxf(m, s[j]); }
+    }
     float l = 0.f, o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int j = 0; j <= TT; ++j) {
-      const float p = exp2f(s[j] - m);
+      const float p = __builtin_amdgcn_exp2f(s[j] - m);      // raw v_exp_f32 (s - m <= 0; no denormal fix-up code)
       l += p;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] += p * bf2f(v[j][e]);
+      for (int e = 0; e < 8; ++e) o[e] += p * (UNPACKED ? vf[UNPACKED ? j : 0][e] : bf2f(v[j][e]));
     }
     if (valid) {
       const float inv = 1.0f / l;
