@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void fold_bias_multi_kernel(const FoldBiasDesc
 // Grid: (64-column strip, row slice) per layer - FG_SPLIT row slices per strip so that ~300 workgroups stream the 70 MB of
 // a block's three layers (one workgroup per strip took 107 us: 190 dependent iterations per thread).  A workgroup is 16
 // float4 column lanes x 16 row lanes, 4 rows in flight per thread; its (dgamma, dbeta) partial sums go to `part`, and the
-// LAST slice of a strip to arrive (ticket counter, agent-scope release / acquire as in cdna_hip_programming.md G16) adds
+// LAST slice of a strip to arrive (ticket counter; partials travel by agent-scope atomics only, so no fence is needed) adds
 // the FG_SPLIT partials in slice order - a fixed order whoever comes last: deterministic.  The counter resets itself.
 constexpr int FG_SPLIT = 16, FG_COLS = 64;
 struct FoldGradDesc {
@@ -327,7 +327,9 @@ __global__ __launch_bounds__(256) void ln_fold_grads_kernel(const FoldGradDesc* 
     float a = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) a += red[which][r][col];
-    mine[threadIdx.x] = a;
+    // published by an atomic exchange (performed at the memory side, acknowledged before the ticket is drawn): no release
+    // fence, i.e. no write-back of the ~40 KB of dW this workgroup has just dirtied in its L2
+    (void)__hip_atomic_exchange(mine + threadIdx.x, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (d.db != d.dbp && local == 0) {                            // accumulate mode: the bias gradient arrived in a scratch vector
     for (int n = threadIdx.x; n < N; n += 256) d.db[n] = acc ? d.db[n] + d.dbp[n] : d.dbp[n];
@@ -336,14 +338,9 @@ __global__ __launch_bounds__(256) void ln_fold_grads_kernel(const FoldGradDesc* 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int t = __hip_atomic_fetch_add(ticket + (blockIdx.x - slice), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last = t == FG_SPLIT - 1;
-    if (s_last) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      ticket[blockIdx.x - slice] = 0;                           // ready for the next launch (stream-ordered after this one)
-    }
+    if (s_last) (void)__hip_atomic_exchange(ticket + (blockIdx.x - slice), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
   }
   __syncthreads();
   if (!s_last) return;
