@@ -208,6 +208,19 @@ int oat_attn_cls_finalize(float* cls_side, void* dqkv, int lddqkv, int B, int T,
 int oat_attn_space_bwd_fin(const void* qkv, int ldqkv, const void* out, int ldo, const float* lse,
                            const void* dout, int lddo, void* dqkv, int lddqkv, float* cls_side, int* done, int B, int T,
                            int N, int H, int D, float scale, void* stream);
+/* Space attention of TWO clips of one geometry (N, H, D, leading dimensions) in one launch each way: the object frame and the
+ * video clip the OA models send through the same encoder (oa_model_global_local.py:170, oa_model_region_mem.py:120; the
+ * reference runs them as one 2B-clip batch).  A one-frame clip alone is B x H problems - a third of the GPU.  n_clips = 1 or 2;
+ * backward = oat_attn_space_bwd_fin per clip (every clip brings its cls_side and ticket buffers). */
+typedef struct OatAttnClip {
+  const void* qkv; void* out; float* lse;          /* rows of this clip (patches, then its B CLS rows) */
+  const void* dout; void* dqkv; float* cls_side; int* done;   /* backward only (NULL in forward) */
+  int B, T;
+} OatAttnClip;
+int oat_attn_space_fwd_clips(const OatAttnClip* clips, int n_clips, int ldqkv, int ldo, int N, int H, int D, float scale,
+                             void* stream);
+int oat_attn_space_bwd_clips(const OatAttnClip* clips, int n_clips, int ldqkv, int ldo, int lddo, int lddqkv, int N, int H,
+                             int D, float scale, void* stream);
 int oat_attn_time_bwd_fin(const void* qkv, int ldqkv, const void* out, int ldo, const float* lse,
                           const void* dout, int lddo, void* dqkv, int lddqkv, float* cls_side, int* done, int B, int T,
                           int N, int H, int D, float scale, void* stream);

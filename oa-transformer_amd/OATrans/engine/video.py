@@ -190,6 +190,8 @@ class VideoEngine:
         # CLS-row gradients of the attention backward written by the attention kernel itself (oat_attn_*_bwd_fin); 0: separate
         # oat_attn_cls_finalize launches (A/B measurements)
         self.fused_finalize = os.environ.get("OAT_FUSED_FINALIZE", "1") != "0"
+        # two clips in one plan (OA models): their space attention as ONE launch each way (0: one launch per clip)
+        self.clip_launch = os.environ.get("OAT_CLIP_LAUNCH", "1") != "0"
         self.fp8 = os.environ.get("OAT_FP8", "0") != "0"
         self.fp8_margin = float(os.environ.get("OAT_FP8_MARGIN", "1.0"))
         # OAT_FP8_BWD=1 (with fp8 on): the data-gradient GEMMs as well (dY as e5m2, W^T as e4m3; weight gradients stay
@@ -485,7 +487,7 @@ class VideoEngine:
         ptrs = tuple(t.data_ptr() for t in params.values())
         gptr = next(iter(grads.values())).data_ptr() if grads else 0
         f8 = (len(self._f8["primed"]), self._f8["key"]) if (self.fp8 and self._f8) else None
-        return (torch.cuda.current_stream().cuda_stream, pl.side.cuda_stream, ptrs, gptr, self.fp8, self.fp8_bwd, f8, self.cls_lane, self.h_u8,
+        return (torch.cuda.current_stream().cuda_stream, pl.side.cuda_stream, self.clip_launch, ptrs, gptr, self.fp8, self.fp8_bwd, f8, self.cls_lane, self.h_u8,
                 self.tail_split, self.bwd_side, self.bwd_nt_grid, self.group_wgrads, self.fold_active(), self.fold_gstream, os.environ.get("OAT_SKIP_Y", "1"), hip.gemm_get_variant(), flags)
 
     @staticmethod
@@ -707,8 +709,13 @@ class VideoEngine:
                                           self.D, self.scale)
                 else:
                     hip.attn_cls_fwd(q, o, l, sg.B, sg.T, sg.N, self.H, self.D, self.scale)
-        for sg in pl.segs:
-            patch_kernel(sg.rows(qkv), sg.rows(out), sg.rows(lse), sg.B, sg.T, sg.N, self.H, self.D, self.scale)
+        if patch_kernel is hip.attn_space_fwd and len(pl.segs) == 2 and pl.segs[0].N == pl.segs[1].N and self.clip_launch:
+            # both clips' frames in ONE launch: the object frame alone is B x H problems, a third of the GPU
+            hip.attn_space_fwd_clips([dict(qkv=sg.rows(qkv), out=sg.rows(out), lse=sg.rows(lse), B=sg.B, T=sg.T) for sg in pl.segs],
+                                     pl.segs[0].N, self.H, self.D, self.scale)
+        else:
+            for sg in pl.segs:
+                patch_kernel(sg.rows(qkv), sg.rows(out), sg.rows(lse), sg.B, sg.T, sg.N, self.H, self.D, self.scale)
         hip.stream_edge(pl.side, cur)
 
     def _region_tap(self, pl, params, x):
@@ -933,6 +940,11 @@ class VideoEngine:
     def _attn_bwd(self, pl, kernel, qkv, o, lse, d_o, d_qkv):
         """attention backward + the CLS-row finalize, per segment (each clip is a self-contained row range)"""
         fin = {hip.attn_space_bwd: hip.attn_space_bwd_fin, hip.attn_time_bwd: hip.attn_time_bwd_fin}[kernel] if self.fused_finalize else None
+        if (fin is hip.attn_space_bwd_fin and len(pl.segs) == 2 and pl.segs[0].N == pl.segs[1].N and self.clip_launch):
+            hip.attn_space_bwd_clips([dict(qkv=sg.rows(qkv), out=sg.rows(o), lse=sg.rows(lse), dout=sg.rows(d_o), dqkv=sg.rows(d_qkv),
+                                           cls_side=sg.cls_side, done=sg.cls_done, B=sg.B, T=sg.T) for sg in pl.segs],
+                                     pl.segs[0].N, self.H, self.D, self.scale)
+            return
         for sg in pl.segs:
             dq = sg.rows(d_qkv)
             if fin is not None:      # one launch: the last workgroup per (sample, head) writes the CLS row (24 launches per step less)

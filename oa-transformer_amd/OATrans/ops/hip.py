@@ -552,6 +552,36 @@ def attn_time_bwd_fin(qkv, out, lse, dout, dqkv, cls_side, done, B, T, N, H, D, 
                   N, H, D, scale)
 
 
+class _AttnClip(ctypes.Structure):
+    _fields_ = [("qkv", ctypes.c_void_p), ("out", ctypes.c_void_p), ("lse", ctypes.c_void_p), ("dout", ctypes.c_void_p),
+                ("dqkv", ctypes.c_void_p), ("cls_side", ctypes.c_void_p), ("done", ctypes.c_void_p), ("B", ctypes.c_int),
+                ("T", ctypes.c_int)]
+
+
+def _clip_array(clips):
+    arr = (_AttnClip * len(clips))()
+    for i, c in enumerate(clips):
+        for k in ("qkv", "out", "lse", "dout", "dqkv", "cls_side", "done"):
+            t = c.get(k)
+            setattr(arr[i], k, t.data_ptr() if t is not None else None)
+        arr[i].B, arr[i].T = c["B"], c["T"]
+    return arr
+
+
+def attn_space_fwd_clips(clips, N, H, D, scale):
+    """clips: list of 1-2 dicts {qkv, out, lse, B, T} (row views of one geometry) -> one launch"""
+    q, o = clips[0]["qkv"], clips[0]["out"]
+    _check(lib().oat_attn_space_fwd_clips(_clip_array(clips), len(clips), q.stride(0), o.stride(0), N, H, D, _f(scale), _stream()),
+           "oat_attn_space_fwd_clips")
+
+
+def attn_space_bwd_clips(clips, N, H, D, scale):
+    """clips: list of 1-2 dicts {qkv, out, lse, dout, dqkv, cls_side, done, B, T}; backward with the fused CLS-row finalize"""
+    c = clips[0]
+    _check(lib().oat_attn_space_bwd_clips(_clip_array(clips), len(clips), c["qkv"].stride(0), c["out"].stride(0), c["dout"].stride(0),
+                                          c["dqkv"].stride(0), N, H, D, _f(scale), _stream()), "oat_attn_space_bwd_clips")
+
+
 def attn_cls_finalize(cls_side, dqkv, B, T, N, H, D):
     _check(lib().oat_attn_cls_finalize(_ptr(cls_side), _ptr(dqkv), dqkv.stride(0), B, T, N, H, D, _stream()),
            "oat_attn_cls_finalize")

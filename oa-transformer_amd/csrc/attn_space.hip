@@ -59,6 +59,10 @@ struct SpaceArgs {
                                    // cls_side[b][h] writes the CLS row of dqkv itself (no oat_attn_cls_finalize launch)
 };
 
+// Two clips in ONE launch (the object frame + the video clip of the OA models: a one-frame clip alone is B x H problems, a third
+// of the GPU): workgroups [0, n0) work on s[0], the rest on s[1].  Single-clip launches set n0 to the grid size.
+struct SpaceArgs2 { SpaceArgs s[2]; int n0; };
+
 // forward: 4 waves, 56 KB LDS -> two workgroups per CU overlap each other's prologue;
 // backward: 116 KB LDS pins one workgroup per CU, so it runs 8 waves (two per SIMD) to hide the
 // MFMA / LDS / exp latency chains (measured 899 -> 526 us at B=32, T=8).
@@ -111,13 +115,16 @@ OAT_DEV void load_tile(char* tile, const bf16* src, int ld, int col, const RowMa
 }
 
 template <int NKT>
-__global__ __launch_bounds__(FWD_THREADS, NKT <= 14 ? 4 : 2) void attn_space_fwd_kernel(SpaceArgs a) {
+__global__ __launch_bounds__(FWD_THREADS, NKT <= 14 ? 4 : 2) void attn_space_fwd_kernel(SpaceArgs2 aa) {
+  const bool second = (int)blockIdx.x >= aa.n0;            // workgroup-uniform
+  const SpaceArgs& a = aa.s[second ? 1 : 0];
+  const int bid = (int)blockIdx.x - (second ? aa.n0 : 0);
   constexpr int NKP = NKT * 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Kt = smem;
   char* Vt = smem + NKP * 128;
-  const int h = blockIdx.x % a.H;
-  const int bf = blockIdx.x / a.H;            // b * T + f
+  const int h = bid % a.H;
+  const int bf = bid / a.H;                   // b * T + f
   const int b = bf / a.T;
   const int N = a.N;
   const size_t base_row = (size_t)bf * N;
@@ -224,7 +231,10 @@ __global__ __launch_bounds__(FWD_THREADS, NKT <= 14 ? 4 : 2) void attn_space_fwd
 // group put 7 M contended atomics on 4.6 K addresses).  TT = frame count at compile time (row <-> (position, frame)
 // is a division per row otherwise).
 template <int NKT, bool BIG, int WIDE, bool TIME = false, int TT = 0>
-__global__ __launch_bounds__(WIDE == 1 ? 1024 : WIDE == 3 ? 64 : 512, WIDE == 2 ? 4 : 2) void attn_space_bwd_kernel(SpaceArgs a) {
+__global__ __launch_bounds__(WIDE == 1 ? 1024 : WIDE == 3 ? 64 : 512, WIDE == 2 ? 4 : 2) void attn_space_bwd_kernel(SpaceArgs2 aa) {
+  const bool second = (int)blockIdx.x >= aa.n0;            // workgroup-uniform
+  const SpaceArgs& a = aa.s[second ? 1 : 0];
+  const int bid = (int)blockIdx.x - (second ? aa.n0 : 0);
   constexpr int NKP = NKT * 16;
   constexpr int THR = WIDE == 1 ? 1024 : WIDE == 3 ? 64 : BWD_THREADS, STEP = (WIDE == 1 || WIDE == 2) ? 1 : 2;
   static_assert(!TIME || (!BIG && NKT == 2), "time mode = 16 local rows + CLS");
@@ -232,8 +242,8 @@ __global__ __launch_bounds__(WIDE == 1 ? 1024 : WIDE == 3 ? 64 : 512, WIDE == 2 
   // TIME: rows 0..16 of a tile are real (16 patch rows + CLS), every padding row reads row 16: 17-row tiles, 8.8 KB per workgroup
   constexpr int TROWS = TIME ? 17 : NKP, RMAX = TIME ? 16 : 0x7fffffff;
   constexpr int BUF = (BIG ? 2 : 4) * TROWS * 128 + 2 * NKP * 4;     // one problem's tiles + (lse, delta); TIME keeps two
-  const int h = blockIdx.x % a.H;
-  const int bf = blockIdx.x / a.H;
+  const int h = bid % a.H;
+  const int bf = bid / a.H;
   const int Tc = TT > 0 ? TT : a.T;
   const int G = TIME ? 16 / Tc : 1, ngrp = TIME ? (a.N + G - 1) / G : a.T;
   const int gpw = TIME ? max(a.gpw, 1) : 1, nchunk = (ngrp + gpw - 1) / gpw;      // bf = b * nchunk + chunk
@@ -592,20 +602,23 @@ __global__ void attn_cls_finalize_kernel(float* side, bf16* dqkv, int lddqkv, in
   dqkv[(cls_row0 + b) * lddqkv + (t >> 6) * D + h * 64 + (t & 63)] = f2bf(v);
 }
 
+static SpaceArgs2 one_clip(const SpaceArgs& a, int blocks) { return SpaceArgs2{{a, a}, blocks}; }
+static SpaceArgs2 two_clips(const SpaceArgs& a, const SpaceArgs& b) { return SpaceArgs2{{a, b}, a.B * a.T * a.H}; }
+static int space_blocks(const SpaceArgs2& aa) { return aa.n0 + (aa.s[1].qkv != aa.s[0].qkv ? aa.s[1].B * aa.s[1].T * aa.s[1].H : 0); }
 template <int NKT>
-static int launch_fwd(const SpaceArgs& a, hipStream_t s) {
+static int launch_fwd(const SpaceArgs2& aa, hipStream_t s) {
   const int lds = 2 * NKT * 16 * 128;
   static bool set = false;
   if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_space_fwd_kernel<NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
-  OAT_LAUNCH(attn_space_fwd_kernel<NKT>, dim3(a.B * a.T * a.H), dim3(FWD_THREADS), lds, s, a);
+  OAT_LAUNCH(attn_space_fwd_kernel<NKT>, dim3(space_blocks(aa)), dim3(FWD_THREADS), lds, s, aa);
   return check_launch("attn_space_fwd");
 }
 template <int NKT, bool BIG = false, int WIDE = 0>
-static int launch_bwd(const SpaceArgs& a, hipStream_t s) {
+static int launch_bwd(const SpaceArgs2& aa, hipStream_t s) {
   const int lds = (BIG ? 2 : 4) * NKT * 16 * 128 + 2 * NKT * 16 * 4;
   static bool set = false;
   if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_space_bwd_kernel<NKT, BIG, WIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
-  OAT_LAUNCH((attn_space_bwd_kernel<NKT, BIG, WIDE>), dim3(a.B * a.T * a.H), dim3(WIDE == 1 ? 1024 : BWD_THREADS), lds, s, a);
+  OAT_LAUNCH((attn_space_bwd_kernel<NKT, BIG, WIDE>), dim3(space_blocks(aa)), dim3(WIDE == 1 ? 1024 : BWD_THREADS), lds, s, aa);
   return check_launch("attn_space_bwd");
 }
 // tuning hook.  0 (default): 97..223 patches -> two 8-wave workgroups per CU on the two-tile layout, one tile per wave;
@@ -615,7 +628,7 @@ static int g_space_variant = 0;
 // time-attention backward through the MFMA kernel: one single-wave workgroup per (sample, group of 16 / T positions, head)
 template <int TT>
 static int launch_time_bwd(const SpaceArgs& a, int blocks, int lds, hipStream_t s) {
-  OAT_LAUNCH((attn_space_bwd_kernel<2, false, 3, true, TT>), dim3(blocks), dim3(64), lds, s, a);
+  OAT_LAUNCH((attn_space_bwd_kernel<2, false, 3, true, TT>), dim3(blocks), dim3(64), lds, s, one_clip(a, blocks));
   return check_launch("attn_time_bwd_mfma");
 }
 int g_time_gpw = 4;        // position groups per workgroup (tuning: oat_attn_time_set_variant bits 8-15)
@@ -647,40 +660,68 @@ static int pick_nkt(int N) {
 
 using namespace oat;
 
-extern "C" int oat_attn_space_fwd(const void* qkv, int ldqkv, void* out, int ldo, float* lse, int B, int T, int N,
-                                  int H, int D, float scale, void* stream) {
+static int space_fwd(const SpaceArgs2& aa, int N, int H, int D, void* stream) {
   if (D != H * 64) { set_error("attn_space: head_dim must be 64"); return -3; }
   const int nkt = pick_nkt(N);
   if (nkt < 0) { set_error("attn_space: patches per frame > 447 not supported by this build"); return -3; }
-  SpaceArgs a{(const bf16*)qkv, ldqkv, (bf16*)out, ldo, lse, nullptr, 0, nullptr, 0, nullptr, B, T, N, H, D, scale};
   hipStream_t s = (hipStream_t)stream;
   switch (nkt) {
-    case 2: return launch_fwd<2>(a, s);
-    case 4: return launch_fwd<4>(a, s);
-    case 8: return launch_fwd<8>(a, s);
-    case 14: return launch_fwd<14>(a, s);
-    default: return launch_fwd<28>(a, s);
+    case 2: return launch_fwd<2>(aa, s);
+    case 4: return launch_fwd<4>(aa, s);
+    case 8: return launch_fwd<8>(aa, s);
+    case 14: return launch_fwd<14>(aa, s);
+    default: return launch_fwd<28>(aa, s);
   }
+}
+extern "C" int oat_attn_space_fwd(const void* qkv, int ldqkv, void* out, int ldo, float* lse, int B, int T, int N,
+                                  int H, int D, float scale, void* stream) {
+  SpaceArgs a{(const bf16*)qkv, ldqkv, (bf16*)out, ldo, lse, nullptr, 0, nullptr, 0, nullptr, B, T, N, H, D, scale};
+  return space_fwd(one_clip(a, B * T * H), N, H, D, stream);
 }
 
 // cls_side: fp32 [B, H, 3, 64], must be ZERO on entry (caller memsets); it receives the CLS row's
 // dq/dk/dv partial sums.  Call oat_attn_cls_finalize afterwards to write them into dqkv (it zeroes cls_side again).
-static int space_bwd(const void* qkv, int ldqkv, const void* out, int ldo, const float* lse, const void* dout, int lddo,
-                     void* dqkv, int lddqkv, float* cls_side, int* done, int B, int T, int N, int H, int D, float scale,
-                     void* stream) {
+static int space_bwd2(const SpaceArgs2& aa, int N, int H, int D, void* stream) {
   if (D != H * 64) { set_error("attn_space: head_dim must be 64"); return -3; }
   const int nkt = pick_nkt(N);
   if (nkt < 0) { set_error("attn_space: patches per frame > 447 not supported by this build"); return -3; }
-  SpaceArgs a{(const bf16*)qkv, ldqkv, (bf16*)out, ldo, (float*)lse, (const bf16*)dout, lddo, (bf16*)dqkv, lddqkv,
-              cls_side, B, T, N, H, D, scale, 0, done};
   hipStream_t s = (hipStream_t)stream;
   switch (nkt) {
-    case 2: return launch_bwd<2>(a, s);
-    case 4: return launch_bwd<4>(a, s);
-    case 8: return launch_bwd<8>(a, s);
-    case 14: return g_space_variant == 1 ? launch_bwd<14>(a, s) : g_space_variant == 2 ? launch_bwd<14, false, 1>(a, s) : launch_bwd<14, true, 2>(a, s);
-    default: return g_space_variant == 1 ? launch_bwd<28, true>(a, s) : launch_bwd<28, true, 1>(a, s);
+    case 2: return launch_bwd<2>(aa, s);
+    case 4: return launch_bwd<4>(aa, s);
+    case 8: return launch_bwd<8>(aa, s);
+    case 14: return g_space_variant == 1 ? launch_bwd<14>(aa, s) : g_space_variant == 2 ? launch_bwd<14, false, 1>(aa, s) : launch_bwd<14, true, 2>(aa, s);
+    default: return g_space_variant == 1 ? launch_bwd<28, true>(aa, s) : launch_bwd<28, true, 1>(aa, s);
   }
+}
+static int space_bwd(const void* qkv, int ldqkv, const void* out, int ldo, const float* lse, const void* dout, int lddo,
+                     void* dqkv, int lddqkv, float* cls_side, int* done, int B, int T, int N, int H, int D, float scale,
+                     void* stream) {
+  SpaceArgs a{(const bf16*)qkv, ldqkv, (bf16*)out, ldo, (float*)lse, (const bf16*)dout, lddo, (bf16*)dqkv, lddqkv,
+              cls_side, B, T, N, H, D, scale, 0, done};
+  return space_bwd2(one_clip(a, B * T * H), N, H, D, stream);
+}
+// Two clips of the same geometry (N, H, D, leading dimensions) in one launch each way - the object frame and the video clip
+// of the OA models (oa_model_global_local.py:170, oa_model_region_mem.py:120).  OatAttnClip: see include/oatrans_hip.h.
+struct OatAttnClip { const void* qkv; void* out; float* lse; const void* dout; void* dqkv; float* cls_side; int* done; int B, T; };
+extern "C" int oat_attn_space_fwd_clips(const OatAttnClip* c, int n_clips, int ldqkv, int ldo, int N, int H, int D, float scale,
+                                        void* stream) {
+  if (!c || n_clips < 1 || n_clips > 2) { set_error("attn_space_fwd_clips: one or two clips"); return -4; }
+  SpaceArgs a[2];
+  for (int i = 0; i < n_clips; ++i)
+    a[i] = SpaceArgs{(const bf16*)c[i].qkv, ldqkv, (bf16*)c[i].out, ldo, c[i].lse, nullptr, 0, nullptr, 0, nullptr, c[i].B, c[i].T, N, H, D, scale};
+  return space_fwd(n_clips == 2 ? two_clips(a[0], a[1]) : one_clip(a[0], a[0].B * a[0].T * H), N, H, D, stream);
+}
+extern "C" int oat_attn_space_bwd_clips(const OatAttnClip* c, int n_clips, int ldqkv, int ldo, int lddo, int lddqkv, int N, int H,
+                                        int D, float scale, void* stream) {
+  if (!c || n_clips < 1 || n_clips > 2) { set_error("attn_space_bwd_clips: one or two clips"); return -4; }
+  SpaceArgs a[2];
+  for (int i = 0; i < n_clips; ++i) {
+    if (!c[i].done || !c[i].cls_side) { set_error("attn_space_bwd_clips: every clip needs its cls_side and ticket buffers"); return -4; }
+    a[i] = SpaceArgs{(const bf16*)c[i].qkv, ldqkv, (bf16*)c[i].out, ldo, c[i].lse, (const bf16*)c[i].dout, lddo, (bf16*)c[i].dqkv, lddqkv,
+                     c[i].cls_side, c[i].B, c[i].T, N, H, D, scale, 0, c[i].done};
+  }
+  return space_bwd2(n_clips == 2 ? two_clips(a[0], a[1]) : one_clip(a[0], a[0].B * a[0].T * H), N, H, D, stream);
 }
 extern "C" int oat_attn_space_bwd(const void* qkv, int ldqkv, const void* out, int ldo, const float* lse,
                                   const void* dout, int lddo, void* dqkv, int lddqkv, float* cls_side, int B, int T,

@@ -519,6 +519,50 @@ def test_attention_space_more_shapes(B, T, N, H):
     _attention_case("space", B, T, N, H)
 
 
+@pytest.mark.parametrize("N,H", [(196, 12), (9, 2), (441, 2)])
+def test_attention_space_two_clips_one_launch(N, H):
+    """oat_attn_space_fwd_clips / _bwd_clips: the object frame (T = 1) and a video clip (T = 3) of the OA models as segments of
+    one row space, one launch each way - forward and patch-row gradients bit-identical to one launch per clip, the CLS rows
+    equal up to the order of their fp32 atomics, side and ticket buffers left zero."""
+    hip = _hip()
+    D = H * 64
+    scale = 64 ** -0.5
+    clips = [(3, 1), (3, 3)]                                   # (B, T)
+    rows = [B * T * N + B for B, T in clips]
+    Mp = (sum(rows) + 255) // 256 * 256
+    qkv = torch.zeros(Mp, 3 * D, dtype=torch.bfloat16, device=DEV); qkv[:sum(rows)] = rnd(sum(rows), 3 * D, scale=1.5, dtype=torch.bfloat16, seed=50)
+    dout = torch.zeros(Mp, D, dtype=torch.bfloat16, device=DEV); dout[:sum(rows)] = rnd(sum(rows), D, dtype=torch.bfloat16, seed=51)
+    def run(together):
+        out = torch.zeros(Mp, D, dtype=torch.bfloat16, device=DEV); lse = torch.zeros(Mp, H, device=DEV)
+        dq = torch.zeros(Mp, 3 * D, dtype=torch.bfloat16, device=DEV)
+        side = [torch.zeros(B, H, 3, 64, device=DEV) for B, _ in clips]
+        done = [torch.zeros(B, H, dtype=torch.int32, device=DEV) for B, _ in clips]
+        segs, r0 = [], 0
+        for (B, T), n, sd, dn in zip(clips, rows, side, done):
+            sl = slice(r0, r0 + n); r0 += n
+            segs.append(dict(qkv=qkv[sl], out=out[sl], lse=lse[sl], dout=dout[sl], dqkv=dq[sl], cls_side=sd, done=dn, B=B, T=T))
+        for sg in segs:                                        # the CLS queries' rows of out / lse (their own kernel)
+            hip.attn_cls_fwd(sg["qkv"], sg["out"], sg["lse"], sg["B"], sg["T"], N, H, D, scale)
+        if together:
+            hip.attn_space_fwd_clips(segs, N, H, D, scale)
+            hip.attn_space_bwd_clips(segs, N, H, D, scale)
+        else:
+            for sg in segs:
+                hip.attn_space_fwd(sg["qkv"], sg["out"], sg["lse"], sg["B"], sg["T"], N, H, D, scale)
+                hip.attn_space_bwd_fin(sg["qkv"], sg["out"], sg["lse"], sg["dout"], sg["dqkv"], sg["cls_side"], sg["done"], sg["B"], sg["T"], N, H, D, scale)
+        assert all(torch.count_nonzero(x) == 0 for x in side + done)
+        return out, lse, dq
+    o1, l1, g1 = run(False)
+    o2, l2, g2 = run(True)
+    assert torch.equal(o1, o2) and torch.equal(l1, l2)
+    r0 = 0
+    for (B, T), n in zip(clips, rows):
+        assert torch.equal(g1[r0:r0 + n - B], g2[r0:r0 + n - B])
+        close(g2[r0 + n - B:r0 + n], g1[r0 + n - B:r0 + n].float(), atol=1e-2 * g1.float().abs().max().item(), rtol=2e-2, what="CLS rows")
+        r0 += n
+    assert torch.count_nonzero(g2[sum(rows):]) == 0
+
+
 @pytest.mark.parametrize("variant", [1, 2])
 @pytest.mark.parametrize("B,T,N,H", [(2, 8, 196, 12), (2, 3, 9, 2), (1, 16, 441, 2), (1, 12, 16, 1)])
 def test_attention_time_bwd_tuning_variants(B, T, N, H, variant):
