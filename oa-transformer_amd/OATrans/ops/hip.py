@@ -52,7 +52,7 @@ def lib():
         if os.environ.get("OAT_GEMM_VARIANT"):           # tuning hooks (see oat_gemm_set_variant / oat_gemm_tn_set_variant)
             _lib.oat_gemm_set_variant(int(os.environ["OAT_GEMM_VARIANT"], 0))
             _gemm_variant[0] = int(os.environ["OAT_GEMM_VARIANT"], 0)
-        if os.environ.get("OAT_SPACE_VARIANT"):          # oat_attn_space_set_variant: bits 0-7 backward schedule, bits 8-15 forward (1 = persistent)
+        if os.environ.get("OAT_SPACE_VARIANT"):          # oat_attn_space_set_variant: backward schedule of the space attention (see the header)
             _lib.oat_attn_space_set_variant(int(os.environ["OAT_SPACE_VARIANT"], 0))
         if os.environ.get("OAT_GEMM_TN_VARIANT"):
             _lib.oat_gemm_tn_set_variant(int(os.environ["OAT_GEMM_TN_VARIANT"], 0))
