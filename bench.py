@@ -95,7 +95,7 @@ def synthetic_batch(args, rank, device):
     return batch
 
 
-def other_config_line(base_args, variant, device, steps=5, warmup=2):
+def other_config_line(base_args, variant, device, steps=10, warmup=3):
     """Config 3 as BASELINE.json words it ("8-frame 224^2 + 10 object regions/frame, bs 32"): the object-aware model
     classes on one object frame + the clip.  Run AFTER the headline's timed region and reported under `other_configs`,
     outside `value`: a short (warmup + steps) single-GPU measurement with the same step function, optimiser and timing

@@ -131,6 +131,23 @@ int oat_layernorm_bwd(const void* dy, int dy_is_bf16, int lddy, const float* x, 
                       float* dgamma, float* dbeta, int accumulate, float* part, int M, int D, void* stream);
 /* dx = LNbwd(dy) + dres ; dx_bf16 = bf16(dx) or, with dx16_excl_res, bf16(LNbwd(dy)) only. */
 
+/* ---- LayerNorm on a bf16 residual stream (round 4) -------------------------------------------------------------------
+ * The three residual adds of a SpaceTimeBlock (video_transformer.py:166,170,175) and the LayerNorms that follow them
+ * (:164,167,174,346) with the token stream x STORED as bf16: s = x + add_a + add_b in fp32, sum16 = bf16(s) (the new stream),
+ * y / y32 = LN(s) from the unrounded sum.  x is bf16, or fp32 when x_is_f32 (block 0 reads the patch embedding's fp32 output);
+ * every addend / output is optional (NULL).  The cosine-similarity matrix is taken from the fp32 CLS lane and does not move;
+ * parameter gradients differ from the fp32 oracle's by 2.0e-2 instead of 1.8e-2 relative L2 (scripts/dev/rounding_study3.py). */
+int oat_layernorm_fwd_r16(const void* x, int x_is_f32, int ldx, const void* add_a_bf16, int ldadd_a, const void* add_b_bf16,
+                          int ldadd_b, void* sum16, int ldsum, const float* gamma, const float* beta, void* y_bf16,
+                          int ldy, float* y_f32, int ldy32, float* mean, float* rstd, int M, int D, float eps,
+                          void* stream);
+/* oat_layernorm_bwd with the forward input x as bf16 and a bf16 residual-gradient addend: dx (fp32 | NULL) and dx16 =
+ * LNbwd(dy) + dres16; dres16 may be dx16 itself (in place).  The final norm and the region tap of the bf16 stream. */
+int oat_layernorm_bwd_r16(const void* dy, int dy_is_bf16, int lddy, const void* x_bf16, int ldx, const float* mean,
+                          const float* rstd, const float* gamma, const void* dres16, int lddres16, float* dx, int lddx,
+                          void* dx16, int lddx16, float* dgamma, float* dbeta, int accumulate, float* part, int M, int D,
+                          void* stream);
+
 /* ---- reductions (bias / positional-table gradients) ------------------------------------- */
 int oat_colsum_rows(int M);     /* partial workspace = rows * N floats */
 int oat_colsum(const void* A, int is_bf16, int lda, int M, int N, float* out, int accumulate,

@@ -221,6 +221,15 @@ def add32_layernorm_fwd(x, add32, sum32, gamma, beta, M, D, eps, y=None, y32=Non
     _check(rc, "oat_add32_layernorm_fwd")
 
 
+def layernorm_fwd_r16(x, M, D, eps, add_a=None, add_b=None, sum16=None, gamma=None, beta=None, y=None, y32=None, mean=None,
+                      rstd=None):
+    """LayerNorm on the bf16 residual stream: s = x + add_a + add_b ; sum16 = bf16(s) ; y / y32 = LN(s).  x bf16 or fp32."""
+    s0 = lambda t: t.stride(0) if t is not None else 0
+    _check(lib().oat_layernorm_fwd_r16(_ptr(x), int(x.dtype == torch.float32), x.stride(0), _ptr(add_a), s0(add_a), _ptr(add_b),
+                                       s0(add_b), _ptr(sum16), s0(sum16), _ptr(gamma), _ptr(beta), _ptr(y), s0(y), _ptr(y32),
+                                       s0(y32), _ptr(mean), _ptr(rstd), M, D, _f(eps), _stream()), "oat_layernorm_fwd_r16")
+
+
 _part_ws = {}
 _retired = []
 
@@ -249,6 +258,19 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, M, D, dx=None, dx16=None, dres=None,
                                  _ptr(dbeta),
                                  int(accumulate), _ptr(part), M, D, _stream())
     _check(rc, "oat_layernorm_bwd")
+
+
+def layernorm_bwd_r16(dy, x16, mean, rstd, gamma, M, D, dx=None, dx16=None, dres16=None, dgamma=None, dbeta=None,
+                      accumulate=False):
+    """LayerNorm backward with the forward input as bf16 and a bf16 residual-gradient addend (may be dx16: in place)."""
+    part = None
+    if dgamma is not None or dbeta is not None:
+        part = _partials(x16.device, lib().oat_ln_bwd_blocks(M) * 2 * D)
+    s0 = lambda t: t.stride(0) if t is not None else 0
+    _check(lib().oat_layernorm_bwd_r16(_ptr(dy), int(dy.dtype == torch.bfloat16), dy.stride(0), _ptr(x16), x16.stride(0),
+                                       _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(dres16), s0(dres16), _ptr(dx), s0(dx),
+                                       _ptr(dx16), s0(dx16), _ptr(dgamma), _ptr(dbeta), int(accumulate), _ptr(part), M, D,
+                                       _stream()), "oat_layernorm_bwd_r16")
 
 
 def layernorm_bwd_xhat(dxh, xhat, rstd, M, D, dx=None, dx16=None, dres=None, dx16_excl_res=False, add_a=None, add_b=None,

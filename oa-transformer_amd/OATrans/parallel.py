@@ -93,18 +93,22 @@ class GradSync:
         if W > 1 and torch.cuda.is_available():
             # RCCL's kernels hold CUs for the length of a collective.  A persistent GEMM launch (one workgroup per
             # CU walking its tiles) that finds some CUs taken runs its remaining workgroups AFTER the others - up to
-            # twice the time; one workgroup per tile adapts to whatever CUs are free (2 % slower on an idle GPU).
-            # The collectives of a step all start inside backward and are waited for before the optimiser step, so
-            # only BACKWARD gives up persistence (VideoEngine.bwd_nt_grid); forward keeps one workgroup per CU.
+            # twice the time.  The collectives of a step all start inside backward and are waited for before the
+            # optimiser step, so only BACKWARD makes room (VideoEngine.bwd_nt_grid); forward keeps one workgroup per CU.
+            # Default at W > 1: persistent grids of 240 workgroups, i.e. 16 CUs left to RCCL - measured FREE on one
+            # MI355X (47.59 vs 47.68 ms per step), where one workgroup per tile (0xffff, adapts to
+            # whatever CUs are free) costs +0.55 ms.  OAT_BWD_NT_GRID overrides (0xffff = the per-tile fallback if RCCL
+            # turns out to hold more than 16 CUs on a real node).
+            grid = int(os.environ.get("OAT_BWD_NT_GRID", "240"), 0)
             engines = [m._engine for m in model.modules() if hasattr(getattr(m, "_engine", None), "bwd_nt_grid")]
             for eng in engines:
-                eng.bwd_nt_grid = 0xffff
+                eng.bwd_nt_grid = grid
             if not engines:
                 try:
                     from .ops import hip
                 except ImportError:                  # entry points run from inside OATrans/ import us as a top-level module
                     from ops import hip
-                hip.gemm_set_variant(0xffff << 16)
+                hip.gemm_set_variant(grid << 16)
         if overlap and (W > 1 or force):     # a single rank leaves the announcements to the eager optimiser (optim.AdamW.attach)
             for m in model.modules():
                 if hasattr(m, "flat_grad") and hasattr(m, "_engine_params"):

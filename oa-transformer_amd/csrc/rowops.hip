@@ -95,17 +95,123 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   if (f8.y8) amax_commit(m8, f8.amax);        // block-uniform branch (kernel argument)
 }
 
+// ------------------------------------------------------------------ LayerNorm forward on a bf16 residual stream
+// s = x + add_a + add_b ; sum16 = bf16(s) ; y = LN(s) computed from the UNROUNDED fp32 sum.
+// The residual stream of the video tower is STORED as bf16 (round 4; scripts/dev/rounding_study3.py: the cosine-similarity
+// matrix - which is taken from the fp32 CLS lane - does not move, parameter gradients go from 1.8e-2 to 2.0e-2 relative L2
+// against the fp32 oracle): x is 2 bytes per element instead of 4 and so is the new stream the kernel leaves, i.e.
+// 385 instead of 539 MB for the block-opening LayerNorm (x + space + mlp), 231 instead of 308 MB for the other two at
+// M = 50208, D = 768.  X32: x is still fp32 (block 0 reads the patch embedding's fp32 output).
+// Access shape: these kernels are bound by memory REQUESTS in flight, not by bytes - the first form (a wave per row, 8-byte
+// bf16x4 lane accesses) ran exactly as long as the fp32 kernel it replaced.  So: HALF a wave (32 lanes) per row, every lane
+// access 16 bytes (8 bf16 / 2 x 4 fp32), 8 rows per workgroup; row sums by xor-shuffles below 32 (they stay inside the half).
+constexpr int LN_MAXC = 4;   // up to 4 chunks of 8 elements per lane -> D <= 1024, D % 8 == 0
+OAT_DEV float half_sum(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+OAT_DEV void ld8(const bf16* p, float (&v)[8]) {
+  const bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = bf2f(t[e]);
+}
+OAT_DEV void ld8(const float* p, float (&v)[8]) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
+}
+OAT_DEV void add8(const bf16* p, float (&v)[8]) {
+  const bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] += bf2f(t[e]);
+}
+OAT_DEV void st8(bf16* p, const float (&v)[8]) {
+  bf16x8 t;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) t[e] = f2bf(v[e]);
+  *reinterpret_cast<bf16x8*>(p) = t;
+}
+OAT_DEV void st8(float* p, const float (&v)[8]) {
+  *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+  *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+}
+template <bool X32>
+__global__ __launch_bounds__(256) void ln_fwd_r16_kernel(const void* __restrict__ x_, int ldx, const bf16* __restrict__ add_a,
+                                                         int lda, const bf16* __restrict__ add_b, int ldb, bf16* sum16,
+                                                         int ldsum, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, bf16* y, int ldy, float* y32,
+                                                         int ldy32, float* mean, float* rstd, int M, int D, float eps) {
+  const int lane = threadIdx.x & 31;
+  const int hw = threadIdx.x >> 5;
+  for (int row = blockIdx.x * 8 + hw; row < M; row += gridDim.x * 8) {
+    float v[LN_MAXC][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+      const int c = (i * 32 + lane) * 8;
+      if (c < D) {
+        if constexpr (X32) ld8((const float*)x_ + (size_t)row * ldx + c, v[i]);
+        else ld8((const bf16*)x_ + (size_t)row * ldx + c, v[i]);
+        if (add_a) add8(add_a + (size_t)row * lda + c, v[i]);
+        if (add_b) add8(add_b + (size_t)row * ldb + c, v[i]);
+        if (sum16) st8(sum16 + (size_t)row * ldsum + c, v[i]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[i][e];
+      }
+    }
+    const float mu = half_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+      const int c = (i * 32 + lane) * 8;
+      if (c < D) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mu; q += d * d; }
+      }
+    }
+    const float rs = rsqrtf(half_sum(q) / D + eps);
+    if (lane == 0 && mean) { mean[row] = mu; rstd[row] = rs; }
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+      const int c = (i * 32 + lane) * 8;
+      if (c < D) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mu) * rs;
+        if (gamma) {
+          float g[8];
+          ld8(gamma + c, g);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] *= g[e];
+        }
+        if (beta) {
+          float b[8];
+          ld8(beta + c, b);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] += b[e];
+        }
+        if (y) st8(y + (size_t)row * ldy + c, o);
+        if (y32) st8(y32 + (size_t)row * ldy32 + c, o);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ LayerNorm backward
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
 // out fp32 dx (+ optional fp32 addend `dres`), optional bf16 copy; per-block partial
 // (dgamma, dbeta) sums go to part[blockIdx][2][D] and are finished by reduce_partials.
-template <bool DY_BF16>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* dy_, int lddy, const float* __restrict__ x,
+// X16: the forward input x is the bf16 residual stream; dres16: a bf16 residual-gradient addend (may alias dx16: a lane reads
+// and writes the same elements).
+template <bool DY_BF16, bool X16>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* dy_, int lddy, const void* __restrict__ x_,
                                                      int ldx, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* dres,
                                                      int lddres, float* dx, int lddx, bf16* dx16, int lddx16,
-                                                     int dx16_excl_res, float* part, int M, int D, LnF8 f8) {
+                                                     int dx16_excl_res, float* part, int M, int D, LnF8 f8,
+                                                     const bf16* dres16, int lddres16) {
   __shared__ float red[4][2][LN_MAXV * 256];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -122,7 +228,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* dy_, int lddy, 
     for (int i = 0; i < LN_MAXV; ++i) {
       const int c = (i * 64 + lane) * 4;
       if (c < D) {
-        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)row * ldx + c);
+        f32x4 xv;
+        if constexpr (X16) {
+          const bf16x4 t = *reinterpret_cast<const bf16x4*>((const bf16*)x_ + (size_t)row * ldx + c);
+          xv = f32x4{bf2f(t[0]), bf2f(t[1]), bf2f(t[2]), bf2f(t[3])};
+        } else {
+          xv = *reinterpret_cast<const f32x4*>((const float*)x_ + (size_t)row * ldx + c);
+        }
         f32x4 dyv;
         if constexpr (DY_BF16) {
           const bf16x4 t = *reinterpret_cast<const bf16x4*>((const bf16*)dy_ + (size_t)row * lddy + c);
@@ -152,6 +264,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* dy_, int lddy, 
         for (int e = 0; e < 4; ++e) o[e] = rs * (g[i][e] - c1 - xh[i][e] * c2);
         const f32x4 o_nores = o;
         if (dres) o += *reinterpret_cast<const f32x4*>(dres + (size_t)row * lddres + c);
+        if (dres16) {
+          const bf16x4 t = *reinterpret_cast<const bf16x4*>(dres16 + (size_t)row * lddres16 + c);
+          o += f32x4{bf2f(t[0]), bf2f(t[1]), bf2f(t[2]), bf2f(t[3])};
+        }
         if (dx) *reinterpret_cast<f32x4*>(dx + (size_t)row * lddx + c) = o;
         if (dx16) {
           const f32x4 w = dx16_excl_res ? o_nores : o;
@@ -194,51 +310,43 @@ __global__ __launch_bounds__(256) void ln_bwd_xhat_kernel(const bf16* __restrict
                                                           int lddres, float* dx, int lddx, bf16* dx16, int lddx16,
                                                           int dx16_excl_res, int M, int D, const bf16* add_a, int ldadd_a,
                                                           const bf16* add_b, int ldadd_b, bf16* dxp16, int lddxp) {
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+  // half a wave per row, 16-byte lane accesses (see ln_fwd_r16_kernel)
+  const int lane = threadIdx.x & 31;
+  const int hw = threadIdx.x >> 5;
+  for (int row = blockIdx.x * 8 + hw; row < M; row += gridDim.x * 8) {
     const float rs = rstd[row];
-    f32x4 xh[LN_MAXV], g[LN_MAXV];
+    float xh[LN_MAXC][8], g[LN_MAXC][8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-      const int c = (i * 64 + lane) * 4;
+    for (int i = 0; i < LN_MAXC; ++i) {
+      const int c = (i * 32 + lane) * 8;
       if (c < D) {
-        const bf16x4 xv = *reinterpret_cast<const bf16x4*>(xh16 + (size_t)row * ldxh + c);
-        const bf16x4 t = *reinterpret_cast<const bf16x4*>(dxh + (size_t)row * lddxh + c);
+        ld8(xh16 + (size_t)row * ldxh + c, xh[i]);
+        ld8(dxh + (size_t)row * lddxh + c, g[i]);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          xh[i][e] = bf2f(xv[e]);
-          g[i][e] = bf2f(t[e]);
-          s1 += g[i][e];
-          s2 += g[i][e] * xh[i][e];
-        }
+        for (int e = 0; e < 8; ++e) { s1 += g[i][e]; s2 += g[i][e] * xh[i][e]; }
       }
     }
-    const float c1 = wave_sum(s1) / D, c2 = wave_sum(s2) / D;
+    const float c1 = half_sum(s1) / D, c2 = half_sum(s2) / D;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-      const int c = (i * 64 + lane) * 4;
+    for (int i = 0; i < LN_MAXC; ++i) {
+      const int c = (i * 32 + lane) * 8;
       if (c < D) {
-        f32x4 o;
+        float o[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = rs * (g[i][e] - c1 - xh[i][e] * c2);
-        const f32x4 o_nores = o;
-        if (dxp16) *reinterpret_cast<bf16x4*>(dxp16 + (size_t)row * lddxp + c) = bf16x4{f2bf(o[0]), f2bf(o[1]), f2bf(o[2]), f2bf(o[3])};
-        if (dres) o += *reinterpret_cast<const f32x4*>(dres + (size_t)row * lddres + c);
-        if (add_a) {
-          const bf16x4 t = *reinterpret_cast<const bf16x4*>(add_a + (size_t)row * ldadd_a + c);
-          o += f32x4{bf2f(t[0]), bf2f(t[1]), bf2f(t[2]), bf2f(t[3])};
+        for (int e = 0; e < 8; ++e) o[e] = rs * (g[i][e] - c1 - xh[i][e] * c2);
+        if (dxp16) st8(dxp16 + (size_t)row * lddxp + c, o);
+        if (dx16 && dx16_excl_res) st8(dx16 + (size_t)row * lddx16 + c, o);
+        if (dres) {
+          float r[8];
+          ld8(dres + (size_t)row * lddres + c, r);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] += r[e];
         }
-        if (add_b) {
-          const bf16x4 t = *reinterpret_cast<const bf16x4*>(add_b + (size_t)row * ldadd_b + c);
-          o += f32x4{bf2f(t[0]), bf2f(t[1]), bf2f(t[2]), bf2f(t[3])};
-        }
-        if (dx) *reinterpret_cast<f32x4*>(dx + (size_t)row * lddx + c) = o;
-        if (dx16) {
-          const f32x4 w = dx16_excl_res ? o_nores : o;
-          *reinterpret_cast<bf16x4*>(dx16 + (size_t)row * lddx16 + c) = bf16x4{f2bf(w[0]), f2bf(w[1]), f2bf(w[2]), f2bf(w[3])};
-        }
+        if (add_a) add8(add_a + (size_t)row * ldadd_a + c, o);
+        if (add_b) add8(add_b + (size_t)row * ldadd_b + c, o);
+        if (dx) st8(dx + (size_t)row * lddx + c, o);
+        if (dx16 && !dx16_excl_res) st8(dx16 + (size_t)row * lddx16 + c, o);
       }
     }
   }
@@ -604,14 +712,18 @@ using namespace oat;
 static int ln_fwd_launch_f8(const float* x, int ldx, const float* gamma, const float* beta, void* y, int ldy, float* mean,
                             float* rstd, int M, int D, float eps, const void* add16, int ldadd, float* sum32, int ldsum,
                             oat::LnF8 f8, void* stream);
+// grid cap of the streaming LayerNorm forwards (4 rows per workgroup; OAT_LN_FWD_BLOCKS)
+static int ln_fwd_cap() {
+  static int cap = 0;
+  if (cap == 0) { const char* e = getenv("OAT_LN_FWD_BLOCKS"); cap = e ? atoi(e) : 8192; if (cap < 1) cap = 8192; }
+  return cap;
+}
 static int ln_fwd_launch(const float* x, int ldx, const float* gamma, const float* beta, void* y, int ldy, float* y32,
                          int ldy32, float* mean, float* rstd, int M, int D, float eps, const void* add16, int ldadd,
                          float* sum32, int ldsum, void* stream) {
   if (M <= 0) return 0;
   if (D % 4 || D > LN_MAXV * 256 || ldx % 4 || (y && ldy % 4)) { set_error("layernorm_fwd: D%4==0, D<=1024 required"); return -3; }
-  static int cap = 0;
-  if (cap == 0) { const char* e = getenv("OAT_LN_FWD_BLOCKS"); cap = e ? atoi(e) : 8192; if (cap < 1) cap = 8192; }
-  int blocks = (M + 3) / 4; if (blocks > cap) blocks = cap;
+  int blocks = (M + 3) / 4; if (blocks > ln_fwd_cap()) blocks = ln_fwd_cap();
   OAT_LAUNCH(ln_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta,
              (bf16*)y, ldy, y32, ldy32, mean, rstd, M, D, eps, (const bf16*)add16, ldadd, sum32, ldsum, (const float*)nullptr, 0,
              oat::LnF8{nullptr, 0, nullptr, nullptr}, (const bf16*)nullptr, 0);
@@ -639,11 +751,33 @@ extern "C" int oat_add2_layernorm_fwd(const float* x, int ldx, const void* add16
   if (!add16 || !add16b) { set_error("add2_layernorm_fwd: both addends are required"); return -4; }
   if (M <= 0) return 0;
   if (D % 4 || D > LN_MAXV * 256 || ldx % 4 || ldadd % 4 || ldaddb % 4 || (y && ldy % 4)) { set_error("layernorm_fwd: D%4==0, D<=1024 required"); return -3; }
-  int blocks = (M + 3) / 4; if (blocks > 8192) blocks = 8192;
+  int blocks = (M + 3) / 4; if (blocks > ln_fwd_cap()) blocks = ln_fwd_cap();
   OAT_LAUNCH(ln_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, beta, (bf16*)y, ldy, y32, ldy32,
              mean, rstd, M, D, eps, (const bf16*)add16, ldadd, sum32, ldsum, (const float*)nullptr, 0,
              oat::LnF8{nullptr, 0, nullptr, nullptr}, (const bf16*)add16b, ldaddb);
   return check_launch("add2_layernorm_fwd");
+}
+
+// LayerNorm on the bf16 residual stream (ln_fwd_r16_kernel): s = x + add_a + add_b ; sum16 = bf16(s) ; y / y32 = LN(s).
+// x: bf16, or fp32 when x_is_f32 (block 0: the patch embedding's output); add_a / add_b / sum16 / y / y32 / mean / rstd
+// optional; sum16 may alias x (bf16 x only).
+extern "C" int oat_layernorm_fwd_r16(const void* x, int x_is_f32, int ldx, const void* add_a, int ldadd_a, const void* add_b,
+                                     int ldadd_b, void* sum16, int ldsum, const float* gamma, const float* beta, void* y,
+                                     int ldy, float* y32, int ldy32, float* mean, float* rstd, int M, int D, float eps,
+                                     void* stream) {
+  if (M <= 0) return 0;
+  if (!x || (!y && !y32 && !sum16)) { set_error("layernorm_fwd_r16: null pointer"); return -4; }
+  if (D % 8 || D > LN_MAXC * 256 || ldx % 8 || ldadd_a % 8 || ldadd_b % 8 || ldsum % 8 || ldy % 8 || ldy32 % 8) {
+    set_error("layernorm_fwd_r16: D%8==0, D<=1024, ld%8==0 required"); return -3;
+  }
+  int blocks = (M + 7) / 8; if (blocks > ln_fwd_cap()) blocks = ln_fwd_cap();
+  if (x_is_f32)
+    OAT_LAUNCH(ln_fwd_r16_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, (const bf16*)add_a, ldadd_a,
+               (const bf16*)add_b, ldadd_b, (bf16*)sum16, ldsum, gamma, beta, (bf16*)y, ldy, y32, ldy32, mean, rstd, M, D, eps);
+  else
+    OAT_LAUNCH(ln_fwd_r16_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, (const bf16*)add_a, ldadd_a,
+               (const bf16*)add_b, ldadd_b, (bf16*)sum16, ldsum, gamma, beta, (bf16*)y, ldy, y32, ldy32, mean, rstd, M, D, eps);
+  return check_launch("layernorm_fwd_r16");
 }
 
 // LayerNorm with the fp8 copy of its output for an fp8 GEMM: y (bf16, kept for backward) and y8 = e4m3(y * *qscale),
@@ -690,18 +824,28 @@ static int ln_bwd_cap() {
 extern "C" int oat_ln_bwd_blocks(int M) { int b = (M + 3) / 4; const int cap = ln_bwd_cap(); return b > cap ? cap : b; }
 
 // part: fp32 workspace of oat_ln_bwd_blocks(M) * 2 * D floats (or NULL to skip dgamma/dbeta)
-static int ln_bwd_launch(const void* dy, int dy_is_bf16, int lddy, const float* x, int ldx,
+static int ln_bwd_launch(const void* dy, int dy_is_bf16, int lddy, const void* x, int x_is_bf16, int ldx,
                          const float* mean, const float* rstd, const float* gamma, const float* dres,
                          int lddres, float* dx, int lddx, void* dx16, int lddx16, int dx16_excl_res,
                          float* dgamma, float* dbeta, int accumulate, float* part, int M, int D, oat::LnF8 f8,
-                         void* stream);
+                         const void* dres16, int lddres16, void* stream);
 extern "C" int oat_layernorm_bwd(const void* dy, int dy_is_bf16, int lddy, const float* x, int ldx,
                                  const float* mean, const float* rstd, const float* gamma, const float* dres,
                                  int lddres, float* dx, int lddx, void* dx16, int lddx16, int dx16_excl_res,
                                  float* dgamma, float* dbeta, int accumulate, float* part, int M, int D,
                                  void* stream) {
-  return ln_bwd_launch(dy, dy_is_bf16, lddy, x, ldx, mean, rstd, gamma, dres, lddres, dx, lddx, dx16, lddx16, dx16_excl_res,
-                       dgamma, dbeta, accumulate, part, M, D, oat::LnF8{nullptr, 0, nullptr, nullptr}, stream);
+  return ln_bwd_launch(dy, dy_is_bf16, lddy, x, 0, ldx, mean, rstd, gamma, dres, lddres, dx, lddx, dx16, lddx16, dx16_excl_res,
+                       dgamma, dbeta, accumulate, part, M, D, oat::LnF8{nullptr, 0, nullptr, nullptr}, nullptr, 0, stream);
+}
+// LayerNorm backward on the bf16 residual stream: x (the layer's forward input) is bf16, the residual-gradient addend
+// dres16 is bf16 (may be dx16 itself: in place), outputs dx (fp32, optional) and dx16 (bf16) = result + dres16.
+extern "C" int oat_layernorm_bwd_r16(const void* dy, int dy_is_bf16, int lddy, const void* x_bf16, int ldx,
+                                     const float* mean, const float* rstd, const float* gamma, const void* dres16,
+                                     int lddres16, float* dx, int lddx, void* dx16, int lddx16, float* dgamma,
+                                     float* dbeta, int accumulate, float* part, int M, int D, void* stream) {
+  if (ldx % 4 || lddres16 % 4 || lddx16 % 4) { oat::set_error("layernorm_bwd_r16: ld%4==0 required"); return -3; }
+  return ln_bwd_launch(dy, dy_is_bf16, lddy, x_bf16, 1, ldx, mean, rstd, gamma, nullptr, 0, dx, lddx, dx16, lddx16, 0,
+                       dgamma, dbeta, accumulate, part, M, D, oat::LnF8{nullptr, 0, nullptr, nullptr}, dres16, lddres16, stream);
 }
 // the same, with an e5m2 copy of dx16 (dx8 = sat(dx16 * *qscale), amax recorded): the producer-side quantisation of the
 // next fp8 data-gradient GEMM's operand
@@ -711,25 +855,24 @@ extern "C" int oat_layernorm_bwd_f8(const void* dy, int dy_is_bf16, int lddy, co
                                     float* dgamma, float* dbeta, int accumulate, float* part, int M, int D,
                                     void* dx8, int ld8, const float* qscale, float* amax, void* stream) {
   if (!dx16 || !dx8 || !qscale || !amax || ld8 % 4) { oat::set_error("layernorm_bwd_f8: dx16, dx8, qscale, amax required"); return -4; }
-  return ln_bwd_launch(dy, dy_is_bf16, lddy, x, ldx, mean, rstd, gamma, dres, lddres, dx, lddx, dx16, lddx16, dx16_excl_res,
-                       dgamma, dbeta, accumulate, part, M, D, oat::LnF8{(uint8_t*)dx8, ld8, qscale, amax}, stream);
+  return ln_bwd_launch(dy, dy_is_bf16, lddy, x, 0, ldx, mean, rstd, gamma, dres, lddres, dx, lddx, dx16, lddx16, dx16_excl_res,
+                       dgamma, dbeta, accumulate, part, M, D, oat::LnF8{(uint8_t*)dx8, ld8, qscale, amax}, nullptr, 0, stream);
 }
-static int ln_bwd_launch(const void* dy, int dy_is_bf16, int lddy, const float* x, int ldx,
+static int ln_bwd_launch(const void* dy, int dy_is_bf16, int lddy, const void* x, int x_is_bf16, int ldx,
                          const float* mean, const float* rstd, const float* gamma, const float* dres,
                          int lddres, float* dx, int lddx, void* dx16, int lddx16, int dx16_excl_res,
                          float* dgamma, float* dbeta, int accumulate, float* part, int M, int D, oat::LnF8 f8,
-                         void* stream) {
+                         const void* dres16, int lddres16, void* stream) {
   if (M <= 0) return 0;
   if (D % 4 || D > LN_MAXV * 256) { set_error("layernorm_bwd: D%4==0, D<=1024 required"); return -3; }
   if ((dgamma || dbeta) && !part) { set_error("layernorm_bwd: dgamma/dbeta need the partial workspace"); return -4; }
   const int blocks = oat_ln_bwd_blocks(M);
   hipStream_t s = (hipStream_t)stream;
-  if (dy_is_bf16)
-    OAT_LAUNCH(ln_bwd_kernel<true>, dim3(blocks), dim3(256), 0, s, dy, lddy, x, ldx, mean, rstd, gamma, dres,
-                       lddres, dx, lddx, (bf16*)dx16, lddx16, dx16_excl_res, part, M, D, f8);
-  else
-    OAT_LAUNCH(ln_bwd_kernel<false>, dim3(blocks), dim3(256), 0, s, dy, lddy, x, ldx, mean, rstd, gamma, dres,
-                       lddres, dx, lddx, (bf16*)dx16, lddx16, dx16_excl_res, part, M, D, f8);
+#define OAT_LN_BWD(DYB, XB) OAT_LAUNCH(ln_bwd_kernel<DYB, XB>, dim3(blocks), dim3(256), 0, s, dy, lddy, x, ldx, mean, rstd, gamma, dres, \
+                                      lddres, dx, lddx, (bf16*)dx16, lddx16, dx16_excl_res, part, M, D, f8, (const bf16*)dres16, lddres16)
+  if (dy_is_bf16) { if (x_is_bf16) OAT_LN_BWD(true, true); else OAT_LN_BWD(true, false); }
+  else { if (x_is_bf16) OAT_LN_BWD(false, true); else OAT_LN_BWD(false, false); }
+#undef OAT_LN_BWD
   int rc = check_launch("layernorm_bwd");
   if (rc || !part) return rc;
   if (dgamma && dbeta)
@@ -754,8 +897,8 @@ extern "C" int oat_layernorm_bwd_xhat(const void* dxh, int lddxh, const void* xh
                                       int dx16_excl_res, const void* add_a, int ldadd_a, const void* add_b, int ldadd_b,
                                       void* dxp16, int lddxp, int M, int D, void* stream) {
   if (M <= 0) return 0;
-  if (D % 4 || D > LN_MAXV * 256 || lddxh % 4 || ldxh % 4 || ldadd_a % 4 || ldadd_b % 4 || lddxp % 4) {
-    set_error("layernorm_bwd_xhat: D%4==0, D<=1024, ld%4==0 required"); return -3;
+  if (D % 8 || D > LN_MAXC * 256 || lddxh % 8 || ldxh % 8 || ldadd_a % 8 || ldadd_b % 8 || lddxp % 8 || lddres % 8 || lddx % 8 || lddx16 % 8) {
+    set_error("layernorm_bwd_xhat: D%8==0, D<=1024, ld%8==0 required"); return -3;
   }
   if (!dxh || !xhat || !rstd || (!dx && !dx16 && !dxp16)) { set_error("layernorm_bwd_xhat: null pointer"); return -4; }
   // no partial-sum rows hang on the grid here (ln_bwd_kernel's cap of 1024 blocks keeps its (dgamma, dbeta) partials small):
@@ -763,7 +906,7 @@ extern "C" int oat_layernorm_bwd_xhat(const void* dxh, int lddxh, const void* xh
   // step 1024 -> 4096 -> 8192: 48.42 -> 47.97 -> 47.88 ms
   static int cap = 0;
   if (cap == 0) { const char* e = getenv("OAT_LN_BWDX_BLOCKS"); cap = e ? atoi(e) : 8192; if (cap < 1) cap = 8192; }
-  int blocks = (M + 3) / 4; if (blocks > cap) blocks = cap;
+  int blocks = (M + 7) / 8; if (blocks > cap) blocks = cap;
   OAT_LAUNCH(ln_bwd_xhat_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)dxh, lddxh,
              (const bf16*)xhat, ldxh, rstd, dres, lddres, dx, lddx, (bf16*)dx16, lddx16, dx16_excl_res, M, D,
              (const bf16*)add_a, ldadd_a, (const bf16*)add_b, ldadd_b, (bf16*)dxp16, lddxp);

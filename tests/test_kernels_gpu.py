@@ -406,6 +406,55 @@ def test_layernorm_fwd_bwd(M, D):
         close(db, br.grad, atol=2e-3, rtol=1e-3, what="ln dbeta")
 
 
+@pytest.mark.parametrize("M,D", [(1000, 768), (37, 128), (5, 1024)])
+@pytest.mark.parametrize("x32", [False, True])
+def test_layernorm_on_bf16_residual_stream(M, D, x32):
+    """oat_layernorm_fwd_r16 / oat_layernorm_bwd_r16 (rowops.hip): the residual adds + LayerNorm of a SpaceTimeBlock with the
+    token stream stored as bf16, against fp32 torch math on the same (bf16-valued) inputs.  The sum is exact in fp32, so
+    sum16 must be bit-identical to bf16(x + a + b); y32 is compared at fp32 resolution, y at bf16 resolution."""
+    hip = _hip()
+    x = (rnd(M, D, scale=2.0, seed=31) + 0.5)
+    x = x if x32 else x.bfloat16()
+    a, b = rnd(M, D, seed=32).bfloat16(), rnd(M, D, scale=0.5, seed=33).bfloat16()
+    gamma = rnd(D, seed=34) * 0.1 + 1.0
+    beta = rnd(D, seed=35) * 0.1
+    s_ref = x.float() + a.float() + b.float()
+    sum16 = torch.zeros(M, D, dtype=torch.bfloat16, device=DEV)
+    y = torch.zeros(M, D, dtype=torch.bfloat16, device=DEV)
+    y32 = torch.zeros(M, D, device=DEV)
+    mean, rstd = torch.zeros(M, device=DEV), torch.zeros(M, device=DEV)
+    hip.layernorm_fwd_r16(x, M, D, 1e-6, add_a=a, add_b=b, sum16=sum16, gamma=gamma, beta=beta, y=y, y32=y32, mean=mean, rstd=rstd)
+    assert torch.equal(sum16, s_ref.bfloat16())
+    ref = torch.nn.functional.layer_norm(s_ref, (D,), gamma, beta, 1e-6)
+    close(y32, ref, atol=2e-5, rtol=1e-5, what="r16 ln fwd f32")
+    close(y, ref, atol=1e-2, rtol=1e-2, what="r16 ln fwd bf16")
+    # the folded form (gamma = beta = NULL -> xhat), one addend, no stored sum: norm1 / norm2 of a block
+    xh = torch.zeros(M, D, dtype=torch.bfloat16, device=DEV)
+    hip.layernorm_fwd_r16(x, M, D, 1e-6, add_a=a, y=xh, mean=mean, rstd=rstd)
+    close(xh, torch.nn.functional.layer_norm(x.float() + a.float(), (D,), None, None, 1e-6), atol=1e-2, rtol=1e-2, what="r16 xhat")
+    if x32:
+        return
+    # backward on the bf16 stream: x bf16, bf16 residual-gradient addend, in place on dx16
+    hip.layernorm_fwd_r16(x, M, D, 1e-6, gamma=gamma, beta=beta, y32=y32, mean=mean, rstd=rstd)
+    xr, gr, br = x.float().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    out = torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-6)
+    for dy_dtype in (torch.bfloat16, torch.float32):
+        dy = rnd(M, D, seed=36).to(dy_dtype)
+        for t in (xr, gr, br):
+            t.grad = None
+        out.backward(dy.float(), retain_graph=True)
+        res = rnd(M, D, seed=37).bfloat16()
+        g16 = res.clone()
+        dx = torch.zeros(M, D, device=DEV)
+        dg, db = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+        hip.layernorm_bwd_r16(dy, x, mean, rstd, gamma, M, D, dx=dx, dx16=g16, dres16=g16, dgamma=dg, dbeta=db)
+        want = xr.grad + res.float()
+        close(dx, want, atol=1e-4, rtol=1e-4, what="r16 ln dx")
+        assert torch.equal(g16, dx.bfloat16())
+        close(dg, gr.grad, atol=2e-3, rtol=1e-3, what="r16 ln dgamma")
+        close(db, br.grad, atol=2e-3, rtol=1e-3, what="r16 ln dbeta")
+
+
 def test_reductions_and_misc():
     hip = _hip()
     M, N = 1003, 2304
