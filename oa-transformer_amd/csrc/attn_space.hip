@@ -45,6 +45,33 @@ OAT_DEV bf16x8 tr_frag(const char* tile, int r0, int dt, int lane, int rmax = 0x
   return out;
 }
 
+// Output tiles leave the matrix pipe as O^T / dQ^T / dK^T / dV^T accumulators: lane (g, col) holds dims 16 dt + 4 g .. + 3 of
+// local row `col`.  Stored from there, one instruction writes 16 rows x 32 contiguous bytes and every 128-byte line of
+// the output is written four times over as a 32-byte fragment; measured (profiles/round4b_attention_ablation.md) the
+// 231 MB of dqkv stores of the TIME backward cost 77 us of its 190 - more than its 385 MB of loads.  So the tile takes
+// one trip through a wave-private LDS scratch (16 rows x (128 + 16) bytes: ds_write_b64 per lane and dt, ds_read_b128
+// back) and leaves as whole 128-byte lines, 16 bytes per lane, 8 rows per store instruction.
+// rowptr(j) -> address of local row j's 64-element head slice, or nullptr (row not stored).  Wave-uniform call.
+constexpr int SCR_PITCH = 144, SCR_BYTES = 16 * SCR_PITCH;
+template <class F>
+OAT_DEV void store_rows16(char* scr, const f32x4 (&acc)[4], float mul, int lane, F&& rowptr) {
+  const int col = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {
+    const bf16x4 o = {f2bf(acc[dt][0] * mul), f2bf(acc[dt][1] * mul), f2bf(acc[dt][2] * mul), f2bf(acc[dt][3] * mul)};
+    *reinterpret_cast<bf16x4*>(scr + col * SCR_PITCH + (dt * 16 + g * 4) * 2) = o;
+  }
+  __builtin_amdgcn_wave_barrier();                       // DS instructions of a wave execute in order: the reads see the writes
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int j = p * 8 + (lane >> 3), ch = lane & 7;
+    const uint4 v = *reinterpret_cast<const uint4*>(scr + j * SCR_PITCH + ch * 16);
+    bf16* dst = rowptr(j);
+    if (dst) *reinterpret_cast<uint4*>(dst + ch * 8) = v;
+  }
+  __builtin_amdgcn_wave_barrier();                       // ... and the next tile's writes come after these reads
+}
+
 struct SpaceArgs {
   const bf16* qkv; int ldqkv;
   bf16* out; int ldo;              // fwd: attention output ; bwd: saved attention output (read)
@@ -61,7 +88,7 @@ struct SpaceArgs {
 
 // Two clips in ONE launch (the object frame + the video clip of the OA models: a one-frame clip alone is B x H problems, a third
 // of the GPU): workgroups [0, n0) work on s[0], the rest on s[1].  Single-clip launches set n0 to the grid size.
-struct SpaceArgs2 { SpaceArgs s[2]; int n0; };
+struct SpaceArgs2 { SpaceArgs s[2]; int n0; int nclips; };
 
 // forward: 4 waves, 56 KB LDS -> two workgroups per CU overlap each other's prologue;
 // backward: 116 KB LDS pins one workgroup per CU, so it runs 8 waves (two per SIMD) to hide the
@@ -123,6 +150,7 @@ __global__ __launch_bounds__(FWD_THREADS, NKT <= 14 ? 4 : 2) void attn_space_fwd
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Kt = smem;
   char* Vt = smem + NKP * 128;
+  char* const scr = smem + 2 * NKP * 128 + (threadIdx.x >> 6) * SCR_BYTES;      // this wave's output scratch
   const int h = bid % a.H;
   const int bf = bid / a.H;                   // b * T + f
   const int b = bf / a.T;
@@ -201,16 +229,11 @@ __global__ __launch_bounds__(FWD_THREADS, NKT <= 14 ? 4 : 2) void attn_space_fwd
         ot[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Vt, u * 32, dt, lane), pb, ot[dt], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (qi < N) {
-      const float inv = 1.0f / l;
-      bf16* orow = a.out + (base_row + qi) * a.ldo + h * 64 + g * 4;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        const bf16x4 o = {f2bf(ot[dt][0] * inv), f2bf(ot[dt][1] * inv), f2bf(ot[dt][2] * inv), f2bf(ot[dt][3] * inv)};
-        *reinterpret_cast<bf16x4*>(orow + dt * 16) = o;
-      }
-      if (g == 0) a.lse[(base_row + qi) * a.H + h] = (m + log2f(l)) * LN2;
-    }
+    store_rows16(scr, ot, 1.0f / l, lane, [&](int j) -> bf16* {
+      const int q = qt * 16 + j;
+      return q < N ? a.out + (base_row + q) * a.ldo + h * 64 : nullptr;
+    });
+    if (qi < N && g == 0) a.lse[(base_row + qi) * a.H + h] = (m + log2f(l)) * LN2;
   }
 }
 
@@ -295,6 +318,10 @@ __global__ __launch_bounds__(WIDE == 1 ? 1024 : WIDE == 3 ? 64 : 512, WIDE == 2 
   char* Dt = BIG ? Vt : buf + 3 * TROWS * 128;           // dO tile
   float* lse_s = reinterpret_cast<float*>(buf + (BIG ? 2 : 4) * TROWS * 128);
   float* del_s = lse_s + NKP;
+  // output scratch (store_rows16).  SPACE: a region per wave behind the tiles.  TIME (one wave, two problem buffers): the
+  // problem's own tile buffer, once phase B is done with it - the dQ tile waits in registers until then.
+  char* const scr = TIME ? buf : smem + BUF + wave * SCR_BYTES;
+  f32x4 dq_keep[4];
   if constexpr (TIME) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this group's tiles (staged one group ago) have landed
   } else {
@@ -409,17 +436,23 @@ __global__ __launch_bounds__(WIDE == 1 ? 1024 : WIDE == 3 ? 64 : 512, WIDE == 2 
         if (two) dqB[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tf, sbB, dqB[dt], 0, 0, 0);
       }
     }
+    // local rows [t0, t0 + 16) of an output tile -> columns `col0` of their dqkv rows
+    auto put_rows = [&](int t0, const f32x4 (&acc)[4], float mul, int col0) {
+      store_rows16(scr, acc, mul, lane, [&](int j) -> bf16* {
+        const int q = t0 + j;
+        return (q < N && rm.live<TIME>(q)) ? a.dqkv + rm.row<TIME>(q) * a.lddqkv + col0 + h * 64 : nullptr;
+      });
+    };
     auto put_q = [&](int qi, const f32x4 (&dq)[4]) {
-      if (qi < N) {
-        if (!rm.live<TIME>(qi)) return;
-        bf16* drow = a.dqkv + rm.row<TIME>(qi) * a.lddqkv + h * 64 + g * 4;
+      if (qi - (lane & 15) < N) {                          // wave-uniform: the tile holds a patch row
+        if constexpr (TIME) {
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          const bf16x4 o = {f2bf(dq[dt][0] * a.scale), f2bf(dq[dt][1] * a.scale), f2bf(dq[dt][2] * a.scale),
-                            f2bf(dq[dt][3] * a.scale)};
-          *reinterpret_cast<bf16x4*>(drow + dt * 16) = o;
+          for (int dt = 0; dt < 4; ++dt) dq_keep[dt] = dq[dt];
+        } else {
+          put_rows(qi - (lane & 15), dq, a.scale, 0);
         }
-      } else if (qi == N) {
+      }
+      if (qi == N) {
         if constexpr (TIME) {
 #pragma unroll
           for (int dt = 0; dt < 4; ++dt) cls_dq[dt] += dq[dt];
@@ -519,19 +552,22 @@ __global__ __launch_bounds__(WIDE == 1 ? 1024 : WIDE == 3 ? 64 : 512, WIDE == 2 
         }
       }
     }
+    auto put_rows = [&](int t0, const f32x4 (&acc)[4], float mul, int col0) {
+      store_rows16(scr, acc, mul, lane, [&](int j) -> bf16* {
+        const int q = t0 + j;
+        return (q < N && rm.live<TIME>(q)) ? a.dqkv + rm.row<TIME>(q) * a.lddqkv + col0 + h * 64 : nullptr;
+      });
+    };
     auto put_kv = [&](int key, const f32x4 (&dk)[4], const f32x4 (&dv)[4]) {
-      if (key < N) {
-        if (!rm.live<TIME>(key)) return;
-        bf16* drow = a.dqkv + rm.row<TIME>(key) * a.lddqkv + h * 64 + g * 4;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          const bf16x4 ok_ = {f2bf(dk[dt][0] * a.scale), f2bf(dk[dt][1] * a.scale), f2bf(dk[dt][2] * a.scale),
-                              f2bf(dk[dt][3] * a.scale)};
-          const bf16x4 ov = {f2bf(dv[dt][0]), f2bf(dv[dt][1]), f2bf(dv[dt][2]), f2bf(dv[dt][3])};
-          *reinterpret_cast<bf16x4*>(drow + a.D + dt * 16) = ok_;
-          *reinterpret_cast<bf16x4*>(drow + 2 * a.D + dt * 16) = ov;
+      const int t0 = key - (lane & 15);
+      if (t0 < N) {                                        // wave-uniform: the tile holds a patch row
+        if constexpr (TIME) {
+          if (t0 == 0) put_rows(0, dq_keep, a.scale, 0);   // the patch tile of the mini problem: its dQ waited for the tile buffer
         }
-      } else if (key == N) {
+        put_rows(t0, dk, a.scale, a.D);
+        put_rows(t0, dv, 1.0f, 2 * a.D);
+      }
+      if (key == N) {
         if constexpr (TIME) {
 #pragma unroll
           for (int dt = 0; dt < 4; ++dt) { cls_dk[dt] += dk[dt]; cls_dv[dt] += dv[dt]; }
@@ -602,12 +638,13 @@ __global__ void attn_cls_finalize_kernel(float* side, bf16* dqkv, int lddqkv, in
   dqkv[(cls_row0 + b) * lddqkv + (t >> 6) * D + h * 64 + (t & 63)] = f2bf(v);
 }
 
-static SpaceArgs2 one_clip(const SpaceArgs& a, int blocks) { return SpaceArgs2{{a, a}, blocks}; }
-static SpaceArgs2 two_clips(const SpaceArgs& a, const SpaceArgs& b) { return SpaceArgs2{{a, b}, a.B * a.T * a.H}; }
-static int space_blocks(const SpaceArgs2& aa) { return aa.n0 + (aa.s[1].qkv != aa.s[0].qkv ? aa.s[1].B * aa.s[1].T * aa.s[1].H : 0); }
+static SpaceArgs2 one_clip(const SpaceArgs& a, int blocks) { return SpaceArgs2{{a, a}, blocks, 1}; }
+static SpaceArgs2 two_clips(const SpaceArgs& a, const SpaceArgs& b) { return SpaceArgs2{{a, b}, a.B * a.T * a.H, 2}; }
+// the clip count is carried explicitly (two clips may share a qkv base pointer)
+static int space_blocks(const SpaceArgs2& aa) { return aa.n0 + (aa.nclips == 2 ? aa.s[1].B * aa.s[1].T * aa.s[1].H : 0); }
 template <int NKT>
 static int launch_fwd(const SpaceArgs2& aa, hipStream_t s) {
-  const int lds = 2 * NKT * 16 * 128;
+  const int lds = 2 * NKT * 16 * 128 + (FWD_THREADS / 64) * SCR_BYTES;
   static bool set = false;
   if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_space_fwd_kernel<NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
   OAT_LAUNCH(attn_space_fwd_kernel<NKT>, dim3(space_blocks(aa)), dim3(FWD_THREADS), lds, s, aa);
@@ -615,7 +652,7 @@ static int launch_fwd(const SpaceArgs2& aa, hipStream_t s) {
 }
 template <int NKT, bool BIG = false, int WIDE = 0>
 static int launch_bwd(const SpaceArgs2& aa, hipStream_t s) {
-  const int lds = (BIG ? 2 : 4) * NKT * 16 * 128 + 2 * NKT * 16 * 4;
+  const int lds = (BIG ? 2 : 4) * NKT * 16 * 128 + 2 * NKT * 16 * 4 + (WIDE == 1 ? 16 : BWD_THREADS / 64) * SCR_BYTES;
   static bool set = false;
   if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_space_bwd_kernel<NKT, BIG, WIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
   OAT_LAUNCH((attn_space_bwd_kernel<NKT, BIG, WIDE>), dim3(space_blocks(aa)), dim3(WIDE == 1 ? 1024 : BWD_THREADS), lds, s, aa);

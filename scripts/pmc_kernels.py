@@ -42,4 +42,20 @@ G = torch.zeros(Mp, D, device="cuda"); dg = torch.zeros(D, device="cuda"); db = 
 for _ in range(3):
     hip.add_layernorm_fwd(x, br, s32, gam, bet, M, D, 1e-6, y=y, mean=mean, rstd=rstd)
     hip.layernorm_bwd(br, s32, mean, rstd, gam, M, D, dx=G, dx16=y, dres=G, dgamma=dg, dbeta=db)
+# round 4: the grouped weight gradients of one ViT block (gemm_tn_sk), the N = 768 GEMM shapes, the LayerNorms of the bf16 stream
+def wprob(n1, n2):
+    P = (torch.randn(Mp, n1, device="cuda") * 0.5).bfloat16(); Q = (torch.randn(Mp, n2, device="cuda") * 0.5).bfloat16()
+    return (P, Q, M, n1, n2, torch.zeros(n1, n2, device="cuda"), torch.zeros(n1, device="cuda"), False)
+blk = [wprob(D, 4 * D), wprob(4 * D, D), wprob(3 * D, D), wprob(3 * D, D), wprob(D, D), wprob(D, D)]
+grp = hip.TnGroup(blk, layers=[[0, 1, 2, 3], [4, 5]])
+for _ in range(3): grp.run()
+del blk, grp
+for (n, k) in [(768, 768), (768, 2304), (3072, 768)]:
+    A = rb(Mp, k); W = (torch.randn(n, k, device="cuda") * k ** -0.5).bfloat16(); o = torch.zeros(Mp, n, device="cuda", dtype=torch.bfloat16)
+    bias = torch.randn(n, device="cuda")
+    for _ in range(3): hip.gemm_nt(A, W, M, n, k, hip.EPI_BF16, o, bias=bias)
+x16 = rb(Mp, D); a16 = rb(Mp, D); b16 = rb(Mp, D); o16 = torch.zeros_like(x16); d16 = rb(Mp, D)
+for _ in range(3):
+    hip.layernorm_fwd_r16(x16, M, D, 1e-6, add_a=a16, add_b=b16, sum16=o16, y=y, mean=mean, rstd=rstd)
+    hip.layernorm_bwd_xhat(d16, y, rstd, M, D, dx16=o16, add_a=a16, add_b=b16)
 torch.cuda.synchronize()
