@@ -247,7 +247,11 @@ int oat_attn_time_bwd_fin(const void* qkv, int ldqkv, const void* out, int ldo, 
  * the 1e-3 sim-matrix bound at negligible FLOPs: the text tower and the CLS row of the video tower (oa_model.py:106-133,
  * video_transformer.py:46-50,102,133 for those rows).  act 0: out32 = out16 = y; 1 (GELU): out32 = out16 = gelu(y),
  * out16b = gelu'(y); 2: ReLU on A while loading (txt_proj, oa_model.py:68-70).  out32 / out16 / out16b / bias / resid may
- * be NULL where unused (at least one of out32, out16).  K % 16 == 0, lda % 4 == 0, ldw % 4 == 0. */
+ * be NULL where unused (at least one of out32, out16).  K % 16 == 0, lda % 4 == 0, ldw % 4 == 0.
+ * M <= 64 (CLS lane, projections): exact fp32 products.  M > 64 with K % 32 == 0 (the text tower): every fp32 operand element
+ * is split into two bf16 (hi + lo, 16 mantissa bits) and the product runs as three bf16 MFMA passes with fp32 accumulation -
+ * 2^-16 relative per product, 1e-5 of |y| max against fp64 (tests/test_kernels_gpu.py), 5x less matrix-pipe time; the launches
+ * sit beside the video tower on a side stream and their duration is what they cost it.  OAT_LIN_X3=0: exact fp32 everywhere. */
 int oat_linear_f32(const float* A, int lda, const float* W, int ldw, const float* bias, int M, int N, int K,
                    float* out32, int ldo, void* out16, int ld16, void* out16b, int ld16b, const float* resid, int ldr,
                    int act, void* stream);

@@ -412,7 +412,7 @@ class VideoEngine:
         """Streams are created only when used: HIP multiplexes streams onto a few hardware queues
         (GPU_MAX_HW_QUEUES, default 4) and two streams that share a queue run in enqueue order."""
         if self._streams is None:
-            self._streams = dict(side=torch.cuda.Stream(), hbm=torch.cuda.Stream())
+            self._streams = dict(side=hip.side_stream("OAT_LANE", dev), hbm=torch.cuda.Stream())
         return self._streams
 
     # ------------------------------------------------------------------ forward

@@ -7,6 +7,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from ..ops import hip
 from ..utils.util import state_dict_data_parallel_fix
 from .layers import HipLinear, ReLULinear, sim_matrix  # noqa: F401  (sim_matrix re-exported like the reference)
 from .text_transformer import DistilBertHIP
@@ -89,7 +90,7 @@ class FrozenInTime(BaseModel):
         # own HIP stream under the video tower; autograd replays each tower's backward on its forward stream
         main = torch.cuda.current_stream()
         if getattr(self, "_text_stream", None) is None:
-            self._text_stream = torch.cuda.Stream()
+            self._text_stream = hip.side_stream("OAT_TEXT")
         side = self._text_stream if os.environ.get("OAT_TEXT_STREAM", "1") != "0" else main     # 0: both towers on one stream (measurement)
         side.wait_stream(main)           # the text stream starts after what is on `main` NOW (the optimiser step)
         # host enqueue order: the text tower first.  Its ~80 launches are queued in about a millisecond and then run

@@ -112,7 +112,7 @@ class FrozenInTime(BaseModel):
         # oa_model.FrozenInTime.forward); autograd replays each side's backward on the stream of its forward
         main = torch.cuda.current_stream()
         if getattr(self, "_text_stream", None) is None:
-            self._text_stream = torch.cuda.Stream()
+            self._text_stream = hip.side_stream("OAT_TEXT")
         side = self._text_stream
         side.wait_stream(main)
         with torch.cuda.stream(side):

@@ -9,6 +9,7 @@ import os
 import torch
 from torch import nn
 
+from ..ops import hip
 from ..utils.util import state_dict_data_parallel_fix
 from .layers import HipLinear, ReLULinear, sim_matrix  # noqa: F401
 from .oa_layers import mean_rows, mix, region_sim
@@ -64,7 +65,7 @@ class FrozenInTime(BaseModel):
         # text side (DistilBERT pass, txt_proj_2 of the class-prompt embeddings) on its own stream beneath the video encoder
         main = torch.cuda.current_stream()
         if getattr(self, "_text_stream", None) is None:
-            self._text_stream = torch.cuda.Stream()
+            self._text_stream = hip.side_stream("OAT_TEXT")
         side = self._text_stream
         side.wait_stream(main)
         with torch.cuda.stream(side):

@@ -686,6 +686,41 @@ def tape_free(tid):
     lib().oat_tape_free(tid)
 
 
+_masked_streams = {}
+
+
+def masked_stream(n_cus, device=None):
+    """A HIP stream whose kernels run on `n_cus` CUs only (hipExtStreamCreateWithCUMask, mask bits 0 .. n_cus - 1; measured on
+    MI355X with a bandwidth-bound kernel: 16 bits -> 1/16 of the machine, scripts/dev/cu_mask_probe.py), wrapped for torch.
+    The side towers run on such a stream so that their workgroups never sit on a CU a persistent GEMM workgroup of the
+    main stream is waiting for.  One stream per (device, n_cus), kept for the life of the process."""
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    key = (dev, int(n_cus))
+    if key not in _masked_streams:
+        rt = ctypes.CDLL("libamdhip64.so")
+        rt.hipExtStreamCreateWithCUMask.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
+        total = torch.cuda.get_device_properties(dev).multi_processor_count
+        words = [0] * ((total + 31) // 32)
+        for b in range(min(int(n_cus), total)):
+            words[b // 32] |= 1 << (b % 32)
+        h = ctypes.c_void_p()
+        with torch.cuda.device(dev):
+            rc = rt.hipExtStreamCreateWithCUMask(ctypes.byref(h), len(words), (ctypes.c_uint32 * len(words))(*words))
+        if rc != 0:
+            raise OatError(f"hipExtStreamCreateWithCUMask failed ({rc})")
+        _masked_streams[key] = torch.cuda.ExternalStream(h.value, device=dev)
+    return _masked_streams[key]
+
+
+def side_stream(prefix, device=None):
+    """The stream of a side tower (`prefix` = OAT_TEXT: the text tower; OAT_LANE: the CLS lane + CLS-query attention).
+    Tuning knobs: <prefix>_PRIO = HIP stream priority (default 0), <prefix>_CUS = n > 0: a CU-masked stream of n CUs."""
+    cus = int(os.environ.get(prefix + "_CUS", "0"))
+    if cus > 0:
+        return masked_stream(cus, device)
+    return torch.cuda.Stream(device=device, priority=int(os.environ.get(prefix + "_PRIO", "0")))
+
+
 def stream_edge(src_stream, dst_stream):
     """Everything enqueued on dst_stream from now on waits for what is on src_stream now (torch streams)."""
     _check(lib().oat_stream_edge(ctypes.c_void_p(src_stream.cuda_stream), ctypes.c_void_p(dst_stream.cuda_stream)), "oat_stream_edge")

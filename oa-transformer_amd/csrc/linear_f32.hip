@@ -17,6 +17,7 @@
 // The next K-step's global loads are in flight while the current one is multiplied.  157 TF/s is the chip's f32 matrix
 // peak; this kernel carries <= ~100 GFLOP per step on side streams and is latency-, not throughput-critical.
 #include "common.h"
+#include <type_traits>
 
 namespace oat {
 
@@ -158,6 +159,148 @@ __global__ __launch_bounds__(256 * KG) void linear_f32_kernel(LinArgs g) {
     }
 }
 
+// Many rows (the text tower, M = B * L >= 1024): the same product on the bf16 matrix pipe at ~fp32 accuracy.
+// Every fp32 operand element is split x = hi + lo, hi = bf16(x), lo = bf16(x - hi) (16 mantissa bits together) and
+//     A W^T ~= Ah Wh^T + Ah Wl^T + Al Wh^T        (fp32 accumulate; the dropped lo x lo term and the split error are 2^-16 relative
+// per product, random in sign: measured 1e-5 of |y| max against an fp64 product, tests/test_kernels_gpu.py)
+// - three v_mfma_f32_16x16x32_bf16 (16 cycles each, K = 32) where the exact path issues eight v_mfma_f32_16x16x4_f32 of 32
+// cycles: 5x less matrix-pipe time.  Why it matters although the text tower is 0.7 % of the FLOPs: its linears run on a
+// side stream BESIDE the video tower, and a 192-workgroup launch of the exact kernel holds 192 CUs for ~40-60 us during which
+// the persistent GEMM workgroups of the main stream wait for their CU; measured by switching these launches off:
+// 0.93 ms of a 46 ms step (frozen), 3.0 ms of 55 (global_local: two text passes).  128 x 128 tiles: 48 workgroups for
+// N = 768, four waves of 64 x 64, K-step 32; global -> registers (next step in flight) -> split -> LDS -> ds_read_b128.
+// KG = 2: two wave quartets split K (each with its own LDS planes; quartet 1 hands its partial tile over through the LDS at the
+// end, a fixed order) and every quartet keeps the global loads of TWO K-steps in flight: the kernel is bound by the
+// global -> register round trip of a K-step (~1.5 us beside the video tower's kernels), not by its 0.4 us of MFMAs.
+template <int ACT, int KG>
+__global__ __launch_bounds__(256 * KG) void linear_x3_kernel(LinArgs g) {
+  constexpr int BM = 128, BN = 128, BK = 32, PITCH = BK * 2 + 16;        // bytes per LDS row: 64 + 16 (conflict-free 16-row reads)
+  constexpr int PLANE = (BM + BN) * PITCH;                                 // one plane (hi or lo) of both operands
+  __shared__ __attribute__((aligned(16))) char smem_all[KG * 2 * PLANE];
+  const int kg = KG == 2 ? (int)(threadIdx.x >> 8) : 0;
+  char* const sm = smem_all + kg * 2 * PLANE;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  const int nsteps = g.K / BK, my_steps = KG == 2 ? (kg == 0 ? (nsteps + 1) / 2 : nsteps / 2) : nsteps;
+  const int kbeg = KG == 2 && kg == 1 ? ((nsteps + 1) / 2) * BK : 0;
+  const int loop_steps = KG == 2 ? (nsteps + 1) / 2 : nsteps;            // both quartets run the same number of barrier pairs
+  f32x4 ra[2][4], rb[2][4];
+  auto load = [&](int st, auto B) {
+    constexpr int bsel = decltype(B)::value;
+    const bool live = st < my_steps;
+    const int k0 = kbeg + st * BK;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      const int idx = tid + l * 256, row = idx >> 3, kq = (idx & 7) * 4;
+      f32x4 v = (live && m0 + row < g.M) ? *reinterpret_cast<const f32x4*>(g.A + (size_t)(m0 + row) * g.lda + k0 + kq) : zero;
+      if constexpr (ACT == 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      ra[bsel][l] = v;
+      rb[bsel][l] = (live && n0 + row < g.N) ? *reinterpret_cast<const f32x4*>(g.W + (size_t)(n0 + row) * g.ldw + k0 + kq) : zero;
+    }
+  };
+  auto split_store = [&](const f32x4 v, char* dst) {
+    const bf16x4 hi = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+    const bf16x4 lo = {f2bf(v[0] - bf2f(hi[0])), f2bf(v[1] - bf2f(hi[1])), f2bf(v[2] - bf2f(hi[2])), f2bf(v[3] - bf2f(hi[3]))};
+    *reinterpret_cast<bf16x4*>(dst) = hi;
+    *reinterpret_cast<bf16x4*>(dst + PLANE) = lo;
+  };
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = zero;
+  const int fr = lane & 15, fk = lane >> 4;
+  const char* const pa = sm + (wm * 64 + fr) * PITCH + fk * 16;
+  const char* const pb = sm + (BM + wn * 64 + fr) * PITCH + fk * 16;
+  using B0 = std::integral_constant<int, 0>;
+  using B1 = std::integral_constant<int, 1>;
+  auto step = [&](int st, auto B) {
+    constexpr int bsel = decltype(B)::value;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      const int idx = tid + l * 256, row = idx >> 3, kq = (idx & 7) * 4;
+      split_store(ra[bsel][l], sm + row * PITCH + kq * 2);
+      split_store(rb[bsel][l], sm + (BM + row) * PITCH + kq * 2);
+    }
+    __syncthreads();
+    load(st + 2, B);                                                     // this register set is free again: two steps ahead
+    if (st < my_steps) {
+      bf16x8 ah[4], al[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ah[i] = *reinterpret_cast<const bf16x8*>(pa + i * 16 * PITCH);
+        al[i] = *reinterpret_cast<const bf16x8*>(pa + i * 16 * PITCH + PLANE);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(pb + j * 16 * PITCH);
+        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(pb + j * 16 * PITCH + PLANE);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          // small terms first, then the leading one
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh, acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  };
+  load(0, B0{});
+  load(1, B1{});
+  for (int st = 0; st < loop_steps; st += 2) {
+    step(st, B0{});
+    if (st + 1 < loop_steps) step(st + 1, B1{});
+  }
+  if constexpr (KG == 2) {                                                // quartet 1 hands over through the (now dead) operand planes
+    float* const sx = reinterpret_cast<float*>(smem_all);
+    if (kg == 1) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(sx + ((wave * 4 + i) * 4 + j) * 256 + lane * 4) = acc[i][j];
+    }
+    __syncthreads();
+    if (kg == 1) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] += *reinterpret_cast<const f32x4*>(sx + ((wave * 4 + i) * 4 + j) * 256 + lane * 4);
+  }
+  // D[row = 4 * (lane >> 4) + r][col = lane & 15]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = n0 + wn * 64 + j * 16 + fr;
+      if (col >= g.N) continue;
+      const float b = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm * 64 + i * 16 + fk * 4 + r;
+        if (row >= g.M) continue;
+        float y = acc[i][j][r] + b;
+        float dg = 0.f;
+        if constexpr (ACT == 1) {
+          float gl;
+          gelu_both(y, gl, dg);
+          y = gl;
+        }
+        if (g.resid) y += g.resid[(size_t)row * g.ldr + col];
+        if (g.out32) g.out32[(size_t)row * g.ldo + col] = y;
+        if (g.out16) g.out16[(size_t)row * g.ld16 + col] = f2bf(y);
+        if constexpr (ACT == 1) {
+          if (g.out16b) g.out16b[(size_t)row * g.ld16b + col] = f2bf(dg);
+        }
+      }
+    }
+}
+
 // Few rows (M <= 64: the CLS lane, the projections): latency is everything, because these launches sit on a side stream
 // beside CU-filling GEMMs and only run in the gaps.  One workgroup per 32 rows x 16 output columns; its four waves split
 // K four ways (each wave streams its quarter of the two operand slabs straight from global memory into MFMA operands:
@@ -231,6 +374,7 @@ __global__ __launch_bounds__(256) void linear_f32_small_kernel(LinArgs g) {
 }
 
 static int g_lin_kg2 = 1;          // 0: one wave quartet per 64 x 64 workgroup (OAT_LIN_KG2=0, A/B measurements)
+static int g_lin_x3 = 1;           // 1 (default): M > 64 runs on the split-bf16 kernel (linear_x3_kernel); OAT_LIN_X3=0: the exact-f32 MFMA
 static int g_lin_bk = 32;          // K-tile depth (OAT_LIN_BK=16 / 32): 32 halves the barrier pairs and global round trips per
                                    // workgroup (text tower forward 2124 -> 1950 us alone; same accumulation order, bit-identical)
 template <int ACT>
@@ -239,11 +383,18 @@ static void launch_linear(const LinArgs& g, hipStream_t s) {
   if (!env) {
     const char* e = getenv("OAT_LIN_KG2"); if (e) g_lin_kg2 = atoi(e);
     e = getenv("OAT_LIN_BK"); if (e) g_lin_bk = atoi(e);
+    e = getenv("OAT_LIN_X3"); if (e) g_lin_x3 = atoi(e);
     env = true;
   }
   const bool bk32 = g_lin_bk == 32 && g.K % 32 == 0;
   if (g.M <= 64 && g.K % 64 == 0) {
     OAT_LAUNCH(linear_f32_small_kernel<ACT>, dim3((g.N + 15) / 16, (g.M + 31) / 32), dim3(256), 0, s, g);
+  } else if (g_lin_x3 && g.M > 64 && g.K % 32 == 0) {
+    // K split between two wave quartets unless the launch already has plenty of workgroups or K is short
+    if (g.K >= 256 && ((g.N + 127) / 128) * ((g.M + 127) / 128) <= 256)
+      OAT_LAUNCH((linear_x3_kernel<ACT, 2>), dim3((g.N + 127) / 128, (g.M + 127) / 128), dim3(512), 0, s, g);
+    else
+      OAT_LAUNCH((linear_x3_kernel<ACT, 1>), dim3((g.N + 127) / 128, (g.M + 127) / 128), dim3(256), 0, s, g);
   } else if (((g.N + 127) / 128) * ((g.M + 127) / 128) >= 128) {
     if (bk32) OAT_LAUNCH((linear_f32_kernel<ACT, 128, 128, 32, 2, 2>), dim3((g.N + 127) / 128, (g.M + 127) / 128), dim3(256), 0, s, g);
     else OAT_LAUNCH((linear_f32_kernel<ACT, 128, 128, 16, 2, 2>), dim3((g.N + 127) / 128, (g.M + 127) / 128), dim3(256), 0, s, g);

@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, os.path.join(ROOT, "oa-transformer_amd")); sys.path.insert(0, ROOT)
 import torch
 from OATrans.ops import hip
-M, D, R = 50208, 768, 4
+M, D, R = int(os.environ.get("M", 50208)), 768, 4
 z16 = lambda: [torch.randn(M, D, device="cuda").bfloat16() for _ in range(R)]
 z32 = lambda: [torch.randn(M, D, device="cuda") for _ in range(R)]
 x32, o32, x16, o16, a16, b16, y16, d16, g16 = z32(), z32(), z16(), z16(), z16(), z16(), z16(), z16(), z16()

@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-OUT=$PWD/gpurun_out/r2oa; rm -rf $OUT; mkdir -p $OUT
+OUT=$PWD/gpurun_out/r4oa; rm -rf $OUT; mkdir -p $OUT
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- python bench.py --variant global_local --frames 8 --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs > $OUT/stats_bench.log 2>&1
 T=$(find $OUT/stats -name "*kernel_trace.csv" | head -1)
 python - <<PY
