@@ -466,6 +466,7 @@ class VideoEngine:
         run = _Run(pl, need_patches, region_layer)
         # folded LayerNorms + bf16 forward: y = x + space is never stored (the next block's norm3 adds both branch outputs)
         pl.skip_y = self.fold_active() and not self.fp8 and os.environ.get("OAT_SKIP_Y", "1") != "0"
+        pl.fwd_modes = (self.fold_active(), pl.skip_y, pl.res16, self.fp8)      # what the saved activations MEAN: backward checks it
         if pl.skip_y and getattr(pl, "branch16s", None) is None:
             pl.branch16s = torch.zeros(pl.Mp, self.D, dtype=torch.bfloat16, device=dev)
         pl.h_u8 = (self.h_u8 and pl.M >= 256 and self.Hd % 256 == 0 and self.Hd <= 4096 and self.D % 128 == 0 and self.D >= 128)
@@ -540,10 +541,27 @@ class VideoEngine:
             out = body()
         except BaseException:
             hip.tape_abort()
+            self._reset_tickets(pl)
             raise
         tid = hip.tape_end()
         setattr(pl, slot, (key, tid, out, hip.lib().oat_tape_segments(tid)))
         return out
+
+    @staticmethod
+    def _reset_tickets(pl):
+        """After a schedule that did not run to its end (a launch raised, a recording was aborted): the device-side state that
+        kernels hand from launch to launch - the CLS-row sums and tickets of the fused attention finalize, the partial sums and
+        tickets of oat_ln_fold_grads - is put back to zero, the state every complete launch leaves behind.  Without this a
+        half-run backward would make every later one compute wrong CLS / dgamma / dbeta gradients without any error."""
+        try:
+            torch.cuda.synchronize()
+            for sg in pl.segs:
+                sg.cls_side.zero_()
+                sg.cls_done.zero_()
+            for _, tab in pl.fold_tabs.values():
+                tab.work.zero_()
+        except Exception:                # the device itself may be gone; the original exception is the one to report
+            pass
 
     def _embed(self, pl, params, C, R):
         D = self.D
@@ -765,6 +783,10 @@ class VideoEngine:
         the gradient all-reduce can start while backward is still running."""
         st = self._get_streams(run.G.device)
         pl = run.pl
+        now = (self.fold_active(), getattr(pl, "skip_y", None), pl.res16, self.fp8)
+        if getattr(pl, "fwd_modes", now) != now:
+            raise hip.OatError(f"engine options changed between a forward and its backward (fold, skip_y, res16, fp8): {pl.fwd_modes} -> {now}; "
+                               "the saved activations would be misread")
         pl.hbm = st["hbm"] if self.bwd_side else None
         pl.acc = bool(accumulate)
         if run.region_layer is not None:

@@ -378,6 +378,8 @@ __global__ __launch_bounds__(256) void fold_bias_multi_kernel(const FoldBiasDesc
 // float4 column lanes x 16 row lanes, 4 rows in flight per thread; its (dgamma, dbeta) partial sums go to `part`, and the
 // LAST slice of a strip to arrive (ticket counter; partials travel by agent-scope atomics only, so no fence is needed) adds
 // the FG_SPLIT partials in slice order - a fixed order whoever comes last: deterministic.  The counter resets itself.
+// (The hand-over below - relaxed agent-scope atomics ordered by `s_waitcnt vmcnt(0)` alone - relies on gfx9 behaviour: vmcnt
+// covers stores and returnless atomics, atomics execute at the memory side.  This file is built for gfx950 only.)
 constexpr int FG_SPLIT = 16, FG_COLS = 64;
 struct FoldGradDesc {
   const float* dWp; const float* dbp; const float* W; const float* gamma; const float* beta;

@@ -834,3 +834,40 @@ def test_gemm_mlp_pair_with_8bit_derivative():
     assert ((o8[:m].float() - ref)[small].abs().max() <= 0.0026 * (dY[:m].float() @ W.float().t())[small].abs().max() + 0.02)
     with pytest.raises(hip.OatError):
         hip.gemm_nt(A, W, m, n - 64, k, hip.EPI_GELU_GRAD | hip.EPI_U8, d8, out2=g8, bias=bias)     # not a ping-pong shape: refused
+
+
+@pytest.mark.parametrize("M,N,K,m224", [(16600, 3072, 128, 0), (16600, 3072, 128, 2), (9000, 2304, 128, 0), (20001, 1280, 256, 2)])
+def test_gemm_nt_band_walk_bit_identical(M, N, K, m224):
+    """gemm_nt_pp.hip PPF_BAND: the band-grouped per-XCD tile walk visits the same tiles with the same per-tile arithmetic,
+    so every group width - including widths that do not divide the number of column tiles, 224-row tiles and a ragged last
+    row panel (M % 256 != 0) - must reproduce the row-major walk bit for bit, for all three epilogues, and leave rows >= M alone.
+    (The walk needs >= 2 rounds of a grid that is a multiple of 8: M is sized for that on 256 CUs.)"""
+    hip = _hip()
+    lib = hip.lib()
+    mp = (M + 255) // 256 * 256
+    A = rnd(mp, K, dtype=torch.bfloat16, seed=60)
+    W = rnd(N, K, scale=K ** -0.5, dtype=torch.bfloat16, seed=61)
+    bias = rnd(N, seed=62)
+    res = {}
+    try:
+        lib.oat_gemm_set_m224(m224)
+        for band in (0, 3, 4, 5, 7):                       # 0 = row-major walk; N / 256 = 12, 9 or 5 column tiles
+            lib.oat_gemm_set_band(band)
+            o = torch.full((mp, N), 7.0, device=DEV, dtype=torch.bfloat16)
+            hip.gemm_nt(A, W, M, N, K, hip.EPI_BF16, o, bias=bias)
+            d8 = torch.full((mp, N), 9, device=DEV, dtype=torch.uint8)
+            g = torch.full((mp, N), 7.0, device=DEV, dtype=torch.bfloat16)
+            hip.gemm_nt(A, W, M, N, K, hip.EPI_GELU_GRAD | hip.EPI_U8, d8, out2=g, bias=bias)
+            m = torch.full((mp, N), 7.0, device=DEV, dtype=torch.bfloat16)
+            hip.gemm_nt(A, W, M, N, K, hip.EPI_MUL_AUX | hip.EPI_U8, m, aux=d8)
+            res[band] = (o, d8, g, m)
+    finally:
+        lib.oat_gemm_set_band(-1)
+        lib.oat_gemm_set_m224(1)
+    for band in (3, 4, 5, 7):
+        for a, b in zip(res[0], res[band]):
+            assert torch.equal(a, b), band
+    o, d8, g, m = res[4]
+    assert bool((o[M:] == 7.0).all()) and bool((d8[M:] == 9).all()) and bool((g[M:] == 7.0).all()) and bool((m[M:] == 7.0).all())
+    ref = A[:M].float() @ W.float().t() + bias
+    assert (o[:M].float() - ref).abs().max().item() <= 2 ** -7 * max(1.0, ref.abs().max().item())
