@@ -412,7 +412,9 @@ class VideoEngine:
         """Streams are created only when used: HIP multiplexes streams onto a few hardware queues
         (GPU_MAX_HW_QUEUES, default 4) and two streams that share a queue run in enqueue order."""
         if self._streams is None:
-            self._streams = dict(side=hip.side_stream("OAT_LANE", dev), hbm=torch.cuda.Stream())
+            self._streams = dict(side=hip.side_stream("OAT_LANE", dev), hbm=None)
+        if self.bwd_side and self._streams["hbm"] is None:          # the slot schedule's stream: only when that option is on
+            self._streams["hbm"] = hip.side_stream("OAT_HBM", dev)
         return self._streams
 
     # ------------------------------------------------------------------ forward
