@@ -38,14 +38,18 @@ def small_model():
     return m.cuda()
 
 
+@pytest.mark.parametrize("res16", [True, False])
 @pytest.mark.parametrize("T", [3, 2])
-def test_small_video_vs_reference_golden(golden_dir, T):
+def test_small_video_vs_reference_golden(golden_dir, T, res16):
+    """res16: the residual / gradient stream stored as bf16 (default) or fp32 (the round-3 kernels, still the fp8 mode's path)"""
     g = torch.load(os.path.join(golden_dir, "small_video.pt"), map_location="cpu", weights_only=False)[f"T{T}"]
     m = small_model()
+    m._engine.res16 = res16
     video = si.seeded_tensor(SEED, "in.video", (2, T, 3, 48, 48)).cuda()
     cls, patches = m(video)
     torch.cuda.synchronize()
     plan = next(iter(m._engine.plans.values()))
+    assert plan.res16 == res16 and plan.blocks[0].out.dtype == (torch.bfloat16 if res16 else torch.float32)
     B, N = 2, 9
     for i, ref in enumerate(g["blocks"]):
         out = plan.blocks[i].out
