@@ -16,7 +16,9 @@ HBM layout
                 other.  Every row-wise kernel (GEMMs, LayerNorm, quantisation, weight gradients) runs once over all
                 segments - a 6304-row object clip alone leaves most CUs idle, as 12 % more rows of the video clip's
                 launches it is free - and only attention, embedding and the CLS rows are handled per segment.
-  residuals   : fp32 [Mp, D]          (x, x+time, x+space, block output)
+  residuals   : bf16 [Mp, D]          one tensor per block, its output x + space + mlp (round 4; sums in fp32, x + time and
+                x + space never stored; the patch embedding x0 and the CLS lane's rows stay fp32; OAT_RES16=0 / fp8 mode:
+                fp32 x, x+time, x+space, block output as in round 3)
   GEMM inputs : bf16 [Mp, D|3D|4D]    (LN outputs, qkv, attention outputs, MLP hidden)
   weights     : fp32 masters (nn.Parameters, reference state_dict names) + bf16 shadows
                 W [out,in] (forward "NT" operand) and W^T [in,out] (data-gradient operand)
