@@ -119,6 +119,15 @@ def enable_splitk(device, on=True):
         _splitk_ws[key] = (ws, ctr)
 
 
+def hu8_unblock(d8, N):
+    """Row-major [rows, N] copy of the BLOCKED 8-bit GELU-derivative tensor that EPI_GELU_GRAD | EPI_U8 writes and
+    EPI_MUL_AUX | EPI_U8 reads ([row / 16][col / 64][lane = 16 fk + frow][r][j] -> row 16 G + 4 fk + r, column 64 C + 4 frow + j;
+    csrc/gemm_nt_pp.hip).  Tests only: the tensor is private to that pair of launches."""
+    rows = d8.numel() // N // 16 * 16
+    t = d8.reshape(-1)[:rows * N].view(rows // 16, N // 64, 4, 16, 4, 4)          # [G, C, fk, frow, r, j]
+    return t.permute(0, 2, 4, 1, 3, 5).reshape(rows, N)
+
+
 def gemm_nt(A, B, M, N, K, epi, out, out2=None, bias=None, resid=None, resid_mod=0, aux=None,
             lda=None, ldb=None, ldc=None, ld2=None, ldr=None, ldaux=None):
     """out[M,N] = A[M,K] @ B[N,K]^T (+epilogue).  Tensors may hold more rows than M."""

@@ -153,6 +153,9 @@ extern "C" int oat_gemm_nt_f8(const void* A8, const void* B8, int M, int N, int 
   if (!A8 || !B8 || !out || !dq_a || !dq_b) { set_error("gemm_nt_f8: null pointer"); return -4; }
   if (epi == EPI_GELU_GRAD && !out2) { set_error("gemm_nt_f8: EPI_GELU_GRAD needs out2"); return -4; }
   if (ldc % 8 != 0) { set_error("gemm_nt_f8: ldc must be a multiple of 8"); return -3; }
+  if (h_u8 && (epi == EPI_GELU_GRAD || epi == EPI_MUL_AUX) && (epi == EPI_GELU_GRAD ? ldc : ldaux) != N) {
+    set_error("gemm_nt_f8: the 8-bit GELU derivative is a dense blocked tensor (ld == N)"); return -3;
+  }
   GemmArgs g{(const bf16*)A8, (const bf16*)B8, M, N, K, lda, ldb, out, ldc, out2, ld2, bias, nullptr, 0, 0, (const bf16*)aux, ldaux, 0, 0,
              nullptr, nullptr, dq_a, dq_b, out8, ld8, q_out, amax_out, h_u8};
   return launch_pp_f8(epi, g, 256, a_e5m2 != 0, (hipStream_t)stream);

@@ -771,6 +771,8 @@ extern "C" int oat_gemm_nt(const void* A, const void* B, int M, int N, int K, in
       return -3;
     }
     if ((epi == EPI_GELU_GRAD && !out2) || (epi == EPI_MUL_AUX && !aux)) { set_error("gemm_nt: missing out2 / aux"); return -4; }
+    // the 8-bit derivative tensor is blocked ([row / 16][col / 64][lane][16 B], gemm_nt_pp.hip): a dense [round_up(M, 16), N] byte array
+    if ((epi == EPI_GELU_GRAD ? ldc : ldaux) != N) { set_error("gemm_nt: the 8-bit GELU derivative is a dense blocked tensor (ld == N)"); return -3; }
     const int slots = g_persist == 0xffff ? 0x7fffffff : g_persist > 0 ? g_persist : cu_count();
     return launch_pp(epi, g, slots, 0, s);
   }

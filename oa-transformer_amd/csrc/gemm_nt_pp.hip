@@ -48,7 +48,8 @@ enum : int { PPF_PRIO = 1, PPF_NOSTAGGER = 2, PPF_LGKM = 4, PPF_BONUS = 8, PPF_N
              PPF_HU8 = 512,                     // the saved GELU derivative travels as 8-bit fixed point (see HU8_*)
              PPF_SPLITK = 1024,                 // split-K of the last, partial round of tiles (see `sk_*` in the kernel)
              PPF_M224 = 2048,                   // 224-row tiles (see TM in the kernel)
-             PPF_BAND = 4096 };                 // band-grouped per-XCD tile walk (see `tile_of` in the kernel)
+             PPF_BAND = 4096,
+             PPF_M192 = 8192 };                 // probe: 192-row tiles                 // band-grouped per-XCD tile walk (see `tile_of` in the kernel)
 
 // gelu'(h) lies in [-0.129, 1.129].  As bf16 it costs 2 bytes per element to write (fc1 forward) and to read back (fc2 data
 // gradient) - 308 MB per launch each way, all of it on top of a GEMM that is otherwise MFMA-bound.  Stored as
@@ -93,15 +94,13 @@ OAT_DEV void mfma_inplace(f32x4& c, const bf16x8 a, const bf16x8 b) {
 
 // Epilogue of one 256x256 tile (no LDS, no barriers): lane (fk, frow) owns rows 16 i + 4 fk + r and the 4 consecutive
 // columns 4 frow + j of its wave tile, so 16 consecutive lanes store one 128-byte line per row.  Returns whether the
-// tile was an interior one (then exactly NST = 32 (64 for EPI_GELU_GRAD) store instructions were issued per lane).
+// tile was an interior one (then exactly NST store instructions were issued per lane, see the kernel).
 template <int EPI, bool WIDE = false, bool F8 = false, bool HU8 = false, int TM = 256>
 OAT_DEV bool pp_epilogue(const GemmArgs& g, const f32x4 (&acc)[8][4], int m0, int n0, int wm, int wn, int lane, float dq = 1.f) {
   // TM: rows of the tile (256, or 224: wave rows of 112 = 7 row groups of 16, acc[7] unused)
   constexpr int WR = TM / 2, NI = WR / 16;
   static_assert(!WIDE || TM == 256, "wide stores: 256-row tiles only");
-  // HU8: the derivative tensor (out of EPI_GELU_GRAD, aux of EPI_MUL_AUX) is one byte per element, ldc / ldaux in bytes
-  constexpr int DSZ = (HU8 && EPI == EPI_GELU_GRAD) ? 1 : 2;      // bytes per element of `out`
-  constexpr int ASZ = (HU8 && EPI == EPI_MUL_AUX) ? 1 : 2;        // bytes per element of `aux`
+  // HU8: the derivative tensor (out of EPI_GELU_GRAD, aux of EPI_MUL_AUX) is one byte per element in a blocked layout (below)
   uint32_t d8 = 0;                                                // HU8 + EPI_GELU_GRAD: the 4 derivative bytes of the last finish()
   // lane-constant store offsets are derived from an opaque copy of the lane id: hoisted out of the tile loop they would
   // sit in VGPRs through the K loop, which has none to spare
@@ -190,77 +189,105 @@ OAT_DEV bool pp_epilogue(const GemmArgs& g, const f32x4 (&acc)[8][4], int m0, in
       return true;
     }
   }
+  // HU8: the derivative tensor is BLOCKED - [row / 16][col / 64][lane][16 bytes]: the 16 rows x 64 columns a wave's row group i
+  // covers are one 1 KB block in which lane (fk, frow) owns 16 consecutive bytes, its rows 4 fk + r times its columns 4 frow + j
+  // in [r][j] order.  Producer (EPI_GELU_GRAD) and consumer (EPI_MUL_AUX) are the only readers of this tensor and both hold exactly
+  // these 16 elements per lane and row group, whatever the tile height: one 16-byte access per lane and row group, 1 KB contiguous per
+  // wave instruction, instead of four 4-byte accesses that each touched four 64-byte row segments.
+  constexpr bool DBLK = HU8 && EPI == EPI_GELU_GRAD, ABLK = HU8 && EPI == EPI_MUL_AUX;
+  const uint32_t blks = (DBLK || ABLK) ? ((uint32_t)g.N >> 6) << 10 : 0;                  // bytes from a row group's block to the next
+  const size_t blk0 = (DBLK || ABLK) ? (((size_t)(wrow0 >> 4) * ((uint32_t)g.N >> 6) + (uint32_t)(wcol00 >> 6)) << 10) + ((uint32_t)lane << 4) : 0;
+  char* const dblk = DBLK ? reinterpret_cast<char*>(g.out) + blk0 : nullptr;
+  const char* const ablk = ABLK ? reinterpret_cast<const char*>(g.aux) + blk0 : nullptr;
   if (interior) {
     const size_t t0 = (size_t)wrow0;
-    char* const ob = reinterpret_cast<char*>(g.out) + (t0 * g.ldc + wcol00) * DSZ;
+    char* const ob = DBLK ? nullptr : reinterpret_cast<char*>(g.out) + (t0 * g.ldc + wcol00) * 2;
     char* const ob2 = EPI == EPI_GELU_GRAD ? reinterpret_cast<char*>(g.out2) + (t0 * g.ld2 + wcol00) * 2 : nullptr;
-    const char* const ab = EPI == EPI_MUL_AUX ? reinterpret_cast<const char*>(g.aux) + (t0 * g.ldaux + wcol00) * ASZ : nullptr;
-    const uint32_t lo = (uint32_t)(fk * 4 * g.ldc + frow * 4) * DSZ;
+    const char* const ab = (EPI == EPI_MUL_AUX && !ABLK) ? reinterpret_cast<const char*>(g.aux) + (t0 * g.ldaux + wcol00) * 2 : nullptr;
+    const uint32_t lo = DBLK ? 0 : (uint32_t)(fk * 4 * g.ldc + frow * 4) * 2;
     const uint32_t lo2 = EPI == EPI_GELU_GRAD ? (uint32_t)(fk * 4 * g.ld2 + frow * 4) * 2 : 0;
-    const uint32_t la = EPI == EPI_MUL_AUX ? (uint32_t)(fk * 4 * g.ldaux + frow * 4) * ASZ : 0;
+    const uint32_t la = (EPI == EPI_MUL_AUX && !ABLK) ? (uint32_t)(fk * 4 * g.ldaux + frow * 4) * 2 : 0;
     auto load_aux = [&](const char* ptr) -> f32x4 {
-      if constexpr (ASZ == 1) return hu8_unpack(*reinterpret_cast<const uint32_t*>(ptr));
-      else {
-        const bf16x4 t = *reinterpret_cast<const bf16x4*>(ptr);
-        return f32x4{bf2f(t[0]), bf2f(t[1]), bf2f(t[2]), bf2f(t[3])};
-      }
+      const bf16x4 t = *reinterpret_cast<const bf16x4*>(ptr);
+      return f32x4{bf2f(t[0]), bf2f(t[1]), bf2f(t[2]), bf2f(t[3])};
     };
+    // EPI_MUL_AUX + HU8: ALL derivative blocks of the tile (NI x 16 bytes per lane) are requested before the first store.
+    // vmcnt retires in issue order: with the loads of row group i + 1 issued behind the stores of group i - 1 (the former
+    // one-group-ahead scheme) every wait for a derivative word also waited for those stores to be WRITTEN - eight
+    // dependent store round trips per tile (259 -> 237 us per launch).  The fragment registers of the K loop are dead
+    // here, so 32 VGPRs are free.
+    uint4 aw[NI] = {};
     f32x4 an[4] = {}, ac[4] = {};
-    if constexpr (EPI == EPI_MUL_AUX) {
+    if constexpr (ABLK) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) an[r] = load_aux(ab + (size_t)(uint32_t)(r * g.ldaux * ASZ) + la);
+      for (int i = 0; i < NI; ++i) aw[i] = *reinterpret_cast<const uint4*>(ablk + (size_t)((uint32_t)i * blks));
+      asm volatile("" ::: "memory");
+    } else if constexpr (EPI == EPI_MUL_AUX) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) an[r] = load_aux(ab + (size_t)(uint32_t)(r * g.ldaux * 2) + la);
     }
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      if constexpr (EPI == EPI_MUL_AUX) {        // the saved derivative of row group i + 1 is requested one group ahead
+      if constexpr (ABLK) {
+        ac[0] = hu8_unpack(aw[i].x); ac[1] = hu8_unpack(aw[i].y); ac[2] = hu8_unpack(aw[i].z); ac[3] = hu8_unpack(aw[i].w);
+      } else if constexpr (EPI == EPI_MUL_AUX) {        // bf16 derivative (non-default): row group i + 1 is requested one group ahead
 #pragma unroll
         for (int r = 0; r < 4; ++r) ac[r] = an[r];
         if (i + 1 < NI) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) an[r] = load_aux(ab + (size_t)(uint32_t)(((i + 1) * 16 + r) * g.ldaux * ASZ) + la);
+          for (int r = 0; r < 4; ++r) an[r] = load_aux(ab + (size_t)(uint32_t)(((i + 1) * 16 + r) * g.ldaux * 2) + la);
         }
       }
+      uint32_t dw[4] = {};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const f32x4 v = f32x4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
         bf16x4 o, o2;
         finish(v, ac[r], o, o2);
         const uint32_t rr = (uint32_t)(i * 16 + r);
-        if constexpr (DSZ == 1) *reinterpret_cast<uint32_t*>(ob + (size_t)(rr * (uint32_t)g.ldc) + lo) = d8;
+        if constexpr (DBLK) dw[r] = d8;
         else *reinterpret_cast<bf16x4*>(ob + (size_t)(rr * (uint32_t)g.ldc * 2) + lo) = o;
         if constexpr (EPI == EPI_GELU_GRAD) *reinterpret_cast<bf16x4*>(ob2 + (size_t)(rr * (uint32_t)g.ld2 * 2) + lo2) = o2;
         if constexpr (Q8) {
           if (o8) *reinterpret_cast<uint32_t*>(o8 + (size_t)(wrow0 + i * 16 + fk * 4 + r) * g.ld8 + wcol00 + frow * 4) = w8;
         }
       }
+      if constexpr (DBLK) *reinterpret_cast<uint4*>(dblk + (size_t)((uint32_t)i * blks)) = uint4{dw[0], dw[1], dw[2], dw[3]};
     }
   } else {
     const int col = wcol00 + frow * 4;
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
+    for (int i = 0; i < NI; ++i) {
+      if (wrow0 + i * 16 >= g.M) continue;               // wave-uniform: no row of this group exists (its derivative block is not touched)
+      uint4 awi = {};
+      if constexpr (ABLK) awi = *reinterpret_cast<const uint4*>(ablk + (size_t)((uint32_t)i * blks));
+      uint32_t dw[4] = {};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = wrow0 + i * 16 + fk * 4 + r;
         const f32x4 v = f32x4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
-        if (row < g.M) {
-          bf16x4 o, o2;
-          f32x4 a = {};
-          if constexpr (EPI == EPI_MUL_AUX) {
-            if constexpr (ASZ == 1) a = hu8_unpack(*reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(g.aux) + (size_t)row * g.ldaux + col));
-            else {
-              const bf16x4 t = *reinterpret_cast<const bf16x4*>(g.aux + (size_t)row * g.ldaux + col);
-              a = f32x4{bf2f(t[0]), bf2f(t[1]), bf2f(t[2]), bf2f(t[3])};
-            }
+        const bool live = row < g.M;
+        bf16x4 o, o2;
+        f32x4 a = {};
+        if constexpr (ABLK) a = hu8_unpack(r == 0 ? awi.x : r == 1 ? awi.y : r == 2 ? awi.z : awi.w);
+        else if constexpr (EPI == EPI_MUL_AUX) {
+          if (live) {
+            const bf16x4 t = *reinterpret_cast<const bf16x4*>(g.aux + (size_t)row * g.ldaux + col);
+            a = f32x4{bf2f(t[0]), bf2f(t[1]), bf2f(t[2]), bf2f(t[3])};
           }
-          finish(v, a, o, o2);
+        }
+        finish(v, a, o, o2);                              // rows >= M of a straddling group: finite values of a re-read row, stored nowhere but in the block
+        if constexpr (DBLK) dw[r] = d8;
+        if (live) {
           if constexpr (EPI == EPI_GELU_GRAD) *reinterpret_cast<bf16x4*>((bf16*)g.out2 + (size_t)row * g.ld2 + col) = o2;
-          if constexpr (DSZ == 1) *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(g.out) + (size_t)row * g.ldc + col) = d8;
-          else *reinterpret_cast<bf16x4*>((bf16*)g.out + (size_t)row * g.ldc + col) = o;
+          if constexpr (!DBLK) *reinterpret_cast<bf16x4*>((bf16*)g.out + (size_t)row * g.ldc + col) = o;
           if constexpr (Q8) {
             if (o8) *reinterpret_cast<uint32_t*>(o8 + (size_t)row * g.ld8 + col) = w8;
           }
         }
       }
+      if constexpr (DBLK) *reinterpret_cast<uint4*>(dblk + (size_t)((uint32_t)i * blks)) = uint4{dw[0], dw[1], dw[2], dw[3]};
+    }
   }
   if constexpr (Q8) {
     if (o8) amax_commit_wave(m8, g.amax_out);
@@ -280,8 +307,10 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs g) {
   // smaller.  The LDS layout stays that of the 256-row tile (wave row wm at LDS rows wm * 128 ..): the second half of a wave
   // row simply has 3 row groups of 16 instead of 4 - 12 MFMAs in two of the four intervals - and the 16 unused LDS rows of
   // each wave row are staged from the wave row's last real row.  Same K order per element: results are bit-identical.
-  constexpr int TM = (FL & PPF_M224) ? 224 : 256, WR = TM / 2, NI = WR / 16, NI1 = NI - 4;
-  constexpr int NST = (EPI == EPI_GELU_GRAD ? 8 : 4) * NI;       // stores per lane of an interior epilogue
+  constexpr int TM = (FL & PPF_M192) ? 192 : (FL & PPF_M224) ? 224 : 256, WR = TM / 2, NI = WR / 16, NI1 = NI - 4;
+  // stores per lane of an interior epilogue (EXACT or an under-count: the head waits of the next tile allow this many ops on top of
+  // the 12 pieces): 4 bf16x4 rows per row group, + 4 more (bf16 derivative) or + 1 (the 16-byte block of the 8-bit one) for EPI_GELU_GRAD
+  constexpr int NST = (EPI == EPI_GELU_GRAD ? ((FL & PPF_HU8) ? 5 : 8) : 4) * NI;
   constexpr int WB = 12 + NST > 63 ? 63 : 12 + NST;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -846,7 +875,7 @@ int launch_pp_cfg(const GemmArgs& g, int grid_slots, hipStream_t s) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
     attr_set = true;
   }
-  constexpr int TMH = (FL & PPF_M224) ? 224 : 256;
+  constexpr int TMH = (FL & PPF_M192) ? 192 : (FL & PPF_M224) ? 224 : 256;
   const int nwg = ((g.M + TMH - 1) / TMH) * (g.N / 256);
   const int grid = nwg < grid_slots ? nwg : grid_slots;
   if constexpr (FL & PPF_PH2) OAT_LAUNCH((gemm_nt_pp2_kernel<EPI, FL>), dim3(grid), dim3(512), PP_LDS, s, g);
@@ -941,6 +970,7 @@ int launch_pp(int epi, const GemmArgs& g, int grid_slots, int flags, hipStream_t
     }
     return epi == EPI_GELU_GRAD ? launch_pp_cfg<EPI_GELU_GRAD, DEF>(g, grid_slots, s) : launch_pp_cfg<EPI_MUL_AUX, DEF>(g, grid_slots, s);
   }
+  if (fl == DEF && g_pp_m224 == 3) return launch_pp_cfg<EPI_BF16, DEF | PPF_M192>(g, grid_slots, s);      // probe
   if (fl == DEF && g.sk_ws != nullptr) return launch_pp_cfg<EPI_BF16, DEF | PPF_SPLITK>(g, grid_slots, s);
   if (fl == DEF) {
     const bool m224 = pp_prefers_224(g, grid_slots);

@@ -779,7 +779,7 @@ def test_gemm_nt_224_row_tiles_bit_identical(M, N, K):
     for a, b in zip(res[0], res[2]):
         assert torch.equal(a, b)
     o, d8, g, m = res[2]
-    assert bool((o[M:] == 7.0).all()) and bool((d8[M:] == 9).all()) and bool((g[M:] == 7.0).all()) and bool((m[M:] == 7.0).all())
+    assert bool((o[M:] == 7.0).all()) and bool((hip.hu8_unblock(d8, N)[(M + 15) // 16 * 16:] == 9).all()) and bool((g[M:] == 7.0).all()) and bool((m[M:] == 7.0).all())
     ref = A[:M].float() @ W.float().t() + bias
     assert (o[:M].float() - ref).abs().max().item() <= 2 ** -7 * max(1.0, ref.abs().max().item())
 
@@ -801,11 +801,12 @@ def test_gemm_mlp_pair_with_8bit_derivative():
     d8 = torch.full((mp, n), 9, device="cuda", dtype=torch.uint8)
     g8 = torch.empty(mp, n, device="cuda", dtype=torch.bfloat16)
     hip.gemm_nt(A, W, m, n, k, hip.EPI_GELU_GRAD | hip.EPI_U8, d8, out2=g8, bias=bias)
-    assert torch.equal(g8[:m], g16[:m]) and bool((d8[m:] == 9).all())
+    d8r = hip.hu8_unblock(d8, n)                         # the 8-bit tensor is blocked by 16 rows x 64 columns (hip.hu8_unblock)
+    assert torch.equal(g8[:m], g16[:m]) and bool((d8r[(m + 15) // 16 * 16:] == 9).all())
     h = A[:m].float() @ W.float().t() + bias
     x = h.double()
     dref = 0.5 * (1 + torch.erf(x / 2 ** 0.5)) + x * torch.exp(-x * x / 2) / (2 * torch.pi) ** 0.5
-    deq = d8[:m].float() * (1.27 / 255) - 0.135
+    deq = d8r[:m].float() * (1.27 / 255) - 0.135
     print("8-bit derivative max err", (deq.double() - dref).abs().max().item())
     assert (deq.double() - dref).abs().max().item() < 0.0025 + 2e-3          # quantisation step / 2 + the kernel's erf approximation
     assert (d16[:m].double() - dref).abs().max().item() < 0.006              # the bf16 derivative is no more accurate
@@ -868,6 +869,6 @@ def test_gemm_nt_band_walk_bit_identical(M, N, K, m224):
         for a, b in zip(res[0], res[band]):
             assert torch.equal(a, b), band
     o, d8, g, m = res[4]
-    assert bool((o[M:] == 7.0).all()) and bool((d8[M:] == 9).all()) and bool((g[M:] == 7.0).all()) and bool((m[M:] == 7.0).all())
+    assert bool((o[M:] == 7.0).all()) and bool((hip.hu8_unblock(d8, N)[(M + 15) // 16 * 16:] == 9).all()) and bool((g[M:] == 7.0).all()) and bool((m[M:] == 7.0).all())
     ref = A[:M].float() @ W.float().t() + bias
     assert (o[:M].float() - ref).abs().max().item() <= 2 ** -7 * max(1.0, ref.abs().max().item())
