@@ -255,6 +255,13 @@ int oat_attn_time_bwd_fin(const void* qkv, int ldqkv, const void* out, int ldo, 
 int oat_linear_f32(const float* A, int lda, const float* W, int ldw, const float* bias, int M, int N, int K,
                    float* out32, int ldo, void* out16, int ld16, void* out16b, int ld16b, const float* resid, int ldr,
                    int act, void* stream);
+/* out[M, 3n] = A[M, K] . [Wq; Wk; Wv]^T + [bq | bk | bv]: the q_lin / k_lin / v_lin of a DistilBERT attention layer (three separate
+ * nn.Linear parameters in HF 4.6 MultiHeadSelfAttention, reached from oa_model.py:27,113) as ONE launch of the split-bf16 kernel -
+ * per output element the arithmetic of three oat_linear_f32 calls (bit-identical), three times the workgroups per launch.
+ * n % 128 == 0, K % 32 == 0, M > 64, lda % 4 == 0, ldw % 4 == 0; biases: all three or none; out32 / out16: at least one. */
+int oat_linear_f32_qkv(const float* A, int lda, const float* Wq, const float* Wk, const float* Wv, int ldw,
+                       const float* bq, const float* bk, const float* bv, int M, int n, int K,
+                       float* out32, int ldo, void* out16, int ld16, void* stream);
 
 /* ---- text encoder (HF DistilBertModel, called at oa_model.py:113; third-party algorithm) ---------
  * ids / mask are int64.  Attention: qkv bf16 [B*L, 3*D]; masked keys are skipped. */

@@ -75,6 +75,7 @@ class TextEngine:
         self.scale = 64 ** -0.5
         self.plans, self.shadow, self.versions = {}, {}, None
         self.use_tape = os.environ.get("OAT_TAPE", "1") != "0"
+        self.qkv_one_launch = os.environ.get("OAT_TEXT_QKV1", "1") != "0"     # q / k / v linears of a layer in one launch (hip.linear_f32_qkv)
         # 1 (default): the 36 weight gradients of a backward pass as one grouped launch at its end; 0: 36 gemm_tn + tn_reduce pairs
         self.group_wgrads = os.environ.get("OAT_GROUP_WGRADS", "1") != "0"
 
@@ -155,7 +156,7 @@ class TextEngine:
             return None
         ptrs = tuple(t.data_ptr() for t in params.values())
         gptr = next(iter(grads.values())).data_ptr() if grads else 0
-        return (torch.cuda.current_stream().cuda_stream, ptrs, gptr, self.group_wgrads, flags)
+        return (torch.cuda.current_stream().cuda_stream, ptrs, gptr, self.group_wgrads, self.qkv_one_launch, flags)
 
     @staticmethod
     def _taped(pl, slot, key, body):
@@ -194,9 +195,14 @@ class TextEngine:
         for i, a in enumerate(pl.layers):
             b = f"transformer.layer.{i}."
             p = lambda s: params[b + s]
-            for j, l in enumerate(("q_lin", "k_lin", "v_lin")):
-                hip.linear_f32(x, p(f"attention.{l}.weight"), M, D, D, bias=p(f"attention.{l}.bias"),
-                               out32=a.qkv32[:, j * D:(j + 1) * D], out16=a.qkv[:, j * D:(j + 1) * D])
+            if self.qkv_one_launch and M > 64 and D % 128 == 0:      # q_lin | k_lin | v_lin: three parameters, one launch
+                hip.linear_f32_qkv(x, p("attention.q_lin.weight"), p("attention.k_lin.weight"), p("attention.v_lin.weight"), M, D, D,
+                                   bq=p("attention.q_lin.bias"), bk=p("attention.k_lin.bias"), bv=p("attention.v_lin.bias"),
+                                   out32=a.qkv32, out16=a.qkv)
+            else:
+                for j, l in enumerate(("q_lin", "k_lin", "v_lin")):
+                    hip.linear_f32(x, p(f"attention.{l}.weight"), M, D, D, bias=p(f"attention.{l}.bias"),
+                                   out32=a.qkv32[:, j * D:(j + 1) * D], out16=a.qkv[:, j * D:(j + 1) * D])
             hip.attn_text_fwd_dual(a.qkv, a.qkv32, pl.mask, a.ctx, a.ctx32, a.lse, B, L, H, D, self.scale,
                                    drop_p=pa, rng=pl.rng if pa > 0 else None, site=self.site(i, "attn"))
             hip.linear_f32(a.ctx32, p("attention.out_lin.weight"), M, D, D, bias=p("attention.out_lin.bias"),

@@ -866,6 +866,15 @@ def linear_f32(A, W, M, N, K, bias=None, out32=None, out16=None, out16b=None, re
                                 int(act), _stream()), "oat_linear_f32")
 
 
+def linear_f32_qkv(A, Wq, Wk, Wv, M, n, K, bq=None, bk=None, bv=None, out32=None, out16=None):
+    """[q | k | v] = A[M,K] @ [Wq; Wk; Wv]^T + [bq | bk | bv] in one launch (three separate fp32 [n, K] weights, one [M, 3n] output);
+    bit-identical to three linear_f32 calls on the column slices.  n % 128 == 0, K % 32 == 0, M > 64."""
+    s0 = lambda t: t.stride(0) if t is not None else 0
+    assert Wq.stride(0) == Wk.stride(0) == Wv.stride(0)
+    _check(lib().oat_linear_f32_qkv(_ptr(A), A.stride(0), _ptr(Wq), _ptr(Wk), _ptr(Wv), Wq.stride(0), _ptr(bq), _ptr(bk), _ptr(bv),
+                                    M, n, K, _ptr(out32), s0(out32), _ptr(out16), s0(out16), _stream()), "oat_linear_f32_qkv")
+
+
 def attn_text_bwd(qkv, mask, out, lse, delta, dout, dqkv, B, L, H, D, scale, drop_p=0.0, rng=None, site=0):
     _check(lib().oat_attn_text_bwd(_ptr(qkv), qkv.stride(0), _ptr(mask), _ptr(out), out.stride(0), _ptr(lse),
                                    _ptr(delta), _ptr(dout), dout.stride(0), _ptr(dqkv), dqkv.stride(0), B, L, H, D,

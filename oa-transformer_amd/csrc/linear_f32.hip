@@ -30,6 +30,9 @@ struct LinArgs {
   bf16* out16; int ld16;
   bf16* out16b; int ld16b;
   const float* resid; int ldr;
+  // PARTS launches (linear_x3_kernel only): the N output columns are `part_n`-wide slices of up to three weight / bias tensors of
+  // their own (W, W2, W3: the q | k | v linears of an attention layer, one launch for one [M, 3 part_n] output); 0 = one tensor
+  const float* W2; const float* W3; const float* bias2; const float* bias3; int part_n;
 };
 
 // The LDS-tiled kernel (many rows):
@@ -183,6 +186,11 @@ __global__ __launch_bounds__(256 * KG) void linear_x3_kernel(LinArgs g) {
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  // PARTS: this workgroup's 128 columns lie in ONE part (part_n % 128 == 0): its weight rows and bias start at column nW0
+  const int part = g.part_n > 0 ? n0 / g.part_n : 0, nW0 = part * g.part_n;        // workgroup-uniform
+  const float* const Wp = part == 0 ? g.W : part == 1 ? g.W2 : g.W3;
+  const float* const bp = part == 0 ? g.bias : part == 1 ? g.bias2 : g.bias3;
+  const int nWend = g.part_n > 0 ? nW0 + g.part_n : g.N;
   const int nsteps = g.K / BK, my_steps = KG == 2 ? (kg == 0 ? (nsteps + 1) / 2 : nsteps / 2) : nsteps;
   const int kbeg = KG == 2 && kg == 1 ? ((nsteps + 1) / 2) * BK : 0;
   const int loop_steps = KG == 2 ? (nsteps + 1) / 2 : nsteps;            // both quartets run the same number of barrier pairs
@@ -200,7 +208,7 @@ __global__ __launch_bounds__(256 * KG) void linear_x3_kernel(LinArgs g) {
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
       }
       ra[bsel][l] = v;
-      rb[bsel][l] = (live && n0 + row < g.N) ? *reinterpret_cast<const f32x4*>(g.W + (size_t)(n0 + row) * g.ldw + k0 + kq) : zero;
+      rb[bsel][l] = (live && n0 + row < nWend) ? *reinterpret_cast<const f32x4*>(Wp + (size_t)(n0 - nW0 + row) * g.ldw + k0 + kq) : zero;
     }
   };
   auto split_store = [&](const f32x4 v, char* dst) {
@@ -279,7 +287,7 @@ __global__ __launch_bounds__(256 * KG) void linear_x3_kernel(LinArgs g) {
     for (int j = 0; j < 4; ++j) {
       const int col = n0 + wn * 64 + j * 16 + fr;
       if (col >= g.N) continue;
-      const float b = g.bias ? g.bias[col] : 0.f;
+      const float b = bp ? bp[col - nW0] : 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = m0 + wm * 64 + i * 16 + fk * 4 + r;
@@ -417,10 +425,30 @@ extern "C" int oat_linear_f32(const float* A, int lda, const float* W, int ldw, 
   if (K % 16 != 0 || lda % 4 != 0 || ldw % 4 != 0) { set_error("linear_f32: K % 16, lda % 4, ldw % 4 must be 0"); return -2; }
   if (!A || !W || (!out32 && !out16)) { set_error("linear_f32: null pointer"); return -4; }
   if (act < 0 || act > 2) { set_error("linear_f32: unknown activation"); return -5; }
-  LinArgs g{A, lda, W, ldw, bias, M, N, K, out32, ldo, (bf16*)out16, ld16, (bf16*)out16b, ld16b, resid, ldr};
+  LinArgs g{A, lda, W, ldw, bias, M, N, K, out32, ldo, (bf16*)out16, ld16, (bf16*)out16b, ld16b, resid, ldr, nullptr, nullptr, nullptr, nullptr, 0};
   hipStream_t s = (hipStream_t)stream;
   if (act == 1) launch_linear<1>(g, s);
   else if (act == 2) launch_linear<2>(g, s);
   else launch_linear<0>(g, s);
   return check_launch("linear_f32");
+}
+
+// out[M, 3 n] = A[M, K] . [Wq; Wk; Wv]^T + [bq | bk | bv]: the three n x K linear layers of an attention block (HF DistilBERT keeps q_lin /
+// k_lin / v_lin as separate parameters, /root/reference/OATrans/model/oa_model.py:27 -> transformers 4.6 MultiHeadSelfAttention) in ONE launch
+// of the split-bf16 kernel - same arithmetic per output element as three oat_linear_f32 calls, three times the workgroups per launch
+// (the text tower's launches are latency-bound: 48 workgroups each).  n % 128 == 0, K % 32 == 0, M > 64.
+extern "C" int oat_linear_f32_qkv(const float* A, int lda, const float* Wq, const float* Wk, const float* Wv, int ldw,
+                                  const float* bq, const float* bk, const float* bv, int M, int n, int K,
+                                  float* out32, int ldo, void* out16, int ld16, void* stream) {
+  using namespace oat;
+  if (M <= 64 || n <= 0 || K <= 0) { set_error("linear_f32_qkv: M > 64, n > 0, K > 0"); return -1; }
+  if (n % 128 != 0 || K % 32 != 0 || lda % 4 != 0 || ldw % 4 != 0) { set_error("linear_f32_qkv: n % 128, K % 32, lda % 4, ldw % 4 must be 0"); return -2; }
+  if (!A || !Wq || !Wk || !Wv || (!out32 && !out16)) { set_error("linear_f32_qkv: null pointer"); return -4; }
+  if ((bq == nullptr) != (bk == nullptr) || (bq == nullptr) != (bv == nullptr)) { set_error("linear_f32_qkv: all three biases or none"); return -4; }
+  LinArgs g{A, lda, Wq, ldw, bq, M, 3 * n, K, out32, ldo, (bf16*)out16, ld16, nullptr, 0, nullptr, 0, Wk, Wv, bk, bv, n};
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((3 * n) / 128, (M + 127) / 128);
+  if (K >= 256 && grid.x * grid.y <= 256) OAT_LAUNCH((linear_x3_kernel<0, 2>), grid, dim3(512), 0, s, g);
+  else OAT_LAUNCH((linear_x3_kernel<0, 1>), grid, dim3(256), 0, s, g);
+  return check_launch("linear_f32_qkv");
 }

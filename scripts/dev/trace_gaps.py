@@ -12,7 +12,8 @@ def short(n):
 # the last step: from the last adamw block backwards to the previous one
 adam = [i for i, r in enumerate(rows) if "adamw" in r["Kernel_Name"]]
 ends = [adam[i] for i in range(len(adam)) if i + 1 == len(adam) or adam[i + 1] - adam[i] > 50]
-lo, hi = ends[-2] + 1, ends[-1] + 1
+_k = int(__import__('os').environ.get('STEP_BACK', '1'))
+lo, hi = ends[-1 - _k] + 1, ends[-_k] + 1
 step = rows[lo:hi]
 t0, t1 = step[0]["s"], max(r["e"] for r in step)
 print(f"last step: {len(step)} kernels, wall {(t1 - t0) / 1e6:.2f} ms")

@@ -13,7 +13,8 @@ def short(n):
     return n[:48]
 adam = [i for i, r in enumerate(rows) if "adamw" in r["Kernel_Name"]]
 ends = [adam[i] for i in range(len(adam)) if i + 1 == len(adam) or adam[i + 1] - adam[i] > 50]
-step = rows[ends[-2] + 1:ends[-1] + 1]
+_k = int(__import__('os').environ.get('STEP_BACK', '1'))      # 1 = the last step (bench.py: the instrumented one), 2 = the step before it
+step = rows[ends[-1 - _k] + 1:ends[-_k] + 1]
 byq = collections.defaultdict(list)
 for r in step: byq[(r["Queue_Id"], r["Stream_Id"])].append(r)
 mainkey = max(byq, key=lambda k: sum(r["e"] - r["s"] for r in byq[k]))

@@ -6,11 +6,12 @@ for r in rows:
     r["s"] = int(r["Start_Timestamp"]); r["e"] = int(r["End_Timestamp"])
 rows.sort(key=lambda r: r["s"])
 def short(n):
-    n = n.replace("void ", "").replace("oat::(anonymous namespace)::", "").replace("oat::", ""); n = re.sub(r"\(.*", "", n)
-    return n[:44]
+    n = n.replace("void ", "").replace("oat::(anonymous namespace)::", "").replace("oat::", ""); n = re.sub(r"\(.*", "", n) if len(n) < 60 or "at::" not in n else n
+    return n[:int(__import__("os").environ.get("NAMELEN", "44"))]
 adam = [i for i, r in enumerate(rows) if "adamw" in r["Kernel_Name"]]
 ends = [adam[i] for i in range(len(adam)) if i + 1 == len(adam) or adam[i + 1] - adam[i] > 50]
-step = rows[ends[-2] + 1:ends[-1] + 1]
+_k = int(__import__('os').environ.get('STEP_BACK', '1'))      # 1 = the last step (bench.py: the instrumented one), 2 = the step before it
+step = rows[ends[-1 - _k] + 1:ends[-_k] + 1]
 t0 = step[0]["s"]
 qs = {}
 for r in step:

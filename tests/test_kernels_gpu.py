@@ -872,3 +872,25 @@ def test_gemm_nt_band_walk_bit_identical(M, N, K, m224):
     assert bool((o[M:] == 7.0).all()) and bool((hip.hu8_unblock(d8, N)[(M + 15) // 16 * 16:] == 9).all()) and bool((g[M:] == 7.0).all()) and bool((m[M:] == 7.0).all())
     ref = A[:M].float() @ W.float().t() + bias
     assert (o[:M].float() - ref).abs().max().item() <= 2 ** -7 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("M,n,K", [(1024, 768, 768), (200, 128, 64), (1000, 256, 3072)])
+def test_linear_f32_qkv_is_three_linears(M, n, K):
+    """oat_linear_f32_qkv (q_lin | k_lin | v_lin of a DistilBERT layer in one launch): bit-identical to three oat_linear_f32 calls
+    on the column slices, ragged M, with and without biases, fp32 and bf16 outputs."""
+    hip = _hip()
+    x = rnd(M, K, seed=70)
+    W = [rnd(n, K, scale=K ** -0.5, seed=71 + j) for j in range(3)]
+    b = [rnd(n, seed=75 + j) for j in range(3)]
+    for bias in (True, False):
+        ref32 = torch.full((M, 3 * n), 7.0, device=DEV); ref16 = torch.full((M, 3 * n), 7.0, device=DEV, dtype=torch.bfloat16)
+        for j in range(3):
+            hip.linear_f32(x, W[j], M, n, K, bias=b[j] if bias else None, out32=ref32[:, j * n:(j + 1) * n], out16=ref16[:, j * n:(j + 1) * n])
+        o32 = torch.full((M, 3 * n), 5.0, device=DEV); o16 = torch.full((M, 3 * n), 5.0, device=DEV, dtype=torch.bfloat16)
+        kw = dict(bq=b[0], bk=b[1], bv=b[2]) if bias else {}
+        hip.linear_f32_qkv(x, W[0], W[1], W[2], M, n, K, out32=o32, out16=o16, **kw)
+        assert torch.equal(o32, ref32) and torch.equal(o16, ref16)
+        want = torch.cat([x.double() @ w.double().t() + (bb.double() if bias else 0) for w, bb in zip(W, b)], 1)
+        assert (o32.double() - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
+    with pytest.raises(hip.OatError):
+        hip.linear_f32_qkv(x, W[0], W[1], W[2], M, n - 64, K, out32=o32)
