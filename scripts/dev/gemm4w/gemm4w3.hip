@@ -1,0 +1,317 @@
+// Dev probe 3 (not part of the library): 4-wave NT bf16 GEMM, 224 x 256 x 64 tiles, ONE wave per SIMD (112 x 128 wave tiles,
+// accumulators in AGPRs), A in a THREE-stage LDS ring (the A panel streams from HBM: ~2 us of latency to cover), B in two stages
+// (weights: L2-resident), bias in LDS: 3 x 28 + 2 x 32 + 12 = 160 KB.  The bf16 epilogue is interleaved with the matrix work of the
+// neighbouring K-tiles: row group i of a finished tile is converted and stored under the MFMAs of the row groups behind it in the
+// tile's LAST half K-tile, the last row group under the NEXT tile's first half K-tile (C = 0 form).  The 8-wave ping-pong kernel
+// (csrc/gemm_nt_pp.hip: 2 waves x 256 registers per SIMD) has no registers for that and pays ~3.5 us per tile, 20 % of a K = 768 launch.
+// hipcc --offload-arch=gfx950 -O3 -I../../../oa-transformer_amd/csrc
+#include "common.h"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include <cmath>
+#include <type_traits>
+using namespace oat;
+namespace oat { void set_error(const char*) {} int check_launch(const char*) { return 0; } bool tape_recording() { return false; } void tape_push(std::function<void()>&&) {} }
+
+constexpr int TM = 224, WR = 112, NI = 7, NG = 14;
+constexpr int ASTG = TM * 128, BSTG = 32768, B_OFF = 3 * ASTG, BIAS_OFF = B_OFF + 2 * BSTG, MAXN = 3072, LDS_BYTES = BIAS_OFF + MAXN * 4;   // 160 KB exactly
+
+struct Args { const bf16* A; const bf16* B; bf16* C; const float* bias; int M, N, K, lda, ldb, ldc; int nostore; };
+
+struct Cursor { const char* p; int kt, tl; int m0; };
+
+template <int DUMMY>
+__global__ __launch_bounds__(256) void gemm4w2_kernel(Args g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntn = g.N >> 8, ntm = (g.M + TM - 1) / TM, ntiles = ntm * ntn;
+  const int nk = g.K >> 6;
+  const int grid = (int)gridDim.x;
+  const int ntl = (ntiles - 1 - (int)blockIdx.x) / grid + 1;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  float* const sbias = reinterpret_cast<float*>(smem + BIAS_OFF);
+  for (int i = tid; i < g.N; i += 256) sbias[i] = g.bias ? g.bias[i] : 0.f;
+  struct Tile { int m0, n0; };
+  auto tile_of = [&](int t) __attribute__((always_inline)) {       // XCD-contiguous, bijective (as gemm_nt_pp)
+    const int w = (int)blockIdx.x + t * grid;
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = w & 7, idx = w >> 3;
+    const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int tm = bid / ntn;
+    return Tile{tm * TM, (bid - tm * ntn) << 8};
+  };
+  // ---- staging.  piece = 8 LDS rows x 128 B.  A: 28 pieces per K-tile, wave w stages pieces 7w .. 7w + 6 (tile rows 56 w ..);
+  // B: 32 pieces, wave w stages 8w .. 8w + 7.  LDS row r of B <- B row (r & ~63) | ((r & 15) << 2) | ((r >> 4) & 3): MFMA column c of
+  // column tile t of a 64-column block is output column 4 c + t, so a lane owns 4 consecutive columns (direct 8-byte stores).
+  const int srow = lane >> 3;
+  const uint32_t lda2 = (uint32_t)g.lda * 2, ldb2 = (uint32_t)g.ldb * 2;
+  const uint32_t c16_0 = (uint32_t)(((lane & 7) ^ (srow >> 1)) << 4);
+  const uint32_t voffA = (uint32_t)srow * lda2 + c16_0;
+  const uint32_t voffB = (uint32_t)(srow * 4) * ldb2 + c16_0;
+  const char* const A0 = reinterpret_cast<const char*>(g.A);
+  const char* const B0 = reinterpret_cast<const char*>(g.B);
+  const int rows_last = g.M - 1;
+  Cursor ca, cb;                                                     // A: K-tile s + 3 of the stream, B: K-tile s + 2
+  { const Tile t = tile_of(0); ca = Cursor{A0 + (size_t)t.m0 * lda2, 0, 0, t.m0}; cb = Cursor{B0 + (size_t)t.n0 * ldb2, 0, 0, 0}; }
+  // One LDS-DMA piece = s_add m0 + (s_nop) + global_load_lds: the wave-uniform part of the global address is the cursor (an SGPR pair
+  // that advances by 128 bytes per K-tile), everything else - 8-row step of the piece, lane row, swizzled chunk - sits in one VGPR per
+  // piece (7 for A, rebuilt when the cursor enters a new tile: ragged M clamps the piece to the tile's last whole piece; 8 for B,
+  // constant).  With ONE wave per SIMD every instruction beside the MFMAs costs an issue slot the matrix pipe waits behind.
+  uint32_t voffAe[7], voffBe[8];
+  auto build_voffA = [&](int m0) __attribute__((always_inline)) {
+    const int last_piece_row = min(TM, g.M - m0) - 8;                 // rows of the tile that exist (a multiple of 8) - 8
+#pragma unroll
+    for (int e = 0; e < 7; ++e) {
+      const int p = wave * 7 + e;
+      voffAe[e] = (voffA ^ (uint32_t)((p & 1) << 6)) + (uint32_t)min(p * 8, last_piece_row) * lda2;
+    }
+  };
+  build_voffA(ca.m0);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int p = wave * 8 + e;
+    voffBe[e] = (voffB ^ (uint32_t)((p & 1) << 6)) + (uint32_t)((p >> 3) * 64 + (p & 1) * 32 + ((p >> 1) & 3)) * ldb2;
+  }
+  auto advance = [&](Cursor& c, bool isA) __attribute__((always_inline)) {
+    ++c.kt; c.p += 128;
+    if (c.kt == nk) {                      // past the end of the stream the cursor stays on its last K-tile (re-reads, never consumed)
+      const bool more = c.tl + 1 < ntl;
+      c.tl += more ? 1 : 0;
+      const Tile t = tile_of(c.tl);
+      c.kt = more ? 0 : nk - 1;
+      const char* np = isA ? A0 + (size_t)t.m0 * lda2 : B0 + (size_t)t.n0 * ldb2;
+      c.p = more ? np : c.p - 128;
+      if (isA && more) { c.m0 = t.m0; build_voffA(t.m0); }
+    }
+  };
+  auto piece = [&](const char* base, uint32_t voff, uint32_t lds_stage_base, int imm) __attribute__((always_inline)) {
+    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds_stage_base), "n"(imm) : "memory", "m0", "scc");
+  };
+  auto dma_a = [&](int e, int stage) __attribute__((always_inline)) {      // e = 0..6; wave-uniform stage base
+    piece(ca.p, voffAe[e], lds0 + stage * ASTG + wave * 7 * 1024, e * 1024);
+  };
+  auto dma_b = [&](int e, int stage) __attribute__((always_inline)) {      // e = 0..7
+    piece(cb.p, voffBe[e], lds0 + B_OFF + stage * BSTG + wave * 8 * 1024, e * 1024);
+  };
+  // ---- fragment addresses ([rows][64 k] bf16 tiles, 16-byte chunk c of row r at c ^ ((r >> 1) & 7))
+  const int frow = lane & 15, fk = lane >> 4, sw = (frow >> 1) & 7;
+  uint32_t pA[2], pB[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    const int ch = ((kk * 4 + fk) ^ sw) << 4;
+    pA[kk] = lds0 + (wm * WR + frow) * 128 + ch;
+    pB[kk] = lds0 + B_OFF + (wn * 128 + frow) * 128 + ch;
+  }
+  typedef const __attribute__((address_space(3))) bf16x8* lds_frag;
+  f32x4 acc[NI][8];
+  bf16x8 a0[NI], b0[8], a1[NI], b1[8];
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  // ---- epilogue pieces: half a row group (one 64-column block) = 4 stores of 8 bytes per lane
+  int em0 = 0, en0 = 0;                 // the tile the finished accumulators belong to
+  auto store_half = [&](int i, int blk) __attribute__((always_inline)) {
+    char* const ob = reinterpret_cast<char*>(g.C) + ((size_t)(em0 + wm * WR + i * 16) * g.ldc + en0 + wn * 128 + blk * 64) * 2;
+    const uint32_t lo = (uint32_t)(fk * 4 * g.ldc + frow * 4) * 2;
+    const bool interior = em0 + TM <= g.M;
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(sbias + en0 + wn * 128 + blk * 64 + frow * 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bf16x4 o = {f2bf(acc[i][4 * blk + 0][r] + bv[0]), f2bf(acc[i][4 * blk + 1][r] + bv[1]),
+                        f2bf(acc[i][4 * blk + 2][r] + bv[2]), f2bf(acc[i][4 * blk + 3][r] + bv[3])};
+      if (g.nostore == 1 && o[0] != (bf16)12345.f) continue;          // probe: conversions without stores
+      if (interior || em0 + wm * WR + i * 16 + fk * 4 + r < g.M)
+        *reinterpret_cast<bf16x4*>(((g.nostore == 2 || (g.nostore == 3 && (blockIdx.x & 3) != 0)) ? reinterpret_cast<char*>(g.C) + (blockIdx.x & 255) * 4096 + wave * 1024 : ob) + (size_t)((uint32_t)r * (uint32_t)g.ldc * 2) + lo) = o;
+    }
+  };
+
+  // ---- prologue: A K-tiles 0, 1, 2 and B K-tiles 0, 1 of the stream
+#pragma unroll
+  for (int e = 0; e < 7; ++e) dma_a(e, 0);
+  advance(ca, true);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) dma_b(e, 0);
+  advance(cb, false);
+#pragma unroll
+  for (int e = 0; e < 7; ++e) dma_a(e, 1);
+  advance(ca, true);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) dma_b(e, 1);
+  advance(cb, false);
+#pragma unroll
+  for (int e = 0; e < 7; ++e) dma_a(e, 2);
+  advance(ca, true);
+  asm volatile("s_waitcnt vmcnt(22)" ::: "memory");      // A(0), B(0) landed
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NI; ++i) a0[i] = *(lds_frag)(uintptr_t)(pA[0] + i * 2048);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) b0[j] = *(lds_frag)(uintptr_t)(pB[0] + j * 2048);
+  __builtin_amdgcn_sched_barrier(0);
+
+  bool pending = false, pend_interior = false;
+  int s = 0, sa = 0;                     // sa = s % 3
+  uint32_t curA = 0, nxtA = ASTG, curB = 0, nxtB = BSTG;
+  // phase 1: kk = 0 from (a0, b0); the kk = 1 fragments of this K-tile are read underneath.  FIRST: C = 0 form (first K-tile of a tile)
+  auto phase1 = [&](auto FIRST_) __attribute__((always_inline)) {
+    constexpr bool FIRST = decltype(FIRST_)::value;
+#pragma unroll
+    for (int gI = 0; gI < NG; ++gI) {
+      // fragment reads in the FIRST half of the phase, two per group (one wave per SIMD: a read issued in the last group would be waited
+      // for at the phase boundary with nothing to hide its latency behind)
+#pragma unroll
+      for (int x = 2 * gI; x < 2 * gI + 2 && x < NI + 8; ++x) {
+        if (x < NI) a1[x] = *(lds_frag)(uintptr_t)(pA[1] + curA + x * 2048);
+        else b1[x - NI] = *(lds_frag)(uintptr_t)(pB[1] + curB + (x - NI) * 2048);
+      }
+      // the previous tile's last row group leaves under the first row groups' MFMAs (they do not touch its accumulators)
+      if (FIRST && gI == 1) { if (pending) store_half(NI - 1, 0); }
+      if (FIRST && gI == 3) { if (pending) store_half(NI - 1, 1); }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int t = gI * 4 + q, i = t >> 3, j = t & 7;
+        if constexpr (FIRST) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[i], b0[j], zero, 0, 0, 0);
+        else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[i], b0[j], acc[i][j], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // middle of a K-tile: K-tile s + 1 landed (this wave's pieces) - behind them only the 7 A pieces of K-tile s + 2 and, in the first
+  // K-tile after an INTERIOR tile, the 36 stores issued behind the first of those pieces (exact; a ragged tile skips stores: plain count)
+  auto middle = [&](bool after_interior) __attribute__((always_inline)) {
+    if (after_interior) asm volatile("s_waitcnt vmcnt(43) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // phase 2: kk = 1 from (a1, b1); B(s + 2) and A(s + 3) are requested into the stages just read, fragments (s + 1, kk = 0) are read.
+  // LAST (the tile's last MFMAs): row group i is final after groups 2i, 2i + 1 and leaves one row group later, under the MFMAs behind it
+  auto phase2 = [&](auto LAST_) __attribute__((always_inline)) {
+    constexpr bool LAST = decltype(LAST_)::value;
+#pragma unroll
+    for (int gI = 0; gI < NG; ++gI) {
+      if (gI < 8) dma_b(gI, s & 1);
+      if (gI >= 7) dma_a(gI - 7, sa);
+#pragma unroll
+      for (int x = 2 * gI; x < 2 * gI + 2 && x < NI + 8; ++x) {
+        if (x < NI) a0[x] = *(lds_frag)(uintptr_t)(pA[0] + nxtA + x * 2048);
+        else b0[x - NI] = *(lds_frag)(uintptr_t)(pB[0] + nxtB + (x - NI) * 2048);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int t = gI * 4 + q, i = t >> 3, j = t & 7;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
+      }
+      if (LAST && gI >= 2 && gI < 2 * NI) store_half((gI - 2) >> 1, gI & 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    advance(cb, false);
+    advance(ca, true);
+    ++s;
+    sa = sa == 2 ? 0 : sa + 1;
+    curA = sa * ASTG; nxtA = (sa == 2 ? 0 : sa + 1) * ASTG; curB = (s & 1) * BSTG; nxtB = ((s + 1) & 1) * BSTG;
+  };
+  using T_ = std::true_type; using F_ = std::false_type;
+  for (int tl = 0; tl < ntl; ++tl) {                    // nk >= 2
+    const Tile tile = tile_of(tl);
+    phase1(T_{});
+    middle(pending && pend_interior);
+    phase2(F_{});
+    for (int kt = 1; kt < nk - 1; ++kt) {
+      phase1(F_{});
+      middle(false);
+      phase2(F_{});
+    }
+    phase1(F_{});
+    middle(false);
+    em0 = tile.m0; en0 = tile.n0;
+    phase2(T_{});
+    pending = true; pend_interior = em0 + TM <= g.M;
+  }
+  if (pending) { store_half(NI - 1, 0); store_half(NI - 1, 1); }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ---------------------------------------------------------------------------------------------------------------- host
+static unsigned short f2b(float f) { unsigned u; memcpy(&u, &f, 4); u += 0x7fff + ((u >> 16) & 1); return (unsigned short)(u >> 16); }
+static float b2f(unsigned short h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; }
+
+__global__ void ref_kernel(const bf16* A, const bf16* B, const float* bias, float* C, int M, int N, int K) {
+  const int n = blockIdx.x * 16 + threadIdx.x, m = blockIdx.y * 16 + threadIdx.y;
+  if (m >= M || n >= N) return;
+  float s = 0.f;
+  for (int k = 0; k < K; ++k) s += (float)A[(size_t)m * K + k] * (float)B[(size_t)n * K + k];
+  C[(size_t)m * N + n] = s + bias[n];
+}
+
+template <int TMX>
+static void launch(const Args& g, int grid_slots) {
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4w2_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); attr = true; }
+  const int nt = ((g.M + TM - 1) / TM) * (g.N / 256);
+  hipLaunchKernelGGL(gemm4w2_kernel<0>, dim3(nt < grid_slots ? nt : grid_slots), dim3(256), LDS_BYTES, 0, g);
+}
+
+int main(int argc, char** argv) {
+  const int only = argc > 1 ? atoi(argv[1]) : 0;
+  // ---- validation: several tiles per workgroup, ragged M, both tile heights
+  for (int tmsel = 0; tmsel < 2 && !only; ++tmsel) {
+    const int M = 1800, N = 768, K = 512, Mp = 2048;
+    std::vector<unsigned short> hA((size_t)Mp * K), hB((size_t)N * K);
+    std::vector<float> hbias(N);
+    srand(3 + tmsel);
+    for (auto& v : hA) v = f2b((rand() % 2001 - 1000) / 1000.f);
+    for (auto& v : hB) v = f2b((rand() % 2001 - 1000) / 1000.f);
+    for (auto& v : hbias) v = (rand() % 2001 - 1000) / 500.f;
+    bf16 *dA, *dB, *dC; float *dbias, *dR;
+    hipMalloc(&dA, hA.size() * 2); hipMalloc(&dB, hB.size() * 2); hipMalloc(&dC, (size_t)Mp * N * 2); hipMalloc(&dbias, N * 4); hipMalloc(&dR, (size_t)M * N * 4);
+    hipMemcpy(dA, hA.data(), hA.size() * 2, hipMemcpyHostToDevice); hipMemcpy(dB, hB.data(), hB.size() * 2, hipMemcpyHostToDevice);
+    hipMemcpy(dbias, hbias.data(), N * 4, hipMemcpyHostToDevice);
+    hipMemset(dC, 0x7f, (size_t)Mp * N * 2);
+    Args g{dA, dB, dC, dbias, M, N, K, K, K, N, 0};
+    if (tmsel == 0) launch<224>(g, 5); else launch<224>(g, 3);
+    hipLaunchKernelGGL(ref_kernel, dim3(N / 16, (M + 15) / 16), dim3(16, 16), 0, 0, dA, dB, dbias, dR, M, N, K);
+    hipDeviceSynchronize();
+    std::vector<unsigned short> hC((size_t)Mp * N); std::vector<float> hR((size_t)M * N);
+    hipMemcpy(hC.data(), dC, hC.size() * 2, hipMemcpyDeviceToHost); hipMemcpy(hR.data(), dR, hR.size() * 4, hipMemcpyDeviceToHost);
+    double maxerr = 0; size_t bad = 0, touched = 0;
+    for (int m = 0; m < M; ++m) for (int n = 0; n < N; ++n) {
+      const double e = fabs(hR[(size_t)m * N + n] - b2f(hC[(size_t)m * N + n])) / fmax(1.0, fabs(hR[(size_t)m * N + n]));
+      if (!(e < 1e-2)) ++bad;
+      if (e == e) maxerr = fmax(maxerr, e);
+    }
+    for (int m = M; m < Mp; ++m) for (int n = 0; n < N; ++n) if (hC[(size_t)m * N + n] != 0x7f7f) ++touched;
+    printf("validation TM %d: max rel err %.3e, %zu bad elements, %zu elements touched beyond M (%s)\n", tmsel ? 224 : 256, maxerr, bad, touched,
+           bad == 0 && touched == 0 ? "ok" : "WRONG");
+    hipFree(dA); hipFree(dB); hipFree(dC); hipFree(dbias); hipFree(dR);
+  }
+  // ---- timing
+  struct Shape { int M, N, K; } shapes[] = {{8192, 3072, 8192}, {50208, 768, 3072}, {50208, 768, 2304}, {50208, 2304, 768}, {50208, 768, 768}, {50208, 3072, 768}};
+  for (auto sh : shapes) {
+    const int Mp = (sh.M + 255) / 256 * 256 + 256;
+    const int NS = 3;
+    bf16 *dA[NS], *dB, *dC[NS]; float* dbias;
+    std::vector<unsigned short> h((size_t)Mp * sh.K);
+    for (auto& v : h) v = (unsigned short)(((rand() & 1) << 15) | ((120 + rand() % 8) << 7) | (rand() & 127));
+    for (int s = 0; s < NS; ++s) { hipMalloc(&dA[s], (size_t)Mp * sh.K * 2); hipMemcpy(dA[s], h.data(), (size_t)Mp * sh.K * 2, hipMemcpyHostToDevice); hipMalloc(&dC[s], (size_t)Mp * sh.N * 2); }
+    hipMalloc(&dB, (size_t)sh.N * sh.K * 2); hipMemcpy(dB, h.data(), (size_t)sh.N * sh.K * 2, hipMemcpyHostToDevice);
+    hipMalloc(&dbias, sh.N * 4); hipMemset(dbias, 0, sh.N * 4);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int nostore = 0; nostore < 4; ++nostore) {
+      const int tmsel = 1;
+      auto run = [&](int s) { Args g{dA[s], dB, dC[s], dbias, sh.M, sh.N, sh.K, sh.K, sh.K, sh.N, nostore}; launch<224>(g, 256); };
+      for (int i = 0; i < 4; ++i) run(i % NS);
+      hipDeviceSynchronize();
+      const int reps = 12;
+      float best = 1e9;
+      for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0); for (int i = 0; i < reps; ++i) run(i % NS); hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); best = fminf(best, ms);
+      }
+      printf("M %6d N %5d K %5d %s: %8.1f us  %7.0f TFLOP/s\n", sh.M, sh.N, sh.K, nostore == 0 ? "stores     " : nostore == 1 ? "no stores  " : nostore == 2 ? "hot stores " : "1/4 real   ", best / reps * 1e3, 2.0 * sh.M * sh.N * sh.K / (best / reps) / 1e9);
+    }
+    for (int s = 0; s < NS; ++s) { hipFree(dA[s]); hipFree(dC[s]); } hipFree(dB); hipFree(dbias);
+  }
+  return 0;
+}
