@@ -42,7 +42,10 @@ class AllGather_multi(torch.autograd.Function):
 
 
 def allgather_pair(a, b, args):
-    """One collective for both embedding sets: [B, da + db] -> split after the gather."""
+    """One collective for both embedding sets: [B, da + db] -> split after the gather.  A single rank has nothing to gather
+    (the reference's AllGather_multi is then the identity, trainer_dist.py:29-45): no pack / copy / split launches."""
+    if args.world_size == 1:
+        return a, b
     packed = AllGather_multi.apply(torch.cat([a, b], dim=1), args.world_size, args)
     return packed[:, :a.shape[1]], packed[:, a.shape[1]:]
 
