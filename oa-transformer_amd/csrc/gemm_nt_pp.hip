@@ -229,7 +229,10 @@ OAT_DEV bool pp_epilogue(const GemmArgs& g, const f32x4 (&acc)[8][4], int m0, in
     f32x4 an[4] = {}, ac[4] = {};
     if constexpr (ABLK) {
 #pragma unroll
-      for (int i = 0; i < NI; ++i) aw[i] = *reinterpret_cast<const uint4*>(ablk + (size_t)((uint32_t)i * blks));
+      for (int i = 0; i < NI; ++i) {           // read once: non-temporal (−3 % alone, equal in the step)
+        const u32x4 t_ = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ablk + (size_t)((uint32_t)i * blks)));
+        aw[i] = uint4{t_[0], t_[1], t_[2], t_[3]};
+      }
       asm volatile("" ::: "memory");
     } else if constexpr (EPI == EPI_MUL_AUX) {
 #pragma unroll
