@@ -263,6 +263,12 @@ int oat_linear_f32_qkv(const float* A, int lda, const float* Wq, const float* Wk
                        const float* bq, const float* bk, const float* bv, int M, int n, int K,
                        float* out32, int ldo, void* out16, int ld16, void* stream);
 
+/* Backward of a FEW-row linear layer y = act(x) W^T + b (the projection heads txt_proj = ReLU -> Linear, vid_proj = Linear on B rows,
+ * oa_model.py:66-78 and their autograd backward): dx [M, K] (NULL: not wanted), dW [N, K] dense, db [N] (NULL: no bias) from dy [M, N] in one
+ * launch of fp32 arithmetic (deterministic row order).  relu_in: act = ReLU.  1 <= M <= 64, K % 16 == 0.  Written, not accumulated. */
+int oat_linear_small_bwd(const float* x, int ldx, const float* dy, int lddy, const float* W, int ldw, int M, int N, int K,
+                         int relu_in, float* dx, int lddx, float* dW, float* db, void* stream);
+
 /* ---- text encoder (HF DistilBertModel, called at oa_model.py:113; third-party algorithm) ---------
  * ids / mask are int64.  Attention: qkv bf16 [B*L, 3*D]; masked keys are skipped. */
 int oat_embed_fwd(const void* ids, const float* word, const float* pos, float* out, int ld, int M, int L,

@@ -6,6 +6,11 @@ from torch import nn
 from ..ops import hip
 
 
+import os
+
+HEAD_FUSED = os.environ.get("OAT_HEAD_FUSED", "1") != "0"     # projection heads / InfoNCE in their few-launch forms (0: the earlier many-launch path)
+
+
 def _round_up(x, m):
     return (x + m - 1) // m * m
 
@@ -20,6 +25,15 @@ class _LinearFn(torch.autograd.Function):
         x = x.float().contiguous()
         M, K = x.shape
         N = weight.shape[0]
+        ctx.small = False
+        if HEAD_FUSED and M <= 64 and K % 16 == 0 and weight.is_contiguous() and (M * (N + 1) + 32 * M + 16 * N) * 4 <= 96 * 1024:
+            # the projection heads (B rows): one launch forward, one launch backward (oat_linear_small_bwd), no bf16 copies
+            y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+            hip.linear_f32(x, weight.detach(), M, N, K, bias=bias.detach() if bias is not None else None, out32=y,
+                           act=hip.LIN_RELU_IN if pre_relu else hip.LIN_NONE)
+            ctx.save_for_backward(x, weight)
+            ctx.small, ctx.pre_relu, ctx.has_bias = True, pre_relu, bias is not None
+            return y
         a16 = torch.zeros(_round_up(M, 64), K, dtype=torch.bfloat16, device=x.device)
         if pre_relu:
             hip.relu_bf16(x, a16, M, K)
@@ -41,6 +55,13 @@ class _LinearFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        if ctx.small:
+            x, weight = ctx.saved_tensors
+            dy = dy.float().contiguous()
+            M, N = dy.shape
+            dx, dW, db = hip.linear_small_bwd(x, dy, weight.detach(), M, N, x.shape[1], relu_in=ctx.pre_relu,
+                                              want_dx=ctx.needs_input_grad[0], want_db=ctx.has_bias)
+            return dx, dW, db, None
         x, a16, wT16 = ctx.saved_tensors
         dy = dy.float().contiguous()
         M, N = dy.shape
@@ -106,6 +127,31 @@ def sim_matrix(a, b, eps=1e-8):
     if not a.is_cuda:
         raise hip.OatError("sim_matrix runs on MI355X only (no CPU path); use the oracle for CPU")
     return _SimFn.apply(a, b, eps)
+
+
+class _InfoNCEFn(torch.autograd.Function):
+    """NormSoftmaxLoss(sim_matrix(t, v)) (trainer_dist.py:159-163: loss.py:13-25 on oa_model.py:192-200) as ONE function on the
+    (gathered) embeddings: oat_infonce produces the loss and both embedding gradients in its forward launches; backward scales
+    them.  Same kernels as the two-function path (sim_matrix + NormSoftmaxLoss), without the autograd glue between them."""
+
+    @staticmethod
+    def forward(ctx, t, v, temperature, eps):
+        t, v = t.float().contiguous(), v.float().contiguous()
+        loss, _, dt, dv = hip.infonce(t, v, temperature, eps, want_grads=True)
+        ctx.save_for_backward(dt, dv)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        dt, dv = ctx.saved_tensors
+        return dt * g, dv * g, None, None
+
+
+def infonce_loss(t, v, temperature=0.05, eps=1e-8):
+    """loss_fn(sim_matrix(t, v)) for a NormSoftmaxLoss(temperature) in one autograd node (t, v: [n, d] embeddings of all ranks)."""
+    if not t.is_cuda:
+        raise hip.OatError("infonce_loss runs on MI355X only (no CPU path); use the oracle for CPU")
+    return _InfoNCEFn.apply(t, v, temperature, eps)
 
 
 class _NormSoftmaxFn(torch.autograd.Function):

@@ -866,6 +866,16 @@ def linear_f32(A, W, M, N, K, bias=None, out32=None, out16=None, out16b=None, re
                                 int(act), _stream()), "oat_linear_f32")
 
 
+def linear_small_bwd(x, dy, W, M, N, K, relu_in=False, want_dx=True, want_db=True):
+    """(dx, dW, db) of y = act(x) @ W^T + b for M <= 64 rows in ONE launch (fp32, deterministic); None where not wanted."""
+    dx = torch.empty(M, K, dtype=torch.float32, device=x.device) if want_dx else None
+    dW = torch.empty(N, K, dtype=torch.float32, device=x.device)
+    db = torch.empty(N, dtype=torch.float32, device=x.device) if want_db else None
+    _check(lib().oat_linear_small_bwd(_ptr(x), x.stride(0), _ptr(dy), dy.stride(0), _ptr(W), W.stride(0), M, N, K, int(relu_in),
+                                      _ptr(dx), dx.stride(0) if dx is not None else 0, _ptr(dW), _ptr(db), _stream()), "oat_linear_small_bwd")
+    return dx, dW, db
+
+
 def linear_f32_qkv(A, Wq, Wk, Wv, M, n, K, bq=None, bk=None, bv=None, out32=None, out16=None):
     """[q | k | v] = A[M,K] @ [Wq; Wk; Wv]^T + [bq | bk | bv] in one launch (three separate fp32 [n, K] weights, one [M, 3n] output);
     bit-identical to three linear_f32 calls on the column slices.  n % 128 == 0, K % 32 == 0, M > 64."""

@@ -1,13 +1,24 @@
 """The hot path proper: ONE optimiser step (trainer_dist.py:156-168 of the reference), shared by the
 trainers, bench.py and the smoke test so that what is benchmarked is what trains."""
 try:
-    from OATrans.model.layers import sim_matrix
+    from OATrans.model import layers as layers_mod
+    from OATrans.model.layers import infonce_loss, sim_matrix
+    from OATrans.model.loss import NormSoftmaxLoss
     from OATrans.model.oa_layers import bce_sum, mean_rows
     from OATrans.parallel import allgather_packed, allgather_pair
 except ImportError:
-    from model.layers import sim_matrix
+    from model import layers as layers_mod
+    from model.layers import infonce_loss, sim_matrix
+    from model.loss import NormSoftmaxLoss
     from model.oa_layers import bce_sum, mean_rows
     from parallel import allgather_packed, allgather_pair
+
+
+def _nce(loss_fn, t, v):
+    """loss_fn(sim_matrix(t, v)); a NormSoftmaxLoss takes the one-node form (same kernels, no autograd glue in between)."""
+    if layers_mod.HEAD_FUSED and type(loss_fn) is NormSoftmaxLoss:
+        return infonce_loss(t, v, loss_fn.temperature)
+    return loss_fn(sim_matrix(t, v))
 
 
 def hot_step(model_dp, loss_fn, optimizer, data, args):
@@ -19,7 +30,7 @@ def hot_step(model_dp, loss_fn, optimizer, data, args):
     optimizer.zero_grad()
     text_embeds, video_embeds = model_dp(data, aug=True)
     video_all, text_all = allgather_pair(video_embeds, text_embeds, args)
-    loss = loss_fn(sim_matrix(text_all, video_all))
+    loss = _nce(loss_fn, text_all, video_all)
     model_dp.backward(loss) if hasattr(model_dp, 'backward') else loss.backward()
     model_dp.sync_gradients()
     optimizer.step()
@@ -44,7 +55,7 @@ def region_mem_step(model_dp, loss_fn, optimizer, data, args):
     if patch_mask.dim() == 4:
         patch_mask = patch_mask.squeeze(1)
     video, text, rsim, patch_mask = allgather_packed([video, text, rsim, patch_mask], args)
-    loss = loss_fn(sim_matrix(text, video))
+    loss = _nce(loss_fn, text, video)
     rs = rsim.reshape(-1, rsim.shape[-1])
     pm = patch_mask.reshape(-1, patch_mask.shape[-1])
     loss = loss + 0.1 * bce_sum(rs, pm) / rs.shape[0]
@@ -60,6 +71,6 @@ def global_local_step(model_dp, loss_fn, optimizer, data, args):
     region_feat, tags_feat = extra[4], extra[5]
     video, pad_text, pad_video, text, region_feat, tags_feat = allgather_packed(
         [video, pad_text, pad_video, text, region_feat, tags_feat], args)
-    loss = loss_fn(sim_matrix(text, video)) + loss_fn(sim_matrix(pad_text, video))
-    loss = loss + loss_fn(sim_matrix(mean_rows(region_feat), mean_rows(tags_feat)))
+    loss = _nce(loss_fn, text, video) + _nce(loss_fn, pad_text, video)
+    loss = loss + _nce(loss_fn, mean_rows(region_feat), mean_rows(tags_feat))
     return _finish(model_dp, optimizer, loss)

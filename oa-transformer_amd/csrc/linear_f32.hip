@@ -433,6 +433,80 @@ extern "C" int oat_linear_f32(const float* A, int lda, const float* W, int ldw, 
   return check_launch("linear_f32");
 }
 
+// ---- backward of a FEW-row linear layer (the projection heads: txt_proj = ReLU -> Linear(768, 256), vid_proj = Linear(768, 256) on B rows,
+// /root/reference/OATrans/model/oa_model.py:66-78): dx, dW and db of y = act(x) W^T + b in ONE launch of plain fp32 arithmetic.  The
+// bf16 GEMM path took a zero-fill, two casts, a weight-gradient GEMM + reduce, a column sum + reduce, a data-gradient GEMM and a ReLU
+// mask - eleven launches of ~5 us around 6 MFLOP, in the serial stretch between the towers' forward and backward.
+// Workgroup = 16 columns of K: dy [M, N] (pitch N + 1), act(x)[:, 16] and W[:, 16] in LDS; thread n owns dW[n, 16], four threads own a row of dx.
+namespace oat {
+struct LinBwdArgs { const float* x; int ldx; const float* dy; int lddy; const float* W; int ldw; int M, N, K, relu_in;
+                    float* dx; int lddx; float* dW; float* db; };
+__global__ __launch_bounds__(256) void linear_small_bwd_kernel(LinBwdArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float lsm[];
+  const int P = g.N + 1;
+  float* const dys = lsm;                       // [M][N + 1]
+  float* const xs = dys + g.M * P;              // [M][16]   act(x)
+  float* const ms = xs + g.M * 16;              // [M][16]   1 where the input passes the ReLU (all ones without it)
+  float* const ws = ms + g.M * 16;              // [N][16]
+  const int k0 = blockIdx.x * 16, tid = threadIdx.x;
+  for (int i = tid; i < g.M * g.N; i += 256) { const int m = i / g.N, n = i - m * g.N; dys[m * P + n] = g.dy[(size_t)m * g.lddy + n]; }
+  for (int i = tid; i < g.M * 16; i += 256) {
+    const int m = i >> 4, kk = i & 15;
+    const float v = g.x[(size_t)m * g.ldx + k0 + kk];
+    const bool pass = !g.relu_in || v > 0.f;
+    xs[i] = pass ? v : 0.f;
+    ms[i] = pass ? 1.f : 0.f;
+  }
+  for (int i = tid; i < g.N * 16; i += 256) ws[i] = g.W[(size_t)(i >> 4) * g.ldw + k0 + (i & 15)];
+  __syncthreads();
+  // dW[n, k0 .. k0 + 16) = sum_m dy[m, n] act(x)[m, k]        (rows in order: deterministic)
+  for (int n = tid; n < g.N; n += 256) {
+    float a[16];
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) a[kk] = 0.f;
+    for (int m = 0; m < g.M; ++m) {
+      const float d = dys[m * P + n];
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) a[kk] = __builtin_fmaf(d, xs[m * 16 + kk], a[kk]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(g.dW + (size_t)n * g.K + k0 + q * 4) = f32x4{a[q * 4], a[q * 4 + 1], a[q * 4 + 2], a[q * 4 + 3]};
+    if (blockIdx.x == 0 && g.db) {
+      float sb = 0.f;
+      for (int m = 0; m < g.M; ++m) sb += dys[m * P + n];
+      g.db[n] = sb;
+    }
+  }
+  // dx[m, k0 .. k0 + 16) = mask * sum_n dy[m, n] W[n, k]
+  if (g.dx) {
+    for (int i = tid; i < g.M * 4; i += 256) {
+      const int m = i >> 2, kq = (i & 3) * 4;
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+      for (int n = 0; n < g.N; ++n) a += dys[m * P + n] * *reinterpret_cast<const f32x4*>(ws + n * 16 + kq);
+      const f32x4 mk = *reinterpret_cast<const f32x4*>(ms + m * 16 + kq);
+      *reinterpret_cast<f32x4*>(g.dx + (size_t)m * g.lddx + k0 + kq) = a * mk;
+    }
+  }
+}
+}  // namespace oat
+
+// dx [M, K] (optional), dW [N, K] (dense), db [N] (optional) of y = act(x) W^T + b given dy [M, N]; relu_in: act = ReLU (txt_proj).
+// M <= 64, K % 16 == 0, (M (N + 1) + 32 M + 16 N) floats of LDS <= 96 KB.  Results are written, not accumulated.
+extern "C" int oat_linear_small_bwd(const float* x, int ldx, const float* dy, int lddy, const float* W, int ldw, int M, int N, int K,
+                                    int relu_in, float* dx, int lddx, float* dW, float* db, void* stream) {
+  using namespace oat;
+  if (M <= 0 || M > 64 || N <= 0 || K <= 0 || K % 16 != 0) { set_error("linear_small_bwd: 1 <= M <= 64, K % 16 == 0"); return -1; }
+  if (!x || !dy || !W || !dW) { set_error("linear_small_bwd: null pointer"); return -4; }
+  const size_t lds = ((size_t)M * (N + 1) + 32 * (size_t)M + 16 * (size_t)N) * sizeof(float);
+  if (lds > 96 * 1024) { set_error("linear_small_bwd: M x N too large for the LDS"); return -3; }
+  if (lddx % 4 != 0 && dx) { set_error("linear_small_bwd: lddx % 4 must be 0"); return -2; }
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_small_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr = true; }
+  LinBwdArgs g{x, ldx, dy, lddy, W, ldw, M, N, K, relu_in, dx, lddx, dW, db};
+  OAT_LAUNCH(linear_small_bwd_kernel, dim3(K / 16), dim3(256), (unsigned)lds, (hipStream_t)stream, g);
+  return check_launch("linear_small_bwd");
+}
+
 // out[M, 3 n] = A[M, K] . [Wq; Wk; Wv]^T + [bq | bk | bv]: the three n x K linear layers of an attention block (HF DistilBERT keeps q_lin /
 // k_lin / v_lin as separate parameters, /root/reference/OATrans/model/oa_model.py:27 -> transformers 4.6 MultiHeadSelfAttention) in ONE launch
 // of the split-bf16 kernel - same arithmetic per output element as three oat_linear_f32 calls, three times the workgroups per launch

@@ -894,3 +894,34 @@ def test_linear_f32_qkv_is_three_linears(M, n, K):
         assert (o32.double() - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
     with pytest.raises(hip.OatError):
         hip.linear_f32_qkv(x, W[0], W[1], W[2], M, n - 64, K, out32=o32)
+
+
+@pytest.mark.parametrize("M,N,K,relu", [(32, 256, 768, False), (32, 256, 768, True), (5, 64, 48, True), (64, 256, 256, False)])
+def test_linear_small_bwd(M, N, K, relu):
+    """oat_linear_small_bwd (backward of the projection heads in one launch): dx, dW, db of y = act(x) W^T + b against fp64 autograd."""
+    hip = _hip()
+    x = rnd(M, K, seed=80); W = rnd(N, K, scale=K ** -0.5, seed=81); dy = rnd(M, N, seed=82)
+    dx, dW, db = hip.linear_small_bwd(x, dy, W, M, N, K, relu_in=relu)
+    xd = x.double().requires_grad_(True); Wd = W.double().requires_grad_(True); bd = torch.zeros(N, dtype=torch.float64, device=DEV, requires_grad=True)
+    y = (torch.relu(xd) if relu else xd) @ Wd.t() + bd
+    y.backward(dy.double())
+    for got, want in ((dx, xd.grad), (dW, Wd.grad), (db, bd.grad)):
+        assert (got.double() - want).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item())
+    dx2, dW2, db2 = hip.linear_small_bwd(x, dy, W, M, N, K, relu_in=relu, want_dx=False, want_db=False)
+    assert dx2 is None and db2 is None and torch.equal(dW2, dW)
+    with pytest.raises(hip.OatError):
+        hip.linear_small_bwd(rnd(65, K, seed=83), rnd(65, N, seed=84), W, 65, N, K)
+
+
+def test_infonce_loss_is_sim_matrix_plus_loss():
+    """model.layers.infonce_loss (one autograd node, what trainer/step.py uses for a NormSoftmaxLoss) gives the loss and the
+    embedding gradients of NormSoftmaxLoss(sim_matrix(t, v)) - same kernels, bit for bit."""
+    _hip()
+    from OATrans.model.layers import infonce_loss, sim_matrix
+    from OATrans.model.loss import NormSoftmaxLoss
+    for n, d in ((32, 256), (7, 64), (96, 256)):
+        t = rnd(n, d, seed=90).requires_grad_(True); v = rnd(n, d, seed=91).requires_grad_(True)
+        la = NormSoftmaxLoss(0.05)(sim_matrix(t, v)); (la * 0.5).backward()
+        ga = (t.grad.clone(), v.grad.clone()); t.grad = None; v.grad = None
+        lb = infonce_loss(t, v, 0.05); (lb * 0.5).backward()
+        assert torch.equal(la.detach(), lb.detach()) and torch.equal(ga[0], t.grad) and torch.equal(ga[1], v.grad)
