@@ -1,3 +1,6 @@
+#!/bin/bash
+# Dev, runs on the GPU box: in-step durations of selected kernels (KERNELS=a,b,..) under rocprofv3 --stats for two library builds:
+# oa-transformer_amd/_ab/lib_base.so (OAT_LIB) against the product library.
 set -u
 cd "${GRAFT_REPO_ROOT:-$(pwd)}"; export TMPDIR=/tmp
 for l in base new; do
@@ -8,8 +11,10 @@ for l in base new; do
 import glob, sys, pandas as pd
 f = glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True)
 d = pd.read_csv(f[0])
-for k in ("tn_sk_fix", "ln_fold_grads", "gemm_tn_sk_kernel"):
-    r = d[d.Name.str.contains(k)]
-    print(sys.argv[2], k, r.Calls.sum(), round(r.TotalDurationNs.sum() / max(1, r.Calls.sum()) / 1e3, 1), "us")
+import os
+pats = os.environ.get("KERNELS", "tn_sk_fix,ln_fold_grads,gemm_tn_sk_kernel").split(",")
+for k in pats:
+    r = d[d.Name.str.contains(k, regex=False)]
+    print(sys.argv[2], k, r.Calls.sum(), round(r.TotalDurationNs.sum() / max(1, r.Calls.sum()) / 1e3, 1), "us", round(r.TotalDurationNs.sum() / 1e6 / 8, 2), "ms per step")
 PY
 done
