@@ -134,11 +134,23 @@ __global__ void adamw_kernel(float* p, const float* g, float* m, float* v, size_
                              const float* coef = nullptr) {
   if (coef != nullptr) { lr = coef[0]; bc1 = coef[1]; bc2 = coef[2]; }
   const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
-  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+  // The four loads of a lane's NEXT quad are requested before the three stores of the current one: vmcnt retires in issue order, so a
+  // load issued behind the stores would only be usable once they are written (one store round trip per iteration and lane).
+  size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  f32x4 pp = {}, gg = {}, mm = {}, vv = {};
+  if (i + 4 <= n) {
+    pp = *reinterpret_cast<f32x4*>(p + i); gg = *reinterpret_cast<const f32x4*>(g + i);
+    mm = *reinterpret_cast<f32x4*>(m + i); vv = *reinterpret_cast<f32x4*>(v + i);
+  }
+  for (; i < n; i += stride) {
     if (i + 4 <= n) {
-      f32x4 pp = *reinterpret_cast<f32x4*>(p + i);
-      const f32x4 gg = *reinterpret_cast<const f32x4*>(g + i) * gscale;
-      f32x4 mm = *reinterpret_cast<f32x4*>(m + i), vv = *reinterpret_cast<f32x4*>(v + i);
+      const size_t j = i + stride;
+      f32x4 pn = {}, gn = {}, mn = {}, vn = {};
+      if (j + 4 <= n) {
+        pn = *reinterpret_cast<f32x4*>(p + j); gn = *reinterpret_cast<const f32x4*>(g + j);
+        mn = *reinterpret_cast<f32x4*>(m + j); vn = *reinterpret_cast<f32x4*>(v + j);
+      }
+      gg *= gscale;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         mm[e] = b1 * mm[e] + (1.f - b1) * gg[e];
@@ -154,6 +166,7 @@ __global__ void adamw_kernel(float* p, const float* g, float* m, float* v, size_
       *reinterpret_cast<f32x4*>(p + i) = pp;
       *reinterpret_cast<f32x4*>(m + i) = mm;
       *reinterpret_cast<f32x4*>(v + i) = vv;
+      pp = pn; gg = gn; mm = mn; vv = vn;
     } else {
       for (size_t k = i; k < n; ++k) {
         const float gk = g[k] * gscale;
