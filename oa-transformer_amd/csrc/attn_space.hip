@@ -398,6 +398,10 @@ __global__ __launch_bounds__(WIDE == 1 ? 1024 : WIDE == 3 ? 64 : 512, WIDE == 2 
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         const int kt = 2 * u + hf;
+        if (hf == 1 && kt * 16 > N) {      // wave-uniform: the pass's second key tile is pure padding (197 keys: tile 13 of 14) - its dS is zero
+          dsA[1] = f32x4{0, 0, 0, 0}; dsB[1] = f32x4{0, 0, 0, 0};
+          continue;
+        }
         // dP - delta comes out of the matrix pipe: the accumulator starts at -delta (this lane's query) instead of zero
         f32x4 sA = {0, 0, 0, 0}, pA = {-dlA, -dlA, -dlA, -dlA}, sB = {0, 0, 0, 0}, pB = {-dlB, -dlB, -dlB, -dlB};
 #pragma unroll
@@ -502,6 +506,10 @@ __global__ __launch_bounds__(WIDE == 1 ? 1024 : WIDE == 3 ? 64 : 512, WIDE == 2 
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         const int q0 = u * 32 + hf * 16;
+        if (hf == 1 && q0 > N) {           // wave-uniform: the pass's second query tile is pure padding - P and dS are zero
+          pvA[1] = f32x4{0, 0, 0, 0}; svA[1] = f32x4{0, 0, 0, 0}; pvB[1] = f32x4{0, 0, 0, 0}; svB[1] = f32x4{0, 0, 0, 0};
+          continue;
+        }
         // this lane's four query rows q0 + 4g .. + 3 are contiguous: one 16-byte read each for lse and delta
         const f32x4 lq4 = *reinterpret_cast<const f32x4*>(lse_s + q0 + g * 4), dl4 = *reinterpret_cast<const f32x4*>(del_s + q0 + g * 4);
         f32x4 sA = {0, 0, 0, 0}, pA = -dl4, sB = {0, 0, 0, 0}, pB = -dl4;      // accumulators start at -delta (row r = query q0 + 4g + r)
