@@ -346,7 +346,7 @@ __global__ __launch_bounds__(WIDE == 1 ? 1024 : WIDE == 3 ? 64 : 512, WIDE == 2 
     d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x141, 0xF, 0xF, true));
     if (c == 0 && j < NKP) {
       del_s[j] = j <= N ? d : 0.f;
-      lse_s[j] = j <= N ? lv[it] * LOG2E : 0.f;
+      lse_s[j] = j <= N ? lv[it] * LOG2E : INFINITY;     // a padding QUERY's exp2(s c2 - lse) is exactly 0: no select in the passes below
     }
   }
   __syncthreads();
@@ -391,10 +391,26 @@ __global__ __launch_bounds__(WIDE == 1 ? 1024 : WIDE == 3 ? 64 : 512, WIDE == 2 
     f32x4 dqA[4], dqB[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) { dqA[dt] = f32x4{0, 0, 0, 0}; dqB[dt] = f32x4{0, 0, 0, 0}; }
+    // SPACE: no masked path.  A padding query has lse = +inf (above); what depends on the KEY - padding keys and the CLS -> CLS pair that
+    // only frame 0 counts - lives in the last pass alone and is folded into the lse OPERAND of its eight rows: lqv[hf][r] = ok ? lse : +inf,
+    // so exp2(s c2 - lqv) is exactly zero where the mask was (no compare / select per element; 21 % of the passes took the masked path)
+    f32x4 lqvA[2] = {f32x4{lqA, lqA, lqA, lqA}, f32x4{lqA, lqA, lqA, lqA}}, lqvB[2] = {f32x4{lqB, lqB, lqB, lqB}, f32x4{lqB, lqB, lqB, lqB}};
+    auto last_pass_lse = [&]() {
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = (2 * (nu - 1) + hf) * 16 + g * 4 + r;
+          const bool clsdup = key == N && f != 0;
+          lqvA[hf][r] = (key <= N && !(qiA == N && clsdup)) ? lqA : INFINITY;
+          lqvB[hf][r] = (key <= N && !(qiB == N && clsdup)) ? lqB : INFINITY;
+        }
+    };
+    if (!TIME && nu == 1) last_pass_lse();
 #pragma unroll 1
     for (int u = 0; u < nu; ++u) {
       f32x4 dsA[2], dsB[2];
-      const bool plain = !TIME && (qt0 + (two ? 2 : 1)) * 16 <= N && u * 32 + 32 <= N;      // wave-uniform
+      const bool plain = !TIME;                                                               // (TIME keeps its block-diagonal masks)
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         const int kt = 2 * u + hf;
@@ -414,11 +430,11 @@ __global__ __launch_bounds__(WIDE == 1 ? 1024 : WIDE == 3 ? 64 : 512, WIDE == 2 
             pB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dfB[ks], pB, 0, 0, 0);
           }
         }
-        if (plain) {          // every query and key of this pass is an ordinary patch row: no masks (the kernel is issue-bound)
+        if (plain) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            dsA[hf][r] = __builtin_amdgcn_exp2f(sA[r] * c2 - lqA) * pA[r];
-            dsB[hf][r] = two ? __builtin_amdgcn_exp2f(sB[r] * c2 - lqB) * pB[r] : 0.f;
+            dsA[hf][r] = __builtin_amdgcn_exp2f(sA[r] * c2 - lqvA[hf][r]) * pA[r];
+            dsB[hf][r] = two ? __builtin_amdgcn_exp2f(sB[r] * c2 - lqvB[hf][r]) * pB[r] : 0.f;
           }
         } else {
 #pragma unroll
@@ -439,6 +455,7 @@ __global__ __launch_bounds__(WIDE == 1 ? 1024 : WIDE == 3 ? 64 : 512, WIDE == 2 
         dqA[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tf, sbA, dqA[dt], 0, 0, 0);
         if (two) dqB[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tf, sbB, dqB[dt], 0, 0, 0);
       }
+      if (!TIME && u == nu - 2) last_pass_lse();              // wave-uniform
     }
     // local rows [t0, t0 + 16) of an output tile -> columns `col0` of their dqkv rows
     auto put_rows = [&](int t0, const f32x4 (&acc)[4], float mul, int col0) {
@@ -502,7 +519,9 @@ __global__ __launch_bounds__(WIDE == 1 ? 1024 : WIDE == 3 ? 64 : 512, WIDE == 2 
 #pragma unroll 1
     for (int u = 0; u < nu; ++u) {
       f32x4 pvA[2], svA[2], pvB[2], svB[2];
-      const bool plain = !TIME && (kt0 + (two ? 2 : 1)) * 16 <= N && u * 32 + 32 <= N;      // wave-uniform
+      // wave-uniform.  Patch keys only: every pass is plain - a padding query has lse = +inf (P = 0 without a select), the CLS query sees
+      // every patch key.  Only the key tile that holds the CLS key and the padding keys keeps the masked form.
+      const bool plain = !TIME && (kt0 + (two ? 2 : 1)) * 16 <= N;
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         const int q0 = u * 32 + hf * 16;
