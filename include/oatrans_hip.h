@@ -238,6 +238,10 @@ int oat_attn_space_fwd_clips(const OatAttnClip* clips, int n_clips, int ldqkv, i
                              void* stream);
 int oat_attn_space_bwd_clips(const OatAttnClip* clips, int n_clips, int ldqkv, int ldo, int lddo, int lddqkv, int N, int H,
                              int D, float scale, void* stream);
+/* TIME attention backward + CLS-row finalize of TWO clips of different frame counts (powers of two <= 16) in one launch: the one-frame
+ * object clip of the OA models (oa_model_global_local.py:170) beside the T-frame video clip; = oat_attn_time_bwd_fin per clip. */
+int oat_attn_time_bwd_clips(const OatAttnClip* clips, int n_clips, int ldqkv, int ldo, int lddo, int lddqkv, int N, int H,
+                            int D, float scale, void* stream);
 int oat_attn_time_bwd_fin(const void* qkv, int ldqkv, const void* out, int ldo, const float* lse,
                           const void* dout, int lddo, void* dqkv, int lddqkv, float* cls_side, int* done, int B, int T,
                           int N, int H, int D, float scale, void* stream);

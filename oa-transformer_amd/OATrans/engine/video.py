@@ -206,6 +206,7 @@ class VideoEngine:
         self.fused_finalize = os.environ.get("OAT_FUSED_FINALIZE", "1") != "0"
         # two clips in one plan (OA models): their space attention as ONE launch each way (0: one launch per clip)
         self.clip_launch = os.environ.get("OAT_CLIP_LAUNCH", "1") != "0"
+        self.time_clip_launch = os.environ.get("OAT_TIME_CLIPS", "1") != "0"      # TIME backward of the object clip + video clip in one launch
         self.fp8 = os.environ.get("OAT_FP8", "0") != "0"
         self.fp8_margin = float(os.environ.get("OAT_FP8_MARGIN", "1.0"))
         # OAT_FP8_BWD=1 (with fp8 on): the data-gradient GEMMs as well (dY as e5m2, W^T as e4m3; weight gradients stay
@@ -505,7 +506,7 @@ class VideoEngine:
         ptrs = tuple(t.data_ptr() for t in params.values())
         gptr = next(iter(grads.values())).data_ptr() if grads else 0
         f8 = (len(self._f8["primed"]), self._f8["key"]) if (self.fp8 and self._f8) else None
-        return (torch.cuda.current_stream().cuda_stream, pl.side.cuda_stream, self.clip_launch, ptrs, gptr, self.fp8, self.fp8_bwd, f8, self.cls_lane, self.h_u8,
+        return (torch.cuda.current_stream().cuda_stream, pl.side.cuda_stream, self.clip_launch, self.time_clip_launch, ptrs, gptr, self.fp8, self.fp8_bwd, f8, self.cls_lane, self.h_u8,
                 self.tail_split, self.bwd_side, self.bwd_nt_grid, self.group_wgrads, self.fold_active(), self.fold_gstream, os.environ.get("OAT_SKIP_Y", "1"), pl.res16, hip.gemm_get_variant(), flags)
 
     @staticmethod
@@ -1004,6 +1005,14 @@ class VideoEngine:
             hip.attn_space_bwd_clips([dict(qkv=sg.rows(qkv), out=sg.rows(o), lse=sg.rows(lse), dout=sg.rows(d_o), dqkv=sg.rows(d_qkv),
                                            cls_side=sg.cls_side, done=sg.cls_done, B=sg.B, T=sg.T) for sg in pl.segs],
                                      pl.segs[0].N, self.H, self.D, self.scale)
+            return
+        pow2 = lambda t: 1 <= t <= 16 and t & (t - 1) == 0
+        if (fin is hip.attn_time_bwd_fin and len(pl.segs) == 2 and pl.segs[0].N == pl.segs[1].N and self.time_clip_launch
+                and pl.segs[0].T == 1 and pl.segs[1].T > 1 and pow2(pl.segs[1].T)):
+            # the one-frame object clip (a 32 us launch on a fraction of the GPU) rides in the video clip's launch
+            hip.attn_time_bwd_clips([dict(qkv=sg.rows(qkv), out=sg.rows(o), lse=sg.rows(lse), dout=sg.rows(d_o), dqkv=sg.rows(d_qkv),
+                                          cls_side=sg.cls_side, done=sg.cls_done, B=sg.B, T=sg.T) for sg in pl.segs],
+                                    pl.segs[0].N, self.H, self.D, self.scale)
             return
         for sg in pl.segs:
             dq = sg.rows(d_qkv)

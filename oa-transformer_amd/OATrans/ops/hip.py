@@ -613,6 +613,13 @@ def attn_space_bwd_clips(clips, N, H, D, scale):
                                           c["dqkv"].stride(0), N, H, D, _f(scale), _stream()), "oat_attn_space_bwd_clips")
 
 
+def attn_time_bwd_clips(clips, N, H, D, scale):
+    """TIME attention backward + fused CLS-row finalize of two clips (frame counts: powers of two <= 16) in one launch"""
+    c = clips[0]
+    _check(lib().oat_attn_time_bwd_clips(_clip_array(clips), len(clips), c["qkv"].stride(0), c["out"].stride(0), c["dout"].stride(0),
+                                         c["dqkv"].stride(0), N, H, D, _f(scale), _stream()), "oat_attn_time_bwd_clips")
+
+
 def attn_cls_finalize(cls_side, dqkv, B, T, N, H, D):
     _check(lib().oat_attn_cls_finalize(_ptr(cls_side), _ptr(dqkv), dqkv.stride(0), B, T, N, H, D, _stream()),
            "oat_attn_cls_finalize")

@@ -254,10 +254,7 @@ __global__ __launch_bounds__(FWD_THREADS, NKT <= 14 ? 4 : 2) void attn_space_fwd
 // group put 7 M contended atomics on 4.6 K addresses).  TT = frame count at compile time (row <-> (position, frame)
 // is a division per row otherwise).
 template <int NKT, bool BIG, int WIDE, bool TIME = false, int TT = 0>
-__global__ __launch_bounds__(WIDE == 1 ? 1024 : WIDE == 3 ? 64 : 512, WIDE == 2 ? 4 : 2) void attn_space_bwd_kernel(SpaceArgs2 aa) {
-  const bool second = (int)blockIdx.x >= aa.n0;            // workgroup-uniform
-  const SpaceArgs& a = aa.s[second ? 1 : 0];
-  const int bid = (int)blockIdx.x - (second ? aa.n0 : 0);
+OAT_DEV void attn_space_bwd_body(const SpaceArgs& a, const int bid) {
   constexpr int NKP = NKT * 16;
   constexpr int THR = WIDE == 1 ? 1024 : WIDE == 3 ? 64 : BWD_THREADS, STEP = (WIDE == 1 || WIDE == 2) ? 1 : 2;
   static_assert(!TIME || (!BIG && NKT == 2), "time mode = 16 local rows + CLS");
@@ -654,6 +651,19 @@ __global__ __launch_bounds__(WIDE == 1 ? 1024 : WIDE == 3 ? 64 : 512, WIDE == 2 
   }
 }
 
+template <int NKT, bool BIG, int WIDE, bool TIME = false, int TT = 0>
+__global__ __launch_bounds__(WIDE == 1 ? 1024 : WIDE == 3 ? 64 : 512, WIDE == 2 ? 4 : 2) void attn_space_bwd_kernel(SpaceArgs2 aa) {
+  const bool second = (int)blockIdx.x >= aa.n0;            // workgroup-uniform
+  attn_space_bwd_body<NKT, BIG, WIDE, TIME, TT>(aa.s[second ? 1 : 0], (int)blockIdx.x - (second ? aa.n0 : 0));
+}
+// TIME backward of two clips with DIFFERENT frame counts in one launch (the one-frame object clip of the OA models beside the T-frame
+// clip): each clip runs the body compiled for its own frame count (a run-time T costs the kernel 16 spilled registers).
+template <int TTA, int TTB>
+__global__ __launch_bounds__(64, 2) void attn_time_bwd2_kernel(SpaceArgs2 aa) {
+  if ((int)blockIdx.x >= aa.n0) attn_space_bwd_body<2, false, 3, true, TTB>(aa.s[1], (int)blockIdx.x - aa.n0);
+  else attn_space_bwd_body<2, false, 3, true, TTA>(aa.s[0], (int)blockIdx.x);
+}
+
 // dqkv[cls row(b)][which*D + h*64 + d] = bf16(side[b][h][which][d]); side is left ZERO again, ready for the next
 // backward launch (saves a memset launch per attention on the backward chain)
 __global__ void attn_cls_finalize_kernel(float* side, bf16* dqkv, int lddqkv, int B, int H, int D, size_t cls_row0) {
@@ -711,6 +721,35 @@ int attn_time_bwd_mfma(const void* qkv, int ldqkv, const void* out, int ldo, con
     case 16: return launch_time_bwd<16>(a, blocks, lds, s);
     default: return launch_time_bwd<0>(a, blocks, lds, s);      // any other T <= 16: runtime row arithmetic
   }
+}
+
+// Two clips of different frame counts in ONE launch: workgroups [0, n0) walk clip 0, the rest clip 1 (each clip with its own rows, CLS
+// side buffer and tickets).  Built for clip 0 = ONE frame (the object frame: alone a 32 us launch on a fraction of the GPU, twelve times
+// per step) and clip 1 = 2, 4, 8 or 16 frames; anything else runs as two launches.
+int attn_time_bwd_mfma_clips(const SpaceArgs& c0, const SpaceArgs& c1, hipStream_t s) {
+  SpaceArgs a[2] = {c0, c1};
+  int blocks[2];
+  for (int i = 0; i < 2; ++i) {
+    a[i].gpw = g_time_gpw > 0 ? g_time_gpw : 4;
+    const int G = 16 / a[i].T, ngrp = (a[i].N + G - 1) / G, nchunk = (ngrp + a[i].gpw - 1) / a[i].gpw;
+    blocks[i] = a[i].B * nchunk * a[i].H;
+  }
+  const int lds = 2 * (4 * 17 * 128 + 2 * 32 * 4);
+  const SpaceArgs2 aa{{a[0], a[1]}, blocks[0], 2};
+  const dim3 grid(blocks[0] + blocks[1]);
+  if (a[0].T == 1 && a[1].T == 2) OAT_LAUNCH((attn_time_bwd2_kernel<1, 2>), grid, dim3(64), lds, s, aa);
+  else if (a[0].T == 1 && a[1].T == 4) OAT_LAUNCH((attn_time_bwd2_kernel<1, 4>), grid, dim3(64), lds, s, aa);
+  else if (a[0].T == 1 && a[1].T == 8) OAT_LAUNCH((attn_time_bwd2_kernel<1, 8>), grid, dim3(64), lds, s, aa);
+  else if (a[0].T == 1 && a[1].T == 16) OAT_LAUNCH((attn_time_bwd2_kernel<1, 16>), grid, dim3(64), lds, s, aa);
+  else {
+    for (int i = 0; i < 2; ++i) {
+      const int rc = attn_time_bwd_mfma(a[i].qkv, a[i].ldqkv, a[i].out, a[i].ldo, a[i].lse, a[i].dout, a[i].lddo, a[i].dqkv, a[i].lddqkv, a[i].cls_side,
+                                        a[i].B, a[i].T, a[i].N, a[i].H, a[i].D, a[i].scale, s, a[i].done);
+      if (rc) return rc;
+    }
+    return 0;
+  }
+  return check_launch("attn_time_bwd_mfma_clips");
 }
 
 static int pick_nkt(int N) {
@@ -786,6 +825,20 @@ extern "C" int oat_attn_space_bwd_clips(const OatAttnClip* c, int n_clips, int l
                      c[i].cls_side, c[i].B, c[i].T, N, H, D, scale, 0, c[i].done};
   }
   return space_bwd2(n_clips == 2 ? two_clips(a[0], a[1]) : one_clip(a[0], a[0].B * a[0].T * H), N, H, D, stream);
+}
+// TIME attention backward (with the fused CLS-row finalize) of two clips in one launch (1 + {2, 4, 8, 16} frames; other pairs: two launches)
+extern "C" int oat_attn_time_bwd_clips(const OatAttnClip* c, int n_clips, int ldqkv, int ldo, int lddo, int lddqkv, int N, int H,
+                                       int D, float scale, void* stream) {
+  if (!c || n_clips != 2) { set_error("attn_time_bwd_clips: two clips"); return -4; }
+  if (D != H * 64) { set_error("attn_time: head_dim must be 64"); return -3; }
+  SpaceArgs a[2];
+  for (int i = 0; i < 2; ++i) {
+    if (!c[i].done || !c[i].cls_side) { set_error("attn_time_bwd_clips: every clip needs its cls_side and ticket buffers"); return -4; }
+    if (c[i].T < 1 || c[i].T > 16) { set_error("attn_time_bwd_clips: 1 <= T <= 16"); return -3; }
+    a[i] = SpaceArgs{(const bf16*)c[i].qkv, ldqkv, (bf16*)c[i].out, ldo, c[i].lse, (const bf16*)c[i].dout, lddo, (bf16*)c[i].dqkv, lddqkv,
+                     c[i].cls_side, c[i].B, c[i].T, N, H, D, scale, 0, c[i].done};
+  }
+  return attn_time_bwd_mfma_clips(a[0], a[1], (hipStream_t)stream);
 }
 extern "C" int oat_attn_space_bwd(const void* qkv, int ldqkv, const void* out, int ldo, const float* lse,
                                   const void* dout, int lddo, void* dqkv, int lddqkv, float* cls_side, int B, int T,

@@ -925,3 +925,53 @@ def test_infonce_loss_is_sim_matrix_plus_loss():
         ga = (t.grad.clone(), v.grad.clone()); t.grad = None; v.grad = None
         lb = infonce_loss(t, v, 0.05); (lb * 0.5).backward()
         assert torch.equal(la.detach(), lb.detach()) and torch.equal(ga[0], t.grad) and torch.equal(ga[1], v.grad)
+
+
+@pytest.mark.parametrize("N,H,T1", [(196, 12, 8), (50, 2, 4), (9, 1, 16)])
+def test_attention_time_bwd_two_clips_one_launch(N, H, T1):
+    """oat_attn_time_bwd_clips: the one-frame object clip and a T-frame clip (powers of two) in ONE launch of the run-time-T
+    instantiation of the MFMA time backward - patch-row gradients bit-identical to one oat_attn_time_bwd_fin launch per clip,
+    CLS rows equal up to the order of their fp32 atomics, side and ticket buffers left zero."""
+    hip = _hip()
+    D = H * 64
+    scale = 64 ** -0.5
+    clips = [(3, 1), (3, T1)]                                  # (B, T)
+    rows = [B * T * N + B for B, T in clips]
+    Mp = (sum(rows) + 255) // 256 * 256
+    qkv = torch.zeros(Mp, 3 * D, dtype=torch.bfloat16, device=DEV); qkv[:sum(rows)] = rnd(sum(rows), 3 * D, scale=1.5, dtype=torch.bfloat16, seed=55)
+    dout = torch.zeros(Mp, D, dtype=torch.bfloat16, device=DEV); dout[:sum(rows)] = rnd(sum(rows), D, dtype=torch.bfloat16, seed=56)
+    out = torch.zeros(Mp, D, dtype=torch.bfloat16, device=DEV); lse = torch.zeros(Mp, H, device=DEV)
+    def segments(dq, side, done):
+        segs, r0 = [], 0
+        for (B, T), n, sd, dn in zip(clips, rows, side, done):
+            sl = slice(r0, r0 + n); r0 += n
+            segs.append(dict(qkv=qkv[sl], out=out[sl], lse=lse[sl], dout=dout[sl], dqkv=dq[sl], cls_side=sd, done=dn, B=B, T=T))
+        return segs
+    def fresh():
+        return (torch.zeros(Mp, 3 * D, dtype=torch.bfloat16, device=DEV), [torch.zeros(B, H, 3, 64, device=DEV) for B, _ in clips],
+                [torch.zeros(B, H, dtype=torch.int32, device=DEV) for B, _ in clips])
+    g0 = fresh()
+    for sg in segments(*g0):                                   # forward (per clip): out / lse of the patch rows and of the CLS rows
+        hip.attn_cls_fwd(sg["qkv"], sg["out"], sg["lse"], sg["B"], sg["T"], N, H, D, scale)
+        hip.attn_time_fwd(sg["qkv"], sg["out"], sg["lse"], sg["B"], sg["T"], N, H, D, scale)
+    res = []
+    for together in (False, True):
+        dq, side, done = fresh()
+        segs = segments(dq, side, done)
+        if together:
+            hip.attn_time_bwd_clips(segs, N, H, D, scale)
+        else:
+            for sg in segs:
+                hip.attn_time_bwd_fin(sg["qkv"], sg["out"], sg["lse"], sg["dout"], sg["dqkv"], sg["cls_side"], sg["done"], sg["B"], sg["T"], N, H, D, scale)
+        assert all(torch.count_nonzero(x) == 0 for x in side + done)
+        res.append(dq)
+    g1, g2 = res
+    r0 = 0
+    for (B, T), n in zip(clips, rows):
+        assert torch.equal(g1[r0:r0 + n - B], g2[r0:r0 + n - B])
+        close(g2[r0 + n - B:r0 + n], g1[r0 + n - B:r0 + n].float(), atol=1e-2 * g1.float().abs().max().item(), rtol=2e-2, what="CLS rows")
+        r0 += n
+    assert torch.count_nonzero(g2[sum(rows):]) == 0
+    with pytest.raises(hip.OatError):
+        bad = segments(*fresh()); bad[1]["T"] = 17
+        hip.attn_time_bwd_clips(bad, N, H, D, scale)
