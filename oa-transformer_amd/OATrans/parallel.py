@@ -54,6 +54,8 @@ def allgather_packed(tensors, args):
     """ONE collective for any number of per-sample tensors [B, ...]: flatten each to [B, -1], concatenate,
     gather with the slice-only backward, split and restore shapes (the reference issues one NCCL call per
     tensor: 6 in trainer_global_local.py:171-182, 4 in trainer_region_mem.py:152-155)."""
+    if args.world_size == 1:      # nothing to gather (cf. allgather_pair): no pack / clone / split launches, no slice backward
+        return [t if t.dtype == torch.float32 else t.float() for t in tensors]
     flat = [t.reshape(t.shape[0], -1).float() for t in tensors]
     widths = [f.shape[1] for f in flat]
     packed = AllGather_multi.apply(torch.cat(flat, dim=1), args.world_size, args)

@@ -5,9 +5,11 @@ sys.path.insert(0, os.path.join(ROOT, "oa-transformer_amd")); sys.path.insert(0,
 import torch
 import bench
 from OATrans.ops import hip
-from OATrans.trainer.step import hot_step
+from OATrans.trainer.step import hot_step as _hs, global_local_step, region_mem_step
 
-args = argparse.Namespace(variant="frozen", frames=8, res=224, batch=32, lr=2e-5, dtype="bf16")
+VAR = os.environ.get("VARIANT", "frozen")
+hot_step = {"frozen": _hs, "global_local": global_local_step, "region_mem": region_mem_step}[VAR]
+args = argparse.Namespace(variant=VAR, frames=8, res=224, batch=32, lr=2e-5, dtype="bf16")
 dev = torch.device("cuda:0")
 dp, opt, loss_fn = bench.build(args, dev)
 data = bench.synthetic_batch(args, 0, dev)
