@@ -1,14 +1,13 @@
 #!/bin/bash
-# Dev, runs on the GPU box: board power / clocks / caps as rocm-smi reports them, idle and while the training step loops.
+# Dev, runs on the GPU box: board power / clocks as rocm-smi reports them while the training step loops (the cap: --showmaxpower).
 cd "${GRAFT_REPO_ROOT:-$(pwd)}"
 OUT=$PWD/gpurun_out/power; mkdir -p "$OUT"
 {
-echo "== idle"; rocm-smi --showpower --showmaxpower --showclocks --showperflevel 2>&1 | grep -v "^=\|^$"
-python bench.py --steps 400 --warmup 3 --no-cpu-baseline --no-other-configs > "$OUT/bench.log" 2>&1 &
+echo "== idle"; rocm-smi --showpower --showmaxpower --showperflevel 2>&1 | grep -i "power\|level"
+python bench.py --steps ${STEPS:-1500} --warmup 3 --no-cpu-baseline --no-other-configs "$@" > "$OUT/bench.log" 2>&1 &
 BP=$!
-sleep 45
-for i in 1 2 3 4 5 6; do echo "== step loop, sample $i"; rocm-smi --showpower --showclocks 2>&1 | grep -i "power\|sclk\|mclk\|fclk"; sleep 1.5; done
+sleep 22
+for i in $(seq 1 14); do echo "== t=$((22 + 2 * i)) s"; rocm-smi --showpower --showclocks --showtemp 2>&1 | grep -i "package power\|sclk\|junction\|hotspot"; sleep 1.6; done
 wait $BP
-tail -1 "$OUT/bench.log" | cut -c1-160
+tail -1 "$OUT/bench.log" | cut -c1-200
 } > "$OUT/power.log" 2>&1
-cat "$OUT/power.log"
