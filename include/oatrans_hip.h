@@ -141,6 +141,13 @@ int oat_layernorm_fwd_r16(const void* x, int x_is_f32, int ldx, const void* add_
                           int ldadd_b, void* sum16, int ldsum, const float* gamma, const float* beta, void* y_bf16,
                           int ldy, float* y_f32, int ldy32, float* mean, float* rstd, int M, int D, float eps,
                           void* stream);
+/* The same with an OCP e4m3 copy of y for an fp8 forward GEMM (config 5: fp8 forward linears ON the bf16 stream):
+ * y8 = e4m3(y * *qscale) with the site's delayed scale, max |y| -> *amax for the next step's scale (cf. oat_layernorm_fwd_f8,
+ * the fp32-stream form).  y (bf16) is still written: backward and the weight gradient read it. */
+int oat_layernorm_fwd_r16_f8(const void* x, int x_is_f32, int ldx, const void* add_a_bf16, int ldadd_a, const void* add_b_bf16,
+                             int ldadd_b, void* sum16, int ldsum, const float* gamma, const float* beta, void* y_bf16,
+                             int ldy, void* y8_e4m3, int ld8, const float* qscale, float* amax, float* mean, float* rstd,
+                             int M, int D, float eps, void* stream);
 /* oat_layernorm_bwd with the forward input x as bf16 and a bf16 residual-gradient addend: dx (fp32 | NULL) and dx16 =
  * LNbwd(dy) + dres16; dres16 may be dx16 itself (in place).  The final norm and the region tap of the bf16 stream. */
 int oat_layernorm_bwd_r16(const void* dy, int dy_is_bf16, int lddy, const void* x_bf16, int ldx, const float* mean,

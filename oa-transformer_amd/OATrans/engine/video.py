@@ -171,7 +171,13 @@ class VideoEngine:
         """The residual stream (and the residual-gradient stream of backward) STORED as bf16: on the folded, bf16, y-not-stored
         path (the default one).  What it costs in parity was measured in the CPU oracle first (scripts/dev/rounding_study3.py):
         sim-matrix error unchanged (it comes from the fp32 CLS lane), gradients 1.8e-2 -> 2.2e-2 relative L2."""
-        return self.res16 and self.fold_active() and not self.fp8 and os.environ.get("OAT_SKIP_Y", "1") != "0"
+        return self.res16 and self.fold_active() and self._fp8_on_stream16() and os.environ.get("OAT_SKIP_Y", "1") != "0"
+
+    def _fp8_on_stream16(self):
+        """May this forward run on the bf16-stream kernels (y not stored, bf16 residual stream)?  bf16: yes.  fp8 forward: yes
+        (OAT_FP8_RES16, default on) - the r16 LayerNorm kernels emit the e4m3 operand themselves (oat_layernorm_fwd_r16_f8);
+        with the fp8 data gradients (OAT_FP8_BWD) the fp32-stream kernels stay."""
+        return not self.fp8 or (self.fp8_res16 and not self.fp8_bwd)
 
     def __init__(self, depth, embed_dim, num_heads, mlp_ratio, patch_size, in_chans, num_frames):
         self.depth, self.D, self.H = depth, embed_dim, num_heads
@@ -215,6 +221,12 @@ class VideoEngine:
         # backward kernels do not write e5m2 themselves yet) while gradient norms drift from <= 5 % to 10-12 % off the
         # fp32 reference in the lowest blocks (tests/test_fp8_gpu.py).
         self.fp8_bwd = os.environ.get("OAT_FP8_BWD", "0") != "0"
+        # fp8 forward on the bf16 residual stream (round 4): until then the fp8 mode kept the fp32 stream and paid 2.5 ms of
+        # LayerNorm bytes for the 2 ms its GEMMs saved.  OAT_FP8_PROJ=0 keeps the two attention projections (K = N = 768) on
+        # bf16: their inputs come from the attention kernels as bf16, so each costs a quantisation pass (measured: still
+        # 0.2 ms per step better on fp8, hence on by default).
+        self.fp8_res16 = os.environ.get("OAT_FP8_RES16", "1") != "0"
+        self.fp8_proj = os.environ.get("OAT_FP8_PROJ", "1") != "0"
         # the saved GELU derivative as 8-bit fixed point where the ping-pong GEMM serves the MLP pair (gemm_nt_pp.hip HU8_*)
         self.h_u8 = os.environ.get("OAT_H_U8", "1") != "0"
         # split-K of the last, 31 %-full round of tiles of the N = 768 GEMMs (gemm_nt_pp.hip PPF_SPLITK).  Correct and
@@ -331,6 +343,11 @@ class VideoEngine:
         """LayerNorm whose output feeds linear j of block i: bf16 y (kept for backward) and its e4m3 copy in pl.x8."""
         q, am, _ = self._f8_site(i, j)
         hip.layernorm_fwd_f8(x, gamma, beta, pl.M, self.D, 1e-6, y, pl.x8, q, am, mean, rstd, add16=add16, sum32=sum32)
+
+    def _ln_f8_kw(self, pl, i, j):
+        """The fp8 arguments of oat_layernorm_fwd_r16_f8 for the LayerNorm in front of linear j of block i."""
+        q, am, _ = self._f8_site(i, j)
+        return dict(y8=pl.x8, qscale=q, amax=am)
 
     def _linear_f8(self, pl, i, j, x16, K, N, epi, out, bias, out2=None, quantised=False):
         """out = x16 @ W^T + bias on fp8 operands.  quantised=True: the producer already left e4m3(x16) in pl.x8 /
@@ -470,7 +487,7 @@ class VideoEngine:
             pl.ga8 = [torch.zeros(pl.Mp, self.D, dtype=torch.uint8, device=dev) for _ in range(3)]   # e5m2 copies of the ga ring
         run = _Run(pl, need_patches, region_layer)
         # folded LayerNorms + bf16 forward: y = x + space is never stored (the next block's norm3 adds both branch outputs)
-        pl.skip_y = self.fold_active() and not self.fp8 and os.environ.get("OAT_SKIP_Y", "1") != "0"
+        pl.skip_y = self.fold_active() and self._fp8_on_stream16() and os.environ.get("OAT_SKIP_Y", "1") != "0"
         pl.fwd_modes = (self.fold_active(), pl.skip_y, pl.res16, self.fp8)      # what the saved activations MEAN: backward checks it
         if pl.skip_y and getattr(pl, "branch16s", None) is None:
             pl.branch16s = torch.zeros(pl.Mp, self.D, dtype=torch.bfloat16, device=dev)
@@ -506,7 +523,7 @@ class VideoEngine:
         ptrs = tuple(t.data_ptr() for t in params.values())
         gptr = next(iter(grads.values())).data_ptr() if grads else 0
         f8 = (len(self._f8["primed"]), self._f8["key"]) if (self.fp8 and self._f8) else None
-        return (torch.cuda.current_stream().cuda_stream, pl.side.cuda_stream, self.clip_launch, self.time_clip_launch, ptrs, gptr, self.fp8, self.fp8_bwd, f8, self.cls_lane, self.h_u8,
+        return (torch.cuda.current_stream().cuda_stream, pl.side.cuda_stream, self.clip_launch, self.time_clip_launch, ptrs, gptr, self.fp8, self.fp8_bwd, self.fp8_proj, f8, self.cls_lane, self.h_u8,
                 self.tail_split, self.bwd_side, self.bwd_nt_grid, self.group_wgrads, self.fold_active(), self.fold_gstream, os.environ.get("OAT_SKIP_Y", "1"), pl.res16, hip.gemm_get_variant(), flags)
 
     @staticmethod
@@ -628,10 +645,11 @@ class VideoEngine:
                         hip.copy_(sg.lane(lane["x"]), x[sg.cls0:sg.end])
                 self._lane_ln(pl, lane["x"], None, None, p("norm3.weight"), p("norm3.bias"), lane["a32"])
         else:
-            if q3:
+            if pl.res16:             # the same on the bf16 stream: out16 = bf16(x + space + mlp), a3 = LN of the unrounded sum
+                hip.layernorm_fwd_r16(pend.xin, M, D, 1e-6, add_a=pl.branch16s, add_b=br, sum16=pend.out, y=a.a3, mean=st[0], rstd=st[1],
+                                      **(self._ln_f8_kw(pl, i, 0) if q3 else {}))
+            elif q3:
                 self._ln_f8(pl, i, 0, pend.y, *ln_gb("norm3"), a.a3, st[0], st[1], add16=br, sum32=pend.out)
-            elif pl.res16:           # the same on the bf16 stream: out16 = bf16(x + space + mlp), a3 = LN of the unrounded sum
-                hip.layernorm_fwd_r16(pend.xin, M, D, 1e-6, add_a=pl.branch16s, add_b=br, sum16=pend.out, y=a.a3, mean=st[0], rstd=st[1])
             elif pl.skip_y:          # out = x + space + mlp of the previous block in one pass (its y = x + space was never stored)
                 hip.add2_layernorm_fwd(pend.xin, pl.branch16s, br, pend.out, *ln_gb("norm3"), M, D, 1e-6, y=a.a3, mean=st[0],
                                        rstd=st[1])
@@ -655,15 +673,15 @@ class VideoEngine:
             self._lane_linear(pl, lane["o32"], p("timeattn.proj.weight"), p("timeattn.proj.bias"), D, D, lane["br32"])
             self._lane_ln(pl, lane["x"], lane["br32"], lane["xt"], p("norm1.weight"), p("norm1.bias"), lane["a32"])
             self._lane_linear(pl, lane["a32"], p("attn.qkv.weight")[:D], p("attn.qkv.bias")[:D], D, D, lane["q32"])
-        if f8:
+        if f8 and self.fp8_proj:
             self._linear_f8(pl, i, 1, a.o_t, D, D, hip.EPI_BF16, br, p("timeattn.proj.bias"))
         else:
             hip.gemm_nt(a.o_t, w("timeattn.proj"), M, D, D, hip.EPI_BF16, br, bias=p("timeattn.proj.bias"))
         q1 = self._f8_primed(i, 2)
-        if q1:
+        if pl.res16:
+            hip.layernorm_fwd_r16(x, M, D, 1e-6, add_a=br, y=a.a1, mean=st[2], rstd=st[3], **(self._ln_f8_kw(pl, i, 2) if q1 else {}))
+        elif q1:
             self._ln_f8(pl, i, 2, x, *ln_gb("norm1"), a.a1, st[2], st[3], add16=br, sum32=None if fold else a.xt)
-        elif pl.res16:
-            hip.layernorm_fwd_r16(x, M, D, 1e-6, add_a=br, y=a.a1, mean=st[2], rstd=st[3])
         else:
             # xt = x + time feeds norm1 only (the space residual comes from x): folded, its fp32 copy is never stored
             hip.add_layernorm_fwd(x, br, None if fold else a.xt, *ln_gb("norm1"), M, D, 1e-6, y=a.a1, mean=st[2],
@@ -682,16 +700,16 @@ class VideoEngine:
             self._lane_linear(pl, lane["g32"], p("mlp.fc2.weight"), p("mlp.fc2.bias"), D, Hd, lane["br32"])
         brs = pl.branch16s if pl.skip_y else br      # skip_y: the space branch keeps its own buffer until the next block's norm3
         a.xin = x
-        if f8:
-            self._linear_f8(pl, i, 3, a.o_s, D, D, hip.EPI_BF16, br, p("attn.proj.bias"))
+        if f8 and self.fp8_proj:
+            self._linear_f8(pl, i, 3, a.o_s, D, D, hip.EPI_BF16, brs, p("attn.proj.bias"))
         else:
             hip.gemm_nt(a.o_s, w("attn.proj"), M, D, D, hip.EPI_BF16, brs, bias=p("attn.proj.bias"))
         # space residual comes from x, NOT from x + time (video_transformer.py:170)
         q2 = self._f8_primed(i, 4)
-        if q2:
-            self._ln_f8(pl, i, 4, x, *ln_gb("norm2"), a.a2, st[4], st[5], add16=br, sum32=a.y)
-        elif pl.res16:
-            hip.layernorm_fwd_r16(x, M, D, 1e-6, add_a=brs, y=a.a2, mean=st[4], rstd=st[5])
+        if pl.res16:
+            hip.layernorm_fwd_r16(x, M, D, 1e-6, add_a=brs, y=a.a2, mean=st[4], rstd=st[5], **(self._ln_f8_kw(pl, i, 4) if q2 else {}))
+        elif q2:
+            self._ln_f8(pl, i, 4, x, *ln_gb("norm2"), a.a2, st[4], st[5], add16=brs, sum32=a.y)
         else:
             hip.add_layernorm_fwd(x, brs, None if pl.skip_y else a.y, *ln_gb("norm2"), M, D, 1e-6, y=a.a2, mean=st[4],
                                   rstd=st[5])                                       # y = x + space

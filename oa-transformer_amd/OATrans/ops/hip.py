@@ -231,9 +231,18 @@ def add32_layernorm_fwd(x, add32, sum32, gamma, beta, M, D, eps, y=None, y32=Non
 
 
 def layernorm_fwd_r16(x, M, D, eps, add_a=None, add_b=None, sum16=None, gamma=None, beta=None, y=None, y32=None, mean=None,
-                      rstd=None):
-    """LayerNorm on the bf16 residual stream: s = x + add_a + add_b ; sum16 = bf16(s) ; y / y32 = LN(s).  x bf16 or fp32."""
+                      rstd=None, y8=None, qscale=None, amax=None):
+    """LayerNorm on the bf16 residual stream: s = x + add_a + add_b ; sum16 = bf16(s) ; y / y32 = LN(s).  x bf16 or fp32.
+    y8 (with qscale, amax): additionally the e4m3 copy of y for an fp8 GEMM (oat_layernorm_fwd_r16_f8)."""
     s0 = lambda t: t.stride(0) if t is not None else 0
+    if y8 is not None:
+        if y32 is not None or y is None:
+            raise OatError("layernorm_fwd_r16: the fp8 form writes y (bf16) and y8, not y32")
+        _check(lib().oat_layernorm_fwd_r16_f8(_ptr(x), int(x.dtype == torch.float32), x.stride(0), _ptr(add_a), s0(add_a), _ptr(add_b),
+                                              s0(add_b), _ptr(sum16), s0(sum16), _ptr(gamma), _ptr(beta), _ptr(y), s0(y), _ptr(y8),
+                                              y8.stride(0), _ptr(qscale), _ptr(amax), _ptr(mean), _ptr(rstd), M, D, _f(eps), _stream()),
+               "oat_layernorm_fwd_r16_f8")
+        return
     _check(lib().oat_layernorm_fwd_r16(_ptr(x), int(x.dtype == torch.float32), x.stride(0), _ptr(add_a), s0(add_a), _ptr(add_b),
                                        s0(add_b), _ptr(sum16), s0(sum16), _ptr(gamma), _ptr(beta), _ptr(y), s0(y), _ptr(y32),
                                        s0(y32), _ptr(mean), _ptr(rstd), M, D, _f(eps), _stream()), "oat_layernorm_fwd_r16")

@@ -136,14 +136,20 @@ OAT_DEV void st8(float* p, const float (&v)[8]) {
   *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
   *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
 }
-template <bool X32>
+// F8 (fp8 forward on the bf16 stream): the normalised row additionally leaves as OCP e4m3 in f8.y8, quantised with the site's
+// delayed scale, 8 bytes per lane and chunk, and max |y| is recorded for the next step's scale - as ln_fwd_kernel does on
+// the fp32 stream; the fp8 GEMM that consumes the row needs no quantisation pass.
+template <bool X32, bool F8 = false>
 __global__ __launch_bounds__(256) void ln_fwd_r16_kernel(const void* __restrict__ x_, int ldx, const bf16* __restrict__ add_a,
                                                          int lda, const bf16* __restrict__ add_b, int ldb, bf16* sum16,
                                                          int ldsum, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, bf16* y, int ldy, float* y32,
-                                                         int ldy32, float* mean, float* rstd, int M, int D, float eps) {
+                                                         int ldy32, float* mean, float* rstd, int M, int D, float eps,
+                                                         LnF8 f8 = LnF8{nullptr, 0, nullptr, nullptr}) {
   const int lane = threadIdx.x & 31;
   const int hw = threadIdx.x >> 5;
+  const float qs = F8 ? f8.qscale[0] : 0.f;
+  float m8 = 0.f;
   for (int row = blockIdx.x * 8 + hw; row < M; row += gridDim.x * 8) {
     float v[LN_MAXC][8];
     float s = 0.f;
@@ -193,9 +199,18 @@ __global__ __launch_bounds__(256) void ln_fwd_r16_kernel(const void* __restrict_
         }
         if (y) st8(y + (size_t)row * ldy + c, o);
         if (y32) st8(y32 + (size_t)row * ldy32 + c, o);
+        if constexpr (F8) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) m8 = fmaxf(m8, fabsf(o[e]));
+          uint2 w;
+          w.x = pack_fp8x4(o[0] * qs, o[1] * qs, o[2] * qs, o[3] * qs);
+          w.y = pack_fp8x4(o[4] * qs, o[5] * qs, o[6] * qs, o[7] * qs);
+          *reinterpret_cast<uint2*>(f8.y8 + (size_t)row * f8.ld8 + c) = w;
+        }
       }
     }
   }
+  if constexpr (F8) amax_commit(m8, f8.amax);
 }
 
 // ------------------------------------------------------------------ LayerNorm backward
@@ -775,11 +790,33 @@ extern "C" int oat_layernorm_fwd_r16(const void* x, int x_is_f32, int ldx, const
   int blocks = (M + 7) / 8; if (blocks > ln_fwd_cap()) blocks = ln_fwd_cap();
   if (x_is_f32)
     OAT_LAUNCH(ln_fwd_r16_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, (const bf16*)add_a, ldadd_a,
-               (const bf16*)add_b, ldadd_b, (bf16*)sum16, ldsum, gamma, beta, (bf16*)y, ldy, y32, ldy32, mean, rstd, M, D, eps);
+               (const bf16*)add_b, ldadd_b, (bf16*)sum16, ldsum, gamma, beta, (bf16*)y, ldy, y32, ldy32, mean, rstd, M, D, eps, oat::LnF8{nullptr, 0, nullptr, nullptr});
   else
     OAT_LAUNCH(ln_fwd_r16_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, (const bf16*)add_a, ldadd_a,
-               (const bf16*)add_b, ldadd_b, (bf16*)sum16, ldsum, gamma, beta, (bf16*)y, ldy, y32, ldy32, mean, rstd, M, D, eps);
+               (const bf16*)add_b, ldadd_b, (bf16*)sum16, ldsum, gamma, beta, (bf16*)y, ldy, y32, ldy32, mean, rstd, M, D, eps, oat::LnF8{nullptr, 0, nullptr, nullptr});
   return check_launch("layernorm_fwd_r16");
+}
+
+// oat_layernorm_fwd_r16 with the e4m3 copy of y for an fp8 GEMM (y8 = e4m3(y * *qscale), max |y| -> *amax): the fp8 forward on the
+// bf16 residual stream.  y (bf16) is still written - backward and the weight gradient read it.
+extern "C" int oat_layernorm_fwd_r16_f8(const void* x, int x_is_f32, int ldx, const void* add_a, int ldadd_a, const void* add_b,
+                                        int ldadd_b, void* sum16, int ldsum, const float* gamma, const float* beta, void* y,
+                                        int ldy, void* y8, int ld8, const float* qscale, float* amax, float* mean, float* rstd,
+                                        int M, int D, float eps, void* stream) {
+  if (M <= 0) return 0;
+  if (!x || !y8 || !qscale || !amax) { set_error("layernorm_fwd_r16_f8: null pointer"); return -4; }
+  if (D % 8 || D > LN_MAXC * 256 || ldx % 8 || ldadd_a % 8 || ldadd_b % 8 || ldsum % 8 || ldy % 8 || ld8 % 8) {
+    set_error("layernorm_fwd_r16_f8: D%8==0, D<=1024, ld%8==0 required"); return -3;
+  }
+  int blocks = (M + 7) / 8; if (blocks > ln_fwd_cap()) blocks = ln_fwd_cap();
+  const oat::LnF8 f8{(uint8_t*)y8, ld8, qscale, amax};
+  if (x_is_f32)
+    OAT_LAUNCH((ln_fwd_r16_kernel<true, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, (const bf16*)add_a, ldadd_a,
+               (const bf16*)add_b, ldadd_b, (bf16*)sum16, ldsum, gamma, beta, (bf16*)y, ldy, (float*)nullptr, 0, mean, rstd, M, D, eps, f8);
+  else
+    OAT_LAUNCH((ln_fwd_r16_kernel<false, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, (const bf16*)add_a, ldadd_a,
+               (const bf16*)add_b, ldadd_b, (bf16*)sum16, ldsum, gamma, beta, (bf16*)y, ldy, (float*)nullptr, 0, mean, rstd, M, D, eps, f8);
+  return check_launch("layernorm_fwd_r16_f8");
 }
 
 // LayerNorm with the fp8 copy of its output for an fp8 GEMM: y (bf16, kept for backward) and y8 = e4m3(y * *qscale),

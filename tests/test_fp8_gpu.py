@@ -61,6 +61,41 @@ def test_fp8_quantise_and_gemm(shape):
         hip.gemm_nt_f8(A8, B8, m, n - 8, k, hip.EPI_BF16, out, sa[2:3], sb[2:3])          # N % 256 != 0: refused, not approximated
 
 
+@pytest.mark.parametrize("x32", [False, True])
+def test_layernorm_r16_with_e4m3_copy(x32):
+    """oat_layernorm_fwd_r16_f8 (fp8 forward on the bf16 residual stream): sum16 / y / mean / rstd bit-equal to the plain
+    r16 kernel, y8 = the e4m3 bytes torch gives for y (fp32, before its bf16 rounding) * qscale, amax = max |y|."""
+    from OATrans.ops import hip
+    torch.manual_seed(3)
+    M, D = 1003, 768
+    x = torch.randn(M, D, device="cuda") * 2
+    x = x if x32 else x.bfloat16()
+    a, b = torch.randn(M, D, device="cuda").bfloat16(), torch.randn(M, D, device="cuda").bfloat16()
+    outs = []
+    for f8 in (False, True):
+        s16 = torch.zeros(M, D, device="cuda", dtype=torch.bfloat16)
+        y = torch.zeros_like(s16)
+        mean, rstd = torch.zeros(M, device="cuda"), torch.zeros(M, device="cuda")
+        y8 = torch.zeros(M, D, device="cuda", dtype=torch.uint8)
+        st = torch.tensor([0.0, 37.5], device="cuda")               # amax (recorded), qscale (given)
+        kw = dict(y8=y8, qscale=st[1:2], amax=st[0:1]) if f8 else {}
+        hip.layernorm_fwd_r16(x, M, D, 1e-6, add_a=a, add_b=b, sum16=s16, y=y, mean=mean, rstd=rstd, **kw)
+        outs.append((s16, y, mean, rstd, y8, st))
+    for u, v in zip(outs[0][:4], outs[1][:4]):
+        assert torch.equal(u, v)
+    s = x.float() + a.float() + b.float()
+    yr = torch.nn.functional.layer_norm(s, (D,), eps=1e-6)
+    y8, st = outs[1][4], outs[1][5]
+    want = (yr * 37.5).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+    diff = (y8 != want)
+    # the kernel's fp32 y and torch's differ in the last bits, which flips an e4m3 rounding on a few elements per million
+    assert diff.float().mean().item() < 1e-3
+    assert (y8.view(torch.float8_e4m3fn).float() - want.view(torch.float8_e4m3fn).float()).abs().max().item() <= 32.0      # one e4m3 step at |q| <= 448
+    assert abs(st[0].item() - yr.abs().max().item()) < 1e-4 * yr.abs().max().item()
+    with pytest.raises(hip.OatError):
+        hip.layernorm_fwd_r16(x, M, D, 1e-6, y=None, y8=y8, qscale=st[1:2], amax=st[0:1])
+
+
 @pytest.mark.parametrize("fp8_bwd", [False, True])
 @pytest.mark.parametrize("frames", [4])
 def test_frozen_in_time_fp8_forward_vs_reference_golden(golden_dir, frames, fp8_bwd):
@@ -98,9 +133,12 @@ def test_frozen_in_time_fp8_forward_vs_reference_golden(golden_dir, frames, fp8_
         assert abs(loss.item() - g["loss"].item()) < 1e-2
     f8 = m.video_model._engine._f8
     # per block: 6 forward inputs (+ 6 incoming gradients with fp8 backward) have a delayed scale; every weight has one
+    assert m.video_model._engine.fp8_proj                    # default: all six forward linears (OAT_FP8_PROJ=0: the projections stay bf16)
     assert len(f8["primed"]) == (12 if fp8_bwd else 6) * 12
     dq = f8["dq"].view(12, 18)
     assert bool((dq[:, :12 if not fp8_bwd else 18] > 0).all())
+    # forward-only fp8 runs on the bf16 residual stream (r16 LayerNorms emit the e4m3 operand); with fp8 data gradients the fp32 stream stays
+    assert all(pl.res16 == (not fp8_bwd) for pl in m.video_model._engine.plans.values())
     params = dict(m.named_parameters())
     errs = {k: abs(params[k].grad.norm().item() - pr["norm"].item()) / pr["norm"].item() for k, pr in g["grad_probe"].items()
             if pr["norm"] > 1e-6}
