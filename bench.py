@@ -42,6 +42,12 @@ def flops_per_pair(T, N=196, D=768, depth=12, Lt=32, clips=None, text_passes=1):
     return 3 * (sum(video(t) for t in (clips or (T,))) + text_passes * text)
 
 
+def pruned_top_gflops(T, N=196, D=768, mlp_ratio=4):
+    """GF per pair that VideoEngine.prune_top does not execute: the top block's space projection (D x D), fc1 and fc2
+    (D x 4D each) on the T*N patch rows of a sample, forward + data gradient + weight gradient."""
+    return 3 * T * N * 2 * D * D * (1 + 2 * mlp_ratio) / 1e9
+
+
 def build(args, device):
     from OATrans import model as module_arch
     from OATrans.optim import AdamW
@@ -102,13 +108,16 @@ def other_config_line(base_args, variant, device, steps=10, warmup=3):
     brackets as the headline."""
     import copy
     import gc
-    from OATrans.trainer.step import global_local_step, region_mem_step
+    from OATrans.trainer.step import global_local_step, hot_step, region_mem_step
     args = copy.copy(base_args)
-    args.variant = variant
-    step_impl = {"region_mem": region_mem_step, "global_local": global_local_step}[variant]
+    pruned = variant == "frozen_pruned"       # the headline model with VideoEngine.prune_top (see pruned_top_gflops)
+    args.variant = "frozen" if pruned else variant
+    step_impl = {"region_mem": region_mem_step, "global_local": global_local_step, "frozen_pruned": hot_step}[variant]
     dp, opt, loss_fn = build(args, device)
     if args.dtype == "fp8":
         dp.module.video_model._engine.fp8 = True
+    if pruned:
+        dp.module.video_model._engine.prune_top = True
     data = synthetic_batch(args, 0, device)
     step_args = argparse.Namespace(world_size=1, rank=0, local_rank=device.index or 0)
     for _ in range(warmup):
@@ -120,6 +129,22 @@ def other_config_line(base_args, variant, device, steps=10, warmup=3):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     value = args.batch * steps / elapsed
+    if pruned:
+        N = (args.res // 16) ** 2
+        full = flops_per_pair(args.frames, N=N) / 1e9
+        gf_pair = full - pruned_top_gflops(args.frames, N)
+        line = {"workload": f"[frozen, top block pruned] the headline model and step with VideoEngine.prune_top (opt-in, OAT_PRUNE_TOP=1): "
+                            f"oa_model.FrozenInTime consumes only the CLS row of the encoder output, so the top block's space projection / "
+                            f"norm2 / fc1 / GELU / fc2 run on the {args.batch} CLS rows instead of all {args.batch * (args.frames * N + 1)} "
+                            f"(forward, data and weight gradients); same loss, same gradients (tests/test_prune_gpu.py)",
+                "value": round(value, 2), "unit": "pairs/s", "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps, "warmup": warmup,
+                "gflop_per_pair_executed": round(gf_pair, 1), "gflop_per_pair_full_graph": round(full, 1),
+                "step_mfma_frac_executed": round(value * gf_pair / 1e3 / BF16_DENSE_PEAK_TFLOPS, 4),
+                "final_loss": round(float(loss.item()), 4)}
+        del dp, opt, data, loss
+        gc.collect()
+        torch.cuda.empty_cache()
+        return line
     gf_pair = flops_per_pair(args.frames, N=(args.res // 16) ** 2, clips=(1, args.frames),
                              text_passes=2 if variant == "global_local" else 1) / 1e9
     n_obj = {"region_mem": 5, "global_local": 10}[variant]
@@ -299,6 +324,9 @@ def main():
                     help="AdamW step size (the reference config uses 2e-4 on PRETRAINED towers; random-init towers on one repeated "
                          "synthetic batch spike at that value, which says nothing about throughput but makes final_loss useless)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prune-top", action="store_true",
+                    help="run the MAIN line with VideoEngine.prune_top (default: full top block; a default run reports the pruned "
+                         "schedule as an extra entry of `other_configs`).  The line then carries the executed GF per pair")
     ap.add_argument("--other-configs", action="store_true",
                     help="append the `other_configs` runs at any --frames / --res (default: only at the headline geometry, 8 x 224^2)")
     ap.add_argument("--no-other-configs", action="store_true",
@@ -328,6 +356,10 @@ def main():
     dp, opt, loss_fn = build(args, device)
     if args.dtype == "fp8":
         dp.module.video_model._engine.fp8 = True
+    if args.prune_top:
+        if args.variant != "frozen":
+            raise SystemExit("--prune-top: only the frozen variant leaves the encoder's patch rows unused")
+        dp.module.video_model._engine.prune_top = True
     data = synthetic_batch(args, rank, device)
     step_args = argparse.Namespace(world_size=world, rank=rank, local_rank=local)
 
@@ -377,9 +409,13 @@ def main():
     oa = args.variant != "frozen"
     gf_pair = flops_per_pair(args.frames, N=(args.res // 16) ** 2, clips=(1, args.frames) if oa else None,
                              text_passes=2 if args.variant == "global_local" else 1) / 1e9
+    if args.prune_top:                 # the utilisation figures of a pruned run count what was executed
+        gf_pair -= pruned_top_gflops(args.frames, (args.res // 16) ** 2)
     n_obj = {"region_mem": 5, "global_local": 10}.get(args.variant)
     clip_txt = f"{args.frames}-frame + {n_obj} obj (one object frame with {n_obj} box masks + the {args.frames}-frame clip, same encoder)" \
         if oa else f"{args.frames}-frame"
+    if args.prune_top:
+        clip_txt += " (top block pruned to the CLS rows: --prune-top, gflop_per_pair = executed)"
     cls_name = {"frozen": "oa_model", "region_mem": "oa_model_region_mem", "global_local": "oa_model_global_local"}[args.variant]
     out = {
         "metric": "video-text pairs/sec fwd+bwd, 8-frame ViT-B/16, 1/2/4/8 MI355X",
@@ -450,7 +486,7 @@ def main():
             gc.collect()
             torch.cuda.empty_cache()
             out["other_configs"] = []
-            for variant in ("global_local", "region_mem"):
+            for variant in ("global_local", "region_mem", "frozen_pruned"):
                 try:
                     out["other_configs"].append(other_config_line(args, variant, device))
                 except Exception as exc:              # the headline line must still be printed

@@ -253,6 +253,13 @@ class VideoEngine:
         # 1 (default): with folded LayerNorms the fp32 residual-gradient stream is read by norm2's backward, skipped by norm1's
         # and read + written once by norm3's (ln_bwd_xhat_kernel); 0: every LayerNorm backward reads and re-writes it
         self.fold_gstream = os.environ.get("OAT_FOLD_GSTREAM", "1") != "0"
+        # 1 (opt-in; default 0 = the reference's full work): when the caller consumes only the CLS rows of the encoder output
+        # (contract class oa_model.FrozenInTime, video_transformer.py:349-351 -> oa_model.py:129-133) the patch rows of the TOP
+        # block's space-attention projection, norm2, fc1 / GELU and fc2 are never read and their output gradient is exactly
+        # zero, so these launches - forward, data gradient and weight gradient - run on the B CLS rows only.  Same loss, same
+        # gradients (the weight-gradient sums lose only exact-zero terms); 49.9 of 1115.9 GF per pair at 8 frames are not
+        # executed (bench.py reports the executed figure).  See _top_tail_fwd / _top_block_bwd_pruned.
+        self.prune_top = os.environ.get("OAT_PRUNE_TOP", "0") != "0"
         self.fbias = {}                     # folded biases b' (fp32), per folded linear
         self._fold_bias = None
         self._fold_tmp = {}                 # accumulate mode: scratch (dW', db') of the folded linears
@@ -488,6 +495,12 @@ class VideoEngine:
         run = _Run(pl, need_patches, region_layer)
         # folded LayerNorms + bf16 forward: y = x + space is never stored (the next block's norm3 adds both branch outputs)
         pl.skip_y = self.fold_active() and self._fp8_on_stream16() and os.environ.get("OAT_SKIP_Y", "1") != "0"
+        pl.prune_top = bool(self.prune_top and not need_patches and region_layer is None and len(pl.segs) == 1 and pl.res16
+                            and pl.skip_y and not self.fp8 and not self.bwd_side)
+        run.prune_top = pl.prune_top
+        if pl.prune_top and getattr(pl, "d_o_top", None) is None:
+            # dL/d(attention output) of the top block: its patch rows are zero and stay zero (only the CLS rows are ever written)
+            pl.d_o_top = torch.zeros(pl.Mp, self.D, dtype=torch.bfloat16, device=dev)
         pl.fwd_modes = (self.fold_active(), pl.skip_y, pl.res16, self.fp8)      # what the saved activations MEAN: backward checks it
         if pl.skip_y and getattr(pl, "branch16s", None) is None:
             pl.branch16s = torch.zeros(pl.Mp, self.D, dtype=torch.bfloat16, device=dev)
@@ -524,7 +537,7 @@ class VideoEngine:
         gptr = next(iter(grads.values())).data_ptr() if grads else 0
         f8 = (len(self._f8["primed"]), self._f8["key"]) if (self.fp8 and self._f8) else None
         return (torch.cuda.current_stream().cuda_stream, pl.side.cuda_stream, self.clip_launch, self.time_clip_launch, ptrs, gptr, self.fp8, self.fp8_bwd, self.fp8_proj, f8, self.cls_lane, self.h_u8,
-                self.tail_split, self.bwd_side, self.bwd_nt_grid, self.group_wgrads, self.fold_active(), self.fold_gstream, os.environ.get("OAT_SKIP_Y", "1"), pl.res16, hip.gemm_get_variant(), flags)
+                self.tail_split, self.bwd_side, self.bwd_nt_grid, self.group_wgrads, self.fold_active(), self.fold_gstream, os.environ.get("OAT_SKIP_Y", "1"), pl.res16, hip.gemm_get_variant(), getattr(pl, "prune_top", False), flags)
 
     @staticmethod
     def _announce_segment(ready, prefixes, recording):
@@ -700,6 +713,9 @@ class VideoEngine:
             self._lane_linear(pl, lane["g32"], p("mlp.fc2.weight"), p("mlp.fc2.bias"), D, Hd, lane["br32"])
         brs = pl.branch16s if pl.skip_y else br      # skip_y: the space branch keeps its own buffer until the next block's norm3
         a.xin = x
+        if pl.prune_top and i == self.depth - 1:
+            self._top_tail_fwd(pl, a, x, brs, br, p, w, lin_b)
+            return a
         if f8 and self.fp8_proj:
             self._linear_f8(pl, i, 3, a.o_s, D, D, hip.EPI_BF16, brs, p("attn.proj.bias"))
         else:
@@ -725,6 +741,19 @@ class VideoEngine:
                 hip.gemm_nt(a.a2, w("mlp.fc1"), M, Hd, D, hip.EPI_GELU_GRAD, a.h, out2=a.g, bias=lin_b("mlp.fc1"))
             hip.gemm_nt(a.g, w("mlp.fc2"), M, D, Hd, hip.EPI_BF16, br, bias=p("mlp.fc2.bias"))
         return a                                                                    # out = y + br, formed lazily
+
+    def _top_tail_fwd(self, pl, a, x, brs, br, p, w, lin_b):
+        """prune_top: the top block from the space-attention projection on, for the B CLS rows only (the tail block of the
+        row space).  The patch rows of brs / a.a2 / a.h / a.g / br keep whatever they held: nothing reads them - the final
+        LayerNorm takes the CLS rows (_final_fwd), backward runs _top_block_bwd_pruned.  The saved GELU derivative of these
+        rows is plain bf16 in a.h (the 8-bit blocked form belongs to the ping-pong GEMM, which does not serve 32-row problems)."""
+        D, Hd = self.D, self.Hd
+        sg = pl.segs[0]
+        c0, Bc, st = sg.cls0, sg.B, a.stats
+        hip.gemm_nt(a.o_s[c0:], w("attn.proj"), Bc, D, D, hip.EPI_BF16, brs[c0:], bias=p("attn.proj.bias"))
+        hip.layernorm_fwd_r16(x[c0:], Bc, D, 1e-6, add_a=brs[c0:], y=a.a2[c0:], mean=st[4][c0:], rstd=st[5][c0:])
+        hip.gemm_nt(a.a2[c0:], w("mlp.fc1"), Bc, Hd, D, hip.EPI_GELU_GRAD, a.h[c0:], out2=a.g[c0:], bias=lin_b("mlp.fc1"))
+        hip.gemm_nt(a.g[c0:], w("mlp.fc2"), Bc, D, Hd, hip.EPI_BF16, br[c0:], bias=p("mlp.fc2.bias"))
 
     def _final_fwd(self, pl, params, need_patches, region_layer):
         """-> ([cls rows per segment], [patch rows per segment] | [None, ...])"""
@@ -858,7 +887,10 @@ class VideoEngine:
             pl.ga8_valid = None              # the top block's dL/d(out) comes from the final LayerNorm: quantised in a pass
             for k, i in enumerate(reversed(range(self.depth))):
                 pl.wq = [] if (self.group_wgrads and not self.bwd_side) else None
-                (self._block_bwd_f8 if f8b else self._block_bwd)(pl, i, run, params, grads, d_region)
+                if getattr(run, "prune_top", False) and i == self.depth - 1:
+                    self._top_block_bwd_pruned(pl, i, params, grads)
+                else:
+                    (self._block_bwd_f8 if f8b else self._block_bwd)(pl, i, run, params, grads, d_region)
                 if pl.wq is not None:
                     self._flush_wgrads(pl, i)
                     pl.wq = None
@@ -961,7 +993,11 @@ class VideoEngine:
             need = hip.lib().oat_tn_group_slab_bytes(hip.TnGroup.plan_layers([[meta[k] for k in ks] for ks in idx], grid)[3]) // 4
             if self._tn_slabs is None or self._tn_slabs.numel() < need:
                 if self._tn_slabs is not None:
-                    self._tn_retired.append(self._tn_slabs)       # launch tapes recorded so far still point at it
+                    # launch tapes recorded so far still point at the old slabs AND at the device tables of the groups built on
+                    # them: both are kept alive (a pruned top block queues three problems, needs less than the six of the block
+                    # below it and is flushed first - its group was dropped here while the tape being recorded held its tables)
+                    self._tn_retired.append(self._tn_slabs)
+                    self._tn_retired.append(dict(pl.tn_groups))
                     pl.tn_groups.clear()
                 self._tn_slabs = torch.empty(need, dtype=torch.float32, device=probs[0][0].device)
             held = (key, hip.TnGroup(probs, grid=grid, slabs=self._tn_slabs, layers=idx))
@@ -995,7 +1031,8 @@ class VideoEngine:
                 hip.layernorm_bwd_r16(pl.dn, pl.x_final, pl.fstats[0], pl.fstats[1], params["norm.weight"], M, D, dx16=g16,
                                       dgamma=grads["norm.weight"], dbeta=grads["norm.bias"], accumulate=pl.acc)
             else:
-                hip.zero_(g16[:M])
+                if not getattr(run, "prune_top", False):     # pruned top block: reads the CLS rows of g16 only
+                    hip.zero_(g16[:M])
                 for k, sg in enumerate(pl.segs):
                     c0 = sg.cls0
                     hip.layernorm_bwd_r16(pl.dn[c0:], pl.x_final[c0:], pl.fstats[0][c0:], pl.fstats[1][c0:], params["norm.weight"],
@@ -1142,6 +1179,59 @@ class VideoEngine:
         self._join(s5)
         if fold:
             pl.fold_pending = i            # finished after the block's weight gradients have run (_flush_wgrads)
+
+    def _top_block_bwd_pruned(self, pl, i, params, grads):
+        """_block_bwd of the top block after a prune_top forward (bf16 streams, folded LayerNorms, in-order schedule).  The
+        incoming gradient ga is non-zero on the B CLS rows only, so fc2 / fc1 / norm2 / the space projection - data and weight
+        gradients - take those rows alone; from the space attention downwards (its keys and values belong to every row) the
+        block runs as usual.  gb (= dL/dy) exists on the CLS rows only: norm3's backward adds it there in a second, B-row launch."""
+        M, D, Hd = pl.M, self.D, self.Hd
+        G, a, st8 = pl.G, pl.blocks[i], pl.sets[i % 2]
+        ga, ga_next = pl.ga[i % 3], pl.ga[(i - 1) % 3]
+        gr = lambda s: grads[f"blocks.{i}.{s}"]
+        wT = lambda s: self.shadow[f"blocks.{i}.{s}.weight"][1]
+        st = a.stats
+        d_h, gb, d_qkv_s, gc, d_qkv_t = st8["d_h"], st8["gb"], st8["d_qkv_s"], st8["gc"], st8["d_qkv_t"]
+        sg = pl.segs[0]
+        c0, Bc = sg.cls0, sg.B
+        R = lambda t: t[c0:]
+
+        def wgrad(P, Q, rows, n1, n2, lin, folded, queue):
+            """as wgrad_folded of _block_bwd; queue=False: a B-row problem, launched on its own (gemm_tn)"""
+            w_, b_, acc = gr(lin + ".weight"), gr(lin + ".bias"), pl.acc
+            if folded and pl.acc:
+                if lin not in self._fold_tmp:
+                    self._fold_tmp[lin] = (torch.empty(n1, n2, dtype=torch.float32, device=P.device),
+                                           torch.empty(n1, dtype=torch.float32, device=P.device))
+                (w_, b_), acc = self._fold_tmp[lin], False
+            self._wgrad(P, Q, rows, n1, n2, w_, b_, acc, pl=pl if queue else None)
+
+        # ---- MLP, CLS rows
+        hip.gemm_nt(R(ga), wT("mlp.fc2"), Bc, Hd, D, hip.EPI_MUL_AUX, R(d_h), aux=R(a.h))
+        hip.gemm_nt(R(d_h), wT("mlp.fc1"), Bc, D, Hd, hip.EPI_BF16, R(pl.d_a))
+        hip.layernorm_bwd_xhat(R(pl.d_a), R(a.a2), st[5][c0:], Bc, D, dx16=R(gb), add_a=R(ga))               # gb = ga + dx2
+        wgrad(R(ga), R(a.g), Bc, D, Hd, "mlp.fc2", False, False)
+        # ---- space attention: the projection on the CLS rows, the attention itself on every row (dO of the patch queries = 0)
+        d_o = pl.d_o_top
+        hip.gemm_nt(R(gb), wT("attn.proj"), Bc, D, D, hip.EPI_BF16, R(d_o))
+        self._attn_bwd(pl, hip.attn_space_bwd, a.qkv_s, a.o_s, a.lse_s, d_o, d_qkv_s)
+        wgrad(R(d_h), R(a.a2), Bc, Hd, D, "mlp.fc1", True, False)
+        wgrad(R(gb), R(a.o_s), Bc, D, D, "attn.proj", False, False)
+        hip.gemm_nt(d_qkv_s, wT("attn.qkv"), M, D, 3 * D, hip.EPI_BF16, pl.d_a)
+        hip.layernorm_bwd_xhat(pl.d_a, a.a1, st[3], M, D, dx16=gc)                                            # gc = dx1
+        wgrad(d_qkv_s, a.a1, M, 3 * D, D, "attn.qkv", True, True)
+        # ---- time attention: as in _block_bwd
+        hip.gemm_nt(gc, wT("timeattn.proj"), M, D, D, hip.EPI_BF16, pl.d_o)
+        self._attn_bwd(pl, hip.attn_time_bwd, a.qkv_t, a.o_t, a.lse_t, pl.d_o, d_qkv_t)
+        wgrad(gc, a.o_t, M, D, D, "timeattn.proj", False, True)
+        hip.gemm_nt(d_qkv_t, wT("timeattn.qkv"), M, D, 3 * D, hip.EPI_BF16, pl.d_a)
+        # ga_next = gb + gc + dx3: gb is zero on the patch rows (not stored there), present on the CLS rows
+        G0 = G if i == 0 else None
+        hip.layernorm_bwd_xhat(pl.d_a, a.a3, st[1], c0, D, dx=G0, dx16=ga_next, add_b=gc)
+        hip.layernorm_bwd_xhat(R(pl.d_a), R(a.a3), st[1][c0:], Bc, D, dx=R(G) if i == 0 else None, dx16=R(ga_next), add_a=R(gb),
+                               add_b=R(gc))
+        wgrad(d_qkv_t, a.a3, M, 3 * D, D, "timeattn.qkv", True, True)
+        pl.fold_pending = i
 
     def _block_bwd_f8(self, pl, i, run, params, grads, d_region):
         """_block_bwd with the six data-gradient GEMMs on fp8 operands (dY e5m2, W^T e4m3; weight gradients stay bf16,

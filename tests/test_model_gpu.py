@@ -170,6 +170,7 @@ def test_frozen_in_time_vitb_vs_reference_golden(golden_dir, frames):
     r = m.load_state_dict(si.frozen_state_dict(SEED, dict(num_frames=T), {}), strict=False)
     assert not r.unexpected_keys and not r.missing_keys, r
     m = m.cuda()
+    m.video_model._engine.prune_top = prune_top
     video = si.seeded_tensor(SEED, f"full.video.{T}", (B, T, 3, 224, 224)).cuda()
     ids = si.seeded_ints(SEED, f"full.ids.{T}", (B, L), 1000, 30000)
     ids[:, 0] = 101
@@ -199,8 +200,13 @@ def test_frozen_in_time_vitb_vs_reference_golden(golden_dir, frames):
     assert not bad, bad[:10]
 
 
-def test_headline_geometry_every_gradient_vs_oracle_autograd():
-    """Every parameter gradient of the 8-frame frozen model (ViT-B/16 + DistilBERT-base, the headline geometry) at B = 2
+@pytest.mark.parametrize("prune_top", [False, True])
+def test_headline_geometry_every_gradient_vs_oracle_autograd(prune_top):
+    """prune_top: the same check with the top block's unused patch rows skipped (engine/video.py: VideoEngine.prune_top) -
+    the reference computes them and discards them (video_transformer.py:349-351, oa_model.py:129-133), so every gradient must
+    still match the oracle's autograd, which runs the full graph.
+
+    Every parameter gradient of the 8-frame frozen model (ViT-B/16 + DistilBERT-base, the headline geometry) at B = 2
     against autograd of the CPU oracle on the same seeded inputs: per-tensor relative L2 and cosine, and the same two figures
     over all parameters at once.  Stated tolerance (bf16 operands, bf16 residual / gradient stream, 8-bit GELU derivative
     against an fp32 reference): per tensor rel-L2 <= 5e-2 and cosine >= 0.998, all parameters rel-L2 <= 3e-2 and
@@ -218,6 +224,7 @@ def test_headline_geometry_every_gradient_vs_oracle_autograd():
     r = m.load_state_dict(sd, strict=False)
     assert not r.unexpected_keys and not r.missing_keys, r
     m = m.cuda()
+    m.video_model._engine.prune_top = prune_top
     video = si.seeded_tensor(SEED, f"full.video.{T}", (B, T, 3, 224, 224))
     ids = si.seeded_ints(SEED, f"full.ids.{T}", (B, L), 1000, 30000)
     ids[:, 0] = 101
@@ -228,6 +235,7 @@ def test_headline_geometry_every_gradient_vs_oracle_autograd():
     loss = module_arch.NormSoftmaxLoss()(module_arch.sim_matrix(t, v))
     loss.backward()
     torch.cuda.synchronize()
+    assert m.video_model._engine.plans and all(pl.prune_top == prune_top for pl in m.video_model._engine.plans.values())
     p = {k: (w.clone().requires_grad_(True) if w.is_floating_point() else w) for k, w in sd.items()}
     oloss, osim, _, _ = orc.train_step_loss(p, video, ids, mask)
     oloss.backward()

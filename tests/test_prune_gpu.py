@@ -1,0 +1,124 @@
+"""VideoEngine.prune_top (opt-in): the contract class oa_model.FrozenInTime consumes only the CLS row of the video encoder
+(reference: video_transformer.py:349-351 returns (x[:, 0], x[:, 1:]), oa_model.py:129-133 drops the second), so the patch
+rows of the TOP block's space projection / norm2 / fc1 / GELU / fc2 are dead in forward and carry an exactly-zero gradient
+in backward.  With the option on those launches run on the B CLS rows only.  Checked here against the SAME model run in
+full: identical embeddings and loss (the CLS embedding comes from the fp32 lane, which reads the unchanged q|k|v buffers),
+gradients equal up to the summation order of the kernels that serve 32-row problems.  Against the reference's own autograd:
+tests/test_model_gpu.py::test_headline_geometry_every_gradient_vs_oracle_autograd[True]."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(frames, depth):
+    from OATrans import model as module_arch
+    torch.manual_seed(3)
+    m = module_arch.FrozenInTime(
+        video_params=dict(model="SpaceTimeTransformer", arch_config="base_patch16_224", num_frames=frames, pretrained=True,
+                          time_init="rand", arch_kwargs=dict(depth=depth)),
+        object_params=dict(model="", input_objects=False),
+        text_params=dict(model="pretrained/distilbert-base-uncased", pretrained=True, input="text", config=dict(n_layers=1)),
+        projection="minimal", load_checkpoint="").cuda()
+    m.text_model.eval()
+    m.set_device(torch.device("cuda"))
+    for sub in (m.video_model, m.text_model):
+        sub.flatten_parameters()
+    return m
+
+
+def _batch(B, T, L=10, seed=11):
+    g = torch.Generator().manual_seed(seed)
+    return {"video": torch.randn(B, T, 3, 224, 224, generator=g).cuda(),
+            "text": {"input_ids": torch.randint(1000, 30000, (B, L), generator=g).cuda(),
+                     "attention_mask": torch.ones(B, L, dtype=torch.int64).cuda()}}
+
+
+def _run(m, data, steps):
+    """`steps` forward + backward passes (the second and later ones replay the launch tapes); returns the last pass."""
+    from OATrans import model as module_arch
+    for _ in range(steps):
+        for p in m.parameters():
+            if p.grad is not None and not getattr(p, "_oat_engine_grad", False):
+                p.grad.zero_()
+        m.begin_step()
+        t, v = m(data)
+        loss = module_arch.NormSoftmaxLoss()(module_arch.sim_matrix(t, v))
+        loss.backward()
+    torch.cuda.synchronize()
+    return loss.detach().clone(), t.detach().clone(), v.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters()
+                                                                           if p.grad is not None}
+
+
+# (B, T, depth): 3140 rows (lockstep GEMMs, one weight gradient per launch) / 4710 rows (ping-pong GEMMs, 8-bit GELU
+# derivative in the lower block, grouped weight gradients) / one block only (the pruned block reads the fp32 embedding)
+@pytest.mark.parametrize("B,T,depth", [(4, 4, 2), (6, 4, 2), (3, 2, 1)])
+def test_pruned_top_block_equals_the_full_run(B, T, depth):
+    m = _model(T, depth)
+    eng = m.video_model._engine
+    # bf16 GELU derivative in both runs: the pruned schedule stores the CLS rows' derivative as bf16 (its 32-row GEMMs are not
+    # the ping-pong kernel's), and the full run's 8-bit form (|error| <= 0.0025) on exactly the rows ALL of the gradient passes
+    # through would be what the comparison measures (1.4e-2 on cls_token); the 8-bit form runs in the second test below
+    eng.h_u8 = False
+    data = _batch(B, T)
+    eng.prune_top = False
+    loss0, t0, v0, g0 = _run(m, data, 2)
+    assert all(not pl.prune_top for pl in eng.plans.values())
+    eng.prune_top = True
+    loss1, t1, v1, g1 = _run(m, data, 3)                 # records new tapes (the option is part of their key), then replays
+    assert any(pl.prune_top for pl in eng.plans.values())
+    assert torch.equal(t0, t1) and torch.equal(v0, v1) and torch.equal(loss0, loss1)
+    worst = ("", 0.0)
+    for k, a in g0.items():
+        b = g1[k]
+        den = a.norm().item()
+        if den < 1e-9:
+            assert b.norm().item() < 1e-6, k
+            continue
+        e = (a - b).norm().item() / den
+        worst = max(worst, (k, e), key=lambda z: z[1])
+    print("worst relative difference pruned vs full:", worst)
+    # the CLS rows of the top block go through the 128x128 GEMM / the plain weight-gradient kernel instead of the ping-pong
+    # and grouped ones: same bf16 operands, another summation order; a bf16 re-rounding of an intermediate can flip
+    assert worst[1] < 5e-3, worst
+    # back to the full schedule: nothing of the pruned schedule lingers in the plan (the loss is bit-identical; gradients
+    # repeat up to the order of the fp32 atomics that sum the CLS query's key / value gradients, csrc/attn_space.hip)
+    eng.prune_top = False
+    loss2, t2, v2, g2 = _run(m, data, 1)
+    assert torch.equal(loss0, loss2)
+    for k in g0:
+        den = g0[k].norm().item()
+        assert den < 1e-9 or (g0[k] - g2[k]).norm().item() / den < 2e-3, k
+
+
+def test_pruned_top_block_with_the_8bit_derivative_below_it():
+    """Default options (8-bit GELU derivative in the blocks that run in full): the pruned run against the full one within
+    the 8-bit form's own error on the top block's CLS rows."""
+    m = _model(4, 2)
+    eng = m.video_model._engine
+    data = _batch(6, 4)
+    eng.prune_top = False
+    loss0, _, _, g0 = _run(m, data, 1)
+    eng.prune_top = True
+    loss1, _, _, g1 = _run(m, data, 2)
+    assert torch.equal(loss0, loss1)
+    num = sum((g0[k] - g1[k]).pow(2).sum().item() for k in g0)
+    den = sum(g0[k].pow(2).sum().item() for k in g0)
+    print("all parameters, pruned vs full:", (num / den) ** 0.5)
+    assert (num / den) ** 0.5 < 3e-2
+
+
+def test_prune_is_refused_where_patch_rows_are_consumed():
+    """need_patches (the OA variants take the mean of the final patch rows) keeps the full top block whatever the option says."""
+    from OATrans.model.video_transformer import SpaceTimeTransformer
+    torch.manual_seed(0)
+    vid = SpaceTimeTransformer(num_frames=2, time_init="rand", depth=1).cuda()
+    vid.head = torch.nn.Identity()
+    vid._engine.prune_top = True
+    x = torch.randn(2, 2, 3, 224, 224, device="cuda")
+    vid.need_patch_tokens = True
+    cls, patches = vid(x)
+    assert patches is not None and all(not pl.prune_top for pl in vid._engine.plans.values())
+    (cls.sum() + patches.sum()).backward()
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(p.grad).all() for p in vid.parameters() if p.grad is not None)
