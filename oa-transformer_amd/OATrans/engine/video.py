@@ -704,7 +704,13 @@ class VideoEngine:
             self._linear_f8(pl, i, 2, a.a1, D, 3 * D, hip.EPI_BF16, a.qkv_s, lin_b("attn.qkv"), quantised=q1)
         else:
             hip.gemm_nt(a.a1, w("attn.qkv"), M, 3 * D, D, hip.EPI_BF16, a.qkv_s, bias=lin_b("attn.qkv"))
-        self._attention(pl, hip.attn_space_fwd, a.qkv_s, a.o_s, a.lse_s)
+        top_pruned = pl.prune_top and i == self.depth - 1
+        if top_pruned:
+            # only the CLS query's output is consumed: the patch queries are not run.  Backward still walks them (their dO is
+            # zero) and needs P = exp2(s - lse) = 0 there whatever the stale rows hold: lse = 3.4e38 (bytes 0x7f; the kernel
+            # scales it by log2(e) to +inf - the form it gives padding queries itself, attn_space.hip)
+            hip.fill_bytes_(a.lse_s[:pl.segs[0].cls0], 0x7f)
+        self._attention(pl, hip.attn_space_fwd, a.qkv_s, a.o_s, a.lse_s, patch=not top_pruned)
         if lane is not None:
             self._lane_linear(pl, lane["o32"], p("attn.proj.weight"), p("attn.proj.bias"), D, D, lane["br32"])
             # space residual comes from x, NOT from x + time (video_transformer.py:170)
@@ -713,7 +719,7 @@ class VideoEngine:
             self._lane_linear(pl, lane["g32"], p("mlp.fc2.weight"), p("mlp.fc2.bias"), D, Hd, lane["br32"])
         brs = pl.branch16s if pl.skip_y else br      # skip_y: the space branch keeps its own buffer until the next block's norm3
         a.xin = x
-        if pl.prune_top and i == self.depth - 1:
+        if top_pruned:
             self._top_tail_fwd(pl, a, x, brs, br, p, w, lin_b)
             return a
         if f8 and self.fp8_proj:
@@ -788,9 +794,10 @@ class VideoEngine:
             cls_out = [sg.lane(lane["out"]) for sg in pl.segs]
         return cls_out, [pl.normed[sg.row0:sg.cls0] if need_patches else None for sg in pl.segs]
 
-    def _attention(self, pl, patch_kernel, qkv, out, lse):
+    def _attention(self, pl, patch_kernel, qkv, out, lse, patch=True):
         """Patch attention on the caller's stream, the independent CLS-query attention (it only writes the
-        CLS rows of out / lse, and the lane's precise context) concurrently on the side stream."""
+        CLS rows of out / lse, and the lane's precise context) concurrently on the side stream.  patch=False (pruned top
+        block): the CLS query alone."""
         cur = torch.cuda.current_stream()
         hip.stream_edge(cur, pl.side)                    # qkv is complete
         with torch.cuda.stream(pl.side):
@@ -801,7 +808,9 @@ class VideoEngine:
                                           self.D, self.scale)
                 else:
                     hip.attn_cls_fwd(q, o, l, sg.B, sg.T, sg.N, self.H, self.D, self.scale)
-        if patch_kernel is hip.attn_space_fwd and len(pl.segs) == 2 and pl.segs[0].N == pl.segs[1].N and self.clip_launch:
+        if not patch:
+            pass
+        elif patch_kernel is hip.attn_space_fwd and len(pl.segs) == 2 and pl.segs[0].N == pl.segs[1].N and self.clip_launch:
             # both clips' frames in ONE launch: the object frame alone is B x H problems, a third of the GPU
             hip.attn_space_fwd_clips([dict(qkv=sg.rows(qkv), out=sg.rows(out), lse=sg.rows(lse), B=sg.B, T=sg.T) for sg in pl.segs],
                                      pl.segs[0].N, self.H, self.D, self.scale)

@@ -766,6 +766,12 @@ def zero_(t):
     _check(lib().oat_memset_async(_ptr(t), 0, ctypes.c_size_t(t.numel() * t.element_size()), _stream()), "oat_memset_async")
 
 
+def fill_bytes_(t, byte):
+    """every BYTE of t (contiguous) set to `byte`, as a recordable launch (0x7f in an fp32 tensor: 3.39e38 per element)"""
+    assert t.is_contiguous() and 0 <= byte <= 255
+    _check(lib().oat_memset_async(_ptr(t), int(byte), ctypes.c_size_t(t.numel() * t.element_size()), _stream()), "oat_memset_async")
+
+
 def copy_(dst, src):
     """dst.copy_(src) for contiguous tensors of one dtype and size, as a recordable launch."""
     assert dst.is_contiguous() and src.is_contiguous() and dst.dtype == src.dtype and dst.numel() == src.numel()
