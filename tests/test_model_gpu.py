@@ -153,9 +153,12 @@ def test_adamw_matches_published_algorithms(hf_style):
     assert torch.allclose(p.double(), pr, atol=2e-6, rtol=1e-5)
 
 
+@pytest.mark.parametrize("prune_top", [False, True])
 @pytest.mark.parametrize("frames", [1, 4, 8])
-def test_frozen_in_time_vitb_vs_reference_golden(golden_dir, frames):
-    """The contract class at ViT-B/16 + DistilBERT-base geometry against the outputs of the reference's own
+def test_frozen_in_time_vitb_vs_reference_golden(golden_dir, frames, prune_top):
+    """prune_top: the same goldens with the top block's unused patch rows skipped (VideoEngine.prune_top, opt-in).
+
+    The contract class at ViT-B/16 + DistilBERT-base geometry against the outputs of the reference's own
     oa_model.FrozenInTime (tests/golden/full_T{1,4,8}.pt): 1 frame = BASELINE config 1's geometry, 4 frames = config 2's,
     8 frames = the headline shape of configs 3 / 4.  Stated tolerance (north_star): sim matrix <= 1e-3 max-abs."""
     from OATrans import model as module_arch

@@ -122,3 +122,36 @@ def test_prune_is_refused_where_patch_rows_are_consumed():
     (cls.sum() + patches.sum()).backward()
     torch.cuda.synchronize()
     assert all(torch.isfinite(p.grad).all() for p in vid.parameters() if p.grad is not None)
+
+
+def test_entry_point_trains_with_the_pruned_top_block(tmp_path):
+    """train_dist_multi.py end to end with OAT_PRUNE_TOP=1: training steps, the no-grad validation pass and the checkpoint
+    (the entry points set no seed, so losses are only checked for being finite; equality with the full graph is the
+    subject of the tests above)."""
+    import json
+    import math
+    import os
+    import re
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "oa-transformer_amd", "OATrans")
+    cfg = json.load(open(os.path.join(pkg, "configs/pt/synthetic/frozen_1f_bs2.json")))
+    cfg["arch"]["args"]["video_params"]["arch_kwargs"] = {"depth": 2}
+    cfg["arch"]["args"]["text_params"]["config"] = {"n_layers": 1}
+    cfg["trainer"].update(epochs=1, max_samples_per_epoch=8, save_dir=str(tmp_path / "exps"), save_period=1)
+    path = tmp_path / "cfg.json"
+    path.write_text(json.dumps(cfg))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", OAT_PRUNE_TOP="1")
+    r = subprocess.run([sys.executable, os.path.join(pkg, "train_dist_multi.py"), "-c", str(path)], cwd=str(tmp_path), env=env,
+                       capture_output=True, text=True, timeout=600)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0, out[-3000:]
+    assert "Saving checkpoint" in out and "val_loss_0" in out, out[-2000:]
+    found = re.findall(r"(val_loss_0|loss_0)\s*:\s*([-+0-9.eE]+)", out)
+    assert found and all(math.isfinite(float(v)) for _, v in found), out[-2000:]
