@@ -1002,12 +1002,13 @@ class VideoEngine:
             need = hip.lib().oat_tn_group_slab_bytes(hip.TnGroup.plan_layers([[meta[k] for k in ks] for ks in idx], grid)[3]) // 4
             if self._tn_slabs is None or self._tn_slabs.numel() < need:
                 if self._tn_slabs is not None:
-                    # launch tapes recorded so far still point at the old slabs AND at the device tables of the groups built on
-                    # them: both are kept alive (a pruned top block queues three problems, needs less than the six of the block
-                    # below it and is flushed first - its group was dropped here while the tape being recorded held its tables)
+                    # The outgrown workspace stays alive and the groups built on it KEEP it (their tables hold its address and it
+                    # is large enough for them; groups run one after the other on one stream, so which workspace each uses does
+                    # not matter).  Until round 4 the plan's groups were dropped here and rebuilt on the new workspace: with a
+                    # pruned top block - three problems, flushed first, smaller need than the six of the block below - that freed
+                    # the tables of a group the tape being recorded had just captured (memory fault on replay), and left the
+                    # group to be rebuilt (a host-to-device copy) inside a later hipGraph capture.
                     self._tn_retired.append(self._tn_slabs)
-                    self._tn_retired.append(dict(pl.tn_groups))
-                    pl.tn_groups.clear()
                 self._tn_slabs = torch.empty(need, dtype=torch.float32, device=probs[0][0].device)
             held = (key, hip.TnGroup(probs, grid=grid, slabs=self._tn_slabs, layers=idx))
             pl.tn_groups[tag] = held
