@@ -5,6 +5,14 @@
 //   C/D      : lane l holds D[row = (l >> 4) * 4 + r][col = l & 15], r = 0..3
 #pragma once
 #include <hip/hip_runtime.h>
+
+// One target.  Several kernels hand data between workgroups with returnless atomics + `s_waitcnt vmcnt(0)` and no fence
+// (rowops.hip: ln_fold_grads, attn_space.hip: the fused CLS-row finalize) and count LDS-DMA / store retirement with vmcnt:
+// that is gfx950 behaviour (vmcnt covers stores and returnless atomics, atomics execute at the memory side) and would be
+// wrong on a target with a separate store counter.  The device pass of any other architecture must not compile.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "liboatrans_hip is written for gfx950 (MI355X / CDNA4) only: build with --offload-arch=gfx950"
+#endif
 #include <stdint.h>
 #include <functional>
 
