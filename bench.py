@@ -110,9 +110,9 @@ def other_config_line(base_args, variant, device, steps=10, warmup=3):
     import gc
     from OATrans.trainer.step import global_local_step, hot_step, region_mem_step
     args = copy.copy(base_args)
-    pruned = variant == "frozen_pruned"       # the headline model with VideoEngine.prune_top (see pruned_top_gflops)
-    args.variant = "frozen" if pruned else variant
-    step_impl = {"region_mem": region_mem_step, "global_local": global_local_step, "frozen_pruned": hot_step}[variant]
+    pruned = variant.endswith("_pruned")      # the same model and step with VideoEngine.prune_top (see pruned_top_gflops)
+    args.variant = variant[:-len("_pruned")] if pruned else variant
+    step_impl = {"region_mem": region_mem_step, "global_local": global_local_step, "frozen": hot_step}[args.variant]
     dp, opt, loss_fn = build(args, device)
     if args.dtype == "fp8":
         dp.module.video_model._engine.fp8 = True
@@ -129,6 +129,22 @@ def other_config_line(base_args, variant, device, steps=10, warmup=3):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     value = args.batch * steps / elapsed
+    if pruned and args.variant == "region_mem":
+        N = (args.res // 16) ** 2
+        full = flops_per_pair(args.frames, N=N, clips=(1, args.frames)) / 1e9
+        gf_pair = full - pruned_top_gflops(args.frames + 1, N)
+        line = {"workload": f"[region_mem, top block pruned] the [region_mem] model and step with VideoEngine.prune_top (opt-in): "
+                            f"oa_model_region_mem.FrozenInTime takes the CLS rows of the encoder output and the patch rows of block 6 "
+                            f"(region tap), never the final patch rows - the top block's space projection / norm2 / fc1 / GELU / fc2 run on "
+                            f"the 2 x {args.batch} CLS rows of the object frame and the clip; same loss, same gradients (tests/test_prune_gpu.py)",
+                "value": round(value, 2), "unit": "pairs/s", "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps, "warmup": warmup,
+                "gflop_per_pair_executed": round(gf_pair, 1), "gflop_per_pair_full_graph": round(full, 1),
+                "step_mfma_frac_executed": round(value * gf_pair / 1e3 / BF16_DENSE_PEAK_TFLOPS, 4),
+                "final_loss": round(float(loss.item()), 4)}
+        del dp, opt, data, loss
+        gc.collect()
+        torch.cuda.empty_cache()
+        return line
     if pruned:
         N = (args.res // 16) ** 2
         full = flops_per_pair(args.frames, N=N) / 1e9
@@ -486,7 +502,7 @@ def main():
             gc.collect()
             torch.cuda.empty_cache()
             out["other_configs"] = []
-            for variant in ("global_local", "region_mem", "frozen_pruned"):
+            for variant in ("global_local", "region_mem", "frozen_pruned", "region_mem_pruned"):
                 try:
                     out["other_configs"].append(other_config_line(args, variant, device))
                 except Exception as exc:              # the headline line must still be printed

@@ -258,7 +258,8 @@ class VideoEngine:
         # block's space-attention projection, norm2, fc1 / GELU and fc2 are never read and their output gradient is exactly
         # zero, so these launches - forward, data gradient and weight gradient - run on the B CLS rows only.  Same loss, same
         # gradients (the weight-gradient sums lose only exact-zero terms); 49.9 of 1115.9 GF per pair at 8 frames are not
-        # executed (bench.py reports the executed figure).  See _top_tail_fwd / _top_block_bwd_pruned.
+        # executed (bench.py reports the executed figure).  Also oa_model_region_mem (CLS rows + the block-6 region tap; both
+        # clips of its plan).  See _top_tail_fwd / _top_block_bwd_pruned.
         self.prune_top = os.environ.get("OAT_PRUNE_TOP", "0") != "0"
         self.fbias = {}                     # folded biases b' (fp32), per folded linear
         self._fold_bias = None
@@ -495,7 +496,9 @@ class VideoEngine:
         run = _Run(pl, need_patches, region_layer)
         # folded LayerNorms + bf16 forward: y = x + space is never stored (the next block's norm3 adds both branch outputs)
         pl.skip_y = self.fold_active() and self._fp8_on_stream16() and os.environ.get("OAT_SKIP_Y", "1") != "0"
-        pl.prune_top = bool(self.prune_top and not need_patches and region_layer is None and len(pl.segs) == 1 and pl.res16
+        # (a region tap BELOW the top block - oa_model_region_mem: block 6 - leaves the top block's patch rows just as unused; a tap
+        # on the encoder output reads them)
+        pl.prune_top = bool(self.prune_top and not need_patches and region_layer != self.depth and pl.res16
                             and pl.skip_y and not self.fp8 and not self.bwd_side)
         run.prune_top = pl.prune_top
         if pl.prune_top and getattr(pl, "d_o_top", None) is None:
@@ -709,7 +712,8 @@ class VideoEngine:
             # only the CLS query's output is consumed: the patch queries are not run.  Backward still walks them (their dO is
             # zero) and needs P = exp2(s - lse) = 0 there whatever the stale rows hold: lse = 3.4e38 (bytes 0x7f; the kernel
             # scales it by log2(e) to +inf - the form it gives padding queries itself, attn_space.hip)
-            hip.fill_bytes_(a.lse_s[:pl.segs[0].cls0], 0x7f)
+            for sg in pl.segs:
+                hip.fill_bytes_(a.lse_s[sg.row0:sg.cls0], 0x7f)
         self._attention(pl, hip.attn_space_fwd, a.qkv_s, a.o_s, a.lse_s, patch=not top_pruned)
         if lane is not None:
             self._lane_linear(pl, lane["o32"], p("attn.proj.weight"), p("attn.proj.bias"), D, D, lane["br32"])
@@ -753,13 +757,13 @@ class VideoEngine:
         row space).  The patch rows of brs / a.a2 / a.h / a.g / br keep whatever they held: nothing reads them - the final
         LayerNorm takes the CLS rows (_final_fwd), backward runs _top_block_bwd_pruned.  The saved GELU derivative of these
         rows is plain bf16 in a.h (the 8-bit blocked form belongs to the ping-pong GEMM, which does not serve 32-row problems)."""
-        D, Hd = self.D, self.Hd
-        sg = pl.segs[0]
-        c0, Bc, st = sg.cls0, sg.B, a.stats
-        hip.gemm_nt(a.o_s[c0:], w("attn.proj"), Bc, D, D, hip.EPI_BF16, brs[c0:], bias=p("attn.proj.bias"))
-        hip.layernorm_fwd_r16(x[c0:], Bc, D, 1e-6, add_a=brs[c0:], y=a.a2[c0:], mean=st[4][c0:], rstd=st[5][c0:])
-        hip.gemm_nt(a.a2[c0:], w("mlp.fc1"), Bc, Hd, D, hip.EPI_GELU_GRAD, a.h[c0:], out2=a.g[c0:], bias=lin_b("mlp.fc1"))
-        hip.gemm_nt(a.g[c0:], w("mlp.fc2"), Bc, D, Hd, hip.EPI_BF16, br[c0:], bias=p("mlp.fc2.bias"))
+        D, Hd, st = self.D, self.Hd, a.stats
+        for sg in pl.segs:                 # every clip's CLS rows are one tail block of its row range
+            c0, Bc = sg.cls0, sg.B
+            hip.gemm_nt(a.o_s[c0:], w("attn.proj"), Bc, D, D, hip.EPI_BF16, brs[c0:], bias=p("attn.proj.bias"))
+            hip.layernorm_fwd_r16(x[c0:], Bc, D, 1e-6, add_a=brs[c0:], y=a.a2[c0:], mean=st[4][c0:], rstd=st[5][c0:])
+            hip.gemm_nt(a.a2[c0:], w("mlp.fc1"), Bc, Hd, D, hip.EPI_GELU_GRAD, a.h[c0:], out2=a.g[c0:], bias=lin_b("mlp.fc1"))
+            hip.gemm_nt(a.g[c0:], w("mlp.fc2"), Bc, D, Hd, hip.EPI_BF16, br[c0:], bias=p("mlp.fc2.bias"))
 
     def _final_fwd(self, pl, params, need_patches, region_layer):
         """-> ([cls rows per segment], [patch rows per segment] | [None, ...])"""
@@ -1202,31 +1206,36 @@ class VideoEngine:
         wT = lambda s: self.shadow[f"blocks.{i}.{s}.weight"][1]
         st = a.stats
         d_h, gb, d_qkv_s, gc, d_qkv_t = st8["d_h"], st8["gb"], st8["d_qkv_s"], st8["gc"], st8["d_qkv_t"]
-        sg = pl.segs[0]
-        c0, Bc = sg.cls0, sg.B
-        R = lambda t: t[c0:]
+        segs = pl.segs
 
-        def wgrad(P, Q, rows, n1, n2, lin, folded, queue):
-            """as wgrad_folded of _block_bwd; queue=False: a B-row problem, launched on its own (gemm_tn)"""
+        def wgrad(P, Q, rows, n1, n2, lin, folded, queue, more=False):
+            """as wgrad_folded of _block_bwd; queue=False: a B-row problem, launched on its own (gemm_tn); more: a later
+            clip's rows of the same weight - added to what the first clip's launch wrote"""
             w_, b_, acc = gr(lin + ".weight"), gr(lin + ".bias"), pl.acc
             if folded and pl.acc:
                 if lin not in self._fold_tmp:
                     self._fold_tmp[lin] = (torch.empty(n1, n2, dtype=torch.float32, device=P.device),
                                            torch.empty(n1, dtype=torch.float32, device=P.device))
                 (w_, b_), acc = self._fold_tmp[lin], False
-            self._wgrad(P, Q, rows, n1, n2, w_, b_, acc, pl=pl if queue else None)
+            self._wgrad(P, Q, rows, n1, n2, w_, b_, acc or more, pl=pl if queue else None)
 
-        # ---- MLP, CLS rows
-        hip.gemm_nt(R(ga), wT("mlp.fc2"), Bc, Hd, D, hip.EPI_MUL_AUX, R(d_h), aux=R(a.h))
-        hip.gemm_nt(R(d_h), wT("mlp.fc1"), Bc, D, Hd, hip.EPI_BF16, R(pl.d_a))
-        hip.layernorm_bwd_xhat(R(pl.d_a), R(a.a2), st[5][c0:], Bc, D, dx16=R(gb), add_a=R(ga))               # gb = ga + dx2
-        wgrad(R(ga), R(a.g), Bc, D, Hd, "mlp.fc2", False, False)
+        # ---- MLP, CLS rows (per clip: its tail block)
+        for k, sg in enumerate(segs):
+            c0, Bc = sg.cls0, sg.B
+            R = lambda t: t[c0:]
+            hip.gemm_nt(R(ga), wT("mlp.fc2"), Bc, Hd, D, hip.EPI_MUL_AUX, R(d_h), aux=R(a.h))
+            hip.gemm_nt(R(d_h), wT("mlp.fc1"), Bc, D, Hd, hip.EPI_BF16, R(pl.d_a))
+            hip.layernorm_bwd_xhat(R(pl.d_a), R(a.a2), st[5][c0:], Bc, D, dx16=R(gb), add_a=R(ga))           # gb = ga + dx2
+            wgrad(R(ga), R(a.g), Bc, D, Hd, "mlp.fc2", False, False, more=k > 0)
         # ---- space attention: the projection on the CLS rows, the attention itself on every row (dO of the patch queries = 0)
         d_o = pl.d_o_top
-        hip.gemm_nt(R(gb), wT("attn.proj"), Bc, D, D, hip.EPI_BF16, R(d_o))
+        for sg in segs:
+            hip.gemm_nt(gb[sg.cls0:], wT("attn.proj"), sg.B, D, D, hip.EPI_BF16, d_o[sg.cls0:])
         self._attn_bwd(pl, hip.attn_space_bwd, a.qkv_s, a.o_s, a.lse_s, d_o, d_qkv_s)
-        wgrad(R(d_h), R(a.a2), Bc, Hd, D, "mlp.fc1", True, False)
-        wgrad(R(gb), R(a.o_s), Bc, D, D, "attn.proj", False, False)
+        for k, sg in enumerate(segs):
+            c0, Bc = sg.cls0, sg.B
+            wgrad(d_h[c0:], a.a2[c0:], Bc, Hd, D, "mlp.fc1", True, False, more=k > 0)
+            wgrad(gb[c0:], a.o_s[c0:], Bc, D, D, "attn.proj", False, False, more=k > 0)
         hip.gemm_nt(d_qkv_s, wT("attn.qkv"), M, D, 3 * D, hip.EPI_BF16, pl.d_a)
         hip.layernorm_bwd_xhat(pl.d_a, a.a1, st[3], M, D, dx16=gc)                                            # gc = dx1
         wgrad(d_qkv_s, a.a1, M, 3 * D, D, "attn.qkv", True, True)
@@ -1236,10 +1245,12 @@ class VideoEngine:
         wgrad(gc, a.o_t, M, D, D, "timeattn.proj", False, True)
         hip.gemm_nt(d_qkv_t, wT("timeattn.qkv"), M, D, 3 * D, hip.EPI_BF16, pl.d_a)
         # ga_next = gb + gc + dx3: gb is zero on the patch rows (not stored there), present on the CLS rows
-        G0 = G if i == 0 else None
-        hip.layernorm_bwd_xhat(pl.d_a, a.a3, st[1], c0, D, dx=G0, dx16=ga_next, add_b=gc)
-        hip.layernorm_bwd_xhat(R(pl.d_a), R(a.a3), st[1][c0:], Bc, D, dx=R(G) if i == 0 else None, dx16=R(ga_next), add_a=R(gb),
-                               add_b=R(gc))
+        for sg in segs:
+            r0, c0, Bc = sg.row0, sg.cls0, sg.B
+            hip.layernorm_bwd_xhat(pl.d_a[r0:], a.a3[r0:], st[1][r0:], c0 - r0, D, dx=G[r0:] if i == 0 else None, dx16=ga_next[r0:],
+                                   add_b=gc[r0:])
+            hip.layernorm_bwd_xhat(pl.d_a[c0:], a.a3[c0:], st[1][c0:], Bc, D, dx=G[c0:] if i == 0 else None, dx16=ga_next[c0:],
+                                   add_a=gb[c0:], add_b=gc[c0:])
         wgrad(d_qkv_t, a.a3, M, 3 * D, D, "timeattn.qkv", True, True)
         pl.fold_pending = i
 

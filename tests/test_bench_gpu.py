@@ -49,12 +49,14 @@ def test_bench_single_rank_line():
     # config 3 as worded (object-aware variants) rides along outside `value`
     oc = rec["other_configs"]
     # ... and the headline model with the opt-in pruned top block (VideoEngine.prune_top), utilisation from the EXECUTED FLOPs
-    assert [o["workload"].split("]")[0] for o in oc] == ["[global_local", "[region_mem", "[frozen, top block pruned"], oc
+    assert [o["workload"].split("]")[0] for o in oc] == ["[global_local", "[region_mem", "[frozen, top block pruned",
+                                                         "[region_mem, top block pruned"], oc
     for o in oc:
         assert "error" not in o, o
         frac = o["step_mfma_frac_executed"] if "pruned" in o["workload"] else o["step_mfma_frac"]
         assert o["value"] > 0 and o["ms_per_step"] > 0 and 0 < frac < 1 and o["unit"] == "pairs/s"
     assert oc[2]["gflop_per_pair_executed"] < oc[2]["gflop_per_pair_full_graph"] == rec["config"]["gflop_per_pair"]
+    assert oc[3]["gflop_per_pair_executed"] < oc[3]["gflop_per_pair_full_graph"] == oc[1]["gflop_per_pair"]
     cb = rec["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "pairs/s" and cb["sample"]
 

@@ -169,15 +169,20 @@ def _check_grads_vs_oracle(model, og, tol=5e-2, skip=("object_embed",)):
     assert not bad, bad[:10]
 
 
-@pytest.mark.parametrize("variant,segments", [("global_local", True), ("region_mem", True), ("global_local", False)])
-def test_native_object_clip_4_frames_vs_oracle(variant, segments, monkeypatch):
-    """BASELINE config 3's shape class at test size: one object frame + a 4-frame clip through the same 12-block
+@pytest.mark.parametrize("variant,segments,prune", [("global_local", True, False), ("region_mem", True, False),
+                                                    ("global_local", False, False), ("region_mem", True, True)])
+def test_native_object_clip_4_frames_vs_oracle(variant, segments, prune, monkeypatch):
+    """prune=True: VideoEngine.prune_top on the region_mem model (it reads the CLS rows and the block-6 region tap, never the
+    final patch rows: the top block's projection / MLP run on the CLS rows of BOTH clips) against the oracle's full graph.
+
+    BASELINE config 3's shape class at test size: one object frame + a 4-frame clip through the same 12-block
     encoder against the fp32 oracle run of the same graph (oracle components pinned by the reference goldens, its
     native layout by test_native_clip_layout_is_the_reference_at_two_frames).  segments=True is the default path (both
     clips as two segments of one launch sequence); segments=False is two encoder calls, the second backward
     ACCUMULATING into the first's gradients (the folded-LayerNorm weight gradients then go through a scratch slab).
     Tolerances: embeddings rel-L2 <= 1e-2, loss rel <= 3e-2, gradients norm <= 5e-2 / cosine >= 0.99."""
     monkeypatch.setenv("OAT_OBJ_SEGMENTS", "1" if segments else "0")
+    monkeypatch.setenv("OAT_PRUNE_TOP", "1" if prune else "0")
     from OATrans.model import NormSoftmaxLoss, sim_matrix
     from OATrans.model.oa_layers import bce_sum, mean_rows
     from OATrans.utils import seeded_init as si
@@ -224,6 +229,8 @@ def test_native_object_clip_4_frames_vs_oracle(variant, segments, monkeypatch):
             loss = L(sim_matrix(t, v)) + 0.1 * bce_sum(rs, pm) / rs.size(0)
         loss.backward()
     torch.cuda.synchronize()
+    plans = list(m.video_model._engine.plans.values())
+    assert plans and all(pl.prune_top == prune for pl in plans), [pl.prune_top for pl in plans]
     if variant == "global_local":
         ot, opt_, ov_, oov, orf, otf = orc.gl_forward(po, d["video"], (d["ids"], d["mask"]), (d["pids"], d["pmask"]),
                                                       d["patch_masks"], d["otm"], object_clip="native")

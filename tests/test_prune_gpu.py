@@ -158,3 +158,53 @@ def test_entry_point_trains_with_the_pruned_top_block(tmp_path):
     assert "Saving checkpoint" in out and "val_loss_0" in out, out[-2000:]
     found = re.findall(r"(val_loss_0|loss_0)\s*:\s*([-+0-9.eE]+)", out)
     assert found and all(math.isfinite(float(v)) for _, v in found), out[-2000:]
+
+
+def test_region_mem_pruned_equals_the_full_run():
+    """Two clips in one plan (object frame + video clip) and a region tap below the top block: oa_model_region_mem at the
+    bench's shape class (ViT-B/16, 12 blocks, 1 + 2 frames, B = 3), pruned against full on the same weights and batch."""
+    import argparse
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    from OATrans.model.oa_layers import bce_sum
+    from OATrans import model as module_arch
+    args = argparse.Namespace(variant="region_mem", frames=2, res=224, batch=3, lr=2e-5, dtype="bf16")
+    dev = torch.device("cuda:0")
+    dp, opt, loss_fn = bench.build(args, dev)
+    m = dp.module
+    m.text_model.eval()
+    eng = m.video_model._engine
+    eng.h_u8 = False
+    data = bench.synthetic_batch(args, 0, dev)
+
+    def run(steps):
+        for _ in range(steps):
+            opt.zero_grad()
+            m.begin_step()
+            text, video, rsim = m(data, aug=True)
+            pm = data["patch_masks"].float()
+            pm = pm.squeeze(1) if pm.dim() == 4 else pm
+            rs = rsim.reshape(-1, rsim.shape[-1])
+            loss = loss_fn(module_arch.sim_matrix(text, video)) + 0.1 * bce_sum(rs, pm.reshape(-1, pm.shape[-1])) / rs.shape[0]
+            loss.backward()
+        torch.cuda.synchronize()
+        return loss.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+
+    eng.prune_top = False
+    loss0, g0 = run(2)
+    assert all(not pl.prune_top for pl in eng.plans.values())
+    eng.prune_top = True
+    loss1, g1 = run(3)
+    assert any(pl.prune_top and len(pl.segs) == 2 for pl in eng.plans.values())
+    assert torch.equal(loss0, loss1)
+    worst = ("", 0.0)
+    for k, a in g0.items():
+        den = a.norm().item()
+        if den < 1e-9:
+            continue
+        worst = max(worst, (k, (a - g1[k]).norm().item() / den), key=lambda z: z[1])
+    print("region_mem, worst relative difference pruned vs full:", worst)
+    assert worst[1] < 1e-2, worst
