@@ -24,6 +24,60 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "oa-transformer_amd"))
 sys.path.insert(0, ROOT)
 
+# dmabuf IPC: without it RCCL's intra-node transport fails with `hipIpcGetMemHandle: invalid argument` on this driver
+# stack.  Must be in the environment before the HIP runtime initialises, i.e. before torch touches the GPU.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+def _self_launch():
+    """`python bench.py --gpus N` with N > 1 and NO launcher around it (no RANK / WORLD_SIZE in the environment):
+    become the launcher - start N copies of this command, one rank per GPU, with the env rendezvous the reference's
+    entry points read (train_dist_multi.py:35-38,127-132: MASTER_ADDR / MASTER_PORT / WORLD_SIZE / RANK / LOCAL_RANK),
+    wait for them, and exit with the first non-zero status.  Rank 0's JSON line goes to this process's stdout.
+    Returns None when there is nothing to launch (N == 1, or a launcher - torch.distributed.run - already set the env)."""
+    pre = argparse.ArgumentParser(add_help=False)
+    pre.add_argument("--gpus", type=int, default=1)
+    n = pre.parse_known_args()[0].gpus
+    if n <= 1 or "WORLD_SIZE" in os.environ or "RANK" in os.environ:
+        return None
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n), RANK=str(r),
+                   LOCAL_RANK=str(r), LOCAL_WORLD_SIZE=str(n), OAT_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code
+                    print(f"bench.py: rank {r} exited with status {code}; stopping the other ranks", file=sys.stderr, flush=True)
+                    for o in pending:
+                        procs[o].terminate()          # exactly the processes started above
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+if __name__ == "__main__":
+    _rc = _self_launch()
+    if _rc is not None:
+        sys.exit(_rc)
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -101,16 +155,19 @@ def synthetic_batch(args, rank, device):
     return batch
 
 
-def other_config_line(base_args, variant, device, steps=10, warmup=3):
-    """Config 3 as BASELINE.json words it ("8-frame 224^2 + 10 object regions/frame, bs 32"): the object-aware model
-    classes on one object frame + the clip.  Run AFTER the headline's timed region and reported under `other_configs`,
-    outside `value`: a short (warmup + steps) single-GPU measurement with the same step function, optimiser and timing
-    brackets as the headline."""
+def other_config_line(base_args, variant, device, steps=10, warmup=3, label=None, **overrides):
+    """One more workload of BASELINE.json's `configs`, run AFTER the headline's timed region and reported under
+    `other_configs`, outside `value`: a short (warmup + steps) single-GPU measurement with the same step function,
+    optimiser and timing brackets as the headline.  variant: frozen | region_mem | global_local, with the suffix
+    `_pruned` for the same model and step under VideoEngine.prune_top (see pruned_top_gflops); overrides: frames /
+    batch / res / dtype of the run (default: the headline's); label: the BASELINE.json config the entry stands for."""
     import copy
     import gc
     from OATrans.trainer.step import global_local_step, hot_step, region_mem_step
     args = copy.copy(base_args)
-    pruned = variant.endswith("_pruned")      # the same model and step with VideoEngine.prune_top (see pruned_top_gflops)
+    for k, v in overrides.items():
+        setattr(args, k, v)
+    pruned = variant.endswith("_pruned")
     args.variant = variant[:-len("_pruned")] if pruned else variant
     step_impl = {"region_mem": region_mem_step, "global_local": global_local_step, "frozen": hot_step}[args.variant]
     dp, opt, loss_fn = build(args, device)
@@ -129,51 +186,57 @@ def other_config_line(base_args, variant, device, steps=10, warmup=3):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     value = args.batch * steps / elapsed
-    if pruned and args.variant == "region_mem":
-        N = (args.res // 16) ** 2
-        full = flops_per_pair(args.frames, N=N, clips=(1, args.frames)) / 1e9
-        gf_pair = full - pruned_top_gflops(args.frames + 1, N)
-        line = {"workload": f"[region_mem, top block pruned] the [region_mem] model and step with VideoEngine.prune_top (opt-in): "
-                            f"oa_model_region_mem.FrozenInTime takes the CLS rows of the encoder output and the patch rows of block 6 "
-                            f"(region tap), never the final patch rows - the top block's space projection / norm2 / fc1 / GELU / fc2 run on "
-                            f"the 2 x {args.batch} CLS rows of the object frame and the clip; same loss, same gradients (tests/test_prune_gpu.py)",
-                "value": round(value, 2), "unit": "pairs/s", "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps, "warmup": warmup,
-                "gflop_per_pair_executed": round(gf_pair, 1), "gflop_per_pair_full_graph": round(full, 1),
-                "step_mfma_frac_executed": round(value * gf_pair / 1e3 / BF16_DENSE_PEAK_TFLOPS, 4),
-                "final_loss": round(float(loss.item()), 4)}
-        del dp, opt, data, loss
-        gc.collect()
-        torch.cuda.empty_cache()
-        return line
+    N = (args.res // 16) ** 2
+    oa = args.variant != "frozen"
+    full = flops_per_pair(args.frames, N=N, clips=(1, args.frames) if oa else None,
+                          text_passes=2 if args.variant == "global_local" else 1) / 1e9
+    cls_name = {"frozen": "oa_model", "region_mem": "oa_model_region_mem", "global_local": "oa_model_global_local"}[args.variant]
+    n_obj = {"region_mem": 5, "global_local": 10}.get(args.variant)
+    dtype = "bf16" if args.dtype == "bf16" else "fp8 e4m3 forward linears (per-tensor delayed scaling) + bf16 backward"
+    common = {"value": round(value, 2), "unit": "pairs/s", "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps,
+              "warmup": warmup, "dtype": dtype, "per_gpu_batch": args.batch, "frames": args.frames, "res": args.res}
     if pruned:
-        N = (args.res // 16) ** 2
-        full = flops_per_pair(args.frames, N=N) / 1e9
-        gf_pair = full - pruned_top_gflops(args.frames, N)
-        line = {"workload": f"[frozen, top block pruned] the headline model and step with VideoEngine.prune_top (opt-in, OAT_PRUNE_TOP=1): "
-                            f"oa_model.FrozenInTime consumes only the CLS row of the encoder output, so the top block's space projection / "
-                            f"norm2 / fc1 / GELU / fc2 run on the {args.batch} CLS rows instead of all {args.batch * (args.frames * N + 1)} "
-                            f"(forward, data and weight gradients); same loss, same gradients (tests/test_prune_gpu.py)",
-                "value": round(value, 2), "unit": "pairs/s", "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps, "warmup": warmup,
-                "gflop_per_pair_executed": round(gf_pair, 1), "gflop_per_pair_full_graph": round(full, 1),
-                "step_mfma_frac_executed": round(value * gf_pair / 1e3 / BF16_DENSE_PEAK_TFLOPS, 4),
-                "final_loss": round(float(loss.item()), 4)}
-        del dp, opt, data, loss
-        gc.collect()
-        torch.cuda.empty_cache()
-        return line
-    gf_pair = flops_per_pair(args.frames, N=(args.res // 16) ** 2, clips=(1, args.frames),
-                             text_passes=2 if variant == "global_local" else 1) / 1e9
-    n_obj = {"region_mem": 5, "global_local": 10}[variant]
-    line = {"workload": f"[{variant}] {args.frames}-frame + {n_obj} obj (one object frame with {n_obj} box masks + the {args.frames}-frame "
-                        f"clip, same encoder) {args.res}^2 ViT-B/16 + DistilBERT-base (oa_model_{variant}.FrozenInTime), bs {args.batch}, "
-                        f"fwd+bwd+AdamW",
-            "value": round(value, 2), "unit": "pairs/s", "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps, "warmup": warmup,
-            "gflop_per_pair": round(gf_pair, 1), "step_mfma_frac": round(value * gf_pair / 1e3 / BF16_DENSE_PEAK_TFLOPS, 4),
-            "final_loss": round(float(loss.item()), 4)}
+        # the utilisation of a pruned run counts what was EXECUTED; the clips of an OA model are pruned one by one
+        gf_pair = full - pruned_top_gflops(args.frames + (1 if oa else 0), N)
+        what = ("oa_model_region_mem.FrozenInTime takes the CLS rows of the encoder output and the patch rows of block 6 (region tap), never "
+                f"the final patch rows - the top block's space projection / norm2 / fc1 / GELU / fc2 run on the 2 x {args.batch} CLS rows of "
+                "the object frame and the clip") if oa else \
+               ("oa_model.FrozenInTime consumes only the CLS row of the encoder output, so the top block's space projection / norm2 / fc1 / "
+                f"GELU / fc2 run on the {args.batch} CLS rows instead of all {args.batch * (args.frames * N + 1)} (forward, data and weight gradients)")
+        line = {"workload": f"[{args.variant}, top block pruned] the [{args.variant}] model and step with VideoEngine.prune_top (opt-in, "
+                            f"OAT_PRUNE_TOP=1): {what}; same loss, same gradients (tests/test_prune_gpu.py)",
+                **common, "gflop_per_pair_executed": round(gf_pair, 1), "gflop_per_pair_full_graph": round(full, 1),
+                "step_mfma_frac_executed": round(value * gf_pair / 1e3 / BF16_DENSE_PEAK_TFLOPS, 4)}
+    else:
+        clip = f"{args.frames}-frame + {n_obj} obj (one object frame with {n_obj} box masks + the {args.frames}-frame clip, same encoder)" \
+            if oa else f"{args.frames}-frame"
+        line = {"workload": f"[{label or args.variant}] {clip} {args.res}^2 ViT-B/16 + DistilBERT-base ({cls_name}.FrozenInTime), "
+                            f"bs {args.batch}, fwd+bwd+AdamW",
+                **common, "gflop_per_pair": round(full, 1),
+                "step_mfma_frac": round(value * full / 1e3 / BF16_DENSE_PEAK_TFLOPS, 4)}    # against the bf16 roof in either dtype
+    line["final_loss"] = round(float(loss.item()), 4)
     del dp, opt, data, loss
     gc.collect()
     torch.cuda.empty_cache()
     return line
+
+
+def other_config_plan(args):
+    """What a default 1-GPU run appends under `other_configs`: config 3 as BASELINE.json words it (both object-aware
+    classes, objects on), the two opt-in pruned schedules, and the per-GPU shapes of configs 2, 4 and 5 (config 5 in
+    both dtypes: bf16 is its in-tolerance form, fp8 forward the opt-in).  At another geometry
+    (--other-configs at test sizes) the shapes scale with the command line: half the frames, twice the batch, and
+    twice the frames at 336^2 with a quarter of the batch."""
+    b, f = args.batch, args.frames
+    c5 = dict(frames=2 * f, res=336 if args.res == 224 else args.res, batch=max(2, b // 4))
+    return [("global_local", dict(label="config 3, global_local")),
+            ("region_mem", dict(label="config 3, region_mem")),
+            ("frozen_pruned", {}),
+            ("region_mem_pruned", {}),
+            ("frozen", dict(label="config 2", frames=max(1, f // 2), steps=5, warmup=2)),
+            ("frozen", dict(label="config 4, per-GPU shape", batch=2 * b, steps=5, warmup=2)),
+            ("global_local", dict(label="config 5 geometry, bf16", dtype="bf16", steps=5, warmup=2, **c5)),
+            ("global_local", dict(label="config 5 geometry, fp8 forward", dtype="fp8", steps=5, warmup=2, **c5))]
 
 
 def _gemm_class(kind, epi, M, N, K):
@@ -190,6 +253,9 @@ def _gemm_class(kind, epi, M, N, K):
     if big and epi in (0, 5, 6) and N <= 4096 and nk >= 2 and nk % 2 == 0:
         return f"gemm_nt_pp_kernel<{epis[epi]}>"
     return f"gemm_nt_kernel<{epis.get(epi, epi)},{'2,4,8,4' if big else '2,2,4,4'}>"
+
+
+_ALGO_BYTES = {}      # kernel class -> [algorithmic bytes of each launch of the instrumented step]
 
 
 def instrumented_gemm_profile(step_fn):
@@ -238,6 +304,7 @@ def instrumented_gemm_profile(step_fn):
         orig_nt(A, B, M, N, K, epi, out, **kw)
         e.record()
         records.append((_gemm_class("nt", epi, M, N, K), 2.0 * M * N * K, s, e))
+        _ALGO_BYTES.setdefault(records[-1][0], []).append(2.0 * (M * K + N * K + M * N))      # bf16 A + W in, bf16 C out
 
     def timed_tn(P, Q, M, N1, N2, out, **kw):
         s, e = Ev(), Ev()
@@ -274,6 +341,124 @@ def instrumented_gemm_profile(step_fn):
         rt.hipEventDestroy(s.h)
         rt.hipEventDestroy(e.h)
     return by
+
+
+def traffic_child(args):
+    """The process the rocprofv3 --pmc passes wrap: the model of the main run, one warm-up step (tapes are recorded)
+    and ONE step - no timing, no instrumentation, no output."""
+    from OATrans.trainer.step import hot_step
+    device = torch.device("cuda:0")
+    dp, opt, loss_fn = build(args, device)
+    if args.dtype == "fp8":
+        dp.module.video_model._engine.fp8 = True
+    data = synthetic_batch(args, 0, device)
+    step_args = argparse.Namespace(world_size=1, rank=0, local_rank=0)
+    for _ in range(2):
+        hot_step(dp, loss_fn, opt, data, step_args)
+    torch.cuda.synchronize()
+
+
+def hbm_traffic(args, kernel_class, algo_bytes):
+    """`roofline.traffic`: L2-miss bytes per launch of the roofline kernel from the PMC counters, collected exactly as
+    /opt/skills/guides/MI355X_MICROARCH.md (HBM section, rocprofv3 PMC slots) prescribes: FETCH_SIZE and WRITE_SIZE in
+    SEPARATE `rocprofv3 --kernel-trace --pmc` passes (they do not fit one pass), counters in KiB, and on gfx950
+    FETCH_SIZE tallies 128-byte requests at 64 bytes, so reads = 2 x FETCH_SIZE.  Infinity-Cache hits are counted, so
+    the figure is an upper bound on HBM bytes.  Each pass wraps `bench.py --traffic-child` (same model, two steps)."""
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return {"skipped": "rocprofv3 not on PATH"}
+    try:
+        import pandas as pd
+    except ImportError:
+        return {"skipped": "pandas missing (needed to read rocprofv3's CSV)"}
+    if "gemm_nt_pp_kernel<EPI_BF16" not in kernel_class:
+        return {"skipped": f"no rocprofv3 name pattern for {kernel_class}"}
+    pattern = "gemm_nt_pp_kernel<0,"          # every <EPI_BF16, flags> instance of the ping-pong GEMM
+    tmp = tempfile.mkdtemp(prefix="oat_pmc_", dir="/tmp")
+    child = [sys.executable, os.path.abspath(__file__), "--traffic-child", "--batch", str(args.batch), "--frames", str(args.frames),
+             "--res", str(args.res), "--dtype", args.dtype, "--lr", str(args.lr)]
+    env = dict(os.environ, TMPDIR="/tmp")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    per = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            r = subprocess.run([exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "run", "--"] + child,
+                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return {"skipped": f"rocprofv3 --pmc {counter} failed (rc {r.returncode}): {(r.stderr or r.stdout)[-300:]}"}
+            df = pd.read_csv(files[0])
+            df = df[(df.Counter_Name == counter) & df.Kernel_Name.str.replace(" ", "").str.contains(pattern, regex=False)]
+            d = df.groupby("Dispatch_Id").Counter_Value.sum()
+            per[counter] = (float(d.mean()) * 1024.0, int(d.count()))
+    except subprocess.TimeoutExpired:
+        return {"skipped": "rocprofv3 pass timed out (600 s)"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    read_b, write_b = 2.0 * per["FETCH_SIZE"][0], per["WRITE_SIZE"][0]
+    algo = sum(algo_bytes) / max(1, len(algo_bytes))
+    return {"read_mb": round(read_b / 1e6, 1), "write_mb": round(write_b / 1e6, 1), "total_mb": round((read_b + write_b) / 1e6, 1),
+            "algorithmic_mb": round(algo / 1e6, 1), "ratio": round((read_b + write_b) / algo, 3), "launches_counted": per["FETCH_SIZE"][1],
+            "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | --pmc WRITE_SIZE (separate passes) around `bench.py --traffic-child` "
+                      "(2 steps of this workload); per-launch mean over every gemm_nt_pp_kernel<EPI_BF16, *> dispatch; reads = 2 x "
+                      "FETCH_SIZE KiB (gfx950 correction), writes = WRITE_SIZE KiB; memory-side L2 counters, Infinity-Cache hits included"}
+
+
+def forced_w1(dp, eager_step, batch, device, steps=5, warmup=2):
+    """The W > 1 launch path on ONE GPU: a 1-rank RCCL group, GradSync(force=True) - the ViT block by block and the text
+    tower announce their gradient ranges from inside backward and each range goes out as an asynchronous all-reduce on
+    RCCL's stream (identity at one rank, but the same kernels, stream edges and tape segments) - and the backward GEMM
+    grid of a multi-rank job.  Timed like the headline; reported beside it as `w1_forced`: the per-GPU cost of the
+    multi-GPU machinery before any link time, i.e. an upper bound on the scaling efficiency a node can show."""
+    import socket
+    from OATrans.parallel import GradSync
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    old_sync = dp.sync
+    engines = [m._engine for m in dp.module.modules() if hasattr(getattr(m, "_engine", None), "bwd_nt_grid")]
+    old_grids = [e.bwd_nt_grid for e in engines]
+    out = {}
+    try:
+        for name, grid_env in (("default (one workgroup per tile in backward)", None), ("OAT_BWD_NT_GRID=auto (CUs - 16 persistent workgroups)", "auto")):
+            prev = os.environ.get("OAT_BWD_NT_GRID")
+            if grid_env is not None:
+                os.environ["OAT_BWD_NT_GRID"] = grid_env
+            try:
+                dp.sync = GradSync(dp.module, overlap=True, force=True)
+            finally:
+                if grid_env is not None:
+                    os.environ.pop("OAT_BWD_NT_GRID") if prev is None else os.environ.__setitem__("OAT_BWD_NT_GRID", prev)
+            for _ in range(warmup):
+                eager_step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                eager_step()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / steps * 1e3
+            out[name] = {"ms_per_step": round(ms, 3), "pairs_per_s": round(batch / ms * 1e3, 2), "bwd_nt_grid": dp.sync.bwd_nt_grid,
+                         "async_all_reduces_per_step": dp.sync.started_last_step}
+    finally:
+        dp.sync = old_sync
+        for m in dp.module.modules():
+            if getattr(m, "grad_ready_hook", None) is not None:
+                m.grad_ready_hook = None
+        for e, g in zip(engines, old_grids):
+            e.bwd_nt_grid = g
+        dist.destroy_process_group()
+    first = next(iter(out.values()))
+    return {"ms_per_step_w1_forced": first["ms_per_step"], "steps": steps, "warmup": warmup, "variants": out,
+            "what": "1-rank RCCL group, GradSync(force=True): per-block asynchronous gradient all-reduces started from inside backward + "
+                    "the multi-rank backward GEMM grid; compare with ms_per_step of this line"}
 
 
 def _cpu_sample(frames, threads, budget, max_iters, min_iters=1):
@@ -340,6 +525,12 @@ def main():
                     help="AdamW step size (the reference config uses 2e-4 on PRETRAINED towers; random-init towers on one repeated "
                          "synthetic batch spike at that value, which says nothing about throughput but makes final_loss useless)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="skip `roofline.traffic` (two rocprofv3 --pmc passes over one step, run as subprocesses of a 1-GPU run)")
+    ap.add_argument("--no-forced-w1", action="store_true",
+                    help="skip `w1_forced` (the W > 1 launch path - asynchronous per-block gradient all-reduces from inside backward, "
+                         "the backward GEMM grid of a multi-rank job - on a 1-rank RCCL group, 1-GPU run only)")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)     # the process rocprofv3 wraps (see hbm_traffic)
     ap.add_argument("--prune-top", action="store_true",
                     help="run the MAIN line with VideoEngine.prune_top (default: full top block; a default run reports the pruned "
                          "schedule as an extra entry of `other_configs`).  The line then carries the executed GF per pair")
@@ -358,10 +549,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    if os.environ.get("OAT_BENCH_ECHO_RANK") == "1":       # launcher test hook: what this rank was started with
+        print(f"bench.py rank {rank}/{world} LOCAL_RANK={local} MASTER_ADDR={os.environ.get('MASTER_ADDR')} MASTER_PORT={os.environ.get('MASTER_PORT')} "
+              f"HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}", file=sys.stderr, flush=True)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path for the product)")
     if os.environ.get("OAT_BENCH_ONE_DEVICE") == "1":      # dry run of the N > 1 path on a one-GPU box (with OAT_BENCH_BACKEND=gloo)
         local = 0
+    if args.traffic_child:
+        return traffic_child(args)
+    if local >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} needs GPU {local} but only {torch.cuda.device_count()} are visible "
+                         f"(--gpus {args.gpus}); OAT_BENCH_ONE_DEVICE=1 OAT_BENCH_BACKEND=gloo runs every rank on GPU 0 as a dry run")
     torch.cuda.set_device(local)
     device = torch.device(f"cuda:{local}")
     if world > 1:
@@ -487,13 +686,24 @@ def main():
                 ranked.sort(key=lambda kv: ("fp8" not in kv[0], -kv[1]["ms"]))
             top = entry(*ranked[0])
             # `traffic` (HBM bytes per launch) needs the PMC counters, which cannot be sampled from inside this process:
-            # null here; the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command are committed under profiles/
+            # a 1-GPU run fills it below from two rocprofv3 --pmc passes over a child process (hbm_traffic)
             out["roofline"] = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["achieved"],
                                "peak": top["peak"], "unit": "TFLOP/s", "frac": top["frac"], "traffic": None,
                                "launches_per_step": top["launches_per_step"], "avg_launch_us": top["avg_launch_us"],
                                "ms_per_step": top["ms_per_step"], "gflop_per_launch": top["gflop_per_launch"],
                                "traffic_profile": "profiles/ (rocprofv3 --pmc passes of this command, per round)",
                                "other_gemm_kernels": [entry(n, d) for n, d in ranked[1:] if d["ms"] > 0.2]}
+        if world == 1 and by and not args.no_traffic and args.variant == "frozen":
+            tr = hbm_traffic(args, out["roofline"]["kernel"], _ALGO_BYTES.get(out["roofline"]["kernel"], []))
+            out["roofline"]["traffic"] = None if "skipped" in tr else tr
+            if "skipped" in tr:
+                out["roofline"]["traffic_skipped"] = tr["skipped"]
+        if world == 1 and not args.no_forced_w1 and args.variant == "frozen":
+            try:
+                out["w1_forced"] = forced_w1(dp, eager_step, args.batch, device)
+                out["ms_per_step_w1_forced"] = out["w1_forced"]["ms_per_step_w1_forced"]
+            except Exception as exc:                  # the headline line must still be printed
+                out["w1_forced"] = {"error": f"{type(exc).__name__}: {exc}"}
         if world == 1 and not args.no_other_configs and args.variant == "frozen" and \
                 (args.other_configs or (args.frames == 8 and args.res == 224)):
             # config 3 as worded (object regions on): outside the timed region and outside `value`
@@ -502,11 +712,13 @@ def main():
             gc.collect()
             torch.cuda.empty_cache()
             out["other_configs"] = []
-            for variant in ("global_local", "region_mem", "frozen_pruned", "region_mem_pruned"):
+            for variant, kw in other_config_plan(args):
                 try:
-                    out["other_configs"].append(other_config_line(args, variant, device))
+                    out["other_configs"].append(other_config_line(args, variant, device, **kw))
                 except Exception as exc:              # the headline line must still be printed
-                    out["other_configs"].append({"workload": f"[{variant}]", "error": f"{type(exc).__name__}: {exc}"})
+                    out["other_configs"].append({"workload": f"[{kw.get('label', variant)}]", "error": f"{type(exc).__name__}: {exc}"})
+                    gc.collect()
+                    torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline and args.variant == "frozen":
             out["cpu_baseline"] = cpu_baseline(args.frames)
         print(json.dumps(out), flush=True)

@@ -196,7 +196,8 @@ class VideoEngine:
         # (49.59 vs 49.67 ms per step; +5...9 % per launch with the lockstep kernel), so off by default: 36 fewer launches
         self.tail_split = os.environ.get("OAT_TAIL_SPLIT", "0") != "0"
         self.wgrad_cus = int(os.environ.get("OAT_WGRAD_CUS", "192"))   # workgroup budget of a weight-gradient GEMM that shares its slot
-        self.bwd_nt_grid = int(os.environ.get("OAT_BWD_NT_GRID", "0"), 0)   # gemm_nt grid during backward (0 = as in forward, 0xffff = one workgroup per tile)
+        _g = os.environ.get("OAT_BWD_NT_GRID", "0")                          # "auto": parallel.GradSync derives it from the device when it is built
+        self.bwd_nt_grid = 0 if _g == "auto" else int(_g, 0)                 # gemm_nt grid during backward (0 = as in forward, 0xffff = one workgroup per tile)
         self.slot_delay_ns = int(os.environ.get("OAT_SLOT_DELAY_NS", "4000"))
         self.cls_lane = os.environ.get("OAT_CLS_LANE", "1") != "0"      # fp32 lane for the CLS rows (see _lane_ln)
         # 1: LayerNorm / attention backward on a side stream beside the weight-gradient GEMMs ("slots").  Measured equal to
@@ -630,7 +631,8 @@ class VideoEngine:
 
     def _lane_linear(self, pl, A, W, bias, N, K, out32, act=0):
         with torch.cuda.stream(pl.side):
-            hip.linear_f32(A, W, pl.Bsum, N, K, bias=bias, out32=out32, act=act)
+            # LIN_EXACT: the lane is what holds the 1e-3 sim-matrix bound - f32 products also when more than 64 clips share a plan
+            hip.linear_f32(A, W, pl.Bsum, N, K, bias=bias, out32=out32, act=act | hip.LIN_EXACT)
 
     def _block_fwd(self, pl, i, params, pend, region_layer):
         """Residual adds are fused into the NEXT LayerNorm (oat_add_layernorm_fwd): the projection / fc2 GEMMs

@@ -30,7 +30,7 @@ class _LinearFn(torch.autograd.Function):
             # the projection heads (B rows): one launch forward, one launch backward (oat_linear_small_bwd), no bf16 copies
             y = torch.empty(M, N, dtype=torch.float32, device=x.device)
             hip.linear_f32(x, weight.detach(), M, N, K, bias=bias.detach() if bias is not None else None, out32=y,
-                           act=hip.LIN_RELU_IN if pre_relu else hip.LIN_NONE)
+                           act=(hip.LIN_RELU_IN if pre_relu else hip.LIN_NONE) | hip.LIN_EXACT)
             ctx.save_for_backward(x, weight)
             ctx.small, ctx.pre_relu, ctx.has_bias = True, pre_relu, bias is not None
             return y
@@ -44,7 +44,7 @@ class _LinearFn(torch.autograd.Function):
         y = torch.empty(M, N, dtype=torch.float32, device=x.device)
         if K % 16 == 0:
             hip.linear_f32(x, weight.detach(), M, N, K, bias=bias.detach() if bias is not None else None, out32=y,
-                           act=hip.LIN_RELU_IN if pre_relu else hip.LIN_NONE)
+                           act=(hip.LIN_RELU_IN if pre_relu else hip.LIN_NONE) | hip.LIN_EXACT)
         else:
             w16 = torch.empty(N, K, dtype=torch.bfloat16, device=x.device)
             hip.cast_bf16(weight.detach().contiguous(), w16, None)
@@ -148,9 +148,13 @@ class _InfoNCEFn(torch.autograd.Function):
 
 
 def infonce_loss(t, v, temperature=0.05, eps=1e-8):
-    """loss_fn(sim_matrix(t, v)) for a NormSoftmaxLoss(temperature) in one autograd node (t, v: [n, d] embeddings of all ranks)."""
+    """loss_fn(sim_matrix(t, v)) for a NormSoftmaxLoss(temperature) in one autograd node (t, v: [n, d] embeddings of all ranks).
+    Under no_grad, or when neither side wants a gradient (validation), only the loss is computed."""
     if not t.is_cuda:
         raise hip.OatError("infonce_loss runs on MI355X only (no CPU path); use the oracle for CPU")
+    if not (torch.is_grad_enabled() and (t.requires_grad or v.requires_grad)):
+        loss, _, _, _ = hip.infonce(t.float().contiguous(), v.float().contiguous(), temperature, eps, want_grads=False)
+        return loss.reshape(())
     return _InfoNCEFn.apply(t, v, temperature, eps)
 
 

@@ -878,10 +878,12 @@ def philox4x32_10(words):
 
 
 LIN_NONE, LIN_GELU, LIN_RELU_IN = 0, 1, 2
+LIN_EXACT = 0x100       # or-ed into `act`: exact-f32 MFMA products at every M (default: M > 64 rows run on the split-bf16 kernel, 2^-16 relative)
 
 
 def linear_f32(A, W, M, N, K, bias=None, out32=None, out16=None, out16b=None, resid=None, act=LIN_NONE, lda=None, ldw=None):
-    """out = act(in(A)[M,K] @ W[N,K]^T + bias) (+ resid): fp32 operands on the exact-f32 MFMA (small M only)."""
+    """out = act(in(A)[M,K] @ W[N,K]^T + bias) (+ resid) on fp32 operands.  M <= 64: exact-f32 MFMA.  M > 64: the split-bf16 three-pass
+    kernel (hi + lo, 2^-16 relative per product: the text tower's forward) unless `act` carries LIN_EXACT (the CLS lane, the projection heads)."""
     s0 = lambda t: t.stride(0) if t is not None else 0
     _check(lib().oat_linear_f32(_ptr(A), lda or A.stride(0), _ptr(W), ldw or W.stride(0), _ptr(bias), M, N, K, _ptr(out32),
                                 s0(out32), _ptr(out16), s0(out16), _ptr(out16b), s0(out16b), _ptr(resid), s0(resid),

@@ -16,6 +16,18 @@ import torch.distributed as dist
 from torch import nn
 
 
+def bwd_nt_grid_default(device=None):
+    """Workgroup count of the data-gradient GEMMs while collectives may be in flight (see GradSync.__init__)."""
+    import os
+    v = os.environ.get("OAT_BWD_NT_GRID", "0xffff")
+    if v == "auto":
+        if device is not None and torch.device(device).type != "cuda":
+            device = None
+        cus = torch.cuda.get_device_properties(device).multi_processor_count      # 256 on an MI355X in SPX mode, less in CPX / DPX
+        return max(1, cus - int(os.environ.get("OAT_RCCL_CU_RESERVE", "16")))
+    return int(v, 0)
+
+
 def world():
     if dist.is_available() and dist.is_initialized():
         return dist.get_world_size(), dist.get_rank()
@@ -92,28 +104,25 @@ class GradSync:
         if grad_dtype not in (torch.float32, torch.bfloat16):
             raise ValueError("grad_dtype: torch.float32 or torch.bfloat16")
         self.grad_dtype = grad_dtype
+        self.started_last_step = 0
+        self.bwd_nt_grid = 0         # what the engines' backward GEMMs were told (0 = untouched)
         self._pending = []           # async work handles of this step
         self._covered = []           # [byte_lo, byte_hi) address ranges already handed to RCCL this step
         W, _ = world()
-        if W > 1 and torch.cuda.is_available():
+        if (W > 1 or force) and torch.cuda.is_available():
             # RCCL's kernels hold CUs for the length of a collective.  A persistent GEMM launch (one workgroup per
             # CU walking its tiles) that finds some CUs taken runs its remaining workgroups AFTER the others - up to
             # twice the time.  The collectives of a step all start inside backward and are waited for before the
             # optimiser step, so only BACKWARD makes room (VideoEngine.bwd_nt_grid); forward keeps one workgroup per CU.
-            # Default at W > 1: persistent grids of 240 workgroups, i.e. 16 CUs left to RCCL - measured FREE on one
-            # MI355X (47.59 vs 47.68 ms per step), where one workgroup per tile (0xffff, adapts to
-            # whatever CUs are free) costs +0.55 ms.  OAT_BWD_NT_GRID overrides (0xffff = the per-tile fallback if RCCL
-            # turns out to hold more than 16 CUs on a real node).
-            grid = int(os.environ.get("OAT_BWD_NT_GRID", "240"), 0)
+            # Default at W > 1: one workgroup per tile (0xffff), which adapts to whatever CUs RCCL leaves free; it costs
+            # +0.55 ms per step on one MI355X with no collective in flight.  Persistent grids that
+            # leave a FIXED reserve to RCCL are opt-in until a multi-GPU run has shown how many CUs RCCL holds:
+            # OAT_BWD_NT_GRID=auto = the device's CU count minus OAT_RCCL_CU_RESERVE (default 16; the launcher clamps a
+            # grid to the tile count), or an explicit number of workgroups.
+            self.bwd_nt_grid = bwd_nt_grid_default(next(model.parameters()).device)
             engines = [m._engine for m in model.modules() if hasattr(getattr(m, "_engine", None), "bwd_nt_grid")]
             for eng in engines:
-                eng.bwd_nt_grid = grid
-            if not engines:
-                try:
-                    from .ops import hip
-                except ImportError:                  # entry points run from inside OATrans/ import us as a top-level module
-                    from ops import hip
-                hip.gemm_set_variant(grid << 16)
+                eng.bwd_nt_grid = self.bwd_nt_grid
         if overlap and (W > 1 or force):     # a single rank leaves the announcements to the eager optimiser (optim.AdamW.attach)
             for m in model.modules():
                 if hasattr(m, "flat_grad") and hasattr(m, "_engine_params"):
@@ -174,8 +183,9 @@ class GradSync:
             work.wait()                      # device-side: the current stream waits for RCCL's stream
             if stage is not None:
                 flat.copy_(stage)
+        self.started_last_step = len(self._pending)      # asynchronous collectives started from inside backward this step
         self._pending, self._covered = [], []
-        if average:
+        if average and W > 1:
             for f in flats:
                 f.div_(W)
 

@@ -12,7 +12,11 @@ import collections
 import os
 import sys
 
-import torch
+# dmabuf IPC (the host driver supports nothing else): without it RCCL's intra-node transport fails with
+# `hipIpcGetMemHandle: invalid argument`.  Read when the HIP runtime initialises, so set it before torch touches the GPU.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from OATrans import model as module_arch, model as module_loss, model as module_metric  # noqa: E402

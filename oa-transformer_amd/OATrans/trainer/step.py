@@ -14,9 +14,17 @@ except ImportError:
     from parallel import allgather_packed, allgather_pair
 
 
+def _is_norm_softmax(loss_fn):
+    """The library's NormSoftmaxLoss itself - whichever import path built it (`OATrans.model.loss` from the package, `model.loss`
+    when an entry point runs from inside OATrans/) - and nothing else: a subclass may override forward, so it takes the general path."""
+    cls = type(loss_fn)
+    return cls is NormSoftmaxLoss or (cls.__qualname__ == "NormSoftmaxLoss" and cls.__module__.rsplit(".", 2)[-2:] == ["model", "loss"]
+                                      and hasattr(loss_fn, "temperature"))
+
+
 def _nce(loss_fn, t, v):
     """loss_fn(sim_matrix(t, v)); a NormSoftmaxLoss takes the one-node form (same kernels, no autograd glue in between)."""
-    if layers_mod.HEAD_FUSED and type(loss_fn) is NormSoftmaxLoss:
+    if layers_mod.HEAD_FUSED and _is_norm_softmax(loss_fn):
         return infonce_loss(t, v, loss_fn.temperature)
     return loss_fn(sim_matrix(t, v))
 

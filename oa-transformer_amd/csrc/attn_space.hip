@@ -682,16 +682,14 @@ static int space_blocks(const SpaceArgs2& aa) { return aa.n0 + (aa.nclips == 2 ?
 template <int NKT>
 static int launch_fwd(const SpaceArgs2& aa, hipStream_t s) {
   const int lds = 2 * NKT * 16 * 128 + (FWD_THREADS / 64) * SCR_BYTES;
-  static bool set = false;
-  if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_space_fwd_kernel<NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
+  OAT_MAX_LDS(attn_space_fwd_kernel<NKT>, lds);
   OAT_LAUNCH(attn_space_fwd_kernel<NKT>, dim3(space_blocks(aa)), dim3(FWD_THREADS), lds, s, aa);
   return check_launch("attn_space_fwd");
 }
 template <int NKT, bool BIG = false, int WIDE = 0>
 static int launch_bwd(const SpaceArgs2& aa, hipStream_t s) {
   const int lds = (BIG ? 2 : 4) * NKT * 16 * 128 + 2 * NKT * 16 * 4 + (WIDE == 1 ? 16 : BWD_THREADS / 64) * SCR_BYTES;
-  static bool set = false;
-  if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_space_bwd_kernel<NKT, BIG, WIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
+  OAT_MAX_LDS((attn_space_bwd_kernel<NKT, BIG, WIDE>), lds);
   OAT_LAUNCH((attn_space_bwd_kernel<NKT, BIG, WIDE>), dim3(space_blocks(aa)), dim3(WIDE == 1 ? 1024 : BWD_THREADS), lds, s, aa);
   return check_launch("attn_space_bwd");
 }

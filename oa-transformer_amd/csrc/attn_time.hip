@@ -558,9 +558,7 @@ static int time_bwd(const void* qkv, int ldqkv, const void* out, int ldo, const 
 #define OAT_TIME_LDS(TT) \
     case TT: { \
       constexpr int LDS = 4 * ((TT + 1) * 64 * 32 + 8 * (TT + 1) * 8); \
-      static bool attr = false; \
-      if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_time_bwd_lds_kernel<TT>), \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; } \
+      OAT_MAX_LDS(attn_time_bwd_lds_kernel<TT>, LDS); \
       OAT_LAUNCH(attn_time_bwd_lds_kernel<TT>, dim3(blocks), dim3(256), LDS, s, a); break; }
     switch (T) {
       OAT_TIME_LDS(1) OAT_TIME_LDS(2) OAT_TIME_LDS(3) OAT_TIME_LDS(4) OAT_TIME_LDS(5) OAT_TIME_LDS(6) OAT_TIME_LDS(7)

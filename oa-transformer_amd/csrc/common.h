@@ -43,6 +43,22 @@ inline void launch(K kernel, dim3 grid, dim3 block, unsigned lds, hipStream_t s,
 }
 #define OAT_LAUNCH(...) ::oat::launch(__VA_ARGS__)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: the "already set" memo of a launch site is
+// keyed on the current device, so every GPU a process drives gets it (one process per GPU is the design; a test or a tool may not be).
+inline bool first_use_on_device(bool (&seen)[64]) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+  if (seen[dev]) return false;
+  seen[dev] = true;
+  return true;
+}
+#define OAT_MAX_LDS(kernel, bytes)                                                                                              \
+  do {                                                                                                                          \
+    static bool seen_[64] = {};                                                                                                 \
+    if (::oat::first_use_on_device(seen_))                                                                                      \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes));   \
+  } while (0)
+
 OAT_DEV float bf2f(bf16 v) { return static_cast<float>(v); }
 OAT_DEV bf16 f2bf(float v) { return static_cast<bf16>(v); }
 

@@ -638,12 +638,7 @@ static int launch_cfg(const GemmArgs& g, hipStream_t s) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
   constexpr int LDS = (NSA * BM + 2 * BN) * BK * 2;
   const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<EPI, WM, WN, TM, TN, NSA, SPREAD, PIPE>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set = true;
-  }
+  OAT_MAX_LDS((gemm_nt_kernel<EPI, WM, WN, TM, TN, NSA, SPREAD, PIPE>), LDS);
   int grid = ntm * ntn;
   GemmArgs a = g;
   if (BM == 256 && g_persist != 0xffff) {        // persistent: one workgroup per CU walks the tiles (+1.8 % per step)

@@ -48,8 +48,7 @@ enum : int { PPF_PRIO = 1, PPF_NOSTAGGER = 2, PPF_LGKM = 4, PPF_BONUS = 8, PPF_N
              PPF_HU8 = 512,                     // the saved GELU derivative travels as 8-bit fixed point (see HU8_*)
              PPF_SPLITK = 1024,                 // split-K of the last, partial round of tiles (see `sk_*` in the kernel)
              PPF_M224 = 2048,                   // 224-row tiles (see TM in the kernel)
-             PPF_BAND = 4096,
-             PPF_M192 = 8192 };                 // probe: 192-row tiles                 // band-grouped per-XCD tile walk (see `tile_of` in the kernel)
+             PPF_BAND = 4096 };                 // band-grouped per-XCD tile walk (see `tile_of` in the kernel)
 
 // gelu'(h) lies in [-0.129, 1.129].  As bf16 it costs 2 bytes per element to write (fc1 forward) and to read back (fc2 data
 // gradient) - 308 MB per launch each way, all of it on top of a GEMM that is otherwise MFMA-bound.  Stored as
@@ -319,7 +318,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs g) {
   // smaller.  The LDS layout stays that of the 256-row tile (wave row wm at LDS rows wm * 128 ..): the second half of a wave
   // row simply has 3 row groups of 16 instead of 4 - 12 MFMAs in two of the four intervals - and the 16 unused LDS rows of
   // each wave row are staged from the wave row's last real row.  Same K order per element: results are bit-identical.
-  constexpr int TM = (FL & PPF_M192) ? 192 : (FL & PPF_M224) ? 224 : 256, WR = TM / 2, NI = WR / 16, NI1 = NI - 4;
+  constexpr int TM = (FL & PPF_M224) ? 224 : 256, WR = TM / 2, NI = WR / 16, NI1 = NI - 4;
   // stores per lane of an interior epilogue (EXACT or an under-count: the head waits of the next tile allow this many ops on top of
   // the 12 pieces): 4 bf16x4 rows per row group, + 4 more (bf16 derivative) or + 1 (the 16-byte block of the 8-bit one) for EPI_GELU_GRAD
   constexpr int NST = (EPI == EPI_GELU_GRAD ? ((FL & PPF_HU8) ? 5 : 8) : 4) * NI;
@@ -877,17 +876,9 @@ __global__ __launch_bounds__(512) void gemm_nt_pp2_kernel(GemmArgs g) {
 
 template <int EPI, int FL>
 int launch_pp_cfg(const GemmArgs& g, int grid_slots, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    if constexpr (FL & PPF_PH2)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_pp2_kernel<EPI, FL>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
-    else
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_pp_kernel<EPI, FL>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
-    attr_set = true;
-  }
-  constexpr int TMH = (FL & PPF_M192) ? 192 : (FL & PPF_M224) ? 224 : 256;
+  if constexpr (FL & PPF_PH2) OAT_MAX_LDS((gemm_nt_pp2_kernel<EPI, FL>), PP_LDS);
+  else OAT_MAX_LDS((gemm_nt_pp_kernel<EPI, FL>), PP_LDS);
+  constexpr int TMH = (FL & PPF_M224) ? 224 : 256;
   const int nwg = ((g.M + TMH - 1) / TMH) * (g.N / 256);
   const int grid = nwg < grid_slots ? nwg : grid_slots;
   if constexpr (FL & PPF_PH2) OAT_LAUNCH((gemm_nt_pp2_kernel<EPI, FL>), dim3(grid), dim3(512), PP_LDS, s, g);
@@ -982,7 +973,6 @@ int launch_pp(int epi, const GemmArgs& g, int grid_slots, int flags, hipStream_t
     }
     return epi == EPI_GELU_GRAD ? launch_pp_cfg<EPI_GELU_GRAD, DEF>(g, grid_slots, s) : launch_pp_cfg<EPI_MUL_AUX, DEF>(g, grid_slots, s);
   }
-  if (fl == DEF && g_pp_m224 == 3) return launch_pp_cfg<EPI_BF16, DEF | PPF_M192>(g, grid_slots, s);      // probe
   if (fl == DEF && g.sk_ws != nullptr) return launch_pp_cfg<EPI_BF16, DEF | PPF_SPLITK>(g, grid_slots, s);
   if (fl == DEF) {
     const bool m224 = pp_prefers_224(g, grid_slots);

@@ -226,12 +226,7 @@ static int launch_tn(TnArgs g, int splits, float* out, float* bias_out, int accu
   constexpr int B1 = WM * TM * 16, B2 = WN * TN * 16;
   constexpr int LDS = NS * TK * (B1 + B2) * 2;
   const int tiles = ((g.N1 + B1 - 1) / B1) * ((g.N2 + B2 - 1) / B2);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<WM, WN, TM, TN>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set = true;
-  }
+  OAT_MAX_LDS((gemm_tn_kernel<WM, WN, TM, TN>), LDS);
   OAT_LAUNCH((gemm_tn_kernel<WM, WN, TM, TN>), dim3(tiles * splits), dim3(WM * WN * 64), LDS, s, g);
   int rc = check_launch("gemm_tn");
   if (rc) return rc;

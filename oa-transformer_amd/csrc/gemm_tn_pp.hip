@@ -260,12 +260,7 @@ __global__ __launch_bounds__(512) void gemm_tn_pp_kernel(TnArgs g) {
 
 template <int FL>
 int launch_tn_pp_cfg(const TnArgs& g, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_pp_kernel<FL>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, TP_LDS);
-    attr_set = true;
-  }
+  OAT_MAX_LDS(gemm_tn_pp_kernel<FL>, TP_LDS);
   const int tiles = (g.N1 / 256) * (g.N2 / 256);
   OAT_LAUNCH((gemm_tn_pp_kernel<FL>), dim3(tiles * g.splits), dim3(512), TP_LDS, s, g);
   return check_launch("gemm_tn_pp");

@@ -447,11 +447,7 @@ extern "C" size_t oat_tn_group_slab_bytes(int nslots) { return (size_t)(nslots >
 extern "C" int oat_tn_group_run(const void* d_problems, const void* d_segs, const void* d_seg_off, int grid,
                                 const void* d_fixes, int nfix, void* d_slabs, void* stream) {
   if (!d_problems || !d_segs || !d_seg_off || grid <= 0 || !d_slabs || (nfix > 0 && !d_fixes)) { set_error("tn_group_run: null pointer"); return -4; }
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_sk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SK_LDS);
-    attr_set = true;
-  }
+  OAT_MAX_LDS(gemm_tn_sk_kernel, SK_LDS);
   hipStream_t s = (hipStream_t)stream;
   OAT_LAUNCH(gemm_tn_sk_kernel, dim3(grid), dim3(512), SK_LDS, s, static_cast<const SkProblem*>(d_problems),
              static_cast<const SkSeg*>(d_segs), static_cast<const int*>(d_seg_off), static_cast<float*>(d_slabs));

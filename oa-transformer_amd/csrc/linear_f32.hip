@@ -386,7 +386,7 @@ static int g_lin_x3 = 1;           // 1 (default): M > 64 runs on the split-bf16
 static int g_lin_bk = 32;          // K-tile depth (OAT_LIN_BK=16 / 32): 32 halves the barrier pairs and global round trips per
                                    // workgroup (text tower forward 2124 -> 1950 us alone; same accumulation order, bit-identical)
 template <int ACT>
-static void launch_linear(const LinArgs& g, hipStream_t s) {
+static void launch_linear(const LinArgs& g, bool exact, hipStream_t s) {
   static bool env = false;
   if (!env) {
     const char* e = getenv("OAT_LIN_KG2"); if (e) g_lin_kg2 = atoi(e);
@@ -397,7 +397,7 @@ static void launch_linear(const LinArgs& g, hipStream_t s) {
   const bool bk32 = g_lin_bk == 32 && g.K % 32 == 0;
   if (g.M <= 64 && g.K % 64 == 0) {
     OAT_LAUNCH(linear_f32_small_kernel<ACT>, dim3((g.N + 15) / 16, (g.M + 31) / 32), dim3(256), 0, s, g);
-  } else if (g_lin_x3 && g.M > 64 && g.K % 32 == 0) {
+  } else if (g_lin_x3 && !exact && g.M > 64 && g.K % 32 == 0) {
     // K split between two wave quartets unless the launch already has plenty of workgroups or K is short
     if (g.K >= 256 && ((g.N + 127) / 128) * ((g.M + 127) / 128) <= 256)
       OAT_LAUNCH((linear_x3_kernel<ACT, 2>), dim3((g.N + 127) / 128, (g.M + 127) / 128), dim3(512), 0, s, g);
@@ -424,12 +424,17 @@ extern "C" int oat_linear_f32(const float* A, int lda, const float* W, int ldw, 
   if (M <= 0 || N <= 0 || K <= 0) { set_error("linear_f32: empty problem"); return -1; }
   if (K % 16 != 0 || lda % 4 != 0 || ldw % 4 != 0) { set_error("linear_f32: K % 16, lda % 4, ldw % 4 must be 0"); return -2; }
   if (!A || !W || (!out32 && !out16)) { set_error("linear_f32: null pointer"); return -4; }
+  // act = activation (0 none, 1 ReLU on the input, 2 GELU) | OAT_LIN_EXACT (0x100): keep the exact-f32 MFMA at every M.  Without the flag
+  // M > 64 rows run on the split-bf16 kernel (2^-16 relative per product: the text tower's forward); the video tower's fp32 CLS lane and
+  // the projection heads - the rows the 1e-3 sim-matrix bound hangs on - pass the flag so that a batch of more than 64 clips keeps f32 products.
+  const bool exact = (act & 0x100) != 0;
+  act &= 0xff;
   if (act < 0 || act > 2) { set_error("linear_f32: unknown activation"); return -5; }
   LinArgs g{A, lda, W, ldw, bias, M, N, K, out32, ldo, (bf16*)out16, ld16, (bf16*)out16b, ld16b, resid, ldr, nullptr, nullptr, nullptr, nullptr, 0};
   hipStream_t s = (hipStream_t)stream;
-  if (act == 1) launch_linear<1>(g, s);
-  else if (act == 2) launch_linear<2>(g, s);
-  else launch_linear<0>(g, s);
+  if (act == 1) launch_linear<1>(g, exact, s);
+  else if (act == 2) launch_linear<2>(g, exact, s);
+  else launch_linear<0>(g, exact, s);
   return check_launch("linear_f32");
 }
 
@@ -500,8 +505,7 @@ extern "C" int oat_linear_small_bwd(const float* x, int ldx, const float* dy, in
   const size_t lds = ((size_t)M * (N + 1) + 32 * (size_t)M + 16 * (size_t)N) * sizeof(float);
   if (lds > 96 * 1024) { set_error("linear_small_bwd: M x N too large for the LDS"); return -3; }
   if (lddx % 4 != 0 && dx) { set_error("linear_small_bwd: lddx % 4 must be 0"); return -2; }
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_small_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr = true; }
+  OAT_MAX_LDS(linear_small_bwd_kernel, 96 * 1024);
   LinBwdArgs g{x, ldx, dy, lddy, W, ldw, M, N, K, relu_in, dx, lddx, dW, db};
   OAT_LAUNCH(linear_small_bwd_kernel, dim3(K / 16), dim3(256), (unsigned)lds, (hipStream_t)stream, g);
   return check_launch("linear_small_bwd");

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Scaling curve in one command, on a node with N >= 1 MI355X:   bash scripts/scale.sh [max_gpus] [steps] [warmup]
-# Runs bench.py at 1, 2, 4, 8 ranks (up to max_gpus, default = GPUs visible), one process per GPU over RCCL/xGMI, exactly as
-# the driver launches it, and prints per N: RCCL rank count, whole-job pairs/s, ms/step and the per-rank step time spread.
+# Runs bench.py at 1, 2, 4, 8 ranks (up to max_gpus, default = GPUs visible), one process per GPU over RCCL/xGMI (plain
+# `python bench.py --gpus N`: it spawns its ranks itself; under torch.distributed.run it uses the launcher's env), and prints per N: RCCL rank count, whole-job pairs/s, ms/step and the per-rank step time spread.
 # OAT_GRAD_DTYPE=bf16 halves the bytes of the gradient exchange (parallel.GradSync docstring).
 set -u
 cd "$(dirname "$0")/.."
@@ -19,12 +19,8 @@ BASE=""
 for N in 1 2 4 8; do
   [ "$N" -gt "$MAX" ] && break
   LOG="$OUT/n$N.log"
-  if [ "$N" -eq 1 ]; then
-    OAT_BENCH_RANK_TIMES=1 timeout 900 python bench.py --gpus 1 --steps "$STEPS" --warmup "$WARMUP" --no-cpu-baseline --no-other-configs > "$LOG" 2> "$OUT/n$N.err"
-  else
-    OAT_BENCH_RANK_TIMES=1 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node "$N" --master-addr 127.0.0.1 \
-      --master-port $((29500 + N)) bench.py --gpus "$N" --steps "$STEPS" --warmup "$WARMUP" --no-cpu-baseline --no-other-configs > "$LOG" 2> "$OUT/n$N.err"
-  fi
+  # plain form at every N: bench.py starts its own ranks when no launcher set RANK / WORLD_SIZE (bench.py:_self_launch)
+  timeout 900 python bench.py --gpus "$N" --steps "$STEPS" --warmup "$WARMUP" --no-cpu-baseline --no-other-configs --no-traffic --no-forced-w1 > "$LOG" 2> "$OUT/n$N.err"
   python - "$LOG" "$N" "${BASE:-0}" <<'PY'
 import json, sys
 line = [l for l in open(sys.argv[1]) if l.startswith("{")]

@@ -49,16 +49,55 @@ def test_bench_single_rank_line():
     # config 3 as worded (object-aware variants) rides along outside `value`
     oc = rec["other_configs"]
     # ... and the headline model with the opt-in pruned top block (VideoEngine.prune_top), utilisation from the EXECUTED FLOPs
-    assert [o["workload"].split("]")[0] for o in oc] == ["[global_local", "[region_mem", "[frozen, top block pruned",
-                                                         "[region_mem, top block pruned"], oc
+    # ... and the per-GPU shapes of BASELINE.json's configs 2, 4 and 5 (config 5 in both dtypes), scaled with the command line
+    assert [o["workload"].split("]")[0] for o in oc] == [
+        "[config 3, global_local", "[config 3, region_mem", "[frozen, top block pruned", "[region_mem, top block pruned",
+        "[config 2", "[config 4, per-GPU shape", "[config 5 geometry, bf16", "[config 5 geometry, fp8 forward"], oc
     for o in oc:
         assert "error" not in o, o
         frac = o["step_mfma_frac_executed"] if "pruned" in o["workload"] else o["step_mfma_frac"]
         assert o["value"] > 0 and o["ms_per_step"] > 0 and 0 < frac < 1 and o["unit"] == "pairs/s"
+        assert o["dtype"] and o["per_gpu_batch"] > 0 and o["frames"] > 0 and ("gflop_per_pair" in o or "gflop_per_pair_executed" in o)
+    assert (oc[4]["frames"], oc[5]["per_gpu_batch"], oc[6]["res"], oc[6]["frames"]) == (1, 8, 336, 4)
+    assert oc[6]["dtype"] == "bf16" and oc[7]["dtype"].startswith("fp8") and oc[6]["gflop_per_pair"] == oc[7]["gflop_per_pair"]
+    # the W > 1 launch path on a 1-rank RCCL group, beside the headline
+    w1 = rec["w1_forced"]
+    assert "error" not in w1, w1
+    assert rec["ms_per_step_w1_forced"] == w1["ms_per_step_w1_forced"] > 0
+    assert all(v["async_all_reduces_per_step"] >= 3 for v in w1["variants"].values()), w1     # text tower + ViT blocks + tables
+    # roofline.traffic: PMC bytes per launch of the roofline kernel, or a stated reason
+    tr = rec["roofline"]["traffic"]
+    if tr is None:
+        assert rec["roofline"]["traffic_skipped"]
+    else:
+        assert tr["read_mb"] > 0 and tr["write_mb"] > 0 and tr["algorithmic_mb"] > 0 and tr["launches_counted"] > 0
+        assert abs(tr["ratio"] - tr["total_mb"] / tr["algorithmic_mb"]) < 0.01 * tr["ratio"] + 1e-3
     assert oc[2]["gflop_per_pair_executed"] < oc[2]["gflop_per_pair_full_graph"] == rec["config"]["gflop_per_pair"]
     assert oc[3]["gflop_per_pair_executed"] < oc[3]["gflop_per_pair_full_graph"] == oc[1]["gflop_per_pair"]
     cb = rec["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "pairs/s" and cb["sample"]
+
+
+def test_bench_gpus_2_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher and no rendezvous variables: bench.py starts the two ranks itself
+    (dry-run form: both on the one GPU, over gloo) and rank 0 prints one line for the group."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(OAT_BENCH_ONE_DEVICE="1", OAT_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4",
+                        "--frames", "2"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    rec = _line(r.stdout)
+    _check(rec, 2)
+    assert rec["ranks_in_group"] == 2 and len(rec["rank_ms_per_step"]) == 2 and rec["config"]["global_batch"] == 8
+
+
+def test_bench_gpus_beyond_the_visible_devices_fails_loudly():
+    n = __import__("torch").cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "OAT_BENCH_ONE_DEVICE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0", "--batch", "2",
+                        "--frames", "1"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode != 0 and "are visible" in r.stderr, r.stderr[-2000:]
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
 
 def test_bench_two_rank_dry_run_terminates():
