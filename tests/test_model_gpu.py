@@ -306,7 +306,7 @@ def test_the_two_storage_departures_are_what_the_gradient_error_is_made_of():
         runs[name] = (vid_rel, vid_cos, max(z[1] for z in per if z[0].startswith("video_model.")))
         print(f"{name:16s}: video tower rel-L2 {vid_rel:.3e} cosine {vid_cos:.6f} worst tensor {runs[name][2]:.3e}; all parameters {all_rel:.3e}")
     d, off = runs["default"], runs["both off"]
-    assert off[0] < 0.93 * d[0], runs                                     # measurably closer with both departures off
+    assert off[0] < 0.85 * d[0], runs                                     # measurably closer with both departures off
     assert off[0] <= runs["fp32 stream"][0] * 1.03 and off[0] <= runs["bf16 derivative"][0] * 1.03, runs
     assert runs["fp32 stream"][0] <= d[0] * 1.03 and runs["bf16 derivative"][0] <= d[0] * 1.03, runs
     assert off[0] <= 3e-2 and off[1] >= 0.9995                            # and still a bf16-operand pipeline: not zero
