@@ -530,6 +530,8 @@ def main():
     ap.add_argument("--no-forced-w1", action="store_true",
                     help="skip `w1_forced` (the W > 1 launch path - asynchronous per-block gradient all-reduces from inside backward, "
                          "the backward GEMM grid of a multi-rank job - on a 1-rank RCCL group, 1-GPU run only)")
+    ap.add_argument("--force-w1-main", action="store_true",
+                    help="dev: run the MAIN timed loop on the W > 1 launch path of a 1-rank RCCL group (what `w1_forced` measures), e.g. under a kernel trace")
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)     # the process rocprofv3 wraps (see hbm_traffic)
     ap.add_argument("--prune-top", action="store_true",
                     help="run the MAIN line with VideoEngine.prune_top (default: full top block; a default run reports the pruned "
@@ -577,6 +579,11 @@ def main():
         dp.module.video_model._engine.prune_top = True
     data = synthetic_batch(args, rank, device)
     step_args = argparse.Namespace(world_size=world, rank=rank, local_rank=local)
+    if args.force_w1_main and world == 1:
+        from OATrans.parallel import GradSync
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1)
+        dp.sync = GradSync(dp.module, overlap=True, force=True)
+        args.no_forced_w1 = args.no_traffic = True
 
     def eager_step():
         return step_impl(dp, loss_fn, opt, data, step_args)

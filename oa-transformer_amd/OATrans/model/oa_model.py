@@ -14,6 +14,9 @@ from .text_transformer import DistilBertHIP
 from .video_transformer import SpaceTimeTransformer
 
 VIT_INIT = "pretrained/jx_vit_base_p16_224-80ecf9dd.pth"
+# the text tower's kernels are enqueued first in forward, its autograd node is created last (DistilBertHIP.launch), so that
+# backward issues the text tower BEFORE the video tower; 0: node and kernels together (the earlier order, for A/B runs)
+TEXT_BWD_FIRST = os.environ.get("OAT_TEXT_BWD_FIRST", "1") != "0"
 
 
 class BaseModel(nn.Module):
@@ -96,18 +99,26 @@ class FrozenInTime(BaseModel):
         # host enqueue order: the text tower first.  Its ~80 launches are queued in about a millisecond and then run
         # beneath the first blocks of the video tower; queued behind the video tower's ~450 launches they started only
         # when the video forward was nearly over and added their whole length (fp32 forward: ~5 ms) to the step
+        # ... and its autograd node LAST (DistilBertHIP.launch): backward then issues the text tower before the video tower
+        early = TEXT_BWD_FIRST and torch.is_grad_enabled()
         with torch.cuda.stream(side):
-            text_embeddings = self.compute_text(data['text'])
+            if early:
+                ticket = self.text_model.launch(input_ids=data['text']['input_ids'], attention_mask=data['text'].get('attention_mask'))
+            else:
+                text_embeddings = self.compute_text(data['text'])
         video_embeddings = self.compute_video(data['video'], aug=aug)
+        if early:
+            with torch.cuda.stream(side):
+                text_embeddings = self.compute_text(data['text'], launched=ticket)
         main.wait_stream(side)
         text_embeddings.record_stream(main)
         if return_embeds:
             return text_embeddings, video_embeddings
         return sim_matrix(text_embeddings, video_embeddings)
 
-    def compute_text(self, text_data, pad=False):
+    def compute_text(self, text_data, pad=False, launched=None):
         hidden = self.text_model(input_ids=text_data['input_ids'],
-                                 attention_mask=text_data.get('attention_mask')).last_hidden_state
+                                 attention_mask=text_data.get('attention_mask'), launched=launched).last_hidden_state
         return self.txt_proj(hidden[:, 0, :].float())
 
     def compute_video(self, video_data, aug=False):

@@ -24,7 +24,7 @@ from ..ops import hip
 from ..utils.util import state_dict_data_parallel_fix
 from .layers import HipLinear, ReLULinear, sim_matrix  # noqa: F401
 from .oa_layers import mask_pool, mean_rows, mix
-from .oa_model import BaseModel, FrozenInTime as _Plain, VIT_INIT
+from .oa_model import BaseModel, FrozenInTime as _Plain, TEXT_BWD_FIRST, VIT_INIT
 from .oa_video_transformer_global_local import SpaceTimeTransformer
 from .text_transformer import DistilBertHIP
 
@@ -115,22 +115,35 @@ class FrozenInTime(BaseModel):
             self._text_stream = hip.side_stream("OAT_TEXT")
         side = self._text_stream
         side.wait_stream(main)
-        with torch.cuda.stream(side):
-            text_embeddings, text_tokens = self.compute_text(data['text'])
-            pad_text_embeddings, pad_tokens = self.compute_text(data['pad_text'])
+        def text_side(t1=None, t2=None):
+            text_embeddings, text_tokens = self.compute_text(data['text'], launched=t1)
+            pad_text_embeddings, pad_tokens = self.compute_text(data['pad_text'], launched=t2)
             n_txt = data['text']['attention_mask'].sum(dim=1)
             tags_masks = hip.tag_masks(data['object_token_masks'].to(torch.int64), n_txt.to(torch.int64), pad_tokens.shape[1])
-            tags_feat = self.text_local_proj(mask_pool(tags_masks, pad_tokens))
+            return text_embeddings, text_tokens, pad_text_embeddings, pad_tokens, self.text_local_proj(mask_pool(tags_masks, pad_tokens))
+
+        # both DistilBERT passes are enqueued now, their autograd nodes (and the small pooling / projection launches behind them)
+        # after the video side: backward then issues the text side first (DistilBertHIP.launch)
+        early = TEXT_BWD_FIRST and torch.is_grad_enabled()
+        with torch.cuda.stream(side):
+            if early:
+                t1 = self.text_model.launch(input_ids=data['text']['input_ids'], attention_mask=data['text'].get('attention_mask'))
+                t2 = self.text_model.launch(input_ids=data['pad_text']['input_ids'], attention_mask=data['pad_text'].get('attention_mask'))
+            else:
+                text_embeddings, text_tokens, pad_text_embeddings, pad_tokens, tags_feat = text_side()
         object_image_embeddings, object_region, video_embeddings, video_region = self.encode_clips(data['video'])
         region_feat = self.vid_local_proj(mask_pool(data['patch_masks'].float(), object_region))
+        if early:
+            with torch.cuda.stream(side):
+                text_embeddings, text_tokens, pad_text_embeddings, pad_tokens, tags_feat = text_side(t1, t2)
         main.wait_stream(side)
         for t in (text_embeddings, text_tokens, pad_text_embeddings, pad_tokens, tags_feat):
             t.record_stream(main)
         return text_embeddings, pad_text_embeddings, video_embeddings, object_image_embeddings, \
             [text_tokens, pad_tokens, video_region, object_region, region_feat, tags_feat]
 
-    def compute_text(self, text_data):
-        hidden = self.text_model(input_ids=text_data['input_ids'], attention_mask=text_data.get('attention_mask')).last_hidden_state
+    def compute_text(self, text_data, launched=None):
+        hidden = self.text_model(input_ids=text_data['input_ids'], attention_mask=text_data.get('attention_mask'), launched=launched).last_hidden_state
         pooled = mix(hidden[:, 0, :], mean_rows(hidden[:, 1:, :]), 1.0, 1.0)
         return self.txt_proj(pooled), hidden
 

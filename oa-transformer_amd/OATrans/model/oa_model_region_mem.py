@@ -13,7 +13,7 @@ from ..ops import hip
 from ..utils.util import state_dict_data_parallel_fix
 from .layers import HipLinear, ReLULinear, sim_matrix  # noqa: F401
 from .oa_layers import mean_rows, mix, region_sim
-from .oa_model import BaseModel, FrozenInTime as _Plain, VIT_INIT
+from .oa_model import BaseModel, FrozenInTime as _Plain, TEXT_BWD_FIRST, VIT_INIT
 from .oa_model_global_local import encode_object_and_video
 from .oa_video_transformer_region import SpaceTimeTransformer
 from .text_transformer import DistilBertHIP
@@ -68,20 +68,28 @@ class FrozenInTime(BaseModel):
             self._text_stream = hip.side_stream("OAT_TEXT")
         side = self._text_stream
         side.wait_stream(main)
+        early = TEXT_BWD_FIRST and torch.is_grad_enabled()       # kernels now, autograd node after the video side (DistilBertHIP.launch)
         with torch.cuda.stream(side):
-            text_embeddings = self.compute_text(data['text'])
-            text_region = self.txt_proj_2(data['text_region_embedding'].float())
+            if early:
+                ticket = self.text_model.launch(input_ids=data['text']['input_ids'], attention_mask=data['text'].get('attention_mask'))
+            else:
+                text_embeddings = self.compute_text(data['text'])
+                text_region = self.txt_proj_2(data['text_region_embedding'].float())
         # clip layouts ('interleaved' = the reference's view(2B, F/2), 'native' = object frame + T-frame video):
         # oa_model_global_local.encode_object_and_video
         _, object_region, video_embeddings, video_region = encode_object_and_video(self, data['video'])
         video_embeddings = mix(video_embeddings, mean_rows(video_region), 0.5, 0.5)
+        if early:
+            with torch.cuda.stream(side):
+                text_embeddings = self.compute_text(data['text'], launched=ticket)
+                text_region = self.txt_proj_2(data['text_region_embedding'].float())
         main.wait_stream(side)
         text_embeddings.record_stream(main)
         text_region.record_stream(main)
         return text_embeddings, video_embeddings, self.compute_region_sim(object_region, text_region)
 
-    def compute_text(self, text_data, pad=False):
-        hidden = self.text_model(input_ids=text_data['input_ids'], attention_mask=text_data.get('attention_mask')).last_hidden_state
+    def compute_text(self, text_data, pad=False, launched=None):
+        hidden = self.text_model(input_ids=text_data['input_ids'], attention_mask=text_data.get('attention_mask'), launched=launched).last_hidden_state
         return self.txt_proj(hidden[:, 0, :].float())
 
     def compute_video(self, video_data):

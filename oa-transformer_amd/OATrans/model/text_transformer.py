@@ -57,8 +57,12 @@ class _Transformer(nn.Module):
 class _HiddenFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, input_ids, attention_mask, call_idx, *params):
-        hidden, plan = module._engine.forward(input_ids, attention_mask, module._param_data(),
-                                              module._weights_signature(), slot=call_idx, drop=module._dropout_args(input_ids.device))
+        launched = module._launched.pop(call_idx, None)
+        if launched is not None:             # DistilBertHIP.launch enqueued this call's kernels earlier: only the graph node is new
+            hidden, plan = launched
+        else:
+            hidden, plan = module._engine.forward(input_ids, attention_mask, module._param_data(),
+                                                  module._weights_signature(), slot=call_idx, drop=module._dropout_args(input_ids.device))
         ctx.module, ctx.plan, ctx.call_idx = module, plan, call_idx
         return hidden.clone()
 
@@ -91,6 +95,7 @@ class DistilBertHIP(EngineModule):
         self._engine = TextEngine(cfg["n_layers"], cfg["dim"], cfg["n_heads"], cfg["hidden_dim"])
         self._bwd_calls = 0
         self._fwd_calls = 0
+        self._launched = {}                  # call index -> (hidden, plan) of forwards enqueued by launch() and not yet attached
         self._rng_state = None
         self.dropout_seed = None             # None: drawn from torch's generator (torch.manual_seed governs it) on first use
 
@@ -129,8 +134,38 @@ class DistilBertHIP(EngineModule):
         """Called once per optimiser step: the next backward overwrites gradients."""
         self._bwd_calls = 0
         self._fwd_calls = 0
+        self._launched.clear()
 
-    def forward(self, input_ids=None, attention_mask=None, **unused):
+    def launch(self, input_ids=None, attention_mask=None, **unused):
+        """Enqueue the forward kernels of one call NOW (on the current stream) and return a ticket for `forward(..., launched=ticket)`,
+        which creates the autograd node LATER.  Why the two are separated: autograd runs ready backward nodes in reverse creation
+        order, and the host issues a tower's whole backward from inside its node.  The model classes enqueue the text tower FIRST
+        in forward (it runs beneath the first ViT blocks), which made its node the oldest and its backward the LAST thing the host
+        issues - behind the video tower's ~350 launches and, with more than one rank, its 13 gradient all-reduce calls; under the
+        queue's back-pressure the GPU then reached the text backward only after the video backward had finished (kernel trace of
+        the W > 1 path: 1.3 ms of text backward alone on the GPU at the end of every step).  With the node created after the video
+        forward, the text backward is issued first and runs beneath the top ViT blocks' backward.  Grad mode only."""
+        if not torch.is_grad_enabled():
+            return None
+        if not input_ids.is_cuda:
+            raise hip.OatError("DistilBertHIP runs on MI355X only (no CPU path); use the oracle for CPU")
+        hip.lib()
+        if attention_mask is None:
+            attention_mask = torch.ones_like(input_ids)
+        self._new_step_guard()
+        idx = self._fwd_calls
+        self._fwd_calls += 1
+        self._launched[idx] = self._engine.forward(input_ids, attention_mask, self._param_data(), self._weights_signature(),
+                                                   slot=idx, drop=self._dropout_args(input_ids.device))
+        return (idx, input_ids, attention_mask)
+
+    def forward(self, input_ids=None, attention_mask=None, launched=None, **unused):
+        if launched is not None:             # ticket of launch(): same call, kernels already enqueued
+            idx, input_ids, attention_mask = launched
+            if idx not in self._launched:
+                raise RuntimeError("DistilBertHIP: stale launch ticket (begin_step() or an optimiser step came in between)")
+            params = [p for _, p in self._engine_params()]
+            return SimpleNamespace(last_hidden_state=_HiddenFn.apply(self, input_ids, attention_mask, idx, *params))
         if not input_ids.is_cuda:
             raise hip.OatError("DistilBertHIP runs on MI355X only (no CPU path); use the oracle for CPU")
         hip.lib()
