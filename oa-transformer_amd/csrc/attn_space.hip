@@ -282,7 +282,28 @@ OAT_DEV void attn_space_bwd_body(const SpaceArgs& a, const int bid) {
   constexpr int ITER = (NKP * 8 + THR - 1) / THR;
   bf16x8 gv[ITER], ov[ITER];
   float lv[ITER];
+  // TIME: delta of a PATCH query is formed inside phase A from the scores themselves (delta_q = sum_k P_qk dP_qk over the 9 keys
+  // the query sees - the same number as rowsum(dO * O), from fp32 P instead of the bf16-rounded O): the saved attention output is
+  // not read at all and dO only as the tile (77 of 616 MB per launch).  The CLS query's delta spans every key of the sample, so it
+  // alone still comes from its dO / O rows, once per workgroup; a group requests the lse of its 17 rows (one lane per row).
+  float cls_delta = 0.f;
+  if constexpr (TIME) {
+    const int c = lane & 7;
+    const bf16x8 gc = *reinterpret_cast<const bf16x8*>(a.dout + cls_row * a.lddo + h * 64 + c * 8);
+    const bf16x8 oc = *reinterpret_cast<const bf16x8*>(a.out + cls_row * a.ldo + h * 64 + c * 8);
+    float d = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) d += bf2f(gc[e]) * bf2f(oc[e]);
+    d += __shfl_xor(d, 1, 64);
+    d += __shfl_xor(d, 2, 64);
+    d += __shfl_xor(d, 4, 64);
+    cls_delta = d;                                     // every lane holds the sum of its 8-lane group = the row's delta
+  }
   auto delta_request = [&](const RowMap& rq) {
+    if constexpr (TIME) {
+      lv[0] = a.lse[rq.row<TIME>(min(lane, N)) * a.H + h];
+      return;
+    }
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
       const int idx = it * THR + threadIdx.x;
@@ -331,6 +352,12 @@ OAT_DEV void attn_space_bwd_body(const SpaceArgs& a, const int bid) {
     const size_t r = j < N ? base_row + j : cls_row;
     return *reinterpret_cast<const bf16x8*>(src + r * ld + col + (ks * 4 + (lane_ >> 4)) * 8);
   };
+  if constexpr (TIME) {
+    if (lane < NKP) {
+      del_s[lane] = lane == N ? cls_delta : 0.f;         // patch rows: written by phase A below
+      lse_s[lane] = lane <= N ? lv[0] * LOG2E : INFINITY;
+    }
+  } else {
 #pragma unroll
   for (int it = 0; it < ITER; ++it) {
     const int idx = it * THR + threadIdx.x;
@@ -345,6 +372,7 @@ OAT_DEV void attn_space_bwd_body(const SpaceArgs& a, const int bid) {
       del_s[j] = j <= N ? d : 0.f;
       lse_s[j] = j <= N ? lv[it] * LOG2E : INFINITY;     // a padding QUERY's exp2(s c2 - lse) is exactly 0: no select in the passes below
     }
+  }
   }
   __syncthreads();
   if constexpr (TIME) {
@@ -408,15 +436,17 @@ OAT_DEV void attn_space_bwd_body(const SpaceArgs& a, const int bid) {
     for (int u = 0; u < nu; ++u) {
       f32x4 dsA[2], dsB[2];
       const bool plain = !TIME;                                                               // (TIME keeps its block-diagonal masks)
+      f32x4 dpA[2];                                      // TIME: dP of tile A (patch queries), whose delta is formed below
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         const int kt = 2 * u + hf;
         if (hf == 1 && kt * 16 > N) {      // wave-uniform: the pass's second key tile is pure padding (197 keys: tile 13 of 14) - its dS is zero
-          dsA[1] = f32x4{0, 0, 0, 0}; dsB[1] = f32x4{0, 0, 0, 0};
+          dsA[1] = f32x4{0, 0, 0, 0}; dsB[1] = f32x4{0, 0, 0, 0}; dpA[1] = f32x4{0, 0, 0, 0};
           continue;
         }
         // dP - delta comes out of the matrix pipe: the accumulator starts at -delta (this lane's query) instead of zero
-        f32x4 sA = {0, 0, 0, 0}, pA = {-dlA, -dlA, -dlA, -dlA}, sB = {0, 0, 0, 0}, pB = {-dlB, -dlB, -dlB, -dlB};
+        const float dA0 = TIME ? 0.f : -dlA;             // TIME: tile A holds the patch queries, delta not known yet
+        f32x4 sA = {0, 0, 0, 0}, pA = {dA0, dA0, dA0, dA0}, sB = {0, 0, 0, 0}, pB = {-dlB, -dlB, -dlB, -dlB};
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
           const bf16x8 kf = row_frag(Kt, kt * 16, ks, lane, RMAX), vf = row_frag(Vt, kt * 16, ks, lane, RMAX);
@@ -440,10 +470,32 @@ OAT_DEV void attn_space_bwd_body(const SpaceArgs& a, const int bid) {
             const bool clsdup = key == N && f != 0;       // CLS->CLS pair is counted once (frame 0)
             const bool okA = key <= N && qiA <= N && !(qiA == N && clsdup) && rm.sees<TIME>(qiA, key);
             const bool okB = key <= N && qiB <= N && !(qiB == N && clsdup) && rm.sees<TIME>(qiB, key);
-            dsA[hf][r] = okA ? __builtin_amdgcn_exp2f(sA[r] * c2 - lqA) * pA[r] : 0.f;
+            if constexpr (TIME) {
+              dsA[hf][r] = okA ? __builtin_amdgcn_exp2f(sA[r] * c2 - lqA) : 0.f;      // P for now; dS after the delta below
+              dpA[hf][r] = pA[r];
+            } else {
+              dsA[hf][r] = okA ? __builtin_amdgcn_exp2f(sA[r] * c2 - lqA) * pA[r] : 0.f;
+            }
             dsB[hf][r] = (two && okB) ? __builtin_amdgcn_exp2f(sB[r] * c2 - lqB) * pB[r] : 0.f;
           }
         }
+      }
+      if constexpr (TIME) {
+        // delta of this lane's patch query: sum over its keys of P dP - 8 accumulator rows in this lane, the other 24 key rows in the
+        // three lanes that share the query column (g = lane >> 4); then dS = P (dP - delta).  Lanes g == 0 leave it for phase B.
+        float dl = 0.f;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dl = __builtin_fmaf(dsA[hf][r], dpA[hf][r], dl);
+        dl += __shfl_xor(dl, 16, 64);
+        dl += __shfl_xor(dl, 32, 64);
+        if (qiA == N) dl = cls_delta;                    // frame counts that do not divide 16: the CLS query sits in tile A (N < 16)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dsA[hf][r] *= dpA[hf][r] - dl;
+        if (g == 0 && qiA < N) del_s[qiA] = dl;
       }
       const bf16x8 sbA = pack8(dsA[0], dsA[1]), sbB = pack8(dsB[0], dsB[1]);
 #pragma unroll
