@@ -750,6 +750,31 @@ def test_linear_f32_matches_fp64(M, N, K, act):
     assert torch.equal(out16, out32.bfloat16())
 
 
+@pytest.mark.parametrize("M,N,K,act", [(128, 768, 768, 0), (96, 3072, 768, 1), (65, 256, 768, 2), (320, 256, 768, 2)])
+def test_linear_f32_exact_flag_keeps_f32_products_above_64_rows(M, N, K, act):
+    """act | LIN_EXACT: the rows the 1e-3 sim-matrix bound hangs on (fp32 CLS lane of more than 64 clips - batch 64, or two clips of more
+    than 32 samples - and the projection heads) keep exact-f32 MFMA products at every M; without the flag M > 64 runs on the split-bf16
+    kernel (2^-16 relative per product).  With the flag the result must sit at fp32 round-off of the fp64 product and be strictly closer
+    to it than the split-bf16 result of the same call."""
+    from OATrans.ops import hip
+    g = torch.Generator().manual_seed(M * 11 + N)
+    A = torch.randn(M, K, generator=g).cuda()
+    W = (torch.randn(N, K, generator=g) * K ** -0.5).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    ex, x3 = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+    hip.linear_f32(A, W, M, N, K, bias=bias, out32=ex, act=act | hip.LIN_EXACT)
+    hip.linear_f32(A, W, M, N, K, bias=bias, out32=x3, act=act)
+    Ad = A.double().clamp_min(0) if act == 2 else A.double()
+    y = Ad @ W.double().t() + bias.double()
+    if act == 1:
+        y = torch.nn.functional.gelu(y)
+    scale = max(1.0, y.abs().max().item())
+    e_ex, e_x3 = (ex.double() - y).abs().max().item(), (x3.double() - y).abs().max().item()
+    assert e_ex < 2e-6 * scale, e_ex                    # fp32 accumulation round-off only
+    assert e_x3 < 3e-5 * scale, e_x3                    # the documented split-bf16 bound
+    assert e_ex < 0.5 * e_x3, (e_ex, e_x3)
+
+
 @pytest.mark.parametrize("M,N,K", [(5000, 768, 256), (256, 256, 128), (257, 256, 256), (481, 256, 128), (4113, 512, 256), (25120, 768, 768)])
 def test_gemm_nt_224_row_tiles_bit_identical(M, N, K):
     """gemm_nt_pp.hip PPF_M224: 224-row tiles (chosen where rounds x tile rows is smaller) must give the bits of the
