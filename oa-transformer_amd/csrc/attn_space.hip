@@ -52,20 +52,28 @@ OAT_DEV bf16x8 tr_frag(const char* tile, int r0, int dt, int lane, int rmax = 0x
 // one trip through a wave-private LDS scratch (16 rows x (128 + 16) bytes: ds_write_b64 per lane and dt, ds_read_b128
 // back) and leaves as whole 128-byte lines, 16 bytes per lane, 8 rows per store instruction.
 // rowptr(j) -> address of local row j's 64-element head slice, or nullptr (row not stored).  Wave-uniform call.
-constexpr int SCR_PITCH = 144, SCR_BYTES = 16 * SCR_PITCH;
+// Scratch layout (round 5): 16 rows x 128 bytes, no padding; the 8-byte slot a lane writes is XOR-ed with a row key so that both sides are
+// free of bank conflicts - slot' = slot ^ ((row & 7) << 1 | row >> 3).  Writes (ds_write_b64, groups of 16 consecutive lanes = 16 rows, one
+// logical slot): 16 distinct slots = all 32 banks once.  Reads (ds_read_b128, 8 lanes per row): the two halves of a 16-byte chunk stay
+// together (the key's upper bits permute chunks, its lowest bit swaps the halves of rows 8..15, undone in registers), and the four rows a
+// 16-lane read group touches land on disjoint quarters of the 64 banks.  The 144-byte pitch this replaces measured
+// SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS = 0.64 in the TIME backward (two-way on every write, partial overlaps on the reads).
+constexpr int SCR_PITCH = 128, SCR_BYTES = 16 * SCR_PITCH;
 template <class F>
 OAT_DEV void store_rows16(char* scr, const f32x4 (&acc)[4], float mul, int lane, F&& rowptr) {
   const int col = lane & 15, g = lane >> 4;
+  const int key = ((col & 7) << 1) | (col >> 3);
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) {
     const bf16x4 o = {f2bf(acc[dt][0] * mul), f2bf(acc[dt][1] * mul), f2bf(acc[dt][2] * mul), f2bf(acc[dt][3] * mul)};
-    *reinterpret_cast<bf16x4*>(scr + col * SCR_PITCH + (dt * 16 + g * 4) * 2) = o;
+    *reinterpret_cast<bf16x4*>(scr + col * SCR_PITCH + (((dt * 4 + g) ^ key) << 3)) = o;       // logical 8-byte slot dt * 4 + g
   }
   __builtin_amdgcn_wave_barrier();                       // DS instructions of a wave execute in order: the reads see the writes
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
     const int j = p * 8 + (lane >> 3), ch = lane & 7;
-    const uint4 v = *reinterpret_cast<const uint4*>(scr + j * SCR_PITCH + ch * 16);
+    uint4 v = *reinterpret_cast<const uint4*>(scr + j * SCR_PITCH + ((ch ^ (j & 7)) << 4));
+    if (p == 1) v = uint4{v.z, v.w, v.x, v.y};           // rows 8..15: the key's lowest bit swapped the two halves of every chunk
     bf16* dst = rowptr(j);
     if (dst) *reinterpret_cast<uint4*>(dst + ch * 8) = v;
   }
