@@ -154,6 +154,8 @@ class DistilBertHIP(EngineModule):
             attention_mask = torch.ones_like(input_ids)
         self._new_step_guard()
         idx = self._fwd_calls
+        if idx == 0:
+            self._launched.clear()           # tickets of a step that was abandoned before its nodes were created
         self._fwd_calls += 1
         self._launched[idx] = self._engine.forward(input_ids, attention_mask, self._param_data(), self._weights_signature(),
                                                    slot=idx, drop=self._dropout_args(input_ids.device))
