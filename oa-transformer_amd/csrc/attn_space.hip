@@ -149,7 +149,11 @@ OAT_DEV void load_tile(char* tile, const bf16* src, int ld, int col, const RowMa
   }
 }
 
-template <int NKT>
+// NFIX: patches per frame known at compile time (196 = 224^2 / 16^2, the shape every BASELINE config but the 336^2 one runs): every
+// "does key tile kt hold a real / a padding key" test of the score pass is wave-uniform AND loop-invariant, and with a run-time N hipcc
+// hoists them as 112 lane masks that it spills to VGPR lanes and reads back (8 v_readlane per key tile) behind four taken branches per
+// key tile - the 28 score MFMAs of a query tile end up in 14 two-instruction basic blocks.  With N a constant the pass is straight-line.
+template <int NKT, int NFIX = 0>
 __global__ __launch_bounds__(FWD_THREADS, NKT <= 14 ? 4 : 2) void attn_space_fwd_kernel(SpaceArgs2 aa) {
   const bool second = (int)blockIdx.x >= aa.n0;            // workgroup-uniform
   const SpaceArgs& a = aa.s[second ? 1 : 0];
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(FWD_THREADS, NKT <= 14 ? 4 : 2) void attn_space_fwd
   const int h = bid % a.H;
   const int bf = bid / a.H;                   // b * T + f
   const int b = bf / a.T;
-  const int N = a.N;
+  const int N = NFIX > 0 ? NFIX : a.N;
   const size_t base_row = (size_t)bf * N;
   const size_t cls_row = (size_t)a.B * a.T * N + b;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -739,9 +743,29 @@ static SpaceArgs2 one_clip(const SpaceArgs& a, int blocks) { return SpaceArgs2{{
 static SpaceArgs2 two_clips(const SpaceArgs& a, const SpaceArgs& b) { return SpaceArgs2{{a, b}, a.B * a.T * a.H, 2}; }
 // the clip count is carried explicitly (two clips may share a qkv base pointer)
 static int space_blocks(const SpaceArgs2& aa) { return aa.n0 + (aa.nclips == 2 ? aa.s[1].B * aa.s[1].T * aa.s[1].H : 0); }
+static int g_space_nfix = 1;       // 1 (default): frames of 196 patches run the compile-time-N kernels; OAT_SPACE_NFIX=0: run-time N everywhere
+static bool space_nfix(const SpaceArgs2& aa, int n) {
+  static bool env = false;
+  if (!env) { const char* e = getenv("OAT_SPACE_NFIX"); if (e) g_space_nfix = atoi(e); env = true; }
+  return g_space_nfix && aa.s[0].N == n && (aa.nclips < 2 || aa.s[1].N == n);
+}
 template <int NKT>
 static int launch_fwd(const SpaceArgs2& aa, hipStream_t s) {
   const int lds = 2 * NKT * 16 * 128 + (FWD_THREADS / 64) * SCR_BYTES;
+  if constexpr (NKT == 14) {
+    if (space_nfix(aa, 196)) {
+      OAT_MAX_LDS((attn_space_fwd_kernel<NKT, 196>), lds);
+      OAT_LAUNCH((attn_space_fwd_kernel<NKT, 196>), dim3(space_blocks(aa)), dim3(FWD_THREADS), lds, s, aa);
+      return check_launch("attn_space_fwd");
+    }
+  }
+  if constexpr (NKT == 28) {
+    if (space_nfix(aa, 441)) {                     // 336^2 / 16^2: config 5's frames
+      OAT_MAX_LDS((attn_space_fwd_kernel<NKT, 441>), lds);
+      OAT_LAUNCH((attn_space_fwd_kernel<NKT, 441>), dim3(space_blocks(aa)), dim3(FWD_THREADS), lds, s, aa);
+      return check_launch("attn_space_fwd");
+    }
+  }
   OAT_MAX_LDS(attn_space_fwd_kernel<NKT>, lds);
   OAT_LAUNCH(attn_space_fwd_kernel<NKT>, dim3(space_blocks(aa)), dim3(FWD_THREADS), lds, s, aa);
   return check_launch("attn_space_fwd");
