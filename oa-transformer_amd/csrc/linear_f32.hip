@@ -250,10 +250,12 @@ __global__ __launch_bounds__(256 * KG) void linear_x3_kernel(LinArgs g) {
         const bf16x8 bl = *reinterpret_cast<const bf16x8*>(pb + j * 16 * PITCH + PLANE);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          // small terms first, then the leading one
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh, acc[i][j], 0, 0, 0);
+          // small terms first, then the leading one.  The WEIGHT fragment is the first operand: the tile comes out transposed - lane
+          // (fk, fr) holds columns 4 fk .. 4 fk + 3 of row fr - so that the epilogue moves 16 bytes (fp32) / 8 bytes (bf16) per lane
+          // and row instead of one element (64 scalar stores per lane and output tensor before, 16 vector stores now)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah[i], acc[i][j], 0, 0, 0);
         }
       }
     }
@@ -280,33 +282,53 @@ __global__ __launch_bounds__(256 * KG) void linear_x3_kernel(LinArgs g) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] += *reinterpret_cast<const f32x4*>(sx + ((wave * 4 + i) * 4 + j) * 256 + lane * 4);
   }
-  // D[row = 4 * (lane >> 4) + r][col = lane & 15]
+  // D^T: lane (fk, fr) holds output row m = .. + fr, columns n = .. + 4 fk + r.  A workgroup's tile is interior (whole vector accesses,
+  // every pointer 16-byte aligned) unless it touches the ragged edge of M or N or a leading dimension is not a multiple of 4.
+  const bool vec = m0 + BM <= g.M && n0 + BN <= g.N && (g.ldo & 3) == 0 && (g.ld16 & 3) == 0 && (g.ld16b & 3) == 0 && (g.ldr & 3) == 0 &&
+                   ((nW0 | n0) & 3) == 0;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 4; ++i) {
+    const int row = m0 + wm * 64 + i * 16 + fr;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int col = n0 + wn * 64 + j * 16 + fr;
-      if (col >= g.N) continue;
-      const float b = bp ? bp[col - nW0] : 0.f;
+      const int col = n0 + wn * 64 + j * 16 + fk * 4;
+      if (vec) {
+        f32x4 y = acc[i][j];
+        if (bp) y += *reinterpret_cast<const f32x4*>(bp + col - nW0);
+        f32x4 dg = zero;
+        if constexpr (ACT == 1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { float gl, d; gelu_both(y[r], gl, d); y[r] = gl; dg[r] = d; }
+        }
+        if (g.resid) y += *reinterpret_cast<const f32x4*>(g.resid + (size_t)row * g.ldr + col);
+        if (g.out32) *reinterpret_cast<f32x4*>(g.out32 + (size_t)row * g.ldo + col) = y;
+        if (g.out16) *reinterpret_cast<bf16x4*>(g.out16 + (size_t)row * g.ld16 + col) = bf16x4{f2bf(y[0]), f2bf(y[1]), f2bf(y[2]), f2bf(y[3])};
+        if constexpr (ACT == 1) {
+          if (g.out16b) *reinterpret_cast<bf16x4*>(g.out16b + (size_t)row * g.ld16b + col) = bf16x4{f2bf(dg[0]), f2bf(dg[1]), f2bf(dg[2]), f2bf(dg[3])};
+        }
+        continue;
+      }
+      if (row >= g.M) continue;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = m0 + wm * 64 + i * 16 + fk * 4 + r;
-        if (row >= g.M) continue;
-        float y = acc[i][j][r] + b;
+        const int c = col + r;
+        if (c >= g.N) continue;
+        float y = acc[i][j][r] + (bp ? bp[c - nW0] : 0.f);
         float dg = 0.f;
         if constexpr (ACT == 1) {
           float gl;
           gelu_both(y, gl, dg);
           y = gl;
         }
-        if (g.resid) y += g.resid[(size_t)row * g.ldr + col];
-        if (g.out32) g.out32[(size_t)row * g.ldo + col] = y;
-        if (g.out16) g.out16[(size_t)row * g.ld16 + col] = f2bf(y);
+        if (g.resid) y += g.resid[(size_t)row * g.ldr + c];
+        if (g.out32) g.out32[(size_t)row * g.ldo + c] = y;
+        if (g.out16) g.out16[(size_t)row * g.ld16 + c] = f2bf(y);
         if constexpr (ACT == 1) {
-          if (g.out16b) g.out16b[(size_t)row * g.ld16b + col] = f2bf(dg);
+          if (g.out16b) g.out16b[(size_t)row * g.ld16b + c] = f2bf(dg);
         }
       }
     }
+  }
 }
 
 // Few rows (M <= 64: the CLS lane, the projections): latency is everything, because these launches sit on a side stream
