@@ -255,6 +255,18 @@ def _gemm_class(kind, epi, M, N, K):
     return f"gemm_nt_kernel<{epis.get(epi, epi)},{'2,4,8,4' if big else '2,2,4,4'}>"
 
 
+PMC_PASS_TIMEOUT_S = 180          # one rocprofv3 --pmc pass over the two-step child takes 10-20 s
+# Optional legs of a default 1-GPU run (traffic, w1_forced, other_configs, cpu_baseline) are skipped - with the reason in the line -
+# once the run has used this much wall time: the ONE JSON line is printed at the very end, and a leg that crawls (a cold box, a
+# profiler that hangs) must not cost the headline.  A normal run takes 70-120 s in all.
+OPTIONAL_LEG_BUDGET_S = float(os.environ.get("OAT_BENCH_BUDGET_S", "900"))
+_T_START = time.time()
+
+
+def _budget_left():
+    return OPTIONAL_LEG_BUDGET_S - (time.time() - _T_START)
+
+
 _ALGO_BYTES = {}      # kernel class -> [algorithmic bytes of each launch of the instrumented step]
 
 
@@ -389,7 +401,7 @@ def hbm_traffic(args, kernel_class, algo_bytes):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, counter)
             r = subprocess.run([exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "run", "--"] + child,
-                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
+                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=PMC_PASS_TIMEOUT_S)
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 return {"skipped": f"rocprofv3 --pmc {counter} failed (rc {r.returncode}): {(r.stderr or r.stdout)[-300:]}"}
@@ -398,7 +410,7 @@ def hbm_traffic(args, kernel_class, algo_bytes):
             d = df.groupby("Dispatch_Id").Counter_Value.sum()
             per[counter] = (float(d.mean()) * 1024.0, int(d.count()))
     except subprocess.TimeoutExpired:
-        return {"skipped": "rocprofv3 pass timed out (600 s)"}
+        return {"skipped": f"rocprofv3 pass timed out ({PMC_PASS_TIMEOUT_S} s)"}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     read_b, write_b = 2.0 * per["FETCH_SIZE"][0], per["WRITE_SIZE"][0]
@@ -701,11 +713,12 @@ def main():
                                "traffic_profile": "profiles/ (rocprofv3 --pmc passes of this command, per round)",
                                "other_gemm_kernels": [entry(n, d) for n, d in ranked[1:] if d["ms"] > 0.2]}
         if world == 1 and by and not args.no_traffic and args.variant == "frozen":
-            tr = hbm_traffic(args, out["roofline"]["kernel"], _ALGO_BYTES.get(out["roofline"]["kernel"], []))
+            tr = hbm_traffic(args, out["roofline"]["kernel"], _ALGO_BYTES.get(out["roofline"]["kernel"], [])) \
+                if _budget_left() > 2 * PMC_PASS_TIMEOUT_S + 120 else {"skipped": "wall-time budget of the optional legs used up"}
             out["roofline"]["traffic"] = None if "skipped" in tr else tr
             if "skipped" in tr:
                 out["roofline"]["traffic_skipped"] = tr["skipped"]
-        if world == 1 and not args.no_forced_w1 and args.variant == "frozen":
+        if world == 1 and not args.no_forced_w1 and args.variant == "frozen" and _budget_left() > 120:
             try:
                 out["w1_forced"] = forced_w1(dp, eager_step, args.batch, device)
                 out["ms_per_step_w1_forced"] = out["w1_forced"]["ms_per_step_w1_forced"]
@@ -720,6 +733,9 @@ def main():
             torch.cuda.empty_cache()
             out["other_configs"] = []
             for variant, kw in other_config_plan(args):
+                if _budget_left() < 90:
+                    out["other_configs"].append({"workload": f"[{kw.get('label', variant)}]", "skipped": "wall-time budget of the optional legs used up"})
+                    continue
                 try:
                     out["other_configs"].append(other_config_line(args, variant, device, **kw))
                 except Exception as exc:              # the headline line must still be printed
@@ -727,7 +743,7 @@ def main():
                     gc.collect()
                     torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline and args.variant == "frozen":
-            out["cpu_baseline"] = cpu_baseline(args.frames)
+            out["cpu_baseline"] = cpu_baseline(args.frames)        # bounded by construction (about 25 s): always reported
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -78,6 +78,20 @@ def test_bench_single_rank_line():
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "pairs/s" and cb["sample"]
 
 
+def test_bench_prints_its_line_when_the_optional_legs_run_out_of_budget():
+    """The one JSON line comes last; optional legs (PMC traffic, w1_forced, other_configs) are skipped with a reason once the
+    wall-time budget is used up, and the headline fields are all there."""
+    env = dict(os.environ, OAT_BENCH_BUDGET_S="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "4", "--frames", "2",
+                        "--other-configs", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    rec = _line(r.stdout)
+    _check(rec, 1)
+    assert rec["roofline"]["traffic"] is None and "budget" in rec["roofline"]["traffic_skipped"]
+    assert "w1_forced" not in rec
+    assert rec["other_configs"] and all("budget" in o["skipped"] for o in rec["other_configs"])
+
+
 def test_bench_gpus_2_launches_its_own_ranks():
     """`python bench.py --gpus 2` with NO launcher and no rendezvous variables: bench.py starts the two ranks itself
     (dry-run form: both on the one GPU, over gloo) and rank 0 prints one line for the group."""
