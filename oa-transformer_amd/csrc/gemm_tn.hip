@@ -85,10 +85,29 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_tn_kernel(TnArgs g) {
     char* base = smem + buf * STAGE;
     const bf16* Pm = g.P + (size_t)chunk * TK * g.ldp;
     const bf16* Qm = g.Q + (size_t)chunk * TK * g.ldq;
+    // The last chunk of a ragged M holds fewer than TK rows.  Its missing rows are zeroed in LDS after they land, but they must not be
+    // FETCHED from beyond row M - 1: the operands of the pruned top block are row slices that start at a clip's CLS rows (3 ... 64 rows
+    // before the end of an [Mp, .] buffer), and up to TK - 1 rows past M then lie past the end of the allocation - an illegal access
+    // whenever the allocator placed the tensor at the end of a mapping (seen once in four runs of the GPU suite, round 5).  Rows past
+    // M - 1 re-read row M - 1 instead.
+    const int valid = g.M - chunk * TK;                     // workgroup-uniform
+    if (valid >= TK) {
 #pragma unroll
-    for (int i = 0; i < GP; ++i) glds16_asm_so(Pm, (uint32_t)p_off[i] * 2u, base + (wave * GP + i) * 1024);
+      for (int i = 0; i < GP; ++i) glds16_asm_so(Pm, (uint32_t)p_off[i] * 2u, base + (wave * GP + i) * 1024);
 #pragma unroll
-    for (int i = 0; i < GQ; ++i) glds16_asm_so(Qm, (uint32_t)q_off[i] * 2u, base + P_BYTES + (wave * GQ + i) * 1024);
+      for (int i = 0; i < GQ; ++i) glds16_asm_so(Qm, (uint32_t)q_off[i] * 2u, base + P_BYTES + (wave * GQ + i) * 1024);
+    } else {
+#pragma unroll
+      for (int i = 0; i < GP; ++i) {
+        const int m = ((wave * GP + i) * 64 + lane) / CP, over = m - min(m, valid - 1);
+        glds16_asm_so(Pm, (uint32_t)(p_off[i] - over * g.ldp) * 2u, base + (wave * GP + i) * 1024);
+      }
+#pragma unroll
+      for (int i = 0; i < GQ; ++i) {
+        const int m = ((wave * GQ + i) * 64 + lane) / CQ, over = m - min(m, valid - 1);
+        glds16_asm_so(Qm, (uint32_t)(q_off[i] - over * g.ldq) * 2u, base + P_BYTES + (wave * GQ + i) * 1024);
+      }
+    }
   };
 
   f32x4 acc[TM][TN], accb[TM];

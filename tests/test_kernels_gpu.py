@@ -206,6 +206,31 @@ def test_gemm_tn(M, N1, N2):
     close(bias, 2 * bref, atol=4e-3 * math.sqrt(M), rtol=2e-3, what="gemm_tn bias accumulate")
 
 
+@pytest.mark.parametrize("M,tail", [(3, 0), (3, 25), (33, 7), (70, 0), (31, 1)])
+def test_gemm_tn_never_reads_past_row_m(M, tail):
+    """The pruned top block hands oat_gemm_tn row SLICES that start at a clip's CLS rows - M = B rows with only `tail` rows of the
+    [Mp, .] buffer behind them (engine/video.py: _top_block_bwd_pruned).  The kernel stages 32-row chunks: the rows of the last chunk
+    past M - 1 used to be fetched (and zeroed in LDS afterwards), i.e. up to 31 rows past the end of the allocation - an illegal access
+    whenever the allocator put the tensor at the end of a mapping (round 5: once in four runs of this suite).  Here the operands end
+    `tail` rows after row M - 1 with the rest of the allocation poisoned with NaN further down; the result must be exact either way,
+    and with tail = 0 any read past M - 1 is a read past the tensor."""
+    hip = _hip()
+    N1, N2, lead = 768, 256, 515
+    bigP = torch.full((lead + M + tail, N1), float("nan"), dtype=torch.bfloat16, device=DEV)
+    bigQ = torch.full((lead + M + tail, N2), float("nan"), dtype=torch.bfloat16, device=DEV)
+    bigP[lead:lead + M] = rnd(M, N1, dtype=torch.bfloat16, seed=21)
+    bigQ[lead:lead + M] = rnd(M, N2, dtype=torch.bfloat16, seed=22)
+    P, Q = bigP[lead:], bigQ[lead:]
+    out = torch.full((N1, N2), 7.0, device=DEV)
+    bias = torch.full((N1,), 9.0, device=DEV)
+    hip.gemm_tn(P, Q, M, N1, N2, out, bias_out=bias)
+    torch.cuda.synchronize()
+    ref = P[:M].float().t() @ Q[:M].float()
+    assert torch.isfinite(out).all() and torch.isfinite(bias).all()
+    close(out, ref, atol=2e-3 * math.sqrt(M), rtol=2e-3, what="gemm_tn tail slice")
+    close(bias, P[:M].float().sum(0), atol=2e-3 * math.sqrt(M), rtol=2e-3, what="gemm_tn tail slice bias")
+
+
 @pytest.mark.parametrize("mode", ["stream", "uniform", "uniform1"])
 def test_gemm_tn_grouped(mode):
     """oat_tn_group_plan / oat_tn_group_run (csrc/gemm_tn_sk.hip): several weight gradients in one launch + one fix-up,
