@@ -77,7 +77,8 @@ void oat_gemm_set_tail_split(int on);
 int oat_gemm_set_tile_counters(void* zeroed_device_ints, size_t bytes);
 
 /* out[N1,N2] (fp32, (+)=) sum_m P[m,N1]^T Q[m,N2]  - weight gradients of every nn.Linear.
- * Rows [M, round_up(M,64)) of P and Q must be readable (contents ignored).
+ * Rows past M - 1 are never read (round 5: the ragged last chunk re-reads row M - 1; earlier builds required rows
+ * [M, round_up(M,64)) to be readable, which a row slice ending at its CLS rows is not).
  * workspace: fp32 split-M slabs; oat_gemm_tn_workspace_bytes(M, ..) is exact for that launch, M <= 0 the worst case. */
 size_t oat_gemm_tn_workspace_bytes(int M, int N1, int N2);
 int oat_gemm_tn(const void* P, const void* Q, int M, int N1, int N2, int ldp, int ldq, float* out,

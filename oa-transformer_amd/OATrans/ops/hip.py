@@ -506,6 +506,12 @@ class TnGroup:
                 raise OatError("TnGroup: out must be a contiguous fp32 [N1, N2] tensor")
             if P.dtype != torch.bfloat16 or Q.dtype != torch.bfloat16 or P.stride(1) != 1 or Q.stride(1) != 1:
                 raise OatError("TnGroup: P and Q must be bf16 with unit column stride")
+            # the grouped kernel fetches whole 64-row K-tiles (the rows of a ragged last tile past M - 1 are zeroed in LDS after they
+            # land): the operands must OWN those rows.  Engine buffers are [Mp, .] with Mp = M rounded up to 256 and are read from row 0;
+            # a row slice that ends before round_up(M, 64) would be read past its end (oat_gemm_tn clamps instead: use it for such slices)
+            need = (M + 63) // 64 * 64
+            if P.shape[0] < need or Q.shape[0] < need:
+                raise OatError(f"TnGroup: P / Q must hold round_up(M, 64) = {need} readable rows (got {P.shape[0]}, {Q.shape[0]})")
             rows.append([P.data_ptr(), Q.data_ptr(), out.data_ptr(), bias_out.data_ptr() if bias_out is not None else 0,
                          (M & 0xffffffff) | (N1 << 32), (N2 & 0xffffffff) | (P.stride(0) << 32),
                          (Q.stride(0) & 0xffffffff) | ((1 if acc else 0) << 32), 0])

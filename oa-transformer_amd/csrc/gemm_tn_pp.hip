@@ -76,12 +76,26 @@ __global__ __launch_bounds__(512) void gemm_tn_pp_kernel(TnArgs g) {
   int cnext = 0;                      // K-tile the cursor points at
   uint32_t dmask = ~0u;               // 0xff once the split's rows are exhausted: the pieces degenerate to re-reads of
                                       // one 256-byte line into regions nobody reads any more (uniform op stream)
+  // The ragged last K-tile (M % 64 rows) is zeroed in LDS beyond row M - 1 after it lands; its rows past M - 1 must not be FETCHED from
+  // beyond the operand (a row slice may end right there: see gemm_tn.hip `stage`): once the cursor stands on that tile the per-lane
+  // row offsets are clamped to its last valid row (they are not needed unclamped again: it is the last tile of the walk).
+  auto clamp_last = [&]() __attribute__((always_inline)) {
+    const uint32_t vlast = (uint32_t)((g.M & 63) - 1);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const uint32_t row = (uint32_t)(4 * (2 * wave + e) + prow), rc = row < vlast ? row : vlast;
+      poff[e] = rc * (uint32_t)g.ldp * 2u + c16;
+      qoff[e] = rc * (uint32_t)g.ldq * 2u + c16;
+    }
+  };
+  if (ragged && n == 1) clamp_last();
   auto advance = [&]() __attribute__((always_inline)) {
     ++cnext;
     const bool more = cnext < n;
     cp = more ? cp + pstep : cp;
     cq = more ? cq + qstep : cq;
     dmask = more ? dmask : 0xffu;
+    if (ragged && cnext == n - 1) clamp_last();          // wave-uniform
   };
   auto stageP = [&](auto cls, int buf) __attribute__((always_inline)) {
     constexpr int A = decltype(cls)::value;

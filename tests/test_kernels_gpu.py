@@ -206,7 +206,7 @@ def test_gemm_tn(M, N1, N2):
     close(bias, 2 * bref, atol=4e-3 * math.sqrt(M), rtol=2e-3, what="gemm_tn bias accumulate")
 
 
-@pytest.mark.parametrize("M,tail", [(3, 0), (3, 25), (33, 7), (70, 0), (31, 1)])
+@pytest.mark.parametrize("M,tail", [(3, 0), (3, 25), (33, 7), (70, 0), (31, 1), (4100, 0), (4159, 3), (8257, 0), (4100, 60), (130, 62)])
 def test_gemm_tn_never_reads_past_row_m(M, tail):
     """The pruned top block hands oat_gemm_tn row SLICES that start at a clip's CLS rows - M = B rows with only `tail` rows of the
     [Mp, .] buffer behind them (engine/video.py: _top_block_bwd_pruned).  The kernel stages 32-row chunks: the rows of the last chunk
@@ -229,6 +229,18 @@ def test_gemm_tn_never_reads_past_row_m(M, tail):
     assert torch.isfinite(out).all() and torch.isfinite(bias).all()
     close(out, ref, atol=2e-3 * math.sqrt(M), rtol=2e-3, what="gemm_tn tail slice")
     close(bias, P[:M].float().sum(0), atol=2e-3 * math.sqrt(M), rtol=2e-3, what="gemm_tn tail slice bias")
+    # M >= 4096 above ran on the ping-pong kernel (gemm_tn_pp.hip: clamped as well).  The GROUPED launch (gemm_tn_sk.hip) keeps its
+    # unclamped 64-row K-tiles - the clamp cost its 256-register kernel 13 more spills and the step 0.15 ms - and states the contract
+    # instead: operands own round_up(M, 64) rows (engine buffers do), anything shorter is refused
+    out2, bias2 = torch.full((N1, N2), 7.0, device=DEV), torch.full((N1,), 9.0, device=DEV)
+    if M + tail < (M + 63) // 64 * 64:
+        with pytest.raises(hip.OatError, match="readable rows"):
+            hip.TnGroup([(P, Q, M, N1, N2, out2, bias2, False)], splits=1)
+    else:
+        grp = hip.TnGroup([(P, Q, M, N1, N2, out2, bias2, False)], splits=2 if M >= 256 else 1)
+        grp.run()
+        torch.cuda.synchronize()
+        close(out2, ref, atol=2e-3 * math.sqrt(M), rtol=2e-3, what="TnGroup tail slice")
 
 
 @pytest.mark.parametrize("mode", ["stream", "uniform", "uniform1"])
