@@ -243,6 +243,22 @@ def test_gemm_tn_never_reads_past_row_m(M, tail):
         close(out2, ref, atol=2e-3 * math.sqrt(M), rtol=2e-3, what="TnGroup tail slice")
 
 
+@pytest.mark.parametrize("M", [3, 33, 4100, 8257])
+def test_gemm_tn_operands_at_the_end_of_their_allocation(M):
+    """The deterministic form of the test above: a subprocess with PyTorch's caching allocator switched off, the operands the last M rows
+    of allocations that end on a 2 MiB boundary (scripts/dev/oob_probe.py).  The round-4 kernels die here with hipErrorIllegalAddress
+    (M = 3, 33: gemm_tn_kernel fetched the whole 32-row chunk; M >= 4096: gemm_tn_pp the whole ragged 64-row K-tile)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTORCH_NO_CUDA_MEMORY_CACHING="1", PYTORCH_NO_HIP_MEMORY_CACHING="1", GRAFT_REPO_ROOT=root)
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "dev", "oob_probe.py"), str(M)], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), (r.stdout + r.stderr)[-1500:]
+    assert float(r.stdout.split()[1]) < 2e-3 * math.sqrt(M) + 1e-3
+
+
 @pytest.mark.parametrize("mode", ["stream", "uniform", "uniform1"])
 def test_gemm_tn_grouped(mode):
     """oat_tn_group_plan / oat_tn_group_run (csrc/gemm_tn_sk.hip): several weight gradients in one launch + one fix-up,
