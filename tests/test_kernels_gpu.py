@@ -259,6 +259,21 @@ def test_gemm_tn_operands_at_the_end_of_their_allocation(M):
     assert float(r.stdout.split()[1]) < 2e-3 * math.sqrt(M) + 1e-3
 
 
+@pytest.mark.parametrize("M", [3, 32])
+def test_b_row_launches_stay_inside_operands_that_end_at_row_m(M):
+    """Every B-row launch of the pruned top block and of the per-clip tails (proj / fc1 + GELU / fc2 forward, their data gradients,
+    the LayerNorms either way, the fc2 weight gradient, the final LayerNorm: engine/video.py _top_tail_fwd, _top_block_bwd_pruned,
+    _final_fwd) on operands that are the LAST M rows of their allocation, caching allocator off (scripts/dev/oob_probe2.py)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTORCH_NO_CUDA_MEMORY_CACHING="1", PYTORCH_NO_HIP_MEMORY_CACHING="1", GRAFT_REPO_ROOT=root)
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "dev", "oob_probe2.py"), str(M)], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert r.returncode == 0 and r.stdout.strip().endswith("done") and r.stdout.count("ok ") == 9, (r.stdout + r.stderr)[-1500:]
+
+
 @pytest.mark.parametrize("mode", ["stream", "uniform", "uniform1"])
 def test_gemm_tn_grouped(mode):
     """oat_tn_group_plan / oat_tn_group_run (csrc/gemm_tn_sk.hip): several weight gradients in one launch + one fix-up,
