@@ -1,7 +1,7 @@
-"""Dev / test helper: oat_gemm_tn on operands that END at the last byte of their hipMalloc (run with PYTORCH_NO_CUDA_MEMORY_CACHING=1: every
+"""Test helper (run as a subprocess by tests/test_kernels_gpu.py): oat_gemm_tn on operands that END at the last byte of their hipMalloc (run with PYTORCH_NO_CUDA_MEMORY_CACHING=1: every
 tensor its own allocation, sized to a multiple of 2 MiB) - any row fetched past M - 1 is an illegal access.  tests/test_kernels_gpu.py runs it."""
 import os, sys
-ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "oa-transformer_amd"))
 import torch
 from OATrans.ops import hip

@@ -1,8 +1,8 @@
-"""Dev / test helper: the B-row launches of the pruned top block and of the per-clip tails (engine/video.py: _top_tail_fwd, _top_block_bwd_pruned, the
+"""Test helper (run as a subprocess by tests/test_kernels_gpu.py): the B-row launches of the pruned top block and of the per-clip tails (engine/video.py: _top_tail_fwd, _top_block_bwd_pruned, the
 final LayerNorm) on operands that END at the last byte of their hipMalloc (PYTORCH_NO_CUDA_MEMORY_CACHING=1, allocations of whole 2 MiB pages): any row
 touched past M - 1 is an illegal access.  Prints "ok <op>" per op."""
 import os, sys
-ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "oa-transformer_amd"))
 import torch
 from OATrans.ops import hip

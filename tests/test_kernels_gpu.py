@@ -246,14 +246,14 @@ def test_gemm_tn_never_reads_past_row_m(M, tail):
 @pytest.mark.parametrize("M", [3, 33, 4100, 8257])
 def test_gemm_tn_operands_at_the_end_of_their_allocation(M):
     """The deterministic form of the test above: a subprocess with PyTorch's caching allocator switched off, the operands the last M rows
-    of allocations that end on a 2 MiB boundary (scripts/dev/oob_probe.py).  The round-4 kernels die here with hipErrorIllegalAddress
+    of allocations that end on a 2 MiB boundary (tests/helpers/oob_gemm_tn.py).  The round-4 kernels die here with hipErrorIllegalAddress
     (M = 3, 33: gemm_tn_kernel fetched the whole 32-row chunk; M >= 4096: gemm_tn_pp the whole ragged 64-row K-tile)."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PYTORCH_NO_CUDA_MEMORY_CACHING="1", PYTORCH_NO_HIP_MEMORY_CACHING="1", GRAFT_REPO_ROOT=root)
-    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "dev", "oob_probe.py"), str(M)], capture_output=True, text=True,
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "helpers", "oob_gemm_tn.py"), str(M)], capture_output=True, text=True,
                        timeout=300, env=env)
     assert r.returncode == 0 and r.stdout.startswith("ok"), (r.stdout + r.stderr)[-1500:]
     assert float(r.stdout.split()[1]) < 2e-3 * math.sqrt(M) + 1e-3
@@ -263,13 +263,13 @@ def test_gemm_tn_operands_at_the_end_of_their_allocation(M):
 def test_b_row_launches_stay_inside_operands_that_end_at_row_m(M):
     """Every B-row launch of the pruned top block and of the per-clip tails (proj / fc1 + GELU / fc2 forward, their data gradients,
     the LayerNorms either way, the fc2 weight gradient, the final LayerNorm: engine/video.py _top_tail_fwd, _top_block_bwd_pruned,
-    _final_fwd) on operands that are the LAST M rows of their allocation, caching allocator off (scripts/dev/oob_probe2.py)."""
+    _final_fwd) on operands that are the LAST M rows of their allocation, caching allocator off (tests/helpers/oob_tail_launches.py)."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PYTORCH_NO_CUDA_MEMORY_CACHING="1", PYTORCH_NO_HIP_MEMORY_CACHING="1", GRAFT_REPO_ROOT=root)
-    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "dev", "oob_probe2.py"), str(M)], capture_output=True, text=True,
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "helpers", "oob_tail_launches.py"), str(M)], capture_output=True, text=True,
                        timeout=300, env=env)
     assert r.returncode == 0 and r.stdout.strip().endswith("done") and r.stdout.count("ok ") == 9, (r.stdout + r.stderr)[-1500:]
 
