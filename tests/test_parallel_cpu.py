@@ -138,7 +138,7 @@ def _overlap_worker(rank, world, port, q):
         toy._announce(("blocks.0.",))
         assert len(sync._pending) == 2
         sync.all_reduce(average=True)
-        assert not sync._pending and not sync._covered
+        assert not sync._pending and not sync._covered and sync.started_last_step == 2      # what bench.py reports as async_all_reduces_per_step
         for i, (n, v) in enumerate(views.items()):
             want = sum((r + 1) * (i + 1) + step for r in range(world)) / world
             assert torch.allclose(v, torch.full_like(v, want)), (n, v, want)     # reduced exactly once
@@ -146,6 +146,36 @@ def _overlap_worker(rank, world, port, q):
     q.put(rank)
     dist.barrier()
     dist.destroy_process_group()
+
+
+def test_forced_single_rank_sync_issues_the_collectives_and_leaves_the_gradients_alone():
+    """GradSync(force=True) on a ONE-rank group - what bench.py's `w1_forced` leg and tests/test_dist_gpu.py run on the GPU: the announced
+    ranges go out as asynchronous all-reduces (identity at one rank), the rest synchronously, and no 1/W pass touches the gradients
+    (at W > 1 the mean is applied to the loss, HipDataParallel.backward, so the path being measured has none either)."""
+    from OATrans.parallel import GradSync
+    port = _free_port()
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        torch.manual_seed(1)
+        toy = _FlatToy()
+        model = torch.nn.ModuleDict({"toy": toy})
+        plain = GradSync(model, overlap=True)                      # one rank, not forced: inert
+        assert toy.grad_ready_hook is None and plain.bwd_nt_grid == 0
+        sync = GradSync(model, overlap=True, force=True)
+        assert toy.grad_ready_hook is not None
+        views = toy._grad_views()
+        for i, v in enumerate(views.values()):
+            v.fill_(float(i + 1))
+        before = toy.flat_grad().clone()
+        toy._announce(("blocks.1.", "norm."))
+        toy._announce(("blocks.0.",))
+        assert len(sync._pending) == 2
+        sync.all_reduce(average=True)
+        assert sync.started_last_step == 2 and not sync._pending
+        assert torch.equal(toy.flat_grad(), before)                # sum over one rank, no division pass
+        toy.grad_ready_hook = None
+    finally:
+        dist.destroy_process_group()
 
 
 def test_two_rank_overlapped_gradient_sync():
