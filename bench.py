@@ -40,17 +40,26 @@ def _self_launch():
     n = pre.parse_known_args()[0].gpus
     if n <= 1 or "WORLD_SIZE" in os.environ or "RANK" in os.environ:
         return None
-    import socket
+    import signal
     import subprocess
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
+    import tempfile
+    # rendezvous through a FILE store in a fresh temp dir (OAT_BENCH_INIT, read by main()): nothing to race for - a port found
+    # by bind(0) + close can be taken by another process before the ranks bind it, and N ranks then hang until RCCL's timeout.
+    # MASTER_ADDR / MASTER_PORT are still exported (what the reference's entry points read, train_dist_multi.py:35-38,127-132).
+    rdv = tempfile.mkdtemp(prefix="oat_bench_rdv_")
     procs = []
     for r in range(n):
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n), RANK=str(r),
-                   LOCAL_RANK=str(r), LOCAL_WORLD_SIZE=str(n), OAT_BENCH_SELF_LAUNCHED="1")
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29500"), WORLD_SIZE=str(n), RANK=str(r),
+                   LOCAL_RANK=str(r), LOCAL_WORLD_SIZE=str(n), OAT_BENCH_SELF_LAUNCHED="1", OAT_BENCH_INIT=f"file://{rdv}/store")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+
+    def _stop(signum, frame):            # SIGTERM / SIGINT to the launcher: take exactly the ranks started above along
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        raise SystemExit(128 + signum)
+
+    old = {sig: signal.signal(sig, _stop) for sig in (signal.SIGTERM, signal.SIGINT)}
     rc = 0
     try:
         pending = set(range(n))
@@ -70,6 +79,10 @@ def _self_launch():
         for p in procs:
             if p.poll() is None:
                 p.kill()
+        for sig, h in old.items():
+            signal.signal(sig, h)
+        import shutil
+        shutil.rmtree(rdv, ignore_errors=True)
     return rc
 
 
@@ -159,26 +172,28 @@ def other_config_line(base_args, variant, device, steps=10, warmup=3, label=None
     """One more workload of BASELINE.json's `configs`, run AFTER the headline's timed region and reported under
     `other_configs`, outside `value`: a short (warmup + steps) single-GPU measurement with the same step function,
     optimiser and timing brackets as the headline.  variant: frozen | region_mem | global_local, with the suffix
-    `_pruned` for the same model and step under VideoEngine.prune_top (see pruned_top_gflops); overrides: frames /
-    batch / res / dtype of the run (default: the headline's); label: the BASELINE.json config the entry stands for."""
+    `_full` for the same model and step with VideoEngine.prune_top OFF (the reference's full graph; the default schedule
+    skips the top block's unused patch rows, see pruned_top_gflops); overrides: frames / batch / res / dtype of the run
+    (default: the headline's); label: the BASELINE.json config the entry stands for."""
     import copy
     import gc
     from OATrans.trainer.step import global_local_step, hot_step, region_mem_step
     args = copy.copy(base_args)
     for k, v in overrides.items():
         setattr(args, k, v)
-    pruned = variant.endswith("_pruned")
-    args.variant = variant[:-len("_pruned")] if pruned else variant
+    full_graph = variant.endswith("_full")
+    args.variant = variant[:-len("_full")] if full_graph else variant
     step_impl = {"region_mem": region_mem_step, "global_local": global_local_step, "frozen": hot_step}[args.variant]
     dp, opt, loss_fn = build(args, device)
     if args.dtype == "fp8":
         dp.module.video_model._engine.fp8 = True
-    if pruned:
-        dp.module.video_model._engine.prune_top = True
+    if full_graph:
+        dp.module.video_model._engine.prune_top = False
     data = synthetic_batch(args, 0, device)
     step_args = argparse.Namespace(world_size=1, rank=0, local_rank=device.index or 0)
     for _ in range(warmup):
         step_impl(dp, loss_fn, opt, data, step_args)
+    pruned = any(pl.prune_top for pl in dp.module.video_model._engine.plans.values())     # what the engine actually ran
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -203,15 +218,19 @@ def other_config_line(base_args, variant, device, steps=10, warmup=3, label=None
                 "the object frame and the clip") if oa else \
                ("oa_model.FrozenInTime consumes only the CLS row of the encoder output, so the top block's space projection / norm2 / fc1 / "
                 f"GELU / fc2 run on the {args.batch} CLS rows instead of all {args.batch * (args.frames * N + 1)} (forward, data and weight gradients)")
-        line = {"workload": f"[{args.variant}, top block pruned] the [{args.variant}] model and step with VideoEngine.prune_top (opt-in, "
-                            f"OAT_PRUNE_TOP=1): {what}; same loss, same gradients (tests/test_prune_gpu.py)",
-                **common, "gflop_per_pair_executed": round(gf_pair, 1), "gflop_per_pair_full_graph": round(full, 1),
-                "step_mfma_frac_executed": round(value * gf_pair / 1e3 / BF16_DENSE_PEAK_TFLOPS, 4)}
-    else:
         clip = f"{args.frames}-frame + {n_obj} obj (one object frame with {n_obj} box masks + the {args.frames}-frame clip, same encoder)" \
             if oa else f"{args.frames}-frame"
         line = {"workload": f"[{label or args.variant}] {clip} {args.res}^2 ViT-B/16 + DistilBERT-base ({cls_name}.FrozenInTime), "
-                            f"bs {args.batch}, fwd+bwd+AdamW",
+                            f"bs {args.batch}, fwd+bwd+AdamW; default schedule (VideoEngine.prune_top): {what}; same loss, same "
+                            "gradients as the full graph (tests/test_prune_gpu.py)",
+                **common, "gflop_per_pair": round(gf_pair, 1), "gflop_per_pair_full_graph": round(full, 1),
+                "step_mfma_frac": round(value * gf_pair / 1e3 / BF16_DENSE_PEAK_TFLOPS, 4)}      # from the EXECUTED FLOPs
+    else:
+        clip = f"{args.frames}-frame + {n_obj} obj (one object frame with {n_obj} box masks + the {args.frames}-frame clip, same encoder)" \
+            if oa else f"{args.frames}-frame"
+        tag = ", full graph (OAT_PRUNE_TOP=0: the top block's discarded patch rows computed as the reference does)" if full_graph else ""
+        line = {"workload": f"[{label or variant}] {clip} {args.res}^2 ViT-B/16 + DistilBERT-base ({cls_name}.FrozenInTime), "
+                            f"bs {args.batch}, fwd+bwd+AdamW{tag}",
                 **common, "gflop_per_pair": round(full, 1),
                 "step_mfma_frac": round(value * full / 1e3 / BF16_DENSE_PEAK_TFLOPS, 4)}    # against the bf16 roof in either dtype
     line["final_loss"] = round(float(loss.item()), 4)
@@ -223,19 +242,21 @@ def other_config_line(base_args, variant, device, steps=10, warmup=3, label=None
 
 def other_config_plan(args):
     """What a default 1-GPU run appends under `other_configs`: config 3 as BASELINE.json words it (both object-aware
-    classes, objects on), the two opt-in pruned schedules, and the per-GPU shapes of configs 2, 4 and 5 (config 5 in
-    both dtypes: bf16 is its in-tolerance form, fp8 forward the opt-in).  At another geometry
+    classes, objects on), the full-graph runs of the two classes whose default schedule prunes the top block, and the
+    per-GPU shapes of configs 2, 4 and 5 (config 5 in both dtypes: bf16 is its in-tolerance form, fp8 forward the opt-in,
+    DESIGN section 7; in bf16 also at twice the per-GPU batch).  At another geometry
     (--other-configs at test sizes) the shapes scale with the command line: half the frames, twice the batch, and
     twice the frames at 336^2 with a quarter of the batch."""
     b, f = args.batch, args.frames
     c5 = dict(frames=2 * f, res=336 if args.res == 224 else args.res, batch=max(2, b // 4))
     return [("global_local", dict(label="config 3, global_local")),
             ("region_mem", dict(label="config 3, region_mem")),
-            ("frozen_pruned", {}),
-            ("region_mem_pruned", {}),
+            ("frozen_full", dict(label="frozen, full graph")),
+            ("region_mem_full", dict(label="region_mem, full graph")),
             ("frozen", dict(label="config 2", frames=max(1, f // 2), steps=5, warmup=2)),
             ("frozen", dict(label="config 4, per-GPU shape", batch=2 * b, steps=5, warmup=2)),
             ("global_local", dict(label="config 5 geometry, bf16", dtype="bf16", steps=5, warmup=2, **c5)),
+            ("global_local", dict(label="config 5 geometry, bf16, twice the batch", dtype="bf16", steps=4, warmup=2, **dict(c5, batch=2 * c5["batch"]))),
             ("global_local", dict(label="config 5 geometry, fp8 forward", dtype="fp8", steps=5, warmup=2, **c5))]
 
 
@@ -428,13 +449,11 @@ def forced_w1(dp, eager_step, batch, device, steps=5, warmup=2):
     RCCL's stream (identity at one rank, but the same kernels, stream edges and tape segments) - and the backward GEMM
     grid of a multi-rank job.  Timed like the headline; reported beside it as `w1_forced`: the per-GPU cost of the
     multi-GPU machinery before any link time, i.e. an upper bound on the scaling efficiency a node can show."""
-    import socket
+    import shutil
+    import tempfile
     from OATrans.parallel import GradSync
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    rdv = tempfile.mkdtemp(prefix="oat_bench_w1_")           # file store: no port to race for
+    dist.init_process_group("nccl", init_method=f"file://{rdv}/store", rank=0, world_size=1)
     old_sync = dp.sync
     engines = [m._engine for m in dp.module.modules() if hasattr(getattr(m, "_engine", None), "bwd_nt_grid")]
     old_grids = [e.bwd_nt_grid for e in engines]
@@ -467,6 +486,7 @@ def forced_w1(dp, eager_step, batch, device, steps=5, warmup=2):
         for e, g in zip(engines, old_grids):
             e.bwd_nt_grid = g
         dist.destroy_process_group()
+        shutil.rmtree(rdv, ignore_errors=True)
     first = next(iter(out.values()))
     return {"ms_per_step_w1_forced": first["ms_per_step"], "steps": steps, "warmup": warmup, "variants": out,
             "what": "1-rank RCCL group, GradSync(force=True): per-block asynchronous gradient all-reduces started from inside backward + "
@@ -545,9 +565,11 @@ def main():
     ap.add_argument("--force-w1-main", action="store_true",
                     help="dev: run the MAIN timed loop on the W > 1 launch path of a 1-rank RCCL group (what `w1_forced` measures), e.g. under a kernel trace")
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)     # the process rocprofv3 wraps (see hbm_traffic)
-    ap.add_argument("--prune-top", action="store_true",
-                    help="run the MAIN line with VideoEngine.prune_top (default: full top block; a default run reports the pruned "
-                         "schedule as an extra entry of `other_configs`).  The line then carries the executed GF per pair")
+    ap.add_argument("--full-graph", action="store_true",
+                    help="run the MAIN line with VideoEngine.prune_top off (= OAT_PRUNE_TOP=0): the reference's full graph, whose top "
+                         "block computes patch rows nothing consumes.  Default: the exact pruned schedule (same loss, same gradients); "
+                         "the line then carries gflop_per_pair = EXECUTED and gflop_per_pair_full_graph beside it, and a default "
+                         "run reports the full graph as an entry of `other_configs`")
     ap.add_argument("--other-configs", action="store_true",
                     help="append the `other_configs` runs at any --frames / --res (default: only at the headline geometry, 8 x 224^2)")
     ap.add_argument("--no-other-configs", action="store_true",
@@ -578,22 +600,23 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device(f"cuda:{local}")
     if world > 1:
-        dist.init_process_group(backend=os.environ.get("OAT_BENCH_BACKEND", "nccl"), init_method="tcp://{}:{}".format(
-            os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ.get("MASTER_PORT", "29500")), rank=rank, world_size=world)
+        # self-launched ranks meet in a file store (no port to race for); under torch.distributed.run the launcher's env rendezvous
+        init = os.environ.get("OAT_BENCH_INIT") or "tcp://{}:{}".format(os.environ.get("MASTER_ADDR", "127.0.0.1"),
+                                                                        os.environ.get("MASTER_PORT", "29500"))
+        dist.init_process_group(backend=os.environ.get("OAT_BENCH_BACKEND", "nccl"), init_method=init, rank=rank, world_size=world)
     from OATrans.trainer.step import global_local_step, hot_step, region_mem_step
     step_impl = {"frozen": hot_step, "region_mem": region_mem_step, "global_local": global_local_step}[args.variant]
     dp, opt, loss_fn = build(args, device)
     if args.dtype == "fp8":
         dp.module.video_model._engine.fp8 = True
-    if args.prune_top:
-        if args.variant != "frozen":
-            raise SystemExit("--prune-top: only the frozen variant leaves the encoder's patch rows unused")
-        dp.module.video_model._engine.prune_top = True
+    if args.full_graph:
+        dp.module.video_model._engine.prune_top = False
     data = synthetic_batch(args, rank, device)
     step_args = argparse.Namespace(world_size=world, rank=rank, local_rank=local)
     if args.force_w1_main and world == 1:
         from OATrans.parallel import GradSync
-        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1)
+        import tempfile
+        dist.init_process_group("nccl", init_method=f"file://{tempfile.mkdtemp(prefix='oat_bench_w1_')}/store", rank=0, world_size=1)
         dp.sync = GradSync(dp.module, overlap=True, force=True)
         args.no_forced_w1 = args.no_traffic = True
 
@@ -643,13 +666,15 @@ def main():
     oa = args.variant != "frozen"
     gf_pair = flops_per_pair(args.frames, N=(args.res // 16) ** 2, clips=(1, args.frames) if oa else None,
                              text_passes=2 if args.variant == "global_local" else 1) / 1e9
-    if args.prune_top:                 # the utilisation figures of a pruned run count what was executed
-        gf_pair -= pruned_top_gflops(args.frames, (args.res // 16) ** 2)
+    gf_full = gf_pair
+    pruned = any(pl.prune_top for pl in dp.module.video_model._engine.plans.values())     # what the engine actually ran
+    if pruned:                         # the utilisation figures of a pruned run count what was EXECUTED
+        gf_pair -= pruned_top_gflops(args.frames + (1 if oa else 0), (args.res // 16) ** 2)
     n_obj = {"region_mem": 5, "global_local": 10}.get(args.variant)
     clip_txt = f"{args.frames}-frame + {n_obj} obj (one object frame with {n_obj} box masks + the {args.frames}-frame clip, same encoder)" \
         if oa else f"{args.frames}-frame"
-    if args.prune_top:
-        clip_txt += " (top block pruned to the CLS rows: --prune-top, gflop_per_pair = executed)"
+    if pruned:
+        clip_txt += " (default schedule: the top block's space projection / norm2 / fc1 / GELU / fc2 run on the CLS rows only - its patch rows are never consumed, video_transformer.py:349-351; gflop_per_pair = executed; --full-graph runs the rest too)"
     cls_name = {"frozen": "oa_model", "region_mem": "oa_model_region_mem", "global_local": "oa_model_global_local"}[args.variant]
     out = {
         "metric": "video-text pairs/sec fwd+bwd, 8-frame ViT-B/16, 1/2/4/8 MI355X",
@@ -660,7 +685,7 @@ def main():
         "config": {"workload": f"[{args.variant}] {clip_txt} {args.res}^2 ViT-B/16 SpaceTimeTransformer + DistilBERT-base ({cls_name}.FrozenInTime), "
                                f"bs {args.batch}/GPU, Lt 32, fwd+bwd+AdamW, InfoNCE over all-gathered embeddings",
                    "per_gpu_batch": args.batch, "global_batch": world * args.batch, "frames": args.frames,
-                   "parallelism": f"dp{world}", "gflop_per_pair": round(gf_pair, 1)},
+                   "parallelism": f"dp{world}", "gflop_per_pair": round(gf_pair, 1), "gflop_per_pair_full_graph": round(gf_full, 1)},
         "step_algorithmic_tflops_per_gpu": round(value / world * gf_pair / 1e3, 1),
         "step_mfma_frac": round(value / world * gf_pair / 1e3 / BF16_DENSE_PEAK_TFLOPS, 4),
         "final_loss": round(loss_val, 4),

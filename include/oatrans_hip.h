@@ -266,6 +266,10 @@ int oat_attn_time_bwd_fin(const void* qkv, int ldqkv, const void* out, int ldo, 
  * sit beside the video tower on a side stream and their duration is what they cost it.  OAT_LIN_X3=0: exact fp32 everywhere.
  * act | 0x100 (OAT_LIN_EXACT): exact fp32 products at EVERY M - what the CLS lane and the projection heads pass, so that a plan of
  * more than 64 clips (batch 64, or two clips of more than 32 samples) keeps the lane's precision. */
+#define OAT_LIN_NONE 0
+#define OAT_LIN_GELU 1      /* GELU (exact erf) on the output */
+#define OAT_LIN_RELU_IN 2   /* ReLU on A while loading */
+#define OAT_LIN_EXACT 0x100 /* or-ed in: exact fp32 products at every M */
 int oat_linear_f32(const float* A, int lda, const float* W, int ldw, const float* bias, int M, int N, int K,
                    float* out32, int ldo, void* out16, int ld16, void* out16b, int ld16b, const float* resid, int ldr,
                    int act, void* stream);

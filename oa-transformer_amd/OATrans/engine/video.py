@@ -254,14 +254,15 @@ class VideoEngine:
         # 1 (default): with folded LayerNorms the fp32 residual-gradient stream is read by norm2's backward, skipped by norm1's
         # and read + written once by norm3's (ln_bwd_xhat_kernel); 0: every LayerNorm backward reads and re-writes it
         self.fold_gstream = os.environ.get("OAT_FOLD_GSTREAM", "1") != "0"
-        # 1 (opt-in; default 0 = the reference's full work): when the caller consumes only the CLS rows of the encoder output
-        # (contract class oa_model.FrozenInTime, video_transformer.py:349-351 -> oa_model.py:129-133) the patch rows of the TOP
-        # block's space-attention projection, norm2, fc1 / GELU and fc2 are never read and their output gradient is exactly
-        # zero, so these launches - forward, data gradient and weight gradient - run on the B CLS rows only.  Same loss, same
-        # gradients (the weight-gradient sums lose only exact-zero terms); 49.9 of 1115.9 GF per pair at 8 frames are not
-        # executed (bench.py reports the executed figure).  Also oa_model_region_mem (CLS rows + the block-6 region tap; both
-        # clips of its plan).  See _top_tail_fwd / _top_block_bwd_pruned.
-        self.prune_top = os.environ.get("OAT_PRUNE_TOP", "0") != "0"
+        # 1 (default since round 6; OAT_PRUNE_TOP=0 = every launch of the reference's graph): when the caller consumes only the
+        # CLS rows of the encoder output (contract class oa_model.FrozenInTime, video_transformer.py:349-351 -> oa_model.py:129-133)
+        # the patch rows of the TOP block's space-attention projection, norm2, fc1 / GELU and fc2 are never read and their output
+        # gradient is exactly zero, so these launches - forward, data gradient and weight gradient - run on the B CLS rows only.
+        # Bit-identical loss, gradients equal to 4e-7 (the weight-gradient sums lose only exact-zero terms; tests/test_prune_gpu.py);
+        # 49.9 of 1115.9 GF per pair at 8 frames are not executed (bench.py reports the executed figure AND the full graph's).
+        # Also oa_model_region_mem (CLS rows + the block-6 region tap; both clips of its plan); never oa_model_global_local
+        # (it averages the final patch rows).  See _top_tail_fwd / _top_block_bwd_pruned.
+        self.prune_top = os.environ.get("OAT_PRUNE_TOP", "1") != "0"
         self.fbias = {}                     # folded biases b' (fp32), per folded linear
         self._fold_bias = None
         self._fold_tmp = {}                 # accumulate mode: scratch (dW', db') of the folded linears

@@ -56,9 +56,11 @@ class _Transformer(nn.Module):
 
 class _HiddenFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, module, input_ids, attention_mask, call_idx, *params):
-        launched = module._launched.pop(call_idx, None)
-        if launched is not None:             # DistilBertHIP.launch enqueued this call's kernels earlier: only the graph node is new
+    def forward(ctx, module, input_ids, attention_mask, call_idx, launched, *params):
+        # launched: (hidden, plan) of a call whose kernels DistilBertHIP.launch enqueued earlier - handed over explicitly by
+        # DistilBertHIP.forward(launched=ticket); a plain forward never looks into module._launched (a ticket left behind by
+        # an abandoned step must not be mistaken for this call's result)
+        if launched is not None:             # only the graph node is new
             hidden, plan = launched
         else:
             hidden, plan = module._engine.forward(input_ids, attention_mask, module._param_data(),
@@ -76,7 +78,7 @@ class _HiddenFn(torch.autograd.Function):
         m._engine.backward(ctx.plan, m._param_data(), m._grad_views(), d_hidden.float().contiguous(), accumulate)
         if m._bwd_calls == m._fwd_calls:
             m._announce(("",))               # last backward of the step: the whole flat gradient is final
-        return (None, None, None, None) + (None,) * m._n_params
+        return (None, None, None, None, None) + (None,) * m._n_params
 
 
 class DistilBertHIP(EngineModule):
@@ -164,10 +166,11 @@ class DistilBertHIP(EngineModule):
     def forward(self, input_ids=None, attention_mask=None, launched=None, **unused):
         if launched is not None:             # ticket of launch(): same call, kernels already enqueued
             idx, input_ids, attention_mask = launched
-            if idx not in self._launched:
+            held = self._launched.pop(idx, None)
+            if held is None:
                 raise RuntimeError("DistilBertHIP: stale launch ticket (begin_step() or an optimiser step came in between)")
             params = [p for _, p in self._engine_params()]
-            return SimpleNamespace(last_hidden_state=_HiddenFn.apply(self, input_ids, attention_mask, idx, *params))
+            return SimpleNamespace(last_hidden_state=_HiddenFn.apply(self, input_ids, attention_mask, idx, held, *params))
         if not input_ids.is_cuda:
             raise hip.OatError("DistilBertHIP runs on MI355X only (no CPU path); use the oracle for CPU")
         hip.lib()
@@ -177,8 +180,10 @@ class DistilBertHIP(EngineModule):
         if torch.is_grad_enabled():
             self._new_step_guard()
             idx = self._fwd_calls
+            if idx == 0:
+                self._launched.clear()       # tickets of a step that was abandoned before its nodes were created
             self._fwd_calls += 1
         else:
             idx = -1                 # no backward will follow (validation): one dedicated plan, reused by every such call
-        hidden = _HiddenFn.apply(self, input_ids, attention_mask, idx, *params)
+        hidden = _HiddenFn.apply(self, input_ids, attention_mask, idx, None, *params)
         return SimpleNamespace(last_hidden_state=hidden)

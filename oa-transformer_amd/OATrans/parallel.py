@@ -21,8 +21,8 @@ def bwd_nt_grid_default(device=None):
     import os
     v = os.environ.get("OAT_BWD_NT_GRID", "0xffff")
     if v == "auto":
-        if device is not None and torch.device(device).type != "cuda":
-            device = None
+        if device is None or torch.device(device).type != "cuda":
+            device = torch.cuda.current_device()          # (older torch versions reject None here)
         cus = torch.cuda.get_device_properties(device).multi_processor_count      # 256 on an MI355X in SPX mode, less in CPX / DPX
         return max(1, cus - int(os.environ.get("OAT_RCCL_CU_RESERVE", "16")))
     return int(v, 0)
@@ -123,6 +123,10 @@ class GradSync:
             engines = [m._engine for m in model.modules() if hasattr(getattr(m, "_engine", None), "bwd_nt_grid")]
             for eng in engines:
                 eng.bwd_nt_grid = self.bwd_nt_grid
+            # A model without an engine that exposes bwd_nt_grid gets no backward grid: the library keeps no process-wide GEMM
+            # grid any more (round 6: the grid is a per-call argument of oat_gemm_nt), so there is nothing left to fall back to.
+            # Known cost of the default, to revisit once a multi-GPU run has shown how many CUs RCCL holds: +0.55 ms per step
+            # against OAT_BWD_NT_GRID=auto.
         if overlap and (W > 1 or force):     # a single rank leaves the announcements to the eager optimiser (optim.AdamW.attach)
             for m in model.modules():
                 if hasattr(m, "flat_grad") and hasattr(m, "_engine_params"):

@@ -284,8 +284,11 @@ __global__ __launch_bounds__(256 * KG) void linear_x3_kernel(LinArgs g) {
   }
   // D^T: lane (fk, fr) holds output row m = .. + fr, columns n = .. + 4 fk + r.  A workgroup's tile is interior (whole vector accesses,
   // every pointer 16-byte aligned) unless it touches the ragged edge of M or N or a leading dimension is not a multiple of 4.
+  // (views with an odd element offset - out32[:, 1:], a bias slice of a flat buffer - take the scalar path: the base pointers' low
+  // address bits are part of the predicate, 16 bytes for the fp32 tensors, 8 for the bf16 ones)
   const bool vec = m0 + BM <= g.M && n0 + BN <= g.N && (g.ldo & 3) == 0 && (g.ld16 & 3) == 0 && (g.ld16b & 3) == 0 && (g.ldr & 3) == 0 &&
-                   ((nW0 | n0) & 3) == 0;
+                   ((nW0 | n0) & 3) == 0 &&
+                   (((uintptr_t)g.out32 | (uintptr_t)g.resid | (uintptr_t)bp) & 15) == 0 && (((uintptr_t)g.out16 | (uintptr_t)g.out16b) & 7) == 0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = m0 + wm * 64 + i * 16 + fr;
@@ -446,7 +449,7 @@ extern "C" int oat_linear_f32(const float* A, int lda, const float* W, int ldw, 
   if (M <= 0 || N <= 0 || K <= 0) { set_error("linear_f32: empty problem"); return -1; }
   if (K % 16 != 0 || lda % 4 != 0 || ldw % 4 != 0) { set_error("linear_f32: K % 16, lda % 4, ldw % 4 must be 0"); return -2; }
   if (!A || !W || (!out32 && !out16)) { set_error("linear_f32: null pointer"); return -4; }
-  // act = activation (0 none, 1 ReLU on the input, 2 GELU) | OAT_LIN_EXACT (0x100): keep the exact-f32 MFMA at every M.  Without the flag
+  // act = activation (0 none, 1 GELU on the output, 2 ReLU on the input: OAT_LIN_GELU / OAT_LIN_RELU_IN of include/oatrans_hip.h) | OAT_LIN_EXACT (0x100): keep the exact-f32 MFMA at every M.  Without the flag
   // M > 64 rows run on the split-bf16 kernel (2^-16 relative per product: the text tower's forward); the video tower's fp32 CLS lane and
   // the projection heads - the rows the 1e-3 sim-matrix bound hangs on - pass the flag so that a batch of more than 64 clips keeps f32 products.
   const bool exact = (act & 0x100) != 0;

@@ -43,17 +43,24 @@ def test_self_launch_is_a_no_op_under_a_launcher_and_at_one_gpu(monkeypatch):
     assert os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"          # set by `import bench` / `import OATrans` before any GPU call
 
 
+def by_variant(plan):
+    return {kw.get("label", v): v for v, kw in plan}
+
+
 def test_other_config_plan_names_every_baseline_config():
     import argparse
     import bench
     plan = bench.other_config_plan(argparse.Namespace(batch=32, frames=8, res=224))
     labels = [kw.get("label", v) for v, kw in plan]
-    assert labels == ["config 3, global_local", "config 3, region_mem", "frozen_pruned", "region_mem_pruned", "config 2",
-                      "config 4, per-GPU shape", "config 5 geometry, bf16", "config 5 geometry, fp8 forward"]
+    assert labels == ["config 3, global_local", "config 3, region_mem", "frozen, full graph", "region_mem, full graph", "config 2",
+                      "config 4, per-GPU shape", "config 5 geometry, bf16", "config 5 geometry, bf16, twice the batch",
+                      "config 5 geometry, fp8 forward"]
+    assert by_variant(plan)["frozen, full graph"] == "frozen_full" and by_variant(plan)["region_mem, full graph"] == "region_mem_full"
     by = {kw.get("label", v): (v, kw) for v, kw in plan}
     assert by["config 2"][1]["frames"] == 4 and by["config 4, per-GPU shape"][1]["batch"] == 64
     c5 = by["config 5 geometry, fp8 forward"]
     assert c5[0] == "global_local" and (c5[1]["frames"], c5[1]["res"], c5[1]["batch"], c5[1]["dtype"]) == (16, 336, 8, "fp8")
+    assert by["config 5 geometry, bf16, twice the batch"][1]["batch"] == 16
     # FLOP model of config 5's geometry: one object frame + 16 frames of 441 patches, two text passes
     assert 5000 < bench.flops_per_pair(16, N=441, clips=(1, 16), text_passes=2) / 1e9 < 6500
 

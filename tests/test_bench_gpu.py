@@ -48,18 +48,23 @@ def test_bench_single_rank_line():
     _check(rec, 1)
     # config 3 as worded (object-aware variants) rides along outside `value`
     oc = rec["other_configs"]
-    # ... and the headline model with the opt-in pruned top block (VideoEngine.prune_top), utilisation from the EXECUTED FLOPs
+    # ... and the two classes whose DEFAULT schedule prunes the top block (VideoEngine.prune_top) once more on the full graph
     # ... and the per-GPU shapes of BASELINE.json's configs 2, 4 and 5 (config 5 in both dtypes), scaled with the command line
     assert [o["workload"].split("]")[0] for o in oc] == [
-        "[config 3, global_local", "[config 3, region_mem", "[frozen, top block pruned", "[region_mem, top block pruned",
-        "[config 2", "[config 4, per-GPU shape", "[config 5 geometry, bf16", "[config 5 geometry, fp8 forward"], oc
+        "[config 3, global_local", "[config 3, region_mem", "[frozen, full graph", "[region_mem, full graph",
+        "[config 2", "[config 4, per-GPU shape", "[config 5 geometry, bf16", "[config 5 geometry, bf16, twice the batch",
+        "[config 5 geometry, fp8 forward"], oc
     for o in oc:
         assert "error" not in o, o
-        frac = o["step_mfma_frac_executed"] if "pruned" in o["workload"] else o["step_mfma_frac"]
-        assert o["value"] > 0 and o["ms_per_step"] > 0 and 0 < frac < 1 and o["unit"] == "pairs/s"
-        assert o["dtype"] and o["per_gpu_batch"] > 0 and o["frames"] > 0 and ("gflop_per_pair" in o or "gflop_per_pair_executed" in o)
-    assert (oc[4]["frames"], oc[5]["per_gpu_batch"], oc[6]["res"], oc[6]["frames"]) == (1, 8, 336, 4)
-    assert oc[6]["dtype"] == "bf16" and oc[7]["dtype"].startswith("fp8") and oc[6]["gflop_per_pair"] == oc[7]["gflop_per_pair"]
+        assert o["value"] > 0 and o["ms_per_step"] > 0 and 0 < o["step_mfma_frac"] < 1 and o["unit"] == "pairs/s"
+        assert o["dtype"] and o["per_gpu_batch"] > 0 and o["frames"] > 0 and "gflop_per_pair" in o
+    assert (oc[4]["frames"], oc[5]["per_gpu_batch"], oc[6]["res"], oc[6]["frames"], oc[7]["per_gpu_batch"]) == (1, 8, 336, 4, 2 * oc[6]["per_gpu_batch"])
+    assert oc[6]["dtype"] == "bf16" and oc[8]["dtype"].startswith("fp8") and oc[6]["gflop_per_pair"] == oc[8]["gflop_per_pair"]
+    # default schedule = pruned top block: the line counts EXECUTED FLOPs and names the full graph's beside them; the full-graph
+    # entries of other_configs count everything
+    assert rec["config"]["gflop_per_pair"] < rec["config"]["gflop_per_pair_full_graph"] == oc[2]["gflop_per_pair"]
+    assert oc[1]["gflop_per_pair"] < oc[1]["gflop_per_pair_full_graph"] == oc[3]["gflop_per_pair"]      # region_mem: pruned by default
+    assert "gflop_per_pair_full_graph" not in oc[0]                                                      # global_local reads the patch rows
     # the W > 1 launch path on a 1-rank RCCL group, beside the headline
     w1 = rec["w1_forced"]
     assert "error" not in w1, w1
@@ -72,8 +77,6 @@ def test_bench_single_rank_line():
     else:
         assert tr["read_mb"] > 0 and tr["write_mb"] > 0 and tr["algorithmic_mb"] > 0 and tr["launches_counted"] > 0
         assert abs(tr["ratio"] - tr["total_mb"] / tr["algorithmic_mb"]) < 0.01 * tr["ratio"] + 1e-3
-    assert oc[2]["gflop_per_pair_executed"] < oc[2]["gflop_per_pair_full_graph"] == rec["config"]["gflop_per_pair"]
-    assert oc[3]["gflop_per_pair_executed"] < oc[3]["gflop_per_pair_full_graph"] == oc[1]["gflop_per_pair"]
     cb = rec["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "pairs/s" and cb["sample"]
 
