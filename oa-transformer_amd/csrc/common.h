@@ -21,6 +21,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 #define OAT_DEV __device__ __forceinline__
@@ -92,7 +93,9 @@ OAT_DEV float dgelu_f(float x) {
   return cdf + x * 0.3989422804f * __expf(-0.5f * x * x);
 }
 // gelu(x) and gelu'(x) from ONE erf / exp evaluation (exp(-x^2/2) is both the A-S tail and the normal density).
-// The GEMM epilogues that call this are VALU-bound (ISA count: 26 issue slots per element, 8 of them the two quarter-rate
+// Since round 6 only the fp32 lanes call this (linear_f32.hip: the CLS lane and the text tower, where the absolute 1.5e-7 matters and
+// the rate does not); the bf16 GEMM epilogues use gelu_pair below.
+// The GEMM epilogues that called this are VALU-bound (ISA count: 26 issue slots per element, 8 of them the two quarter-rate
 // transcendentals), so the constants are folded: m = |x| sqrt(log2(e)/2) makes exp(-x^2/2) = exp2(-m^2) (v_exp_f32 IS
 // exp2) and 0.3275911 |x|/sqrt(2) = C m; the A-S coefficients are halved so that 0.5 (1 - p t e) is one fma.
 OAT_DEV void gelu_both(float x, float& gl, float& dg) {
@@ -107,6 +110,56 @@ OAT_DEV void gelu_both(float x, float& gl, float& dg) {
   const float cdf = 0.5f + copysignf(__builtin_fmaf(-(p * t), e, 0.5f), x);
   gl = x * cdf;
   dg = __builtin_fmaf(x * 0.3989422804f, e, cdf);
+}
+
+// ---- GELU of the bf16 GEMM epilogues (round 6): gelu(x) and gelu'(x) - 1/2 for TWO elements on packed fp32 math.
+// The fc1 epilogue is VALU-bound (the matrix pipe idles while a tile is finished: 12.5 of a K = 768 tile's 31 us), so what
+// counts is issue slots per element.  gelu_both above costs 20.75 (ISA count: two quarter-rate transcendentals = 8, the
+// A-S polynomial in t = 1 / (1 + p |x|), sign handling, 8-bit pack); this form costs 16:
+//     a = min(|x|, 6)       e = exp2(-a^2 log2(e) / 2) = exp(-a^2 / 2)        q(a) = Phi(-a) exp(a^2 / 2) = erfcx(a / sqrt 2) / 2
+//     Phi(-a) = e q(a)      gelu(x) = max(x, 0) - a e q(a)                    gelu'(x) - 1/2 = copysign((a / sqrt(2 pi) - q(a)) e + 1/2, x)
+// ONE transcendental (v_exp_f32), no reciprocal: q is smooth and well conditioned on [0, 6] - a degree-8 minimax polynomial in a
+// holds it to 3.0e-4 RELATIVE (Lawson iteration on 6000 Chebyshev nodes, scripts/dev/gelu_fit.py), so Phi(-a) keeps its relative
+// accuracy down the tail where the A-S form (absolute error 1.5e-7) is 5e-3 off at x = -4 and 50 % at x = -5.  Everything but
+// min / max / exp / copysign is v_pk_{fma,mul}_f32 (two elements per issue slot).  (a/sqrt(2 pi) - q) e + 1/2 >= 0 for every a
+// (it is 0 at a = 0 and rises), so one copysign carries the derivative's odd part.  Beyond |x| = 6 the tail term is frozen at
+// 6 Phi(-6) = 6e-9 (a is clamped: no overflow of the polynomial, never a NaN from a finite input).
+// Against fp64 erf-GELU on 2e6 points of [-8, 8] (tests/test_kernels_gpu.py::test_gelu_pair_dense_sweep): the bf16 result is within
+// 0.58 bf16 ulp or 1e-7 absolute (A-S form: 1.8 ulp), gelu' within 1.5e-4 absolute.
+// nn.GELU default = exact erf (video_transformer.py:37,45-51).
+OAT_DEV f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+OAT_DEV f32x2 pk_bc(float v) { return f32x2{v, v}; }
+OAT_DEV void gelu_pair(const f32x2 x, f32x2& gl, f32x2& dgh) {
+  // fminf / fmaxf canonicalise their operands first (one more v_max each).  a: v_med3_f32 does not, takes |x| as a source modifier and
+  // -1.0 as an inline constant - median(|x|, -1, 6) = min(|x|, 6); max(x, 0) has no such form hipcc leaves alone (it folds
+  // median(x, 0, inf) back into a canonicalising fmax), so that one instruction is spelled out
+  const f32x2 a = {__builtin_amdgcn_fmed3f(__builtin_fabsf(x[0]), -1.0f, 6.0f), __builtin_amdgcn_fmed3f(__builtin_fabsf(x[1]), -1.0f, 6.0f)};
+  f32x2 r;
+  asm("v_max_f32_e32 %0, 0, %1" : "=v"(r[0]) : "v"(x[0]));
+  asm("v_max_f32_e32 %0, 0, %1" : "=v"(r[1]) : "v"(x[1]));
+  const f32x2 earg = (a * a) * -0.72134752f;
+  const f32x2 e = {__builtin_amdgcn_exp2f(earg[0]), __builtin_amdgcn_exp2f(earg[1])};
+  f32x2 q = pk_fma(pk_bc(2.672734809e-06f), a, pk_bc(-7.911286957e-05f));
+  q = pk_fma(q, a, pk_bc(1.008693944e-03f));
+  q = pk_fma(q, a, pk_bc(-7.307060994e-03f));
+  q = pk_fma(q, a, pk_bc(3.360059857e-02f));
+  q = pk_fma(q, a, pk_bc(-1.048302799e-01f));
+  q = pk_fma(q, a, pk_bc(2.347224802e-01f));
+  q = pk_fma(q, a, pk_bc(-3.954404891e-01f));
+  q = pk_fma(q, a, pk_bc(4.998524785e-01f));
+  gl = pk_fma(-a, e * q, r);
+  const f32x2 z = pk_fma(pk_fma(a, pk_bc(0.3989422804f), -q), e, pk_bc(0.5f));
+  dgh = f32x2{__builtin_copysignf(z[0], x[0]), __builtin_copysignf(z[1], x[1])};
+}
+// four elements: gelu and the full derivative
+OAT_DEV void gelu_quad(const f32x4 v, f32x4& gl, f32x4& dg) {
+  f32x2 g0, d0, g1, d1;
+  gelu_pair(f32x2{v[0], v[1]}, g0, d0);
+  gelu_pair(f32x2{v[2], v[3]}, g1, d1);
+  d0 += 0.5f;
+  d1 += 0.5f;
+  gl = f32x4{g0[0], g0[1], g1[0], g1[1]};
+  dg = f32x4{d0[0], d0[1], d1[0], d1[1]};
 }
 
 // 16-byte async global -> LDS copy: lane i's 16 B land at lds_base + 16 * i.

@@ -361,12 +361,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
     const int col = wcol00 + frow * 4;
     auto finish = [&](const f32x4 v, const bf16x4 a, bf16x4& o, bf16x4& o2) {
       if constexpr (EPI == EPI_GELU_GRAD) {
+        f32x4 gl, dg;                       // the arithmetic of the ping-pong kernel's epilogue, bit for bit (common.h: gelu_pair)
+        gelu_quad(v, gl, dg);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float gl, dg;
-          gelu_both(v[e], gl, dg);
-          o[e] = f2bf(dg);
-          o2[e] = f2bf(gl);
+          o[e] = f2bf(dg[e]);
+          o2[e] = f2bf(gl[e]);
         }
       } else if constexpr (EPI == EPI_MUL_AUX) {
 #pragma unroll
@@ -449,12 +449,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
             bf16x4 o;
             if (pass == 0) {
               const f32x4 v = acc[rh * 4 + i][cg * 4 + j] + bias_v[cg * 4 + j];
+              f32x4 gl, dg;
+              gelu_quad(v, gl, dg);
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
-                float gl, dg;
-                gelu_both(v[e], gl, dg);
-                o[e] = f2bf(dg);
-                glv[i][j][e] = f2bf(gl);
+                o[e] = f2bf(dg[e]);
+                glv[i][j][e] = f2bf(gl[e]);
               }
             } else {
               o = glv[i][j];

@@ -55,17 +55,6 @@ enum : int { PPF_PRIO = 1, PPF_NOSTAGGER = 2, PPF_LGKM = 4, PPF_BONUS = 8, PPF_N
 // q = round((g' + 0.135) * 255 / 1.27) in ONE byte the absolute error is <= 0.0025, the size of bf16's own rounding
 // error for values near 1 (2^-9 = 0.002), at half the traffic.
 constexpr float HU8_OFF = 0.135f, HU8_SCALE = 255.f / 1.27f, HU8_INV = 1.27f / 255.f;
-OAT_DEV uint32_t hu8_pack(float a, float b, float c, float d) {
-  // v_cvt_pk_u8_f32 rounds to nearest, saturates to [0, 255] and inserts the byte: one fma + one convert per element
-  // (g' of a finite h lies in [-0.129, 1.129], i.e. q in [1.2, 253.8]; a NaN becomes 0)
-  constexpr float B = HU8_OFF * HU8_SCALE;
-  uint32_t w = 0;
-  w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(a, HU8_SCALE, B), 0, w);
-  w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(b, HU8_SCALE, B), 1, w);
-  w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(c, HU8_SCALE, B), 2, w);
-  w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(d, HU8_SCALE, B), 3, w);
-  return w;
-}
 OAT_DEV f32x4 hu8_unpack(uint32_t w) {
   return f32x4{(float)(w & 255u) * HU8_INV - HU8_OFF, (float)((w >> 8) & 255u) * HU8_INV - HU8_OFF,
                (float)((w >> 16) & 255u) * HU8_INV - HU8_OFF, (float)(w >> 24) * HU8_INV - HU8_OFF};
@@ -121,20 +110,49 @@ OAT_DEV bool pp_epilogue(const GemmArgs& g, const f32x4 (&acc)[8][4], int m0, in
   const float q8 = (Q8 && o8) ? g.q_out[0] : 0.f;
   float m8 = 0.f;
   uint32_t w8 = 0;                                     // the 4 quantised values of the last finish() call
-  auto finish = [&](f32x4 v, const f32x4 a, bf16x4& o, bf16x4& o2) {
-    if constexpr (F8) v *= dq;
-    if constexpr (EPI == EPI_GELU_GRAD) {
-      float gq[4], dq4[4];
+  // EPI_GELU_GRAD: gelu / gelu' of a row group are formed COLUMN-wise before its rows are stored - an accumulator's four registers
+  // (rows r = 0..3 of one column) are two aligned register pairs, so the packed fp32 math of gelu_pair (common.h) runs on them in
+  // place; taken row-wise (four columns = four different accumulators) every packed operand would first be gathered by a v_mov.
+  // Gc[j][r] = gelu, Hc[j][r] = the derivative: 8-bit code as a float (HU8: affine map applied, packed) or gelu' itself.
+  f32x4 Gc[4], Hc[4];
+  auto gelu_group = [&](int i) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float gl, dg;
-        gelu_both(v[e], gl, dg);
-        o[e] = f2bf(dg);
-        o2[e] = f2bf(gl);
-        gq[e] = gl;
-        dq4[e] = dg;
+    for (int j = 0; j < 4; ++j) {
+      f32x4 v = acc[i][j];
+      if constexpr (F8) v *= dq;
+      f32x2 g01, g23, h01, h23;
+      gelu_pair(f32x2{v[0], v[1]}, g01, h01);
+      gelu_pair(f32x2{v[2], v[3]}, g23, h23);
+      if constexpr (HU8) {
+        constexpr float B = (HU8_OFF + 0.5f) * HU8_SCALE;
+        h01 = pk_fma(h01, pk_bc(HU8_SCALE), pk_bc(B));
+        h23 = pk_fma(h23, pk_bc(HU8_SCALE), pk_bc(B));
+      } else {
+        h01 += 0.5f;
+        h23 += 0.5f;
       }
-      if constexpr (HU8) d8 = hu8_pack(dq4[0], dq4[1], dq4[2], dq4[3]);
+      Gc[j] = f32x4{g01[0], g01[1], g23[0], g23[1]};
+      Hc[j] = f32x4{h01[0], h01[1], h23[0], h23[1]};
+    }
+  };
+  auto finish = [&](f32x4 v, const f32x4 a, bf16x4& o, bf16x4& o2, int r) {
+    if constexpr (F8 && EPI != EPI_GELU_GRAD) v *= dq;
+    if constexpr (EPI == EPI_GELU_GRAD) {
+      const float gq[4] = {Gc[0][r], Gc[1][r], Gc[2][r], Gc[3][r]};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o2[e] = f2bf(gq[e]);
+      if constexpr (HU8) {
+        // v_cvt_pk_u8_f32 rounds to nearest, saturates to [0, 255] and inserts the byte (the code of a finite h lies in [1.2, 253.8])
+        uint32_t w = 0;
+        w = __builtin_amdgcn_cvt_pk_u8_f32(Hc[0][r], 0, w);
+        w = __builtin_amdgcn_cvt_pk_u8_f32(Hc[1][r], 1, w);
+        w = __builtin_amdgcn_cvt_pk_u8_f32(Hc[2][r], 2, w);
+        w = __builtin_amdgcn_cvt_pk_u8_f32(Hc[3][r], 3, w);
+        d8 = w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = f2bf(Hc[e][r]);
+      }
       if constexpr (Q8) {
         if (o8) {
           m8 = fmaxf(fmaxf(m8, fmaxf(fabsf(gq[0]), fabsf(gq[1]))), fmaxf(fabsf(gq[2]), fabsf(gq[3])));
@@ -250,11 +268,12 @@ OAT_DEV bool pp_epilogue(const GemmArgs& g, const f32x4 (&acc)[8][4], int m0, in
         }
       }
       uint32_t dw[4] = {};
+      if constexpr (EPI == EPI_GELU_GRAD) gelu_group(i);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const f32x4 v = f32x4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
         bf16x4 o, o2;
-        finish(v, ac[r], o, o2);
+        finish(v, ac[r], o, o2, r);
         const uint32_t rr = (uint32_t)(i * 16 + r);
         if constexpr (DBLK) dw[r] = d8;
         else st_nt(reinterpret_cast<bf16x4*>(ob + (size_t)(rr * (uint32_t)g.ldc * 2) + lo), o);
@@ -273,6 +292,7 @@ OAT_DEV bool pp_epilogue(const GemmArgs& g, const f32x4 (&acc)[8][4], int m0, in
       uint4 awi = {};
       if constexpr (ABLK) awi = *reinterpret_cast<const uint4*>(ablk + (size_t)((uint32_t)i * blks));
       uint32_t dw[4] = {};
+      if constexpr (EPI == EPI_GELU_GRAD) gelu_group(i);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = wrow0 + i * 16 + fk * 4 + r;
@@ -287,7 +307,7 @@ OAT_DEV bool pp_epilogue(const GemmArgs& g, const f32x4 (&acc)[8][4], int m0, in
             a = f32x4{bf2f(t[0]), bf2f(t[1]), bf2f(t[2]), bf2f(t[3])};
           }
         }
-        finish(v, a, o, o2);                              // rows >= M of a straddling group: finite values of a re-read row, stored nowhere but in the block
+        finish(v, a, o, o2, r);                           // rows >= M of a straddling group: finite values of a re-read row, stored nowhere but in the block
         if constexpr (DBLK) dw[r] = d8;
         if (live) {
           if constexpr (EPI == EPI_GELU_GRAD) *reinterpret_cast<bf16x4*>((bf16*)g.out2 + (size_t)row * g.ld2 + col) = o2;

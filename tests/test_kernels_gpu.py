@@ -98,6 +98,71 @@ def test_gemm_nt_gelu_and_dgelu():
     close(out, hf.grad, atol=2e-2, rtol=1.5e-2, what="dgelu")
 
 
+def _bf16_ulp(v):
+    """spacing of bf16 numbers at |v| (8 significant bits), as float64"""
+    e = torch.floor(torch.log2(v.abs().clamp_min(1e-45)))
+    return torch.pow(torch.tensor(2.0, dtype=torch.float64, device=v.device), e - 7)
+
+
+@pytest.mark.parametrize("u8", [True, False])
+def test_gelu_epilogue_dense_sweep_vs_fp64_erf(u8):
+    """The fc1 epilogue's GELU (csrc/common.h: gelu_pair - one v_exp_f32 and a degree-8 polynomial of the scaled complementary
+    error function, packed fp32) against float64 erf-GELU (nn.GELU default, video_transformer.py:37,45-51) on a DENSE sweep:
+    every bf16 value of [-8, 8] as a row, 256 fp32 offsets as columns (h = x_m * 1 + b_n is formed exactly once rounded by the
+    GEMM), 8.6 M pre-activations.  Stated bounds: the stored bf16 gelu(h) is within ONE bf16 ulp of the exact value or within
+    1e-7 absolute (the deep negative tail, where the fp32 reference itself - 0.5 (1 + erf) - has no relative accuracy left);
+    gelu'(h) within 0.0025 + 2e-4 as the 8-bit code, within one bf16 ulp + 2e-4 as bf16.  Both kernels that serve the MLP
+    pair (ping-pong and lockstep) run the same arithmetic: bit-identical."""
+    hip = _hip()
+    bits = torch.arange(0, 1 << 16, dtype=torch.int32)
+    xs = (bits << 16).view(torch.float32)
+    xs = xs[torch.isfinite(xs) & (xs.abs() <= 8.0)]
+    M, N, K = xs.numel(), 256, 128
+    assert M > 30000
+    Mp = (M + 255) // 256 * 256
+    A = torch.zeros(Mp, K, dtype=torch.bfloat16, device=DEV)
+    A[:M, 0] = xs.to(DEV).bfloat16()
+    W = torch.zeros(N, K, dtype=torch.bfloat16, device=DEV)
+    W[:, 0] = 1.0
+    g = torch.Generator(device="cpu").manual_seed(5)
+    bias = ((torch.rand(N, generator=g) - 0.5) * 0.03).to(DEV)
+    bias[0] = 0.0
+    gl = torch.zeros(Mp, N, dtype=torch.bfloat16, device=DEV)
+    if u8:
+        d8 = torch.zeros(Mp, N, dtype=torch.uint8, device=DEV)
+        hip.gemm_nt(A, W, M, N, K, hip.EPI_GELU_GRAD | hip.EPI_U8, d8, out2=gl, bias=bias)
+        dg = hip.hu8_unblock(d8, N)[:M].double() * (1.27 / 255) - 0.135
+    else:
+        d16 = torch.zeros(Mp, N, dtype=torch.bfloat16, device=DEV)
+        hip.gemm_nt(A, W, M, N, K, hip.EPI_GELU_GRAD, d16, out2=gl, bias=bias)
+        dg = d16[:M].double()
+    h = (A[:M, 0].float()[:, None] + bias[None, :]).double()              # the accumulator: bias + x * 1, one fp32 rounding
+    Phi = 0.5 * torch.erfc(-h / 2 ** 0.5)
+    g_ref = h * Phi
+    d_ref = Phi + h * torch.exp(-h * h / 2) / (2 * math.pi) ** 0.5
+    err = (gl[:M].double() - g_ref).abs()
+    ok = (err <= _bf16_ulp(g_ref)) | (err <= 1e-7)
+    worst = torch.where(err > 1e-7, err / _bf16_ulp(g_ref), torch.zeros_like(err)).max().item()
+    print(f"gelu: worst error {worst:.3f} bf16 ulp over {err.numel()} points; gelu' max abs err {(dg - d_ref).abs().max().item():.2e}")
+    assert bool(ok.all()), f"{(~ok).sum().item()} of {ok.numel()} points beyond 1 bf16 ulp / 1e-7; worst {worst:.3f} ulp"
+    derr = (dg - d_ref).abs()
+    if u8:
+        assert derr.max().item() <= 0.0025 + 2e-4                           # half a code step + the polynomial
+    else:
+        assert bool((derr <= _bf16_ulp(d_ref) + 2e-4).all())
+    # the lockstep kernel (shapes the ping-pong kernel does not serve: M < 4096 without the 8-bit flag) - same arithmetic
+    m2 = 1000
+    g2 = torch.zeros(1024, N, dtype=torch.bfloat16, device=DEV)
+    d2 = torch.zeros(1024, N, dtype=torch.bfloat16, device=DEV)
+    sel = torch.linspace(0, M - 1, m2).long().to(DEV)
+    A2 = torch.zeros(1024, K, dtype=torch.bfloat16, device=DEV)
+    A2[:m2] = A[sel]
+    hip.gemm_nt(A2, W, m2, N, K, hip.EPI_GELU_GRAD, d2, out2=g2, bias=bias)
+    assert torch.equal(g2[:m2], gl[sel])
+    if not u8:
+        assert torch.equal(d2[:m2], d16[sel])
+
+
 @pytest.mark.parametrize("M,N,K", [(515, 512, 128), (1300, 768, 192), (4400, 328, 64), (97, 40, 64)])
 def test_gemm_nt_gelu_grad_and_mul_aux(M, N, K):
     """The MLP pair the engine uses: forward stores gelu'(h) next to gelu(h) (one erf / exp evaluation on the fp32
