@@ -10,8 +10,10 @@ were copied to the GPU as they left the decoder (a quarter of the bytes of the f
   oa      Resize((input_res, input_res)) + Normalize   -> 1 launch
 
 Decoding itself (cv2 / decord / av) stays with the caller: there is no codec on the device side of this repository.
-The random parameters follow torchvision's algorithms (RandomResizedCrop.get_params) but draw from Python's `random`,
-so a seeded run is reproducible; torch's own generator stream is not reproduced.
+The random parameters follow torchvision's algorithms (RandomResizedCrop.get_params).  rng="torch" draws them from torch's
+global generator in torchvision 0.9.1's own call order (crop area, aspect ratio, top, left, flip, ColorJitter's order draw), so
+that under the same torch.manual_seed a sample gets the crop box and flip the reference's Compose would give it
+(torchvision_train_draws; known-answer test in tests/test_frames_cpu.py); the default draws from Python's `random`.
 
 TokenCache: the reference tokenises the captions of every batch inside the training step (trainer_dist.py:151-153);
 captions repeat every epoch, so their ids are cached per string and only padded / stacked per batch."""
@@ -43,6 +45,36 @@ def random_resized_crop_params(H, W, scale=(0.5, 1.0), ratio=(3.0 / 4.0, 4.0 / 3
     return (W - w) // 2, (H - h) // 2, w, h
 
 
+def torchvision_train_draws(H, W, scale=(0.5, 1.0), ratio=(3.0 / 4.0, 4.0 / 3.0)):
+    """The draws of the reference's 'train' Compose (data_loader/transforms.py:11-16) on torch's global generator, in the order
+    torchvision 0.9.1 (environment.yml:162) makes them: RandomResizedCrop.get_params (area ~ U(scale), log-aspect ~ U(log ratio) in
+    float32, top then left by torch.randint; ten tries, then the central fallback), RandomHorizontalFlip (torch.rand(1) < 0.5),
+    ColorJitter (its torch.randperm(4), drawn although all factors are zero).  -> ((x0, y0, w, h), flip)"""
+    area, box = H * W, None
+    lo, hi = torch.log(torch.tensor(ratio)).tolist()
+    for _ in range(10):
+        target = area * torch.empty(1).uniform_(scale[0], scale[1]).item()
+        ar = torch.exp(torch.empty(1).uniform_(lo, hi)).item()
+        w, h = int(round(math.sqrt(target * ar))), int(round(math.sqrt(target / ar)))
+        if 0 < w <= W and 0 < h <= H:
+            y0 = torch.randint(0, H - h + 1, size=(1,)).item()
+            x0 = torch.randint(0, W - w + 1, size=(1,)).item()
+            box = (x0, y0, w, h)
+            break
+    if box is None:
+        in_ratio = W / H
+        if in_ratio < ratio[0]:
+            w, h = W, int(round(W / ratio[0]))
+        elif in_ratio > ratio[1]:
+            h, w = H, int(round(H * ratio[1]))
+        else:
+            w, h = W, H
+        box = ((W - w) // 2, (H - h) // 2, w, h)
+    flip = bool(torch.rand(1) < 0.5)
+    torch.randperm(4)
+    return box, flip
+
+
 def resize_shorter_side(H, W, size):
     """torchvision Resize(int): the shorter side becomes `size`, the other int(size * long / short)."""
     if W <= H:
@@ -57,8 +89,12 @@ def clip_from_frames(frames, split="train", input_res=224, center_crop=256, rand
     F, H, W, _ = frames.shape
     R = input_res
     if split == "train":
-        crop = random_resized_crop_params(H, W, randcrop_scale, rng=rng)
-        return hip.frames_resize(frames, (R, R), crop=crop, flip=rng.random() < 0.5, out=out, dtype=dtype)
+        if rng == "torch":
+            crop, flip = torchvision_train_draws(H, W, randcrop_scale)
+        else:
+            crop = random_resized_crop_params(H, W, randcrop_scale, rng=rng)
+            flip = rng.random() < 0.5
+        return hip.frames_resize(frames, (R, R), crop=crop, flip=flip, out=out, dtype=dtype)
     if split == "oa":
         return hip.frames_resize(frames, (R, R), out=out, dtype=dtype)
     if split not in ("val", "test"):

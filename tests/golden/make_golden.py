@@ -129,6 +129,34 @@ def gen_small_video(SpaceTimeTransformer):
     return out
 
 
+def gen_video_336(SpaceTimeTransformer):
+    """Reference SpaceTimeTransformer(img_size=336): 21 x 21 = 441 patches per frame (BASELINE config 5's frame geometry; the class
+    takes img_size, video_transformer.py:195,233-236) on the narrow test width (128-d, 2 blocks, 2 heads, 2 frames, B = 2) - the
+    inputs and the linear functional of tests/test_engine_gpu.py::test_336_geometry_vs_oracle.  Outputs, per-block activations of the
+    CLS rows and every parameter gradient."""
+    geo = dict(embed_dim=128, depth=2, mlp_ratio=4, num_frames=2, patches_per_frame=441, patch=16)
+    torch.manual_seed(0)
+    m = SpaceTimeTransformer(img_size=336, patch_size=16, embed_dim=128, depth=2, num_heads=2, num_frames=2, time_init="rand")
+    m.head = nn.Identity()
+    m.pre_logits = nn.Identity()
+    sd = si.seeded_state_dict(si.video_param_shapes(**geo), SEED, "video_model.")
+    missing, unexpected = m.load_state_dict({k[len("video_model."):]: v for k, v in sd.items()}, strict=False)
+    assert not unexpected and all(k.startswith("head") for k in missing), (missing, unexpected)
+    m.eval()
+    video = si.seeded_tensor(SEED, "in.video.336", (2, 2, 3, 336, 336))
+    blocks = []
+    hooks = [b.register_forward_hook(lambda mod, i, o: blocks.append(o[:, 0].detach().clone())) for b in m.blocks]
+    cls, patches = m(video)
+    for h in hooks:
+        h.remove()
+    assert patches.shape == (2, 2 * 441, 128), patches.shape
+    gc = si.seeded_tensor(SEED, "g.cls.336", cls.shape)
+    gp = si.seeded_tensor(SEED, "g.patches.336", patches.shape, std=0.05)
+    ((cls * gc).sum() + (patches * gp).sum()).backward()
+    grads = {k: v.grad.detach().clone() for k, v in m.named_parameters() if v.grad is not None}
+    return dict(cls=cls.detach(), patches=patches.detach(), block_cls=blocks, grads=grads)
+
+
 def gen_small_chain(SpaceTimeTransformer, sim_matrix, NormSoftmaxLoss):
     """Small full chain: ref video encoder + HF DistilBERT + ref sim_matrix + ref loss."""
     from transformers import DistilBertConfig, DistilBertModel
@@ -354,7 +382,7 @@ def main():
     from OATrans.model.oa_model import FrozenInTime, sim_matrix
     from OATrans.model.loss import NormSoftmaxLoss
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["small", "loss", "full", "oa"]
+    which = sys.argv[1:] or ["small", "loss", "full", "oa", "v336"]
     if "oa" in which:
         torch.save(gen_region_mem(NormSoftmaxLoss, sim_matrix), os.path.join(HERE, "oa_region_mem.pt"))
         print("region_mem done")
@@ -365,6 +393,9 @@ def main():
         torch.save(gen_small_chain(SpaceTimeTransformer, sim_matrix, NormSoftmaxLoss),
                    os.path.join(HERE, "small_chain.pt"))
         print("small done")
+    if "v336" in which:
+        torch.save(gen_video_336(SpaceTimeTransformer), os.path.join(HERE, "video_336.pt"))
+        print("video 336 done")
     if "loss" in which:
         torch.save(gen_loss_cases(sim_matrix, NormSoftmaxLoss), os.path.join(HERE, "loss_cases.pt"))
         print("loss done")

@@ -53,6 +53,30 @@ def test_small_video_forward_and_grads(golden_dir, T):
         assert (mine - ref).abs().max() / scale < 2e-4, k
 
 
+def test_video_336_geometry_forward_and_grads(golden_dir):
+    """The oracle against the REFERENCE run at 336^2 (441 patches per frame, BASELINE config 5's frame geometry:
+    SpaceTimeTransformer(img_size=336), video_transformer.py:195,233-236) - until round 6 the oracle was pinned at 224^2 and 48^2 only."""
+    g = _load(golden_dir, "video_336.pt")
+    geo = dict(embed_dim=128, depth=2, mlp_ratio=4, num_frames=2, patches_per_frame=441, patch=16)
+    p = si.seeded_state_dict(si.video_param_shapes(**geo), SEED, "video_model.")
+    for v in p.values():
+        v.requires_grad_(True)
+    video = si.seeded_tensor(SEED, "in.video.336", (2, 2, 3, 336, 336))
+    cls, patches, blocks = orc.video_encoder(video, p, num_heads=2, return_blocks=True)
+    for i, b in enumerate(blocks):
+        assert torch.allclose(b[:, 0], g["block_cls"][i], atol=2e-5, rtol=1e-5), f"block {i}"
+    assert torch.allclose(cls, g["cls"], atol=2e-5, rtol=1e-5)
+    assert torch.allclose(patches, g["patches"], atol=2e-5, rtol=1e-5)
+    gc = si.seeded_tensor(SEED, "g.cls.336", cls.shape)
+    gp = si.seeded_tensor(SEED, "g.patches.336", patches.shape, std=0.05)
+    ((cls * gc).sum() + (patches * gp).sum()).backward()
+    for k, ref in g["grads"].items():
+        mine = p["video_model." + k].grad
+        assert mine is not None, k
+        scale = ref.abs().max().clamp_min(1e-4)
+        assert (mine - ref).abs().max() / scale < 2e-4, k
+
+
 def test_small_chain(golden_dir):
     g = _load(golden_dir, "small_chain.pt")
     p = si.frozen_state_dict(SEED, SMALL_VIDEO, SMALL_TEXT, proj_dim=64)
