@@ -198,7 +198,14 @@ def test_frozen_in_time_vitb_vs_reference_golden(golden_dir, frames, prune_top):
         nerr = abs(gr.norm().item() - pr["norm"].item()) / pr["norm"].item()
         scale = pr["norm"].item() / gr.numel() ** 0.5
         perr = ((gr.flatten()[pr["idx"].cuda()].cpu() - pr["val"]).abs() / scale).max().item()
-        if nerr > 5e-2 or perr > 1.0:      # sampled entries, in units of the tensor RMS (bs 2: heavy cancellation)
+        # Eight sampled entries per tensor, in units of the tensor RMS: a SANITY bound (a wrong kernel is off by tens of RMS), not the
+        # parity statement - the goldens keep only these samples of the reference's gradients.  The per-tensor rel-L2 / cosine bounds
+        # are asserted on EVERY element against the oracle's autograd (test_four_frame_geometry_every_gradient_vs_oracle_autograd, test_headline_geometry_every_gradient_vs_oracle_autograd; the oracle
+        # is pinned to the reference by tests/test_oracle_golden.py).  Why not 1.0 any more (round 6): pos_embed's RMS is dominated by
+        # its CLS row (14 x the patch rows; the sampled row-0 entry is -2.3 RMS inside a row of RMS 14), so a 3 % rel-L2 error puts that
+        # one entry anywhere within +- 1.3 RMS: 0.22 with round 5's GELU arithmetic, 1.21 with round 6's, at the same rel-L2 (2.95e-2
+        # / 3.01e-2 for pos_embed, scripts/dev/grad_rel_probe.py).
+        if nerr > 5e-2 or perr > 2.0:
             bad.append((k, nerr, perr))
     assert not bad, bad[:10]
 
@@ -206,11 +213,11 @@ def test_frozen_in_time_vitb_vs_reference_golden(golden_dir, frames, prune_top):
 _HEADLINE_ORACLE = {}
 
 
-def _headline_oracle_grads():
-    """Loss and every parameter gradient of the 8-frame frozen model at B = 2 from autograd of the CPU oracle (computed once per session)."""
-    if not _HEADLINE_ORACLE:
+def _headline_oracle_grads(T=8):
+    """Loss and every parameter gradient of the T-frame frozen model at B = 2 from autograd of the CPU oracle (computed once per session)."""
+    if T not in _HEADLINE_ORACLE:
         from oracle import oatrans_oracle as orc
-        T, B, L = 8, 2, 12
+        B, L = 2, 12
         sd = si.frozen_state_dict(SEED, dict(num_frames=T), {})
         video = si.seeded_tensor(SEED, f"full.video.{T}", (B, T, 3, 224, 224))
         ids = si.seeded_ints(SEED, f"full.ids.{T}", (B, L), 1000, 30000)
@@ -220,18 +227,18 @@ def _headline_oracle_grads():
         p = {k: (w.clone().requires_grad_(True) if w.is_floating_point() else w) for k, w in sd.items()}
         oloss, _, _, _ = orc.train_step_loss(p, video, ids, mask)
         oloss.backward()
-        _HEADLINE_ORACLE.update(sd=sd, video=video, ids=ids, mask=mask, loss=oloss.item(),
-                                grads={k: w.grad for k, w in p.items() if w.is_floating_point() and w.grad is not None})
-    return _HEADLINE_ORACLE
+        _HEADLINE_ORACLE[T] = dict(sd=sd, video=video, ids=ids, mask=mask, loss=oloss.item(),
+                                   grads={k: w.grad for k, w in p.items() if w.is_floating_point() and w.grad is not None})
+    return _HEADLINE_ORACLE[T]
 
 
-def _headline_gradient_errors(prune_top=False, res16=None, h_u8=None):
-    """One forward + backward of the HIP model at the headline geometry (B = 2) against the oracle's autograd.
+def _headline_gradient_errors(prune_top=False, res16=None, h_u8=None, frames=8):
+    """One forward + backward of the HIP model at the headline geometry (B = 2; `frames` frames) against the oracle's autograd.
     Returns (loss error, [(name, rel-L2, cosine)], all-parameter rel-L2, all-parameter cosine, the same two over the video tower alone)."""
     from OATrans import model as module_arch
-    o = _headline_oracle_grads()
+    o = _headline_oracle_grads(frames)
     m = module_arch.FrozenInTime(
-        video_params=dict(model="SpaceTimeTransformer", arch_config="base_patch16_224", num_frames=8, pretrained=True, time_init="rand"),
+        video_params=dict(model="SpaceTimeTransformer", arch_config="base_patch16_224", num_frames=frames, pretrained=True, time_init="rand"),
         object_params=dict(model="", input_objects=False),
         text_params=dict(model="pretrained/distilbert-base-uncased", pretrained=True, input="text"),
         projection="minimal", load_checkpoint="")
@@ -271,6 +278,19 @@ def _headline_gradient_errors(prune_top=False, res16=None, h_u8=None):
     rel = lambda a: (a[0] / a[1]) ** 0.5
     cos = lambda a: a[2] / (a[3] * a[4]) ** 0.5
     return abs(loss.item() - o["loss"]), per, rel(acc["all"]), cos(acc["all"]), rel(acc["video"]), cos(acc["video"])
+
+
+@pytest.mark.parametrize("prune_top", [False, True])
+def test_four_frame_geometry_every_gradient_vs_oracle_autograd(prune_top):
+    """The same all-element check at 4 frames (config 2's geometry; half the rows to average the bf16 noise over): per tensor
+    rel-L2 <= 5e-2 and cosine >= 0.998, all parameters rel-L2 <= 3.5e-2 (measured 3.1e-2; 2.2e-2 at 8 frames)."""
+    dloss, per, all_rel, all_cos, _, _ = _headline_gradient_errors(prune_top=prune_top, frames=4)
+    assert dloss < 2e-2
+    worst_rel, worst_cos = max(per, key=lambda z: z[1]), min(per, key=lambda z: z[2])
+    print(f"4 frames: worst rel-L2 {worst_rel[:2]}, worst cosine {(worst_cos[0], worst_cos[2])}, all parameters rel-L2 {all_rel:.3e} cosine {all_cos:.6f}")
+    bad = [z for z in per if z[1] > 5e-2 or z[2] < 0.998]
+    assert not bad, bad[:10]
+    assert all_rel <= 3.5e-2 and all_cos >= 0.9993, (all_rel, all_cos)
 
 
 @pytest.mark.parametrize("prune_top", [False, True])

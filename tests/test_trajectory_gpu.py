@@ -9,14 +9,15 @@ optimiser: transformers.AdamW as the reference configs resolve it (train_dist_mu
 eps 1e-6, no weight decay, bias correction on).  DistilBERT in .eval() on both sides (torch's dropout stream cannot be
 reproduced; tests/test_text_dropout_gpu.py pins training-mode dropout with shared Philox masks).
 
-Stated bounds (measured values are printed; DESIGN section 2 quotes them):
-  * per-step loss: |loss_hip - loss_oracle| <= LOSS_TOL * max(1, |loss_oracle|) at every step;
+Stated bounds (measured values are printed and quoted beside the bounds below; DESIGN section 2 has them too):
+  * per-step loss: |loss_hip - loss_oracle| <= loss_tol * max(1, |loss_oracle|) at every step (1.5e-2 on the small geometry,
+    8e-3 at ViT-B/16: about three times the measured deviations);
   * cumulative update of all parameters after K steps, delta = theta_K - theta_0 (Adam's first steps are sign descent, so
     elements whose gradient is smaller than its bf16 error take a step of the same size in either direction - the bound is
-    on direction and size of the whole update, not on elements): cosine(delta_hip, delta_oracle) >= COS_MIN and
-    | ||delta_hip|| / ||delta_oracle|| - 1 | <= NORM_TOL;
+    on direction and size of the whole update, not on elements): cosine(delta_hip, delta_oracle) >= 0.998 (small) / 0.99 (ViT-B/16)
+    and | ||delta_hip|| / ||delta_oracle|| - 1 | <= 0.01;
   * the default storage choices are not systematically worse than the run with both switched off (fp32 residual stream,
-    bf16 derivative): |mean signed loss deviation| of the default <= that of the off-run + BIAS_SLACK.
+    bf16 derivative): |mean signed loss deviation| of the default <= that of the off-run + 3e-3.
 Parameters whose gradient is analytically zero (the key biases: softmax is invariant to them) are driven by rounding noise
 through Adam's normalisation on both sides and are left out of the update comparison."""
 import argparse
@@ -148,9 +149,11 @@ def test_twenty_adamw_steps_small_chain_geometry_track_the_oracle():
     lo, op = _oracle_run(sd, batches, lr, heads=2, text_heads=2)
     lh, hp = _hip_run(make, sd, batches, lr)
     lf, fp = _hip_run(make, sd, batches, lr, res16=False, h_u8=False)
-    b_def = _check("small, default", lo, lh, sd, hp, op, loss_tol=3e-2, cos_min=0.90, norm_tol=0.10)
-    b_off = _check("small, fp32 stream", lo, lf, sd, fp, op, loss_tol=3e-2, cos_min=0.90, norm_tol=0.10)
-    assert abs(b_def) <= abs(b_off) + 5e-3, (b_def, b_off)
+    # measured (round 6): worst per-step loss deviation 5.1e-3 / 5.6e-3, mean signed -1.0e-3 / -3.6e-4, update cosine 0.9996 / 0.9996,
+    # norm ratio 0.9998 / 0.9998 (default / fp32 stream)
+    b_def = _check("small, default", lo, lh, sd, hp, op, loss_tol=1.5e-2, cos_min=0.998, norm_tol=0.01)
+    b_off = _check("small, fp32 stream", lo, lf, sd, fp, op, loss_tol=1.5e-2, cos_min=0.998, norm_tol=0.01)
+    assert abs(b_def) <= abs(b_off) + 3e-3, (b_def, b_off)
 
 
 def test_five_adamw_steps_headline_geometry_track_the_oracle():
@@ -171,6 +174,8 @@ def test_five_adamw_steps_headline_geometry_track_the_oracle():
     lo, op = _oracle_run(sd, batches, lr, heads=12, text_heads=12)
     lh, hp = _hip_run(make, sd, batches, lr)
     lf, fp = _hip_run(make, sd, batches, lr, res16=False, h_u8=False)
-    b_def = _check("ViT-B/16 8f, default", lo, lh, sd, hp, op, loss_tol=3e-2, cos_min=0.90, norm_tol=0.10)
-    b_off = _check("ViT-B/16 8f, both departures off", lo, lf, sd, fp, op, loss_tol=3e-2, cos_min=0.90, norm_tol=0.10)
-    assert abs(b_def) <= abs(b_off) + 5e-3, (b_def, b_off)
+    # measured (round 6): worst per-step loss deviation 2.2e-3 / 1.6e-3, mean signed +1.3e-4 / +1.3e-3, update cosine 0.9971 / 0.9990,
+    # norm ratio 1.0001 / 0.9999 (default / both departures off)
+    b_def = _check("ViT-B/16 8f, default", lo, lh, sd, hp, op, loss_tol=8e-3, cos_min=0.99, norm_tol=0.01)
+    b_off = _check("ViT-B/16 8f, both departures off", lo, lf, sd, fp, op, loss_tol=8e-3, cos_min=0.99, norm_tol=0.01)
+    assert abs(b_def) <= abs(b_off) + 3e-3, (b_def, b_off)
