@@ -142,8 +142,7 @@ def build(args, device):
         m.flatten_parameters()
     dp = HipDataParallel(model)
     opt = AdamW([p for p in model.parameters() if p.requires_grad], lr=args.lr)
-    if os.environ.get("OAT_EAGER_ADAM", "0") == "1":
-        opt.attach(model)          # parameter updates start under backward: measured SLOWER (56.5 -> 57.2 ms), opt-in
+    # (optim.AdamW.attach - parameter updates start under backward - measured SLOWER, 56.5 -> 57.2 ms: not used here)
     loss_fn = module_arch.NormSoftmaxLoss()
     return dp, opt, loss_fn
 
@@ -625,10 +624,10 @@ def main():
 
     # Launch path.  Default: the encoders' forward / backward schedules replay from launch tapes (csrc/tape.hip: the
     # recorded launches are re-issued from C at ~4 us each), the ~150 remaining launches of a step (loss, projections,
-    # optimiser, collectives) are issued eagerly - the same path at every rank count.  OAT_GRAPH=1 (one rank only)
+    # optimiser, collectives) are issued eagerly - the same path at every rank count.  OAT_GRAPH_STEP=1 (one rank only)
     # additionally captures the whole step into a hipGraph (trainer/graph_step.py); measured equal on the GPU, and
     # hipGraphLaunch costs more host time per kernel node than the tapes do.
-    use_graph = world == 1 and os.environ.get("OAT_GRAPH", "0") == "1"
+    use_graph = world == 1 and os.environ.get("OAT_GRAPH_STEP", "0") == "1"
     if use_graph:
         from OATrans.trainer.graph_step import GraphedStep
         graphed = GraphedStep(step_impl, dp, loss_fn, opt, step_args, warmup=2)

@@ -9,6 +9,10 @@
  *     (thread-local).  Nothing is allocated, freed or synchronised inside the library: all
  *     buffers, including workspaces, are caller-owned device memory; every launch is ordered
  *     on the `stream` argument (a hipStream_t passed as void*).
+ *   - no hidden state: what a launch does is fixed by its arguments (launch policy included: the `tune` / `grid` arguments of
+ *     oat_gemm_nt / oat_gemm_tn).  No environment variable is read, no setter exists (oat_abi_version() >= 2).  The one thing the
+ *     library keeps between calls is what the caller asks it to keep: launch tapes (oat_tape_begin .. oat_tape_end record the
+ *     launches of the calling thread, oat_tape_replay re-issues them, oat_tape_free drops them).
  *   - bf16 tensors are passed as `void*` (raw uint16 storage), fp32 as `float*`.
  *   - token-row layout used engine-wide: patch (b,f,n) -> row (b*T+f)*N+n ; CLS(b) -> row
  *     B*T*N+b  (M = B*T*N + B rows).  ld* arguments are row pitches in ELEMENTS.
@@ -23,12 +27,6 @@ extern "C" {
 
 const char* oat_last_error(void);
 int oat_abi_version(void);
-/* Stream-ordered delay of ~`nanoseconds` (one sleeping wave).  Scheduling aid, no reference counterpart: the engine
- * puts it in front of an HBM-bound kernel on a side stream so that the CU-filling GEMM launched beside it on the main
- * stream gets its workgroups placed first (two kernels that become runnable together are otherwise dispatched
- * interleaved, and the small blocks of the streaming kernel keep the GEMM's 128-KB-LDS workgroups off every CU). */
-int oat_delay(int nanoseconds, void* stream);
-
 /* ---- GEMM -------------------------------------------------------------------------------
  * C[M,N] = A[M,K] * B[N,K]^T (+epilogue), bf16 in, fp32 accumulate.  K % 64 == 0.
  * Replaces nn.Linear forward / dgrad: video_transformer.py:102 (qkv), :133 (proj), :46-50
@@ -42,48 +40,31 @@ int oat_delay(int nanoseconds, void* stream);
  *      epi | 0x100 (with 5 / 6, shapes the ping-pong kernel covers: N % 256 == 0, N <= 4096, K / 64 even, M >= 256):
  *      the derivative tensor - `out` of 5, `aux` of 6 - is 8-bit fixed point, q = round((g' + 0.135) * 255 / 1.27),
  *      ONE byte per element with ldc / ldaux in bytes: half the traffic at bf16's own absolute error (0.0025).
- *      bias/resid/out2/aux may be NULL where unused. */
+ *      bias/resid/out2/aux may be NULL where unused.
+ * Per-call launch policy (round 6: the library keeps NO tuning state between calls - the oat_gemm_set_* entry points of
+ * rounds 1-5 are gone):
+ *   tune  0 = the shipped choice.  bits 0-7: kernel - 0 auto, 1 force 128x128 tiles (4 waves), 2 force the lockstep 256x256
+ *         kernel, 4 force the ping-pong 256x256 kernel where it applies (tests: both 256x256 kernels are bit-identical);
+ *         bits 16-17: 224-row tiles of the ping-pong kernel - 0 auto (where rounds x tile rows is smaller than with 256-row
+ *         tiles, e.g. M = 50208, N = 768: 3 rounds of 224 rows instead of 3 of 256), 1 never, 2 always; bits 18-25:
+ *         band-grouped tile walk of the ping-pong kernel - 0 auto (the fc1 forward launch only, where it measures faster),
+ *         1 off (row-major walk), n + 1 = groups of n column tiles.  Every choice gives bit-identical results.
+ *   grid  workgroups of the persistent 256x256 launch: 0 = one per CU, 0xffff = one workgroup per tile (what a multi-rank
+ *         job uses in backward, so that a persistent GEMM never waits for a CU RCCL holds), else the count. */
 int oat_gemm_nt(const void* A, const void* B, int M, int N, int K, int lda, int ldb, int epi,
                 void* out, int ldc, void* out2, int ld2, const float* bias, const float* resid,
-                int ldr, int resid_mod, const void* aux, int ldaux, void* stream);
-
-/* Split-K of the last, less-than-half-full round of 256x256 tiles of the persistent ping-pong kernel (epi 0): its tiles are
- * shared by 2-4 workgroups that leave fp32 partial tiles in `ws`; the last one to arrive sums them in a fixed order and
- * runs the epilogue.  ws: caller-owned device memory (128 MiB covers every launch), 256 zeroed ints; NULL = off.
- * Launches that use it must be ordered on one stream. */
-int oat_gemm_set_splitk_workspace(void* ws, size_t bytes, void* zeroed_256_ints);
-/* 224-row tiles of the ping-pong kernel (epi 0): 0 never, 1 where rounds x tile rows is smaller than with 256-row tiles
- * (default; e.g. M = 50208, N = 768: 3 rounds of 224 rows instead of 3 rounds of 256), 2 always.  Results are bit-identical. */
-void oat_gemm_set_m224(int mode);
-/* Band-grouped tile walk of the ping-pong kernel: inside an XCD's chunk of tiles the whole row panels are walked in groups
- * of `tiles` column tiles, so that a round of 32 tiles needs `tiles` column bands of B and 32 / tiles row panels of A instead
- * of all of B (which overflows the 4 MB L2 at N >= 2304).  0 = off (row-major walk), -1 = auto (default: the fc1 forward
- * launch only, where it measures faster), > 0 = group width.
- * Results are bit-identical. */
-void oat_gemm_set_band(int tiles);
-
-/* tuning hook.  bits 0-7: 0 = auto tile choice, 1 = force 128x128 (4 waves), 2 = force 256x256 (8 waves),
- * 3 = 256x256 with 4 hand-pipelined waves; bits 8-15: flags (ablations: 128 = static tile walk even with counters, 1 = skip the epilogue, 4 = all row panels write the first 1024
- * output rows, 8 = no global stores, 16 / 32 = every workgroup stages A / B tile 0; 64 = split the
- * last, mostly empty round of 256x256 tiles into 128x128 tiles [opt-in]);
- * bits 16-31: grid of the persistent 256x256 launch (0 = one workgroup per CU, 0xffff = one per tile) */
-void oat_gemm_set_variant(int v);
-/* launch policy, not tuning: 1 = split the last, mostly empty round of 256x256 tiles into 128x128 tiles.  Pays when
- * nothing else shares the GPU (the forward pass), costs when a second stream would have used the idle CUs (backward). */
-void oat_gemm_set_tail_split(int on);
-/* Optional: 32 KiB of ZEROED device memory that persistent gemm_nt launches use as atomic tile counters (dynamic tile
- * scheduling: a workgroup whose CU was busy at launch takes fewer tiles).  Caller-owned, must outlive every launch;
- * NULL returns to the static walk.  The library never allocates. */
-int oat_gemm_set_tile_counters(void* zeroed_device_ints, size_t bytes);
+                int ldr, int resid_mod, const void* aux, int ldaux, int tune, int grid, void* stream);
 
 /* out[N1,N2] (fp32, (+)=) sum_m P[m,N1]^T Q[m,N2]  - weight gradients of every nn.Linear.
  * Rows past M - 1 are never read (round 5: the ragged last chunk re-reads row M - 1; earlier builds required rows
  * [M, round_up(M,64)) to be readable, which a row slice ending at its CLS rows is not).
- * workspace: fp32 split-M slabs; oat_gemm_tn_workspace_bytes(M, ..) is exact for that launch, M <= 0 the worst case. */
-size_t oat_gemm_tn_workspace_bytes(int M, int N1, int N2);
+ * workspace: fp32 split-M slabs; oat_gemm_tn_workspace_bytes(M, .., tune) is exact for that launch, M <= 0 the worst case.
+ * tune (per call, 0 = the shipped choice): tile shape - 0 auto, 1 force 128x128, 2 force the lockstep 256x256 kernel,
+ * 4 force the ping-pong 256x256 kernel (N1, N2 multiples of 256). */
+size_t oat_gemm_tn_workspace_bytes(int M, int N1, int N2, int tune);
 int oat_gemm_tn(const void* P, const void* Q, int M, int N1, int N2, int ldp, int ldq, float* out,
                 float* bias_out /* [N1] column sums of P, or NULL */, int accumulate, void* workspace,
-                size_t workspace_bytes, void* stream);
+                size_t workspace_bytes, int tune, void* stream);
 /* ---- grouped weight gradients (csrc/gemm_tn_sk.hip): out_p (+)= P_p^T Q_p, bias_p (+)= colsum(P_p) for a LIST of
  * problems in ONE persistent launch + one fix-up launch.  Replaces the per-layer `dW = dY^T X` of autograd for the six
  * nn.Linear of a SpaceTimeBlock (/root/reference/OATrans/model/video_transformer.py:46-50,102,133) and the 36 of a
@@ -104,9 +85,6 @@ int oat_tn_group_plan(const void* problems, int n, int grid, int splits, void* s
 size_t oat_tn_group_slab_bytes(int nslots);
 int oat_tn_group_run(const void* d_problems, const void* d_segs, const void* d_seg_off, int grid,
                      const void* d_fixes, int nfix, void* d_slabs, void* stream);
-void oat_gemm_tn_set_variant(int v);   /* bits 0-7: 0 auto, 1 force 128x128, 2 force 256x256 tiles; bits 8-15: ablations (1 = no
-                                          * global loads after the ring fill, 2 = no slab store); bits 16-31: workgroup budget of the
-                                          * 256x256 launch (0 = 256): the caller's share of the CUs when another stream needs the rest */
 
 /* ---- LayerNorm (video_transformer.py:164,167,174,346; DistilBERT LayerNorms) ------------- */
 int oat_layernorm_fwd(const float* x, int ldx, const float* gamma, const float* beta, void* y_bf16,
@@ -208,14 +186,12 @@ int oat_attn_space_fwd(const void* qkv, int ldqkv, void* out, int ldo, float* ls
                        int H, int D, float scale, void* stream);
 int oat_attn_time_fwd(const void* qkv, int ldqkv, void* out, int ldo, float* lse, int B, int T, int N,
                       int H, int D, float scale, void* stream);
-void oat_attn_time_set_variant(int v);   /* tuning hook for the backward: 0 = MFMA kernel on 16-row mini problems (default), 1 = two-pass VALU kernel, 2 = VALU kernels (single-read LDS kernel for T <= 8, two-pass above) */
 int oat_attn_cls_fwd(const void* qkv, int ldqkv, void* out, int ldo, float* lse, int B, int T, int N,
                      int H, int D, float scale, void* stream);
 /* CLS query attention with a second, PRECISE query: q32 fp32 [B, D] attends the same bf16 keys / values, context written
  * in fp32 to o32 [B, D].  out / lse of the CLS row (the bf16 path backward uses) as oat_attn_cls_fwd. */
 int oat_attn_cls_fwd_dual(const void* qkv, int ldqkv, void* out, int ldo, float* lse, const float* q32, int ldq32,
                           float* o32, int ldo32, int B, int T, int N, int H, int D, float scale, void* stream);
-int oat_attn_space_set_variant(int v);   /* tuning hook for the backward at >= 97 patches: 0 = default (97..223 patches: two 8-wave workgroups per CU, one 16-row tile per wave, K,V then Q,dO in LDS; 224..447: 16 waves), 1 = 8 waves x tile pairs, 2 = 16 waves x one tile with all four tiles in LDS */
 /* cls_side: fp32 [B,H,3,64], zero on entry; finish with oat_attn_cls_finalize, which writes the CLS row of dqkv and
  * leaves cls_side zero again for the next backward launch. */
 int oat_attn_space_bwd(const void* qkv, int ldqkv, const void* out, int ldo, const float* lse,
@@ -228,8 +204,7 @@ int oat_attn_cls_finalize(float* cls_side, void* dqkv, int lddqkv, int B, int T,
                           void* stream);
 /* The two steps above in ONE launch (replaces the same ATen work, video_transformer.py:99-135 backward): `done` = int [B,H]
  * tickets, zero on entry and on exit; the last workgroup that feeds cls_side[b][h] swaps the sums out (atomic exchange: cls_side
- * is left zero), writes the CLS row of dqkv and resets its ticket.  The VALU tuning variants of the time backward
- * (oat_attn_time_set_variant 1 / 2, T > 16) run the finalize as a second launch. */
+ * is left zero), writes the CLS row of dqkv and resets its ticket.  Backward: T <= 16 (the MFMA kernel on 16-row mini problems). */
 int oat_attn_space_bwd_fin(const void* qkv, int ldqkv, const void* out, int ldo, const float* lse,
                            const void* dout, int lddo, void* dqkv, int lddqkv, float* cls_side, int* done, int B, int T,
                            int N, int H, int D, float scale, void* stream);
@@ -336,26 +311,19 @@ int oat_copy_async(void* dst, const void* src, size_t bytes, void* stream);
  * serves the nn.Linear forwards of video_transformer.py:46-50,102,133).  A quantisation site owns three device floats:
  * amax (running max |x| of this step), qscale (q = sat(x * qscale)), dq = 1 / qscale. */
 int oat_fp8_quant(const void* x, int is_bf16, int ldx, void* out8, int ld8, int M, int K, const float* qscale,
-                  float* amax_or_null, int e5m2, void* stream);       /* quantise with *qscale (e4m3, or e5m2 for gradients), record amax of x */
+                  float* amax_or_null, void* stream);       /* quantise with *qscale (e4m3), record amax of x */
 int oat_fp8_amax(const void* x, int is_bf16, int ldx, int M, int K, float* amax, void* stream);
 int oat_fp8_chunk_elems(void);
 /* many contiguous bf16 matrices in one launch; desc rows int64 {src, dst, n, site, first_block}, owner: block -> row */
 int oat_fp8_multi(const void* desc, const int* owner, int total_blocks, const float* qscale, float* amax, int quant,
                   void* stream);
-int oat_fp8_update_scales(float* amax, float* qscale, float* dq, int n_sites, float margin, int e5m2, void* stream);
+int oat_fp8_update_scales(float* amax, float* qscale, float* dq, int n_sites, float margin, void* stream);
 /* C = dq_a dq_b (A8 . B8^T) + bias ; epi 0 (bf16 out) or 5 (out = gelu'(h), out2 = gelu(h)); K % 256 == 0,
  * N % 256 == 0, N <= 4096, M >= 256; lda / ldb in elements (bytes) */
 int oat_gemm_nt_f8(const void* A8, const void* B8, int M, int N, int K, int lda, int ldb, int epi, void* out, int ldc,
                    void* out2, int ld2, const float* bias, const float* dq_a, const float* dq_b,
-                   int a_e5m2,                                  /* A8 holds e5m2 gradients (data-gradient GEMMs); B8 is e4m3 */
-                   const void* aux, int ldaux,                  /* epi 6 (EPI_MUL_AUX): out = (acc + bias) * aux */
-                   void* out8_or_null, int ld8, const float* q_out, float* amax_out,   /* epi 5: e4m3 copy of out2; epi 6: e5m2 copy of out */
+                   void* out8_or_null, int ld8, const float* q_out, float* amax_out,   /* epi 5: e4m3 copy of out2 for the next GEMM */
                    void* stream);
-/* LayerNorm backward that also leaves dx16 as e5m2 (next data-gradient GEMM's operand) */
-int oat_layernorm_bwd_f8(const void* dy, int dy_is_bf16, int lddy, const float* x, int ldx, const float* mean,
-                         const float* rstd, const float* gamma, const float* dres, int lddres, float* dx, int lddx,
-                         void* dx16, int lddx16, int dx16_excl_res, float* dgamma, float* dbeta, int accumulate,
-                         float* part, int M, int D, void* dx8, int ld8, const float* qscale, float* amax, void* stream);
 /* LayerNorm (optionally of x + add16, sum32 = the sum) writing y as bf16 AND as e4m3 (y8 = sat(y * *qscale)), amax of y
  * recorded: the producer-side quantisation of the fp8 GEMM operand */
 int oat_layernorm_fwd_f8(const float* x, int ldx, const void* add16_or_null, int ldadd, float* sum32, int ldsum,

@@ -75,9 +75,8 @@ class TextEngine:
         self.scale = 64 ** -0.5
         self.plans, self.shadow, self.versions = {}, {}, None
         self.use_tape = os.environ.get("OAT_TAPE", "1") != "0"
-        self.qkv_one_launch = os.environ.get("OAT_TEXT_QKV1", "1") != "0"     # q / k / v linears of a layer in one launch (hip.linear_f32_qkv)
-        # 1 (default): the 36 weight gradients of a backward pass as one grouped launch at its end; 0: 36 gemm_tn + tn_reduce pairs
-        self.group_wgrads = os.environ.get("OAT_GROUP_WGRADS", "1") != "0"
+        self.qkv_one_launch = True      # q / k / v linears of a layer in one launch (hip.linear_f32_qkv); False: three (bit-identical, tests)
+        self.group_wgrads = True        # the 36 weight gradients of a backward pass as one grouped launch at its end; False: 36 gemm_tn + tn_reduce pairs
 
     def refresh_shadows(self, params, sig=None):
         names = []

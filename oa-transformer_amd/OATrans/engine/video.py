@@ -27,7 +27,7 @@ Concurrency (HIP streams and events, no graph compiler)
   * Every kernel of the video tower runs in order on the caller's stream and owns the whole GPU.  Measured on MI355X:
     two MFMA-bound kernels side by side only split the machine, and the HBM-bound kernels (LayerNorm, attention) are
     limited by per-CU load throughput, so confined to the CUs a GEMM leaves free they slow down by as much as the
-    overlap would gain (the `bwd_side` option keeps that "slot" schedule for experiments).
+    overlap would gain (the "slot" schedule of rounds 1-5 that ran them beside the weight gradients left the engine in round 6).
   * forward: the CLS-query attention (independent of the patch attention) runs beside it on a side stream; the text
     tower (0.7 % of the FLOPs, latency-bound) runs on its own stream beside the video tower.
 """
@@ -53,11 +53,9 @@ class _BlockActs:
         self.o_t, self.o_s = z16(D), z16(D)
         self.h, self.g = z16(Hd), z16(Hd)
         self.h8 = None                       # 8-bit view of h (engine.h_u8)
-        if res16:                            # bf16 residual stream: only the block output is stored, as bf16
-            self.xt = self.y = None
-            self.out = z16(D)
-        else:
-            self.xt, self.y, self.out = z32(D), z32(D), z32(D)
+        # only the block output is stored (x + time and y = x + space are formed inside the LayerNorm kernels): bf16 on the
+        # bf16 residual stream (default), fp32 with res16 off
+        self.out = z16(D) if res16 else z32(D)
         self.lse_t, self.lse_s = z32(H), z32(H)
         self.stats = torch.zeros(6, Mp, dtype=torch.float32, device=dev)   # mean/rstd of norm3, norm1, norm2
 
@@ -161,23 +159,11 @@ class VideoEngine:
     LINEARS = ("attn.qkv", "attn.proj", "timeattn.qkv", "timeattn.proj", "mlp.fc1", "mlp.fc2")
     FOLDED = {"timeattn.qkv": "norm3", "attn.qkv": "norm1", "mlp.fc1": "norm2"}     # linear <- the LayerNorm folded into it
 
-    def fold_active(self):
-        """LayerNorm folding runs on the in-order path with a bf16 backward (fp8 FORWARD linears included: their e4m3 weights
-        are quantised from the folded bf16 shadows, their LayerNorm kernels quantise the plain normalised row); the fp8
-        data-gradient path (OAT_FP8_BWD) keeps the unfolded kernels."""
-        return self.fold_ln and not self.bwd_side and not (self.fp8 and self.fp8_bwd)
-
     def res16_active(self):
-        """The residual stream (and the residual-gradient stream of backward) STORED as bf16: on the folded, bf16, y-not-stored
-        path (the default one).  What it costs in parity was measured in the CPU oracle first (scripts/dev/rounding_study3.py):
+        """The residual stream (and the residual-gradient stream of backward) STORED as bf16 (the default; OAT_RES16=0 / res16 = False:
+        fp32, the round-3 kernels).  What it costs in parity was measured in the CPU oracle first (scripts/dev/rounding_study3.py):
         sim-matrix error unchanged (it comes from the fp32 CLS lane), gradients 1.8e-2 -> 2.2e-2 relative L2."""
-        return self.res16 and self.fold_active() and self._fp8_on_stream16() and os.environ.get("OAT_SKIP_Y", "1") != "0"
-
-    def _fp8_on_stream16(self):
-        """May this forward run on the bf16-stream kernels (y not stored, bf16 residual stream)?  bf16: yes.  fp8 forward: yes
-        (OAT_FP8_RES16, default on) - the r16 LayerNorm kernels emit the e4m3 operand themselves (oat_layernorm_fwd_r16_f8);
-        with the fp8 data gradients (OAT_FP8_BWD) the fp32-stream kernels stay."""
-        return not self.fp8 or (self.fp8_res16 and not self.fp8_bwd)
+        return bool(self.res16)
 
     def __init__(self, depth, embed_dim, num_heads, mlp_ratio, patch_size, in_chans, num_frames):
         self.depth, self.D, self.H = depth, embed_dim, num_heads
@@ -192,49 +178,17 @@ class VideoEngine:
         self.shadow = {}
         self.shadow_versions = None
         self._cast = None
-        # re-tile the last, mostly empty round of the N = 768 GEMMs as 128x128: measured equal with the ping-pong kernel
-        # (49.59 vs 49.67 ms per step; +5...9 % per launch with the lockstep kernel), so off by default: 36 fewer launches
-        self.tail_split = os.environ.get("OAT_TAIL_SPLIT", "0") != "0"
-        self.wgrad_cus = int(os.environ.get("OAT_WGRAD_CUS", "192"))   # workgroup budget of a weight-gradient GEMM that shares its slot
         _g = os.environ.get("OAT_BWD_NT_GRID", "0")                          # "auto": parallel.GradSync derives it from the device when it is built
         self.bwd_nt_grid = 0 if _g == "auto" else int(_g, 0)                 # gemm_nt grid during backward (0 = as in forward, 0xffff = one workgroup per tile)
-        self.slot_delay_ns = int(os.environ.get("OAT_SLOT_DELAY_NS", "4000"))
         self.cls_lane = os.environ.get("OAT_CLS_LANE", "1") != "0"      # fp32 lane for the CLS rows (see _lane_ln)
-        # 1: LayerNorm / attention backward on a side stream beside the weight-gradient GEMMs ("slots").  Measured equal to
-        # the plain in-order schedule (48.9-49.4 vs 49.2 ms): the streaming kernels are bound by per-CU load throughput
-        # (~27 GB/s per CU), so on the quarter of the CUs a GEMM leaves them they take 2-2.5x as long - what the overlap
-        # gains, the partition loses.  Default: every kernel alone on the GPU, in order, on the caller's stream.
-        self.bwd_side = os.environ.get("OAT_BWD_SIDE", "0") != "0"
         # fp8 forward (BASELINE.json config 5): the six linears of every block run on OCP e4m3 operands with per-tensor
-        # delayed scaling (csrc/fp8.hip, gemm_nt_pp.hip PPF_F8); attention, LayerNorm, the CLS lane, the loss and the
-        # whole backward stay bf16 / fp32.  Set by OAT_FP8=1 or by the caller (bench.py --dtype fp8).
-        # CLS-row gradients of the attention backward written by the attention kernel itself (oat_attn_*_bwd_fin); 0: separate
-        # oat_attn_cls_finalize launches (A/B measurements)
-        self.fused_finalize = os.environ.get("OAT_FUSED_FINALIZE", "1") != "0"
-        # two clips in one plan (OA models): their space attention as ONE launch each way (0: one launch per clip)
-        self.clip_launch = os.environ.get("OAT_CLIP_LAUNCH", "1") != "0"
-        self.time_clip_launch = os.environ.get("OAT_TIME_CLIPS", "1") != "0"      # TIME backward of the object clip + video clip in one launch
+        # delayed scaling (csrc/fp8.hip, gemm_nt_pp.hip PPF_F8), on the bf16 residual stream (oat_layernorm_fwd_r16_f8); attention,
+        # LayerNorm, the CLS lane, the loss and the whole backward stay bf16 / fp32.  Set by OAT_FP8=1 or by the caller
+        # (bench.py --dtype fp8).  (fp8 data gradients - measured equal in time, gradient norms 10-12 % off - left in round 6.)
         self.fp8 = os.environ.get("OAT_FP8", "0") != "0"
-        self.fp8_margin = float(os.environ.get("OAT_FP8_MARGIN", "1.0"))
-        # OAT_FP8_BWD=1 (with fp8 on): the data-gradient GEMMs as well (dY as e5m2, W^T as e4m3; weight gradients stay
-        # bf16).  Off by default: measured EQUAL in time at the headline shape (49.58 vs 49.69 ms: what the six GEMMs gain,
-        # ~260 us per block, goes into quantising dY - the two d_qkv tensors take a 60 us pass each because the attention
-        # backward kernels do not write e5m2 themselves yet) while gradient norms drift from <= 5 % to 10-12 % off the
-        # fp32 reference in the lowest blocks (tests/test_fp8_gpu.py).
-        self.fp8_bwd = os.environ.get("OAT_FP8_BWD", "0") != "0"
-        # fp8 forward on the bf16 residual stream (round 4): until then the fp8 mode kept the fp32 stream and paid 2.5 ms of
-        # LayerNorm bytes for the 2 ms its GEMMs saved.  OAT_FP8_PROJ=0 keeps the two attention projections (K = N = 768) on
-        # bf16: their inputs come from the attention kernels as bf16, so each costs a quantisation pass (measured: still
-        # 0.2 ms per step better on fp8, hence on by default).
-        self.fp8_res16 = os.environ.get("OAT_FP8_RES16", "1") != "0"
-        self.fp8_proj = os.environ.get("OAT_FP8_PROJ", "1") != "0"
+        self.fp8_margin = 1.0
         # the saved GELU derivative as 8-bit fixed point where the ping-pong GEMM serves the MLP pair (gemm_nt_pp.hip HU8_*)
         self.h_u8 = os.environ.get("OAT_H_U8", "1") != "0"
-        # split-K of the last, 31 %-full round of tiles of the N = 768 GEMMs (gemm_nt_pp.hip PPF_SPLITK).  Correct and
-        # deterministic, but the fix-up (256 KB write-through per workgroup, 2-3 partial tiles read back by the last arriver)
-        # costs ~30 us of the 22-43 us it saves: -5 us at K = 3072, +6 us at K = 2304 (scripts/bench_pp.py SPLITK=1): off
-        self.splitk = os.environ.get("OAT_SPLITK", "0") != "0"
-        self._splitk_set = False
         # launch tapes (csrc/tape.hip): forward and backward are recorded once per plan and replayed from C
         self.use_tape = os.environ.get("OAT_TAPE", "1") != "0"
         self._f8 = None
@@ -242,18 +196,15 @@ class VideoEngine:
         self._tn_ws = None
         self._tn_retired = []
         self._tn_slabs = None               # fp32 partial-tile workspace shared by every grouped weight-gradient launch
-        # 1 (default): the six weight gradients of a block are queued and launched together at the block's end
-        # (csrc/gemm_tn_sk.hip); 0: one gemm_tn + tn_reduce pair per weight, where its dY becomes available
-        self.group_wgrads = os.environ.get("OAT_GROUP_WGRADS", "1") != "0"
-        # 1 (default, bf16 path): norm3 / norm1 / norm2 are FOLDED into the linear layer that follows them (timeattn.qkv /
-        # attn.qkv / mlp.fc1): the shadows are W' = W diag(gamma), the bias b' = b + W beta, LayerNorm forward writes the plain
-        # normalised row xhat, LayerNorm backward reads the saved bf16 xhat + rstd instead of the fp32 input (no fp32 copy of
-        # x + time is kept at all), and (dW, dgamma, dbeta) come out of dW' by oat_ln_fold_grads: the same function and
-        # the same gradients with 77 MB less per LayerNorm backward and 154 MB less in norm1's forward (rowops.hip)
-        self.fold_ln = os.environ.get("OAT_FOLD_LN", "1") != "0"
-        # 1 (default): with folded LayerNorms the fp32 residual-gradient stream is read by norm2's backward, skipped by norm1's
-        # and read + written once by norm3's (ln_bwd_xhat_kernel); 0: every LayerNorm backward reads and re-writes it
-        self.fold_gstream = os.environ.get("OAT_FOLD_GSTREAM", "1") != "0"
+        # Fixed parts of the schedule (each was a knob while it was being measured):
+        #  * the six weight gradients of a block are queued and launched together at the block's end (csrc/gemm_tn_sk.hip);
+        #  * norm3 / norm1 / norm2 are FOLDED into the linear layer that follows them (timeattn.qkv / attn.qkv / mlp.fc1): the
+        #    shadows are W' = W diag(gamma), the bias b' = b + W beta, LayerNorm forward writes the plain normalised row xhat,
+        #    LayerNorm backward reads the saved bf16 xhat + rstd instead of the fp32 input, and (dW, dgamma, dbeta) come out of dW'
+        #    by oat_ln_fold_grads: the same function and the same gradients with 77 MB less per LayerNorm backward (rowops.hip);
+        #  * y = x + space is never stored (the next block's norm3 adds both branch outputs);
+        #  * the CLS-row gradients of the attention backward are written by the attention kernel itself (oat_attn_*_bwd_fin);
+        #  * two clips in one plan (OA models) share their space-attention and TIME-backward launches.
         # 1 (default since round 6; OAT_PRUNE_TOP=0 = every launch of the reference's graph): when the caller consumes only the
         # CLS rows of the encoder output (contract class oa_model.FrozenInTime, video_transformer.py:349-351 -> oa_model.py:129-133)
         # the patch rows of the TOP block's space-attention projection, norm2, fc1 / GELU and fc2 are never read and their output
@@ -273,13 +224,12 @@ class VideoEngine:
         (`sig` = EngineModule._weights_signature())."""
         names = [f"blocks.{i}.{l}.weight" for i in range(self.depth) for l in self.LINEARS]
         names.append("patch_embed.proj.weight")
-        fold = self.fold_active()
-        sig = (sig, fold) if sig is not None else None
+        fold = True                              # norm3 / norm1 / norm2 are folded into the linear that follows them
         if sig is not None and sig == self.shadow_versions:
             return
         srcs = [params[n].detach().reshape(params[n].shape[0], -1) for n in names]
-        key = tuple(w.data_ptr() for w in srcs) + (fold,)
-        if self._cast is None or self._cast.key != key:           # masters moved (first call, .to(), flatten) or the fold flag changed
+        key = tuple(w.data_ptr() for w in srcs)
+        if self._cast is None or self._cast.key != key:           # masters moved (first call, .to(), flatten)
             entries, fb = [], []
             for n, w in zip(names, srcs):
                 self.shadow[n] = (torch.empty_like(w, dtype=torch.bfloat16),
@@ -308,13 +258,13 @@ class VideoEngine:
     F8_LINEARS = ("timeattn.qkv", "timeattn.proj", "attn.qkv", "attn.proj", "mlp.fc1", "mlp.fc2")
 
     def _fp8_state(self, dev):
-        """Quantisation sites of block i, linear j: weight 18 i + j (e4m3, shared by W and W^T), forward input
-        18 i + 6 + j (e4m3), incoming gradient dY of that linear 18 i + 12 + j (e5m2).  amax / qscale / dq are rows of one
+        """Quantisation sites of block i, linear j: weight 18 i + j (e4m3), forward input 18 i + 6 + j (e4m3); sites 18 i + 12 + j are
+        unused since round 6 (they held the incoming gradients of the fp8 data-gradient mode).  amax / qscale / dq are rows of one
         device tensor."""
         if self._f8 is None:
             n = 18 * self.depth
             st = torch.zeros(3, n, dtype=torch.float32, device=dev)
-            self._f8 = dict(n=n, amax=st[0], qscale=st[1], dq=st[2], w8={}, wT8={}, table=None, qtable=None, primed=set(), key=None)
+            self._f8 = dict(n=n, amax=st[0], qscale=st[1], dq=st[2], w8={}, table=None, primed=set(), key=None)
         return self._f8
 
     def _refresh_fp8_weights(self):
@@ -325,29 +275,25 @@ class VideoEngine:
         f8 = self._fp8_state(dev)
         key = tuple(self.shadow[n][0].data_ptr() for _, _, n in names)
         if f8["key"] != key:
-            entries, tentries = [], []
+            entries = []
             for i, j, n in names:
-                w16, wT16 = self.shadow[n]
+                w16 = self.shadow[n][0]
                 f8["w8"][n] = torch.empty(w16.shape, dtype=torch.uint8, device=dev)
-                f8["wT8"][n] = torch.empty(wT16.shape, dtype=torch.uint8, device=dev)
                 entries.append((w16, f8["w8"][n], 18 * i + j))
-                tentries.append((wT16, f8["wT8"][n], 18 * i + j))       # W^T (data-gradient operand): same values, same scale
             f8["table"], f8["key"] = hip.Fp8Table(entries), key
-            f8["qtable"] = hip.Fp8Table(entries + tentries) if self.fp8_bwd else f8["table"]
         f8["table"].run(f8["qscale"], f8["amax"], quant=False)
-        hip.fp8_update_scales(f8["amax"], f8["qscale"], f8["dq"], f8["n"], 1.0)       # activation / gradient sites: amax == 0, untouched
-        f8["qtable"].run(f8["qscale"], f8["amax"], quant=True)
+        hip.fp8_update_scales(f8["amax"], f8["qscale"], f8["dq"], f8["n"], 1.0)       # activation sites: amax == 0, untouched
+        f8["table"].run(f8["qscale"], f8["amax"], quant=True)
 
-    def _f8_site(self, i, j, grad=False):
-        """(qscale, amax, dq) one-element views of the forward-input (grad=False) or incoming-gradient (grad=True) site of
-        linear j of block i."""
-        f8, s = self._f8, 18 * i + (12 if grad else 6) + j
+    def _f8_site(self, i, j):
+        """(qscale, amax, dq) one-element views of the forward-input site of linear j of block i."""
+        f8, s = self._f8, 18 * i + 6 + j
         return f8["qscale"][s:s + 1], f8["amax"][s:s + 1], f8["dq"][s:s + 1]
 
-    def _f8_primed(self, i, j, grad=False):
+    def _f8_primed(self, i, j):
         """Has this GEMM operand been seen (does its delayed scale exist)?  Producers quantise in their own epilogue only
         then; the very first step quantises in a separate pass with the CURRENT amax."""
-        return self.fp8 and (18 * i + (12 if grad else 6) + j) in self._f8["primed"]
+        return self.fp8 and (18 * i + 6 + j) in self._f8["primed"]
 
     def _ln_f8(self, pl, i, j, x, gamma, beta, y, mean, rstd, add16=None, sum32=None):
         """LayerNorm whose output feeds linear j of block i: bf16 y (kept for backward) and its e4m3 copy in pl.x8."""
@@ -382,48 +328,6 @@ class VideoEngine:
         hip.gemm_nt_f8(x8, w8, M, N, K, epi, out, dq, f8["dq"][wsite:wsite + 1], out2=out2, bias=bias, **kw)
         return bool(kw)
 
-    def _dgrad_f8(self, pl, i, j, dy16, K, N, epi, out, aux=None, quantised=False, dy8=None):
-        """Data gradient of linear j of block i on fp8 operands: out = dY @ W (W^T shadow as e4m3, dY as e5m2).
-        quantised=True: the producer of dY already left its e5m2 copy in `dy8`.  The fc2 data gradient (j == 5,
-        EPI_MUL_AUX) leaves the e5m2 copy of ITS output for the fc1 data gradient once that site is primed."""
-        f8 = self._f8
-        site, wsite = 18 * i + 12 + j, 18 * i + j
-        M = pl.M
-        q, am, dq = self._f8_site(i, j, grad=True)
-        if dy8 is None:
-            dy8 = pl.x8_wide if K == self.Hd else (pl.x8_qkv if K == 3 * self.D else pl.x8)
-        if not quantised:
-            if site not in f8["primed"]:
-                hip.fp8_amax(dy16, M, K, am)
-                hip.fp8_update_scales(am, q, dq, 1, self.fp8_margin, e5m2=True)
-                f8["primed"].add(site)
-            hip.fp8_quant(dy16, dy8, M, K, q, am, e5m2=True)
-        wT8 = f8["wT8"][f"blocks.{i}.{self.F8_LINEARS[j]}.weight"]
-        kw = {}
-        if j == 5 and self._f8_primed(i, 4, grad=True):
-            q4, am4, _ = self._f8_site(i, 4, grad=True)
-            kw = dict(out8=pl.x8_wide, q_out=q4, amax_out=am4)
-        hip.gemm_nt_f8(dy8, wT8, M, N, K, epi, out, dq, f8["dq"][wsite:wsite + 1], a_e5m2=True, aux=aux, **kw)
-        return bool(kw)
-
-    def _ln_bwd(self, pl, i, j, dy, x, mean, rstd, gamma, dx16, dgamma, dbeta, dx8=None, **kw):
-        """LayerNorm backward whose bf16 output dx16 is the incoming gradient of linear j of block i: with fp8 backward
-        and a primed site it also writes the e5m2 copy (into dx8, default pl.x8).  Returns whether it did."""
-        M, D = pl.M, self.D
-        if i >= 0 and self.fp8 and self.fp8_bwd and self._f8_primed(i, j, grad=True):
-            q, am, _ = self._f8_site(i, j, grad=True)
-            hip.layernorm_bwd_f8(dy, x, mean, rstd, gamma, M, D, dx8 if dx8 is not None else pl.x8, q, am, dx=pl.G, dx16=dx16,
-                                 dres=pl.G, dgamma=dgamma, dbeta=dbeta, accumulate=pl.acc, **kw)
-            return True
-        hip.layernorm_bwd(dy, x, mean, rstd, gamma, M, D, dx=pl.G, dx16=dx16, dres=pl.G, dgamma=dgamma, dbeta=dbeta,
-                          accumulate=pl.acc, **kw)
-        return False
-
-    def _fp8_end_of_backward(self):
-        """Next step's gradient scales (e5m2) from this step's amax; the other sites saw no amax since their own update."""
-        f8 = self._f8
-        hip.fp8_update_scales(f8["amax"], f8["qscale"], f8["dq"], f8["n"], self.fp8_margin, e5m2=True)
-
     def _fp8_end_of_forward(self):
         """Next step's activation scales from this step's amax (weight sites saw no amax: unchanged)."""
         f8 = self._f8
@@ -442,9 +346,7 @@ class VideoEngine:
         """Streams are created only when used: HIP multiplexes streams onto a few hardware queues
         (GPU_MAX_HW_QUEUES, default 4) and two streams that share a queue run in enqueue order."""
         if self._streams is None:
-            self._streams = dict(side=hip.side_stream("OAT_LANE", dev), hbm=None)
-        if self.bwd_side and self._streams["hbm"] is None:          # the slot schedule's stream: only when that option is on
-            self._streams["hbm"] = hip.side_stream("OAT_HBM", dev)
+            self._streams = dict(side=hip.side_stream("lane", dev))
         return self._streams
 
     # ------------------------------------------------------------------ forward
@@ -468,9 +370,6 @@ class VideoEngine:
             shapes.append((v.shape[0], v.shape[1], N))
         self.refresh_shadows(params, sig)
         dev = clips[0].device
-        if self.splitk and not self._splitk_set:
-            hip.enable_splitk(dev)               # the N = 768 GEMMs run 2.31 rounds of tiles: share the last round's K range
-            self._splitk_set = True
         st = self._get_streams(dev)
         pl = self.plan(shapes, dev, call)
         pl.side = st["side"]
@@ -488,26 +387,21 @@ class VideoEngine:
                            br32=z(self.D), g32=z(self.Hd))
         elif not self.cls_lane:
             pl.lane = None
-        # every GEMM has the GPU to itself: the third, 31 %-full round of the N = 768 GEMMs (591 tiles on 256 CUs) is
-        # re-tiled as 128x128 (see gemm_nt.hip)
         if self.fp8 and getattr(pl, "x8", None) is None:
             pl.x8 = torch.zeros(pl.Mp, self.D, dtype=torch.uint8, device=dev)          # fp8 GEMM inputs (one in flight)
             pl.x8_wide = torch.zeros(pl.Mp, self.Hd, dtype=torch.uint8, device=dev)
-            pl.x8_qkv = torch.zeros(pl.Mp, 3 * self.D, dtype=torch.uint8, device=dev)      # e5m2 d_qkv (backward)
-            pl.ga8 = [torch.zeros(pl.Mp, self.D, dtype=torch.uint8, device=dev) for _ in range(3)]   # e5m2 copies of the ga ring
+        if self.fp8 and not pl.res16:
+            raise hip.OatError("the fp8 forward runs on the bf16 residual stream (res16): OAT_RES16=0 / res16 = False is the bf16 engine's fp32-stream option")
         run = _Run(pl, need_patches, region_layer)
-        # folded LayerNorms + bf16 forward: y = x + space is never stored (the next block's norm3 adds both branch outputs)
-        pl.skip_y = self.fold_active() and self._fp8_on_stream16() and os.environ.get("OAT_SKIP_Y", "1") != "0"
         # (a region tap BELOW the top block - oa_model_region_mem: block 6 - leaves the top block's patch rows just as unused; a tap
         # on the encoder output reads them)
-        pl.prune_top = bool(self.prune_top and not need_patches and region_layer != self.depth and pl.res16
-                            and pl.skip_y and not self.fp8 and not self.bwd_side)
+        pl.prune_top = bool(self.prune_top and not need_patches and region_layer != self.depth and pl.res16 and not self.fp8)
         run.prune_top = pl.prune_top
         if pl.prune_top and getattr(pl, "d_o_top", None) is None:
             # dL/d(attention output) of the top block: its patch rows are zero and stay zero (only the CLS rows are ever written)
             pl.d_o_top = torch.zeros(pl.Mp, self.D, dtype=torch.bfloat16, device=dev)
-        pl.fwd_modes = (self.fold_active(), pl.skip_y, pl.res16, self.fp8)      # what the saved activations MEAN: backward checks it
-        if pl.skip_y and getattr(pl, "branch16s", None) is None:
+        pl.fwd_modes = (pl.res16, self.fp8)      # what the saved activations MEAN: backward checks it
+        if getattr(pl, "branch16s", None) is None:     # the space branch keeps its own buffer until the next block's norm3
             pl.branch16s = torch.zeros(pl.Mp, self.D, dtype=torch.bfloat16, device=dev)
         pl.h_u8 = (self.h_u8 and pl.M >= 256 and self.Hd % 256 == 0 and self.Hd <= 4096 and self.D % 128 == 0 and self.D >= 128)
         if pl.h_u8 and pl.blocks[0].h8 is None:
@@ -515,7 +409,6 @@ class VideoEngine:
                 a.h8 = a.h.view(torch.uint8).view(-1)[:pl.Mp * self.Hd].view(pl.Mp, self.Hd)
 
         def body():
-            hip.gemm_set_tail_split(self.tail_split)
             self._embed(pl, params, C, R)
             pend = None
             for i in range(self.depth):
@@ -523,7 +416,6 @@ class VideoEngine:
             out = self._final_fwd(pl, params, need_patches, region_layer)
             if self.fp8:
                 self._fp8_end_of_forward()
-            hip.gemm_set_tail_split(False)
             return out
 
         key = self._tape_key(pl, params, None, need_patches, region_layer, C, R)
@@ -536,13 +428,13 @@ class VideoEngine:
     def _tape_key(self, pl, params, grads, *flags):
         """Everything a recorded schedule depends on besides the plan itself: the streams, where parameters / gradients
         live, the option flags and the state of the fp8 sites."""
-        if not self.use_tape or self.bwd_side:       # the slot schedule (bwd_side) orders its streams with torch events
+        if not self.use_tape:
             return None
         ptrs = tuple(t.data_ptr() for t in params.values())
         gptr = next(iter(grads.values())).data_ptr() if grads else 0
         f8 = (len(self._f8["primed"]), self._f8["key"]) if (self.fp8 and self._f8) else None
-        return (torch.cuda.current_stream().cuda_stream, pl.side.cuda_stream, self.clip_launch, self.time_clip_launch, ptrs, gptr, self.fp8, self.fp8_bwd, self.fp8_proj, f8, self.cls_lane, self.h_u8,
-                self.tail_split, self.bwd_side, self.bwd_nt_grid, self.group_wgrads, self.fold_active(), self.fold_gstream, os.environ.get("OAT_SKIP_Y", "1"), pl.res16, hip.gemm_get_variant(), getattr(pl, "prune_top", False), flags)
+        return (torch.cuda.current_stream().cuda_stream, pl.side.cuda_stream, ptrs, gptr, self.fp8, f8, self.cls_lane, self.h_u8,
+                self.bwd_nt_grid, pl.res16, getattr(pl, "prune_top", False), flags)
 
     @staticmethod
     def _announce_segment(ready, prefixes, recording):
@@ -636,27 +528,26 @@ class VideoEngine:
             hip.linear_f32(A, W, pl.Bsum, N, K, bias=bias, out32=out32, act=act | hip.LIN_EXACT)
 
     def _block_fwd(self, pl, i, params, pend, region_layer):
-        """Residual adds are fused into the NEXT LayerNorm (oat_add_layernorm_fwd): the projection / fc2 GEMMs
-        write their branch output as bf16 and the streaming LN kernel forms x + branch, stores the new fp32
-        stream and the normalised bf16 operand in one pass.  `pend` = the previous block, whose
-        out = y + branch is still to be formed."""
+        """Residual adds are fused into the NEXT LayerNorm: the projection / fc2 GEMMs write their branch output as bf16 and
+        the streaming LN kernel forms x + branch (in fp32), stores the new stream where one is needed and the normalised bf16
+        operand in one pass.  `pend` = the previous block, whose out = x + space + mlp is still to be formed.  The LayerNorms
+        are folded into the linear that follows them: the kernels write the plain normalised row (gamma = beta = None), the
+        linear layers take W' = W diag(gamma) and the folded bias."""
         M, D, Hd = pl.M, self.D, self.Hd
-        a, br = pl.blocks[i], pl.branch16
+        a, br, brs = pl.blocks[i], pl.branch16, pl.branch16s
         p = lambda s: params[f"blocks.{i}.{s}"]
         w = lambda s: self.shadow[f"blocks.{i}.{s}.weight"][0]
         st = a.stats
         lane = pl.lane
-        fold = self.fold_active()
-        # folded LayerNorms write the plain normalised row (gamma = beta = None); their linear layers take the folded bias
-        ln_gb = lambda n: (None, None) if fold else (p(n + ".weight"), p(n + ".bias"))
-        lin_b = lambda n: self.fbias[f"blocks.{i}.{n}.bias"] if fold else p(n + ".bias")
+        lin_b = lambda n: self.fbias[f"blocks.{i}.{n}.bias"]
+        f8 = self.fp8
         q3 = self._f8_primed(i, 0)          # fp8: LayerNorm outputs are quantised by the LayerNorm kernel itself
         if pend is None:
             x = pl.x0
             if q3:
-                self._ln_f8(pl, i, 0, x, *ln_gb("norm3"), a.a3, st[0], st[1])
+                self._ln_f8(pl, i, 0, x, None, None, a.a3, st[0], st[1])
             else:
-                hip.layernorm_fwd(x, *ln_gb("norm3"), M, D, 1e-6, y=a.a3, mean=st[0], rstd=st[1])
+                hip.layernorm_fwd(x, None, None, M, D, 1e-6, y=a.a3, mean=st[0], rstd=st[1])
             if lane is not None:                         # the lane starts from the embedding's CLS rows
                 hip.stream_edge(torch.cuda.current_stream(), pl.side)
                 with torch.cuda.stream(pl.side):
@@ -664,16 +555,12 @@ class VideoEngine:
                         hip.copy_(sg.lane(lane["x"]), x[sg.cls0:sg.end])
                 self._lane_ln(pl, lane["x"], None, None, p("norm3.weight"), p("norm3.bias"), lane["a32"])
         else:
-            if pl.res16:             # the same on the bf16 stream: out16 = bf16(x + space + mlp), a3 = LN of the unrounded sum
-                hip.layernorm_fwd_r16(pend.xin, M, D, 1e-6, add_a=pl.branch16s, add_b=br, sum16=pend.out, y=a.a3, mean=st[0], rstd=st[1],
+            # out = x + space + mlp of the previous block in one pass (its y = x + space was never stored)
+            if pl.res16:             # bf16 stream: out16 = bf16(x + space + mlp), a3 = LN of the unrounded sum
+                hip.layernorm_fwd_r16(pend.xin, M, D, 1e-6, add_a=brs, add_b=br, sum16=pend.out, y=a.a3, mean=st[0], rstd=st[1],
                                       **(self._ln_f8_kw(pl, i, 0) if q3 else {}))
-            elif q3:
-                self._ln_f8(pl, i, 0, pend.y, *ln_gb("norm3"), a.a3, st[0], st[1], add16=br, sum32=pend.out)
-            elif pl.skip_y:          # out = x + space + mlp of the previous block in one pass (its y = x + space was never stored)
-                hip.add2_layernorm_fwd(pend.xin, pl.branch16s, br, pend.out, *ln_gb("norm3"), M, D, 1e-6, y=a.a3, mean=st[0],
-                                       rstd=st[1])
             else:
-                hip.add_layernorm_fwd(pend.y, br, pend.out, *ln_gb("norm3"), M, D, 1e-6, y=a.a3, mean=st[0], rstd=st[1])
+                hip.add2_layernorm_fwd(pend.xin, brs, br, pend.out, None, None, M, D, 1e-6, y=a.a3, mean=st[0], rstd=st[1])
             x = pend.out
             if lane is not None:                         # x = y + mlp of the previous block
                 self._lane_ln(pl, lane["y"], lane["br32"], lane["x"], p("norm3.weight"), p("norm3.bias"), lane["a32"])
@@ -682,7 +569,6 @@ class VideoEngine:
         # ---- time attention
         if lane is not None:
             self._lane_linear(pl, lane["a32"], p("timeattn.qkv.weight")[:D], p("timeattn.qkv.bias")[:D], D, D, lane["q32"])
-        f8 = self.fp8
         if f8:
             self._linear_f8(pl, i, 0, a.a3, D, 3 * D, hip.EPI_BF16, a.qkv_t, lin_b("timeattn.qkv"), quantised=q3)
         else:
@@ -692,19 +578,16 @@ class VideoEngine:
             self._lane_linear(pl, lane["o32"], p("timeattn.proj.weight"), p("timeattn.proj.bias"), D, D, lane["br32"])
             self._lane_ln(pl, lane["x"], lane["br32"], lane["xt"], p("norm1.weight"), p("norm1.bias"), lane["a32"])
             self._lane_linear(pl, lane["a32"], p("attn.qkv.weight")[:D], p("attn.qkv.bias")[:D], D, D, lane["q32"])
-        if f8 and self.fp8_proj:
+        if f8:
             self._linear_f8(pl, i, 1, a.o_t, D, D, hip.EPI_BF16, br, p("timeattn.proj.bias"))
         else:
             hip.gemm_nt(a.o_t, w("timeattn.proj"), M, D, D, hip.EPI_BF16, br, bias=p("timeattn.proj.bias"))
+        # xt = x + time feeds norm1 only (the space residual comes from x): it is never stored
         q1 = self._f8_primed(i, 2)
         if pl.res16:
             hip.layernorm_fwd_r16(x, M, D, 1e-6, add_a=br, y=a.a1, mean=st[2], rstd=st[3], **(self._ln_f8_kw(pl, i, 2) if q1 else {}))
-        elif q1:
-            self._ln_f8(pl, i, 2, x, *ln_gb("norm1"), a.a1, st[2], st[3], add16=br, sum32=None if fold else a.xt)
         else:
-            # xt = x + time feeds norm1 only (the space residual comes from x): folded, its fp32 copy is never stored
-            hip.add_layernorm_fwd(x, br, None if fold else a.xt, *ln_gb("norm1"), M, D, 1e-6, y=a.a1, mean=st[2],
-                                  rstd=st[3])                                       # xt = x + time
+            hip.add_layernorm_fwd(x, br, None, None, None, M, D, 1e-6, y=a.a1, mean=st[2], rstd=st[3])
         # ---- space attention
         if f8:
             self._linear_f8(pl, i, 2, a.a1, D, 3 * D, hip.EPI_BF16, a.qkv_s, lin_b("attn.qkv"), quantised=q1)
@@ -724,24 +607,20 @@ class VideoEngine:
             self._lane_ln(pl, lane["x"], lane["br32"], lane["y"], p("norm2.weight"), p("norm2.bias"), lane["a32"])
             self._lane_linear(pl, lane["a32"], p("mlp.fc1.weight"), p("mlp.fc1.bias"), Hd, D, lane["g32"], act=hip.LIN_GELU)
             self._lane_linear(pl, lane["g32"], p("mlp.fc2.weight"), p("mlp.fc2.bias"), D, Hd, lane["br32"])
-        brs = pl.branch16s if pl.skip_y else br      # skip_y: the space branch keeps its own buffer until the next block's norm3
         a.xin = x
         if top_pruned:
             self._top_tail_fwd(pl, a, x, brs, br, p, w, lin_b)
             return a
-        if f8 and self.fp8_proj:
+        if f8:
             self._linear_f8(pl, i, 3, a.o_s, D, D, hip.EPI_BF16, brs, p("attn.proj.bias"))
         else:
             hip.gemm_nt(a.o_s, w("attn.proj"), M, D, D, hip.EPI_BF16, brs, bias=p("attn.proj.bias"))
-        # space residual comes from x, NOT from x + time (video_transformer.py:170)
+        # space residual comes from x, NOT from x + time (video_transformer.py:170); y = x + space is not stored
         q2 = self._f8_primed(i, 4)
         if pl.res16:
             hip.layernorm_fwd_r16(x, M, D, 1e-6, add_a=brs, y=a.a2, mean=st[4], rstd=st[5], **(self._ln_f8_kw(pl, i, 4) if q2 else {}))
-        elif q2:
-            self._ln_f8(pl, i, 4, x, *ln_gb("norm2"), a.a2, st[4], st[5], add16=brs, sum32=a.y)
         else:
-            hip.add_layernorm_fwd(x, brs, None if pl.skip_y else a.y, *ln_gb("norm2"), M, D, 1e-6, y=a.a2, mean=st[4],
-                                  rstd=st[5])                                       # y = x + space
+            hip.add_layernorm_fwd(x, brs, None, None, None, M, D, 1e-6, y=a.a2, mean=st[4], rstd=st[5])
         # ---- MLP
         if f8:
             gq = self._linear_f8(pl, i, 4, a.a2, D, Hd, hip.EPI_GELU_GRAD | (hip.EPI_U8 if pl.h_u8 else 0), a.h8 if pl.h_u8 else a.h,
@@ -753,7 +632,7 @@ class VideoEngine:
             else:
                 hip.gemm_nt(a.a2, w("mlp.fc1"), M, Hd, D, hip.EPI_GELU_GRAD, a.h, out2=a.g, bias=lin_b("mlp.fc1"))
             hip.gemm_nt(a.g, w("mlp.fc2"), M, D, Hd, hip.EPI_BF16, br, bias=p("mlp.fc2.bias"))
-        return a                                                                    # out = y + br, formed lazily
+        return a                                                                    # out = x + brs + br, formed lazily
 
     def _top_tail_fwd(self, pl, a, x, brs, br, p, w, lin_b):
         """prune_top: the top block from the space-attention projection on, for the B CLS rows only (the tail block of the
@@ -781,10 +660,8 @@ class VideoEngine:
             if pl.res16:
                 hip.layernorm_fwd_r16(last.xin[r0:], rows, D, 1e-6, add_a=pl.branch16s[r0:], add_b=br[r0:], sum16=last.out[r0:],
                                       gamma=g, beta=bt, **kw)
-            elif pl.skip_y:
-                hip.add2_layernorm_fwd(last.xin[r0:], pl.branch16s[r0:], br[r0:], last.out[r0:], g, bt, rows, D, 1e-6, **kw)
             else:
-                hip.add_layernorm_fwd(last.y[r0:], br[r0:], last.out[r0:], g, bt, rows, D, 1e-6, **kw)
+                hip.add2_layernorm_fwd(last.xin[r0:], pl.branch16s[r0:], br[r0:], last.out[r0:], g, bt, rows, D, 1e-6, **kw)
 
         if need_patches or tap_last:
             final_ln(0, M)
@@ -817,7 +694,7 @@ class VideoEngine:
                     hip.attn_cls_fwd(q, o, l, sg.B, sg.T, sg.N, self.H, self.D, self.scale)
         if not patch:
             pass
-        elif patch_kernel is hip.attn_space_fwd and len(pl.segs) == 2 and pl.segs[0].N == pl.segs[1].N and self.clip_launch:
+        elif patch_kernel is hip.attn_space_fwd and len(pl.segs) == 2 and pl.segs[0].N == pl.segs[1].N:
             # both clips' frames in ONE launch: the object frame alone is B x H problems, a third of the GPU
             hip.attn_space_fwd_clips([dict(qkv=sg.rows(qkv), out=sg.rows(out), lse=sg.rows(lse), B=sg.B, T=sg.T) for sg in pl.segs],
                                      pl.segs[0].N, self.H, self.D, self.scale)
@@ -843,19 +720,17 @@ class VideoEngine:
         None (contract class oa_model.FrozenInTime discards patch outputs); d_region fp32 [B*T*N, D] =
         gradient of run.region (enters the residual stream below block `region_layer`).
 
-        Schedule (see the module docstring): GEMMs in order on the caller's stream; LayerNorm / attention backward on
-        the `hbm` side stream inside the slot after the GEMM that feeds them, beside weight-gradient GEMMs.
+        Schedule (see the module docstring): every kernel in order on the caller's stream; a block's six weight gradients
+        as one grouped launch at the block's end.
 
         `ready(prefixes)` (optional) is called - on the caller's stream, after everything that writes them - as soon
         as all gradients of the parameters named by `prefixes` are enqueued: one call per block, top to bottom, so
         the gradient all-reduce can start while backward is still running."""
-        st = self._get_streams(run.G.device)
         pl = run.pl
-        now = (self.fold_active(), getattr(pl, "skip_y", None), pl.res16, self.fp8)
+        now = (pl.res16, self.fp8)
         if getattr(pl, "fwd_modes", now) != now:
-            raise hip.OatError(f"engine options changed between a forward and its backward (fold, skip_y, res16, fp8): {pl.fwd_modes} -> {now}; "
+            raise hip.OatError(f"engine options changed between a forward and its backward (res16, fp8): {pl.fwd_modes} -> {now}; "
                                "the saved activations would be misread")
-        pl.hbm = st["hbm"] if self.bwd_side else None
         pl.acc = bool(accumulate)
         if run.region_layer is not None:
             ready = None                     # region_norm gradients arrive out of block order: reduce after backward
@@ -894,72 +769,30 @@ class VideoEngine:
             for sg in pl.segs:
                 hip.zero_(sg.cls_side)   # once per backward; every attn_cls_finalize leaves it zero for the next one
             self._final_bwd(pl, run, params, grads, have_patches, d_region)
-            hip.gemm_set_tail_split(self.tail_split and not self.bwd_side)
-            hip.gemm_tn_set_variant((self.wgrad_cus << 16) if self.bwd_side else 0)
-            nt_prev = hip.gemm_get_variant()
-            if self.bwd_nt_grid and (nt_prev >> 16) == 0:
-                hip.gemm_set_variant((nt_prev & 0xffff) | (self.bwd_nt_grid << 16))
-            f8b = self.fp8 and self.fp8_bwd and not self.bwd_side
-            pl.ga8_valid = None              # the top block's dL/d(out) comes from the final LayerNorm: quantised in a pass
+            # the data-gradient GEMMs of a multi-rank job leave room for RCCL's kernels (parallel.GradSync sets bwd_nt_grid): a per-call
+            # argument of oat_gemm_nt, not a mode of the library
+            pl.bwd_grid = self.bwd_nt_grid
             for k, i in enumerate(reversed(range(self.depth))):
-                pl.wq = [] if (self.group_wgrads and not self.bwd_side) else None
+                pl.wq = []
                 if getattr(run, "prune_top", False) and i == self.depth - 1:
                     self._top_block_bwd_pruned(pl, i, params, grads)
                 else:
-                    (self._block_bwd_f8 if f8b else self._block_bwd)(pl, i, run, params, grads, d_region)
-                if pl.wq is not None:
-                    self._flush_wgrads(pl, i)
-                    pl.wq = None
+                    self._block_bwd(pl, i, run, params, grads, d_region)
+                self._flush_wgrads(pl, i)
+                pl.wq = None
                 if getattr(pl, "fold_pending", None) == i:
                     self._fold_grads(pl, i, params, grads)
                     pl.fold_pending = None
                 if use_marks:
                     self._announce_segment(ready, prefixes[k], recording)
-            if f8b:
-                self._fp8_end_of_backward()
             self._embed_bwd(pl, grads)
             if use_marks:
                 self._announce_segment(ready, prefixes[-1], recording)
-            hip.gemm_tn_set_variant(0)
-            hip.gemm_set_tail_split(False)
-            if hip.gemm_get_variant() != nt_prev:
-                hip.gemm_set_variant(nt_prev)
 
         key = self._tape_key(pl, params, grads, "bwd", run.need_patches, run.region_layer, have_patches, d_region is not None,
                              pl.acc, use_marks)
         recording = key is not None
         self._taped(pl, "tape_bwd", key, body, segments=(lambda k: ready(prefixes[k])) if use_marks else None)
-
-    def _slot(self, pl, fn, wgrads=()):
-        """One slot of backward: the weight-gradient GEMMs `wgrads` (callables) on the caller's stream and, beside
-        them, the HBM-bound kernel(s) `fn` on the side stream; both ordered after everything enqueued so far on the
-        caller's stream.  The GEMM is enqueued first and the side stream starts `slot_delay_ns` late, so the GEMM's
-        workgroups are placed before the streaming kernel takes what is left (the other way round its small blocks
-        land on every CU and the GEMM waits for them to drain).  Returns the event the consumer of `fn`'s outputs
-        waits for (None: everything ran in stream order)."""
-        if pl.hbm is None:
-            fn()
-            for w in wgrads:
-                w()
-            return None
-        cur = torch.cuda.current_stream()
-        ev = torch.cuda.Event()
-        ev.record(cur)
-        for w in wgrads:
-            w()
-        pl.hbm.wait_event(ev)
-        with torch.cuda.stream(pl.hbm):
-            if wgrads and self.slot_delay_ns:
-                hip.delay(self.slot_delay_ns)
-            fn()
-            done = torch.cuda.Event()
-            done.record(pl.hbm)
-        return done
-
-    @staticmethod
-    def _join(done):
-        if done is not None:
-            torch.cuda.current_stream().wait_event(done)
 
     def _wgrad(self, P, Q, rows, n1, n2, w, b, acc=False, pl=None):
         """One weight gradient w (+)= P[:rows]^T Q[:rows], b (+)= colsum(P).  With a plan whose queue is open (`pl.wq`,
@@ -967,7 +800,7 @@ class VideoEngine:
         if pl is not None and pl.wq is not None and n1 % 256 == 0 and n2 % 256 == 0:
             pl.wq.append((P, Q, rows, n1, n2, w, b, bool(acc)))
             return
-        need = hip.lib().oat_gemm_tn_workspace_bytes(rows, n1, n2) // 4     # exact for this (rows, shape)
+        need = hip.lib().oat_gemm_tn_workspace_bytes(rows, n1, n2, 0) // 4     # exact for this (rows, shape)
         if self._tn_ws is None or self._tn_ws.numel() < need:
             if self._tn_ws is not None:
                 self._tn_retired.append(self._tn_ws)       # launch tapes recorded so far still point at it
@@ -1070,37 +903,33 @@ class VideoEngine:
             for k in ("region_norm.weight", "region_norm.bias"):
                 hip.zero_(grads[k])
 
-    def _attn_bwd(self, pl, kernel, qkv, o, lse, d_o, d_qkv):
-        """attention backward + the CLS-row finalize, per segment (each clip is a self-contained row range)"""
-        fin = {hip.attn_space_bwd: hip.attn_space_bwd_fin, hip.attn_time_bwd: hip.attn_time_bwd_fin}[kernel] if self.fused_finalize else None
-        if (fin is hip.attn_space_bwd_fin and len(pl.segs) == 2 and pl.segs[0].N == pl.segs[1].N and self.clip_launch):
-            hip.attn_space_bwd_clips([dict(qkv=sg.rows(qkv), out=sg.rows(o), lse=sg.rows(lse), dout=sg.rows(d_o), dqkv=sg.rows(d_qkv),
-                                           cls_side=sg.cls_side, done=sg.cls_done, B=sg.B, T=sg.T) for sg in pl.segs],
-                                     pl.segs[0].N, self.H, self.D, self.scale)
+    def _attn_bwd(self, pl, fin, qkv, o, lse, d_o, d_qkv):
+        """attention backward with the fused CLS-row finalize (fin = hip.attn_space_bwd_fin | hip.attn_time_bwd_fin: the last workgroup
+        per (sample, head) writes the CLS row), per segment - each clip is a self-contained row range; two clips of one geometry
+        share a launch"""
+        clips = lambda: [dict(qkv=sg.rows(qkv), out=sg.rows(o), lse=sg.rows(lse), dout=sg.rows(d_o), dqkv=sg.rows(d_qkv),
+                              cls_side=sg.cls_side, done=sg.cls_done, B=sg.B, T=sg.T) for sg in pl.segs]
+        two = len(pl.segs) == 2 and pl.segs[0].N == pl.segs[1].N
+        if fin is hip.attn_space_bwd_fin and two:
+            hip.attn_space_bwd_clips(clips(), pl.segs[0].N, self.H, self.D, self.scale)
             return
         pow2 = lambda t: 1 <= t <= 16 and t & (t - 1) == 0
-        if (fin is hip.attn_time_bwd_fin and len(pl.segs) == 2 and pl.segs[0].N == pl.segs[1].N and self.time_clip_launch
-                and pl.segs[0].T == 1 and pl.segs[1].T > 1 and pow2(pl.segs[1].T)):
+        if fin is hip.attn_time_bwd_fin and two and pl.segs[0].T == 1 and pl.segs[1].T > 1 and pow2(pl.segs[1].T):
             # the one-frame object clip (a 32 us launch on a fraction of the GPU) rides in the video clip's launch
-            hip.attn_time_bwd_clips([dict(qkv=sg.rows(qkv), out=sg.rows(o), lse=sg.rows(lse), dout=sg.rows(d_o), dqkv=sg.rows(d_qkv),
-                                          cls_side=sg.cls_side, done=sg.cls_done, B=sg.B, T=sg.T) for sg in pl.segs],
-                                    pl.segs[0].N, self.H, self.D, self.scale)
+            hip.attn_time_bwd_clips(clips(), pl.segs[0].N, self.H, self.D, self.scale)
             return
         for sg in pl.segs:
-            dq = sg.rows(d_qkv)
-            if fin is not None:      # one launch: the last workgroup per (sample, head) writes the CLS row (24 launches per step less)
-                fin(sg.rows(qkv), sg.rows(o), sg.rows(lse), sg.rows(d_o), dq, sg.cls_side, sg.cls_done, sg.B, sg.T, sg.N, self.H, self.D, self.scale)
-                continue
-            kernel(sg.rows(qkv), sg.rows(o), sg.rows(lse), sg.rows(d_o), dq, sg.cls_side, sg.B, sg.T, sg.N, self.H, self.D, self.scale)
-            hip.attn_cls_finalize(sg.cls_side, dq, sg.B, sg.T, sg.N, self.H, self.D)
+            fin(sg.rows(qkv), sg.rows(o), sg.rows(lse), sg.rows(d_o), sg.rows(d_qkv), sg.cls_side, sg.cls_done, sg.B, sg.T, sg.N, self.H,
+                self.D, self.scale)
 
     def _block_bwd(self, pl, i, run, params, grads, d_region):
         M = pl.M
-        D, Hd, H = self.D, self.Hd, self.H
+        D, Hd = self.D, self.Hd
         G = pl.G
         a = pl.blocks[i]
         st8 = pl.sets[i % 2]
         ga, ga_next = pl.ga[i % 3], pl.ga[(i - 1) % 3]     # dL/d(block output) bf16 ; written by this block's LN3 bwd
+        grid = pl.bwd_grid
         rl = run.region_layer
         if rl is not None and d_region is not None and i + 1 == rl:
             # region tokens branch off the output of block rl-1: add their gradient to the stream
@@ -1113,44 +942,36 @@ class VideoEngine:
                 hip.layernorm_bwd(d_region, a.out, pl.rstats[0], pl.rstats[1], params["region_norm.weight"],
                                   M, D, dx=G, dx16=ga, dres=G, dgamma=grads["region_norm.weight"],
                                   dbeta=grads["region_norm.bias"], accumulate=pl.acc)
-        x = pl.blocks[i - 1].out if i > 0 else pl.x0
-        p = lambda s: params[f"blocks.{i}.{s}"]
         gr = lambda s: grads[f"blocks.{i}.{s}"]
         wT = lambda s: self.shadow[f"blocks.{i}.{s}.weight"][1]
         st = a.stats
         d_h, gb, d_qkv_s, gc, d_qkv_t = st8["d_h"], st8["gb"], st8["d_qkv_s"], st8["gc"], st8["d_qkv_t"]
-        fold = self.fold_active()
 
-        def ln_bwd(norm, k, xin, xhat, dx16, **kw):
-            """backward of norm3 / norm1 / norm2 (stats rows 2k, 2k + 1): folded -> from the saved bf16 xhat and rstd.  Folded,
-            the fp32 stream G is only read by norm2 (its own dx stays bf16 in pl.dx2_16), untouched by norm1 (gc = its dx)
-            and read + written once by norm3, which adds the two bf16 increments: G_out = G_in + dx2 + dx1 + dx3."""
+        def ln_bwd(norm, k, xhat, dx16):
+            """backward of norm3 / norm1 / norm2 (rstd = stats row 2k + 1) from the saved bf16 xhat.
+            bf16 gradient stream (res16): gb = dL/dy = ga + dx2 (the space branch's dY AND the stream), gc = dx1 alone, and the block's
+            outgoing gradient ga_next = gb + gc + dx3; block 0 also leaves the fp32 copy G the embedding reads.
+            fp32 gradient stream: G is read by norm2 (its own dx stays bf16 in pl.dx2_16), untouched by norm1 (gc = its dx) and read +
+            written once by norm3, which adds the two bf16 increments: G_out = G_in + dx2 + dx1 + dx3."""
             if pl.res16:
-                # bf16 gradient stream: gb = dL/dy = ga + dx2 (the space branch's dY AND the stream), gc = dx1 alone, and the
-                # block's outgoing gradient ga_next = gb + gc + dx3; block 0 also leaves the fp32 copy the embedding reads
                 if norm == "norm2":
                     hip.layernorm_bwd_xhat(pl.d_a, xhat, st[2 * k + 1], M, D, dx16=dx16, add_a=ga)
                 elif norm == "norm1":
                     hip.layernorm_bwd_xhat(pl.d_a, xhat, st[2 * k + 1], M, D, dx16=dx16)
                 else:
                     hip.layernorm_bwd_xhat(pl.d_a, xhat, st[2 * k + 1], M, D, dx=G if i == 0 else None, dx16=dx16, add_a=gb, add_b=gc)
-            elif fold and not self.fold_gstream:
-                hip.layernorm_bwd_xhat(pl.d_a, xhat, st[2 * k + 1], M, D, dx=G, dx16=dx16, dres=G, **kw)
-            elif fold and norm == "norm2":
+            elif norm == "norm2":
                 hip.layernorm_bwd_xhat(pl.d_a, xhat, st[2 * k + 1], M, D, dx16=dx16, dres=G, dxp16=pl.dx2_16)
-            elif fold and norm == "norm1":
+            elif norm == "norm1":
                 hip.layernorm_bwd_xhat(pl.d_a, xhat, st[2 * k + 1], M, D, dx16=dx16)
-            elif fold:
-                hip.layernorm_bwd_xhat(pl.d_a, xhat, st[2 * k + 1], M, D, dx=G, dx16=dx16, dres=G, add_a=pl.dx2_16, add_b=gc)
             else:
-                hip.layernorm_bwd(pl.d_a, xin, st[2 * k], st[2 * k + 1], p(norm + ".weight"), M, D, dx=G, dx16=dx16, dres=G,
-                                  dgamma=gr(norm + ".weight"), dbeta=gr(norm + ".bias"), accumulate=pl.acc, **kw)
+                hip.layernorm_bwd_xhat(pl.d_a, xhat, st[2 * k + 1], M, D, dx=G, dx16=dx16, dres=G, add_a=pl.dx2_16, add_b=gc)
 
         def wgrad_folded(P, Q, n1, n2, lin):
-            """weight gradient of a linear layer that may carry a folded LayerNorm: dW' (and db') then go to the gradient
-            buffers (in place; oat_ln_fold_grads finishes them at the block's end) or - when this backward ACCUMULATES into
-            gradients an earlier backward of the step already finished - to scratch buffers the fold kernel adds from."""
-            if fold and pl.acc:
+            """weight gradient of a linear layer that carries a folded LayerNorm: dW' (and db') go to the gradient buffers (in
+            place; oat_ln_fold_grads finishes them at the block's end) or - when this backward ACCUMULATES into gradients an
+            earlier backward of the step already finished - to scratch buffers the fold kernel adds from."""
+            if pl.acc:
                 if lin not in self._fold_tmp:
                     self._fold_tmp[lin] = (torch.empty(n1, n2, dtype=torch.float32, device=P.device),
                                            torch.empty(n1, dtype=torch.float32, device=P.device))
@@ -1161,41 +982,28 @@ class VideoEngine:
 
         # ---- MLP: out = y + fc2(gelu(fc1(LN2(y))))
         if pl.h_u8:
-            hip.gemm_nt(ga, wT("mlp.fc2"), M, Hd, D, hip.EPI_MUL_AUX | hip.EPI_U8, d_h, aux=a.h8)
+            hip.gemm_nt(ga, wT("mlp.fc2"), M, Hd, D, hip.EPI_MUL_AUX | hip.EPI_U8, d_h, aux=a.h8, grid=grid)
         else:
-            hip.gemm_nt(ga, wT("mlp.fc2"), M, Hd, D, hip.EPI_MUL_AUX, d_h, aux=a.h)
-        hip.gemm_nt(d_h, wT("mlp.fc1"), M, D, Hd, hip.EPI_BF16, pl.d_a)
-        s1 = self._slot(pl, lambda: ln_bwd("norm2", 2, a.y, a.a2, gb),                                          # G = dL/dy
-            [lambda: self._wgrad(ga, a.g, M, D, Hd, gr("mlp.fc2.weight"), gr("mlp.fc2.bias"), pl.acc, pl=pl)])
-        self._join(s1)
+            hip.gemm_nt(ga, wT("mlp.fc2"), M, Hd, D, hip.EPI_MUL_AUX, d_h, aux=a.h, grid=grid)
+        hip.gemm_nt(d_h, wT("mlp.fc1"), M, D, Hd, hip.EPI_BF16, pl.d_a, grid=grid)
+        ln_bwd("norm2", 2, a.a2, gb)                                                                 # gb = dL/dy
+        self._wgrad(ga, a.g, M, D, Hd, gr("mlp.fc2.weight"), gr("mlp.fc2.bias"), pl.acc, pl=pl)
         # ---- space attention: y = x + proj(attn(LN1(xt)))
-        hip.gemm_nt(gb, wT("attn.proj"), M, D, D, hip.EPI_BF16, pl.d_o)
-
-        def space_bwd():
-            self._attn_bwd(pl, hip.attn_space_bwd, a.qkv_s, a.o_s, a.lse_s, pl.d_o, d_qkv_s)
-        s2 = self._slot(pl, space_bwd,
-                        [lambda: wgrad_folded(d_h, a.a2, Hd, D, "mlp.fc1")])
-        self._join(s2)
-        hip.gemm_nt(d_qkv_s, wT("attn.qkv"), M, D, 3 * D, hip.EPI_BF16, pl.d_a)
-        # G <- dL/dy + dL/dxt (both reach x directly); gc <- dL/dxt alone (feeds the time branch)
-        s3 = self._slot(pl, lambda: ln_bwd("norm1", 1, a.xt, a.a1, gc, dx16_excl_res=True),
-            [lambda: wgrad_folded(d_qkv_s, a.a1, 3 * D, D, "attn.qkv")])
-        self._join(s3)
+        hip.gemm_nt(gb, wT("attn.proj"), M, D, D, hip.EPI_BF16, pl.d_o, grid=grid)
+        self._attn_bwd(pl, hip.attn_space_bwd_fin, a.qkv_s, a.o_s, a.lse_s, pl.d_o, d_qkv_s)
+        wgrad_folded(d_h, a.a2, Hd, D, "mlp.fc1")
+        hip.gemm_nt(d_qkv_s, wT("attn.qkv"), M, D, 3 * D, hip.EPI_BF16, pl.d_a, grid=grid)
+        ln_bwd("norm1", 1, a.a1, gc)                                                                 # gc = dL/dxt alone (feeds the time branch)
+        wgrad_folded(d_qkv_s, a.a1, 3 * D, D, "attn.qkv")
         # ---- time attention: xt = x + proj(attn(LN3(x)))
-        hip.gemm_nt(gc, wT("timeattn.proj"), M, D, D, hip.EPI_BF16, pl.d_o)
-
-        def time_bwd():
-            self._attn_bwd(pl, hip.attn_time_bwd, a.qkv_t, a.o_t, a.lse_t, pl.d_o, d_qkv_t)
-        s4 = self._slot(pl, time_bwd,
-                        [lambda: self._wgrad(gb, a.o_s, M, D, D, gr("attn.proj.weight"), gr("attn.proj.bias"), pl.acc, pl=pl),
-                         lambda: self._wgrad(gc, a.o_t, M, D, D, gr("timeattn.proj.weight"), gr("timeattn.proj.bias"), pl.acc, pl=pl)])
-        self._join(s4)
-        hip.gemm_nt(d_qkv_t, wT("timeattn.qkv"), M, D, 3 * D, hip.EPI_BF16, pl.d_a)
-        s5 = self._slot(pl, lambda: ln_bwd("norm3", 0, x, a.a3, ga_next),                                       # G = dL/dx
-            [lambda: wgrad_folded(d_qkv_t, a.a3, 3 * D, D, "timeattn.qkv")])
-        self._join(s5)
-        if fold:
-            pl.fold_pending = i            # finished after the block's weight gradients have run (_flush_wgrads)
+        hip.gemm_nt(gc, wT("timeattn.proj"), M, D, D, hip.EPI_BF16, pl.d_o, grid=grid)
+        self._attn_bwd(pl, hip.attn_time_bwd_fin, a.qkv_t, a.o_t, a.lse_t, pl.d_o, d_qkv_t)
+        self._wgrad(gb, a.o_s, M, D, D, gr("attn.proj.weight"), gr("attn.proj.bias"), pl.acc, pl=pl)
+        self._wgrad(gc, a.o_t, M, D, D, gr("timeattn.proj.weight"), gr("timeattn.proj.bias"), pl.acc, pl=pl)
+        hip.gemm_nt(d_qkv_t, wT("timeattn.qkv"), M, D, 3 * D, hip.EPI_BF16, pl.d_a, grid=grid)
+        ln_bwd("norm3", 0, a.a3, ga_next)                                                            # ga_next = dL/dx
+        wgrad_folded(d_qkv_t, a.a3, 3 * D, D, "timeattn.qkv")
+        pl.fold_pending = i            # dW' -> dW, dgamma, dbeta after the block's weight gradients have run (_flush_wgrads)
 
     def _top_block_bwd_pruned(self, pl, i, params, grads):
         """_block_bwd of the top block after a prune_top forward (bf16 streams, folded LayerNorms, in-order schedule).  The
@@ -1234,19 +1042,19 @@ class VideoEngine:
         d_o = pl.d_o_top
         for sg in segs:
             hip.gemm_nt(gb[sg.cls0:], wT("attn.proj"), sg.B, D, D, hip.EPI_BF16, d_o[sg.cls0:])
-        self._attn_bwd(pl, hip.attn_space_bwd, a.qkv_s, a.o_s, a.lse_s, d_o, d_qkv_s)
+        self._attn_bwd(pl, hip.attn_space_bwd_fin, a.qkv_s, a.o_s, a.lse_s, d_o, d_qkv_s)
         for k, sg in enumerate(segs):
             c0, Bc = sg.cls0, sg.B
             wgrad(d_h[c0:], a.a2[c0:], Bc, Hd, D, "mlp.fc1", True, False, more=k > 0)
             wgrad(gb[c0:], a.o_s[c0:], Bc, D, D, "attn.proj", False, False, more=k > 0)
-        hip.gemm_nt(d_qkv_s, wT("attn.qkv"), M, D, 3 * D, hip.EPI_BF16, pl.d_a)
+        hip.gemm_nt(d_qkv_s, wT("attn.qkv"), M, D, 3 * D, hip.EPI_BF16, pl.d_a, grid=pl.bwd_grid)
         hip.layernorm_bwd_xhat(pl.d_a, a.a1, st[3], M, D, dx16=gc)                                            # gc = dx1
         wgrad(d_qkv_s, a.a1, M, 3 * D, D, "attn.qkv", True, True)
         # ---- time attention: as in _block_bwd
-        hip.gemm_nt(gc, wT("timeattn.proj"), M, D, D, hip.EPI_BF16, pl.d_o)
-        self._attn_bwd(pl, hip.attn_time_bwd, a.qkv_t, a.o_t, a.lse_t, pl.d_o, d_qkv_t)
+        hip.gemm_nt(gc, wT("timeattn.proj"), M, D, D, hip.EPI_BF16, pl.d_o, grid=pl.bwd_grid)
+        self._attn_bwd(pl, hip.attn_time_bwd_fin, a.qkv_t, a.o_t, a.lse_t, pl.d_o, d_qkv_t)
         wgrad(gc, a.o_t, M, D, D, "timeattn.proj", False, True)
-        hip.gemm_nt(d_qkv_t, wT("timeattn.qkv"), M, D, 3 * D, hip.EPI_BF16, pl.d_a)
+        hip.gemm_nt(d_qkv_t, wT("timeattn.qkv"), M, D, 3 * D, hip.EPI_BF16, pl.d_a, grid=pl.bwd_grid)
         # ga_next = gb + gc + dx3: gb is zero on the patch rows (not stored there), present on the CLS rows
         for sg in segs:
             r0, c0, Bc = sg.row0, sg.cls0, sg.B
@@ -1256,54 +1064,6 @@ class VideoEngine:
                                    add_a=gb[c0:], add_b=gc[c0:])
         wgrad(d_qkv_t, a.a3, M, 3 * D, D, "timeattn.qkv", True, True)
         pl.fold_pending = i
-
-    def _block_bwd_f8(self, pl, i, run, params, grads, d_region):
-        """_block_bwd with the six data-gradient GEMMs on fp8 operands (dY e5m2, W^T e4m3; weight gradients stay bf16,
-        in order on the caller's stream).  Producers of dY write the e5m2 copy themselves once the site has a scale:
-        LayerNorm backward (gb, gc, the next block's ga), the fc2 data gradient's epilogue (d_h); the attention
-        backward outputs and the top block's ga take one quantisation pass."""
-        M = pl.M
-        D, Hd, H = self.D, self.Hd, self.H
-        a = pl.blocks[i]
-        st8 = pl.sets[i % 2]
-        ga, ga_next = pl.ga[i % 3], pl.ga[(i - 1) % 3]
-        ga8, ga8_next = pl.ga8[i % 3], pl.ga8[(i - 1) % 3]
-        rl = run.region_layer
-        if rl is not None and d_region is not None and i + 1 == rl:
-            hip.layernorm_bwd(d_region, a.out, pl.rstats[0], pl.rstats[1], params["region_norm.weight"],
-                              M, D, dx=pl.G, dx16=ga, dres=pl.G, dgamma=grads["region_norm.weight"],
-                              dbeta=grads["region_norm.bias"], accumulate=pl.acc)
-            pl.ga8_valid = None                    # ga changed: its e5m2 copy is stale
-        x = pl.blocks[i - 1].out if i > 0 else pl.x0
-        p = lambda s: params[f"blocks.{i}.{s}"]
-        gr = lambda s: grads[f"blocks.{i}.{s}"]
-        st = a.stats
-        d_h, gb, d_qkv_s, gc, d_qkv_t = st8["d_h"], st8["gb"], st8["d_qkv_s"], st8["gc"], st8["d_qkv_t"]
-        # ---- MLP
-        dh_q = self._dgrad_f8(pl, i, 5, ga, D, Hd, hip.EPI_MUL_AUX | (hip.EPI_U8 if pl.h_u8 else 0), d_h,
-                              aux=a.h8 if pl.h_u8 else a.h, quantised=pl.ga8_valid == i, dy8=ga8)
-        self._dgrad_f8(pl, i, 4, d_h, Hd, D, hip.EPI_BF16, pl.d_a, quantised=dh_q)
-        gb_q = self._ln_bwd(pl, i, 3, pl.d_a, a.y, st[4], st[5], p("norm2.weight"), gb, gr("norm2.weight"), gr("norm2.bias"))
-        self._wgrad(ga, a.g, M, D, Hd, gr("mlp.fc2.weight"), gr("mlp.fc2.bias"), pl.acc, pl=pl)
-        # ---- space attention
-        self._dgrad_f8(pl, i, 3, gb, D, D, hip.EPI_BF16, pl.d_o, quantised=gb_q)
-        self._attn_bwd(pl, hip.attn_space_bwd, a.qkv_s, a.o_s, a.lse_s, pl.d_o, d_qkv_s)
-        self._wgrad(d_h, a.a2, M, Hd, D, gr("mlp.fc1.weight"), gr("mlp.fc1.bias"), pl.acc, pl=pl)
-        self._dgrad_f8(pl, i, 2, d_qkv_s, 3 * D, D, hip.EPI_BF16, pl.d_a)
-        gc_q = self._ln_bwd(pl, i, 1, pl.d_a, a.xt, st[2], st[3], p("norm1.weight"), gc, gr("norm1.weight"), gr("norm1.bias"),
-                            dx16_excl_res=True)
-        self._wgrad(d_qkv_s, a.a1, M, 3 * D, D, gr("attn.qkv.weight"), gr("attn.qkv.bias"), pl.acc, pl=pl)
-        # ---- time attention
-        self._dgrad_f8(pl, i, 1, gc, D, D, hip.EPI_BF16, pl.d_o, quantised=gc_q)
-        self._attn_bwd(pl, hip.attn_time_bwd, a.qkv_t, a.o_t, a.lse_t, pl.d_o, d_qkv_t)
-        self._wgrad(gb, a.o_s, M, D, D, gr("attn.proj.weight"), gr("attn.proj.bias"), pl.acc, pl=pl)
-        self._wgrad(gc, a.o_t, M, D, D, gr("timeattn.proj.weight"), gr("timeattn.proj.bias"), pl.acc, pl=pl)
-        self._dgrad_f8(pl, i, 0, d_qkv_t, 3 * D, D, hip.EPI_BF16, pl.d_a)
-        # LayerNorm-3 backward writes dL/d(output of block i-1): the fc2 data gradient's operand of the NEXT block to run
-        nxt_q = self._ln_bwd(pl, i - 1, 5, pl.d_a, x, st[0], st[1], p("norm3.weight"), ga_next, gr("norm3.weight"),
-                             gr("norm3.bias"), dx8=ga8_next)
-        pl.ga8_valid = i - 1 if nxt_q else None
-        self._wgrad(d_qkv_t, a.a3, M, 3 * D, D, gr("timeattn.qkv.weight"), gr("timeattn.qkv.bias"), pl.acc, pl=pl)
 
     def _embed_bwd(self, pl, grads):
         """x0[patch] = cols @ Wp^T + b + pos[1+n] + temporal[f] ; x0[cls] = cls + pos[0]"""

@@ -8,7 +8,7 @@ from ..ops import hip
 
 import os
 
-HEAD_FUSED = os.environ.get("OAT_HEAD_FUSED", "1") != "0"     # projection heads / InfoNCE in their few-launch forms (0: the earlier many-launch path)
+HEAD_FUSED = True     # projection heads / InfoNCE in their few-launch forms (False, set by tests: the earlier many-launch path)
 
 
 def _round_up(x, m):

@@ -16,7 +16,7 @@ from .video_transformer import SpaceTimeTransformer
 VIT_INIT = "pretrained/jx_vit_base_p16_224-80ecf9dd.pth"
 # the text tower's kernels are enqueued first in forward, its autograd node is created last (DistilBertHIP.launch), so that
 # backward issues the text tower BEFORE the video tower; 0: node and kernels together (the earlier order, for A/B runs)
-TEXT_BWD_FIRST = os.environ.get("OAT_TEXT_BWD_FIRST", "1") != "0"
+TEXT_BWD_FIRST = True
 
 
 class BaseModel(nn.Module):
@@ -93,8 +93,8 @@ class FrozenInTime(BaseModel):
         # own HIP stream under the video tower; autograd replays each tower's backward on its forward stream
         main = torch.cuda.current_stream()
         if getattr(self, "_text_stream", None) is None:
-            self._text_stream = hip.side_stream("OAT_TEXT")
-        side = self._text_stream if os.environ.get("OAT_TEXT_STREAM", "1") != "0" else main     # 0: both towers on one stream (measurement)
+            self._text_stream = hip.side_stream("text")
+        side = self._text_stream
         side.wait_stream(main)           # the text stream starts after what is on `main` NOW (the optimiser step)
         # host enqueue order: the text tower first.  Its ~80 launches are queued in about a millisecond and then run
         # beneath the first blocks of the video tower; queued behind the video tower's ~450 launches they started only

@@ -48,7 +48,8 @@ def encode_object_and_video(model, v):
     # Both clips go through the encoder as two SEGMENTS of one launch sequence (engine/video.py): alone on the GPU the object
     # clip's GEMMs are 75-300 tiles wide and leave most CUs idle (it cost 14 ms for 12.5 % of the tokens; a second stream
     # beside the video clip did not help, 70.2 vs 69.8 ms), as extra rows of the video clip's launches it is nearly free.
-    if os.environ.get("OAT_OBJ_SEGMENTS", "1") != "0" and hasattr(model, "compute_videos"):
+    # (video_params['object_clip_segments'] = False: two encoder calls, the second backward accumulating into the first's gradients)
+    if model.video_params.get('object_clip_segments', True) and hasattr(model, "compute_videos"):
         (obj_emb, obj_region), (vid_emb, vid_region) = model.compute_videos([v[:, :1], v[:, 1:]])
         return obj_emb, obj_region, vid_emb, vid_region
     obj_emb, obj_region = model.compute_video(v[:, :1])
@@ -112,7 +113,7 @@ class FrozenInTime(BaseModel):
         # oa_model.FrozenInTime.forward); autograd replays each side's backward on the stream of its forward
         main = torch.cuda.current_stream()
         if getattr(self, "_text_stream", None) is None:
-            self._text_stream = hip.side_stream("OAT_TEXT")
+            self._text_stream = hip.side_stream("text")
         side = self._text_stream
         side.wait_stream(main)
         def text_side(t1=None, t2=None):

@@ -65,7 +65,7 @@ class FrozenInTime(BaseModel):
         # text side (DistilBERT pass, txt_proj_2 of the class-prompt embeddings) on its own stream beneath the video encoder
         main = torch.cuda.current_stream()
         if getattr(self, "_text_stream", None) is None:
-            self._text_stream = hip.side_stream("OAT_TEXT")
+            self._text_stream = hip.side_stream("text")
         side = self._text_stream
         side.wait_stream(main)
         early = TEXT_BWD_FIRST and torch.is_grad_enabled()       # kernels now, autograd node after the video side (DistilBertHIP.launch)

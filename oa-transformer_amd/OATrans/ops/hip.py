@@ -45,17 +45,6 @@ def lib():
         for name in declared_symbols():
             if not hasattr(_lib, name):
                 raise OatError(f"liboatrans_hip.so lacks symbol {name}")
-        if os.environ.get("OAT_GEMM_M224"):              # 0 never / 1 auto (default) / 2 always: 224-row tiles of the ping-pong gemm_nt
-            _lib.oat_gemm_set_m224(int(os.environ["OAT_GEMM_M224"]))
-        if os.environ.get("OAT_GEMM_BAND"):              # band-grouped tile walk of the ping-pong gemm_nt: 0 off / -1 auto / n column tiles per group
-            _lib.oat_gemm_set_band(int(os.environ["OAT_GEMM_BAND"]))
-        if os.environ.get("OAT_GEMM_VARIANT"):           # tuning hooks (see oat_gemm_set_variant / oat_gemm_tn_set_variant)
-            _lib.oat_gemm_set_variant(int(os.environ["OAT_GEMM_VARIANT"], 0))
-            _gemm_variant[0] = int(os.environ["OAT_GEMM_VARIANT"], 0)
-        if os.environ.get("OAT_SPACE_VARIANT"):          # oat_attn_space_set_variant: backward schedule of the space attention (see the header)
-            _lib.oat_attn_space_set_variant(int(os.environ["OAT_SPACE_VARIANT"], 0))
-        if os.environ.get("OAT_GEMM_TN_VARIANT"):
-            _lib.oat_gemm_tn_set_variant(int(os.environ["OAT_GEMM_TN_VARIANT"], 0))
     return _lib
 
 
@@ -84,39 +73,20 @@ EPI_BF16, EPI_F32, EPI_GELU_DUAL, EPI_DGELU, EPI_F32_BF16, EPI_GELU_GRAD, EPI_MU
 EPI_U8 = 0x100      # or-ed into EPI_GELU_GRAD / EPI_MUL_AUX: the saved GELU derivative is 8-bit fixed point (1 byte per element)
 
 
-def delay(nanoseconds):
-    _check(lib().oat_delay(int(nanoseconds), _stream()), "oat_delay")
+# Launch policy of oat_gemm_nt / oat_gemm_tn is PER CALL (the `tune` / `grid` arguments; the library keeps no tuning state):
+GEMM_AUTO, GEMM_128, GEMM_LOCKSTEP, GEMM_PINGPONG = 0, 1, 2, 4        # tune bits 0-7: kernel choice
+GRID_PER_TILE = 0xffff                                                # grid: one workgroup per tile (0 = one per CU, else the count)
 
 
-_tile_counters = {}
-_DYNAMIC_TILES = os.environ.get("OAT_GEMM_DYNAMIC", "0") == "1"     # opt-in: slower on an idle GPU (see gemm_nt.hip)
-
-
-def _ensure_tile_counters(device):
-    """32 KiB of zeroed device ints for the dynamic tile scheduler of persistent gemm_nt launches (caller-owned)."""
-    key = str(device)
-    if key not in _tile_counters:
-        buf = torch.zeros(8192, dtype=torch.int32, device=device)
-        _check(lib().oat_gemm_set_tile_counters(_ptr(buf), ctypes.c_size_t(buf.numel() * 4)), "oat_gemm_set_tile_counters")
-        _tile_counters[key] = buf
-
-
-_splitk_ws = {}
-
-
-def enable_splitk(device, on=True):
-    """Register (or drop) the split-K workspace of the ping-pong gemm_nt: the last, less-than-half-full round of tiles of a
-    persistent launch is shared among the idle workgroups (oat_gemm_set_splitk_workspace).  One process drives one GPU."""
-    if not on:
-        _check(lib().oat_gemm_set_splitk_workspace(ctypes.c_void_p(0), ctypes.c_size_t(0), ctypes.c_void_p(0)), "oat_gemm_set_splitk_workspace")
-        _splitk_ws.clear()
-        return
-    key = str(device)
-    if key not in _splitk_ws:
-        ws = torch.empty(128 << 20, dtype=torch.uint8, device=device)
-        ctr = torch.zeros(256, dtype=torch.int32, device=device)
-        _check(lib().oat_gemm_set_splitk_workspace(_ptr(ws), ctypes.c_size_t(ws.numel()), _ptr(ctr)), "oat_gemm_set_splitk_workspace")
-        _splitk_ws[key] = (ws, ctr)
+def gemm_tune(kernel=GEMM_AUTO, m224=None, band=None):
+    """`tune` word of gemm_nt.  m224: None auto / 0 never / 2 always 224-row tiles of the ping-pong kernel; band: None auto /
+    0 off / n column tiles per group of its band-grouped tile walk.  Every choice is bit-identical (tests/test_kernels_gpu.py)."""
+    t = int(kernel)
+    if m224 is not None:
+        t |= {0: 1, 1: 0, 2: 2}[int(m224)] << 16
+    if band is not None:
+        t |= (0 if int(band) < 0 else int(band) + 1) << 18
+    return t
 
 
 def hu8_unblock(d8, N):
@@ -129,37 +99,15 @@ def hu8_unblock(d8, N):
 
 
 def gemm_nt(A, B, M, N, K, epi, out, out2=None, bias=None, resid=None, resid_mod=0, aux=None,
-            lda=None, ldb=None, ldc=None, ld2=None, ldr=None, ldaux=None):
-    """out[M,N] = A[M,K] @ B[N,K]^T (+epilogue).  Tensors may hold more rows than M."""
-    if M >= 4096 and _DYNAMIC_TILES:
-        _ensure_tile_counters(A.device)
+            lda=None, ldb=None, ldc=None, ld2=None, ldr=None, ldaux=None, tune=0, grid=0):
+    """out[M,N] = A[M,K] @ B[N,K]^T (+epilogue).  Tensors may hold more rows than M.  tune / grid: per-call launch policy
+    (gemm_tune, GRID_PER_TILE; 0 = the shipped choice)."""
     rc = lib().oat_gemm_nt(_ptr(A), _ptr(B), M, N, K, lda or A.stride(0), ldb or B.stride(0), epi,
                            _ptr(out), ldc or out.stride(0), _ptr(out2),
                            (ld2 or (out2.stride(0) if out2 is not None else 0)), _ptr(bias), _ptr(resid),
                            (ldr or (resid.stride(0) if resid is not None else 0)), resid_mod, _ptr(aux),
-                           (ldaux or (aux.stride(0) if aux is not None else 0)), _stream())
+                           (ldaux or (aux.stride(0) if aux is not None else 0)), int(tune), int(grid), _stream())
     _check(rc, "oat_gemm_nt")
-
-
-_gemm_variant = [0]
-
-
-def gemm_set_variant(v):
-    _gemm_variant[0] = int(v)
-    lib().oat_gemm_set_variant(int(v))
-
-
-def gemm_get_variant():
-    """last value passed to gemm_set_variant (the library keeps no getter)"""
-    return _gemm_variant[0]
-
-
-def gemm_set_tail_split(on):
-    lib().oat_gemm_set_tail_split(int(bool(on)))
-
-
-def gemm_tn_set_variant(v):
-    lib().oat_gemm_tn_set_variant(int(v))
 
 
 _tn_ws = {}
@@ -170,8 +118,8 @@ def _stream_key(device):
     return (str(device), torch.cuda.current_stream().cuda_stream)
 
 
-def tn_workspace(device, M, N1, N2):
-    need = lib().oat_gemm_tn_workspace_bytes(M, N1, N2)
+def tn_workspace(device, M, N1, N2, tune=0):
+    need = lib().oat_gemm_tn_workspace_bytes(M, N1, N2, int(tune))
     key = _stream_key(device)
     ws = _tn_ws.get(key)
     if ws is None or ws.numel() * 4 < need:
@@ -182,14 +130,14 @@ def tn_workspace(device, M, N1, N2):
     return ws
 
 
-def gemm_tn(P, Q, M, N1, N2, out, accumulate=False, ldp=None, ldq=None, bias_out=None, ws=None):
+def gemm_tn(P, Q, M, N1, N2, out, accumulate=False, ldp=None, ldq=None, bias_out=None, ws=None, tune=0):
     """out[N1,N2] (+)= P[:M,:N1]^T @ Q[:M,:N2]  (weight gradient); bias_out[N1] (+)= colsum(P).
     `ws`: caller-owned fp32 slab workspace (a launch stream needs its own; default = a per-device one
-    for the current stream)."""
+    for the current stream).  tune: tile choice of this call (GEMM_AUTO / GEMM_128 / GEMM_LOCKSTEP / GEMM_PINGPONG)."""
     if ws is None:
-        ws = tn_workspace(out.device, M, N1, N2)
+        ws = tn_workspace(out.device, M, N1, N2, tune)
     rc = lib().oat_gemm_tn(_ptr(P), _ptr(Q), M, N1, N2, ldp or P.stride(0), ldq or Q.stride(0), _ptr(out),
-                           _ptr(bias_out), int(accumulate), _ptr(ws), ctypes.c_size_t(ws.numel() * 4), _stream())
+                           _ptr(bias_out), int(accumulate), _ptr(ws), ctypes.c_size_t(ws.numel() * 4), int(tune), _stream())
     _check(rc, "oat_gemm_tn")
 
 
@@ -717,47 +665,20 @@ def tape_free(tid):
     lib().oat_tape_free(tid)
 
 
-_masked_streams = {}
 _side_streams = {}
 
 
-def masked_stream(n_cus, device=None):
-    """A HIP stream whose kernels run on `n_cus` CUs only (hipExtStreamCreateWithCUMask, mask bits 0 .. n_cus - 1; measured on
-    MI355X with a bandwidth-bound kernel: 16 bits -> 1/16 of the machine, scripts/dev/cu_mask_probe.py), wrapped for torch.
-    The side towers run on such a stream so that their workgroups never sit on a CU a persistent GEMM workgroup of the
-    main stream is waiting for.  One stream per (device, n_cus), kept for the life of the process."""
-    dev = torch.cuda.current_device() if device is None else torch.device(device).index
-    key = (dev, int(n_cus))
-    if key not in _masked_streams:
-        rt = ctypes.CDLL("libamdhip64.so")
-        rt.hipExtStreamCreateWithCUMask.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
-        total = torch.cuda.get_device_properties(dev).multi_processor_count
-        words = [0] * ((total + 31) // 32)
-        for b in range(min(int(n_cus), total)):
-            words[b // 32] |= 1 << (b % 32)
-        h = ctypes.c_void_p()
-        with torch.cuda.device(dev):
-            rc = rt.hipExtStreamCreateWithCUMask(ctypes.byref(h), len(words), (ctypes.c_uint32 * len(words))(*words))
-        if rc != 0:
-            raise OatError(f"hipExtStreamCreateWithCUMask failed ({rc})")
-        _masked_streams[key] = torch.cuda.ExternalStream(h.value, device=dev)
-    return _masked_streams[key]
-
-
 def side_stream(prefix, device=None):
-    """The stream of a side tower (`prefix` = OAT_TEXT: the text tower; OAT_LANE: the CLS lane + CLS-query attention).
-    Tuning knobs: <prefix>_PRIO = HIP stream priority (default 0), <prefix>_CUS = n > 0: a CU-masked stream of n CUs."""
-    cus = int(os.environ.get(prefix + "_CUS", "0"))
-    if cus > 0:
-        return masked_stream(cus, device)
+    """The stream of a side tower (`prefix` = "text": the text tower; "lane": the CLS lane + CLS-query attention).  (CU-masked side
+    streams and stream priorities were measured in round 4 - 58-63 ms per step on 16 / 32 CUs, priorities equal - and are gone.)"""
     # ONE stream per (role, device) for the whole process: HIP multiplexes streams onto a handful of hardware queues
     # (GPU_MAX_HW_QUEUES, 4 by default) and two streams that share a queue run in enqueue order - a second model built in the
     # same process (bench.py's `other_configs`, validation models) used to get fresh streams that landed on the queue of its
     # own main stream: global_local measured 575 pairs/s inside bench.py against 603 alone
     dev = torch.cuda.current_device() if device is None else torch.device(device).index
-    key = (prefix, dev, int(os.environ.get(prefix + "_PRIO", "0")))
+    key = (prefix, dev)
     if key not in _side_streams:
-        _side_streams[key] = torch.cuda.Stream(device=dev, priority=key[2])
+        _side_streams[key] = torch.cuda.Stream(device=dev)
     return _side_streams[key]
 
 
@@ -785,17 +706,17 @@ def copy_(dst, src):
 
 
 # ---- fp8 (OCP e4m3fn) forward GEMMs ------------------------------------------------------------------------------
-def fp8_quant(x, out8, M, K, qscale, amax=None, e5m2=False):
+def fp8_quant(x, out8, M, K, qscale, amax=None):
     _check(lib().oat_fp8_quant(_ptr(x), int(x.dtype == torch.bfloat16), x.stride(0), _ptr(out8), out8.stride(0), M, K,
-                               _ptr(qscale), _ptr(amax), int(e5m2), _stream()), "oat_fp8_quant")
+                               _ptr(qscale), _ptr(amax), _stream()), "oat_fp8_quant")
 
 
 def fp8_amax(x, M, K, amax):
     _check(lib().oat_fp8_amax(_ptr(x), int(x.dtype == torch.bfloat16), x.stride(0), M, K, _ptr(amax), _stream()), "oat_fp8_amax")
 
 
-def fp8_update_scales(amax, qscale, dq, n, margin=1.0, e5m2=False):
-    _check(lib().oat_fp8_update_scales(_ptr(amax), _ptr(qscale), _ptr(dq), n, _f(margin), int(e5m2), _stream()), "oat_fp8_update_scales")
+def fp8_update_scales(amax, qscale, dq, n, margin=1.0):
+    _check(lib().oat_fp8_update_scales(_ptr(amax), _ptr(qscale), _ptr(dq), n, _f(margin), _stream()), "oat_fp8_update_scales")
 
 
 class Fp8Table:
@@ -821,25 +742,11 @@ class Fp8Table:
                                    _stream()), "oat_fp8_multi")
 
 
-def gemm_nt_f8(A8, B8, M, N, K, epi, out, dq_a, dq_b, out2=None, bias=None, out8=None, q_out=None, amax_out=None,
-               a_e5m2=False, aux=None):
+def gemm_nt_f8(A8, B8, M, N, K, epi, out, dq_a, dq_b, out2=None, bias=None, out8=None, q_out=None, amax_out=None):
     s0 = lambda t: t.stride(0) if t is not None else 0
     _check(lib().oat_gemm_nt_f8(_ptr(A8), _ptr(B8), M, N, K, A8.stride(0), B8.stride(0), int(epi), _ptr(out), out.stride(0),
-                                _ptr(out2), s0(out2), _ptr(bias), _ptr(dq_a), _ptr(dq_b), int(a_e5m2), _ptr(aux), s0(aux),
+                                _ptr(out2), s0(out2), _ptr(bias), _ptr(dq_a), _ptr(dq_b),
                                 _ptr(out8), s0(out8), _ptr(q_out), _ptr(amax_out), _stream()), "oat_gemm_nt_f8")
-
-
-def layernorm_bwd_f8(dy, x, mean, rstd, gamma, M, D, dx8, qscale, amax, dx=None, dx16=None, dres=None, dgamma=None, dbeta=None,
-                     accumulate=False, dx16_excl_res=False):
-    """layernorm_bwd that also writes dx16 as e5m2 (dx8) with the site's delayed scale."""
-    part = None
-    if dgamma is not None or dbeta is not None:
-        part = _partials(x.device, lib().oat_ln_bwd_blocks(M) * 2 * D)
-    s0 = lambda t: t.stride(0) if t is not None else 0
-    _check(lib().oat_layernorm_bwd_f8(_ptr(dy), int(dy.dtype == torch.bfloat16), dy.stride(0), _ptr(x), x.stride(0), _ptr(mean),
-                                      _ptr(rstd), _ptr(gamma), _ptr(dres), s0(dres), _ptr(dx), s0(dx), _ptr(dx16), s0(dx16),
-                                      int(dx16_excl_res), _ptr(dgamma), _ptr(dbeta), int(accumulate), _ptr(part), M, D,
-                                      _ptr(dx8), dx8.stride(0), _ptr(qscale), _ptr(amax), _stream()), "oat_layernorm_bwd_f8")
 
 
 def layernorm_fwd_f8(x, gamma, beta, M, D, eps, y, y8, qscale, amax, mean, rstd, add16=None, sum32=None):

@@ -743,12 +743,8 @@ static SpaceArgs2 one_clip(const SpaceArgs& a, int blocks) { return SpaceArgs2{{
 static SpaceArgs2 two_clips(const SpaceArgs& a, const SpaceArgs& b) { return SpaceArgs2{{a, b}, a.B * a.T * a.H, 2}; }
 // the clip count is carried explicitly (two clips may share a qkv base pointer)
 static int space_blocks(const SpaceArgs2& aa) { return aa.n0 + (aa.nclips == 2 ? aa.s[1].B * aa.s[1].T * aa.s[1].H : 0); }
-static int g_space_nfix = 1;       // 1 (default): frames of 196 patches run the compile-time-N kernels; OAT_SPACE_NFIX=0: run-time N everywhere
-static bool space_nfix(const SpaceArgs2& aa, int n) {
-  static bool env = false;
-  if (!env) { const char* e = getenv("OAT_SPACE_NFIX"); if (e) g_space_nfix = atoi(e); env = true; }
-  return g_space_nfix && aa.s[0].N == n && (aa.nclips < 2 || aa.s[1].N == n);
-}
+// frames of 196 / 441 patches (224^2 / 336^2) run the compile-time-N forward kernels (straight-line score pass, round 5)
+static bool space_nfix(const SpaceArgs2& aa, int n) { return aa.s[0].N == n && (aa.nclips < 2 || aa.s[1].N == n); }
 template <int NKT>
 static int launch_fwd(const SpaceArgs2& aa, hipStream_t s) {
   const int lds = 2 * NKT * 16 * 128 + (FWD_THREADS / 64) * SCR_BYTES;
@@ -777,9 +773,9 @@ static int launch_bwd(const SpaceArgs2& aa, hipStream_t s) {
   OAT_LAUNCH((attn_space_bwd_kernel<NKT, BIG, WIDE>), dim3(space_blocks(aa)), dim3(WIDE == 1 ? 1024 : BWD_THREADS), lds, s, aa);
   return check_launch("attn_space_bwd");
 }
-// tuning hook.  0 (default): 97..223 patches -> two 8-wave workgroups per CU on the two-tile layout, one tile per wave;
-// 224..447 patches -> 16 waves x one tile.  1 = 8 waves x tile pairs (the earlier kernel).  2 = 16 waves x one tile, four-tile layout.
-static int g_space_variant = 0;
+// 97..223 patches: two 8-wave workgroups per CU on the two-tile layout, one tile per wave; 224..447 patches: 16 waves x one tile.
+// (The 8-wave tile-pair kernel and the 16-wave four-tile layout of rounds 3-5 - measured slower, DESIGN section 4 - left the library
+// in round 6.)
 
 // time-attention backward through the MFMA kernel: one single-wave workgroup per (sample, group of 16 / T positions, head)
 template <int TT>
@@ -787,7 +783,7 @@ static int launch_time_bwd(const SpaceArgs& a, int blocks, int lds, hipStream_t 
   OAT_LAUNCH((attn_space_bwd_kernel<2, false, 3, true, TT>), dim3(blocks), dim3(64), lds, s, one_clip(a, blocks));
   return check_launch("attn_time_bwd_mfma");
 }
-int g_time_gpw = 4;        // position groups per workgroup (tuning: oat_attn_time_set_variant bits 8-15)
+constexpr int g_time_gpw = 4;        // position groups per workgroup
 int attn_time_bwd_mfma(const void* qkv, int ldqkv, const void* out, int ldo, const float* lse, const void* dout, int lddo,
                        void* dqkv, int lddqkv, float* cls_side, int B, int T, int N, int H, int D, float scale, hipStream_t s,
                        int* done) {
@@ -875,8 +871,8 @@ static int space_bwd2(const SpaceArgs2& aa, int N, int H, int D, void* stream) {
     case 2: return launch_bwd<2>(aa, s);
     case 4: return launch_bwd<4>(aa, s);
     case 8: return launch_bwd<8>(aa, s);
-    case 14: return g_space_variant == 1 ? launch_bwd<14>(aa, s) : g_space_variant == 2 ? launch_bwd<14, false, 1>(aa, s) : launch_bwd<14, true, 2>(aa, s);
-    default: return g_space_variant == 1 ? launch_bwd<28, true>(aa, s) : launch_bwd<28, true, 1>(aa, s);
+    case 14: return launch_bwd<14, true, 2>(aa, s);
+    default: return launch_bwd<28, true, 1>(aa, s);
   }
 }
 static int space_bwd(const void* qkv, int ldqkv, const void* out, int ldo, const float* lse, const void* dout, int lddo,
@@ -934,8 +930,6 @@ extern "C" int oat_attn_space_bwd_fin(const void* qkv, int ldqkv, const void* ou
   if (!done) { set_error("attn_space_bwd_fin: null ticket buffer"); return -4; }
   return space_bwd(qkv, ldqkv, out, ldo, lse, dout, lddo, dqkv, lddqkv, cls_side, done, B, T, N, H, D, scale, stream);
 }
-
-extern "C" int oat_attn_space_set_variant(int v) { g_space_variant = v; return 0; }
 
 extern "C" int oat_attn_cls_finalize(float* cls_side, void* dqkv, int lddqkv, int B, int T, int N, int H, int D,
                                      void* stream) {

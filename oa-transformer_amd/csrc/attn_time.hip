@@ -139,227 +139,8 @@ __global__ __launch_bounds__(256, 2) void attn_time_fwd_kernel(TimeArgs a) {
   }
 }
 
-// backward: queries i = 0..T (i = T is the CLS query, global LSE), keys j = 0..T (j = T = CLS key).
-// Two passes keep the live register set small (<= 9 packed rows + one accumulator set):
-//   pass A (query-major): dQ_i, and the per-query scalars (delta_i, lse_i)
-//   pass B (key-major)  : dK_j, dV_j   (scores are recomputed; loads hit L1/L2)
-template <int TT>
-__global__ __launch_bounds__(256) void attn_time_bwd_kernel(TimeArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int ng = (a.N + 7) / 8;
-  if (wid >= a.B * a.H * ng) return;
-  const int bh = wid / ng, b = bh / a.H, h = bh % a.H;
-  const int n = (wid % ng) * 8 + (lane >> 3);
-  const int pl = lane & 7;
-  const bool valid = n < a.N;
-  const int nn = valid ? n : a.N - 1;
-  const size_t cls_row = (size_t)a.B * a.T * a.N + b;
-  const int col = h * 64 + pl * 8;
-  const size_t row0 = (size_t)b * TT * a.N + nn;     // row of frame j = row0 + j * N
-  const float c2 = a.scale * T_LOG2E;
-  float* side = a.cls_side + ((size_t)b * a.H + h) * 192;
-  {
-    bf16x8 k[TT + 1], v[TT + 1];
-#pragma unroll
-    for (int j = 0; j <= TT; ++j) {
-      const size_t r = j < TT ? row0 + (size_t)j * a.N : cls_row;
-      k[j] = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + a.D + col);
-      v[j] = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + 2 * a.D + col);
-    }
-    // outer loop deliberately NOT unrolled: keeps the live set at k[], v[] + one query (occupancy)
-#pragma unroll 1
-    for (int i = 0; i <= TT; ++i) {
-      // opaque touch: stops the compiler hoisting the 144 bf16->fp32 conversions of k[], v[] out of
-      // this loop (that hoist alone costs 144 VGPRs and pins the kernel at one wave per SIMD)
-#pragma unroll
-      for (int j = 0; j <= TT; ++j) { asm volatile("" : "+v"(k[j])); asm volatile("" : "+v"(v[j])); }
-      const size_t r = i < TT ? row0 + (size_t)i * a.N : cls_row;
-      const bf16x8 q = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + col);
-      const bf16x8 go = *reinterpret_cast<const bf16x8*>(a.dout + r * a.lddo + col);
-      const bf16x8 oo = *reinterpret_cast<const bf16x8*>(a.out + r * a.ldo + col);
-      const float lse2 = a.lse[r * a.H + h] * T_LOG2E;
-      const float delta = red8(dot8(go, oo));
-      float dq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-      for (int j = 0; j <= TT; ++j) {
-        float p = exp2f(red8(dot8(q, k[j])) * c2 - lse2);
-        if (i == TT && j == TT && n != 0) p = 0.f;        // CLS->CLS pair is counted once (n == 0)
-        const float ds = p * (red8(dot8(go, v[j])) - delta) * a.scale;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) dq[e] += ds * bf2f(k[j][e]);
-      }
-      if (i < TT) {
-        if (valid) {
-          const bf16x8 ob = {f2bf(dq[0]), f2bf(dq[1]), f2bf(dq[2]), f2bf(dq[3]), f2bf(dq[4]), f2bf(dq[5]), f2bf(dq[6]), f2bf(dq[7])};
-          *reinterpret_cast<bf16x8*>(a.dqkv + r * a.lddqkv + col) = ob;
-        }
-      } else {
-        // CLS query: reduce the 8 problems of this wave (same b,h), then one atomic per slot
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float t = valid ? dq[e] : 0.f;
-          t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
-          if (lane < 8) atomicAdd(side + pl * 8 + e, t);
-        }
-      }
-    }
-  }
-  {
-    bf16x8 q[TT + 1], go[TT + 1];
-    float delta[TT + 1], lse2[TT + 1];
-#pragma unroll
-    for (int i = 0; i <= TT; ++i) {
-      const size_t r = i < TT ? row0 + (size_t)i * a.N : cls_row;
-      q[i] = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + col);
-      go[i] = *reinterpret_cast<const bf16x8*>(a.dout + r * a.lddo + col);
-      const bf16x8 oo = *reinterpret_cast<const bf16x8*>(a.out + r * a.ldo + col);
-      delta[i] = red8(dot8(go[i], oo));
-      lse2[i] = a.lse[r * a.H + h] * T_LOG2E;
-    }
-#pragma unroll 1
-    for (int j = 0; j <= TT; ++j) {
-#pragma unroll
-      for (int i = 0; i <= TT; ++i) { asm volatile("" : "+v"(q[i])); asm volatile("" : "+v"(go[i])); }
-      const size_t r = j < TT ? row0 + (size_t)j * a.N : cls_row;
-      const bf16x8 kk = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + a.D + col);
-      const bf16x8 vv = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + 2 * a.D + col);
-      float dk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-      for (int i = 0; i <= TT; ++i) {
-        float p = exp2f(red8(dot8(q[i], kk)) * c2 - lse2[i]);
-        if (i == TT && j == TT && n != 0) p = 0.f;
-        const float ds = p * (red8(dot8(go[i], vv)) - delta[i]) * a.scale;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { dk[e] += ds * bf2f(q[i][e]); dv[e] += p * bf2f(go[i][e]); }
-      }
-      if (j < TT) {
-        if (valid) {
-          const bf16x8 kb = {f2bf(dk[0]), f2bf(dk[1]), f2bf(dk[2]), f2bf(dk[3]), f2bf(dk[4]), f2bf(dk[5]), f2bf(dk[6]), f2bf(dk[7])};
-          const bf16x8 vb = {f2bf(dv[0]), f2bf(dv[1]), f2bf(dv[2]), f2bf(dv[3]), f2bf(dv[4]), f2bf(dv[5]), f2bf(dv[6]), f2bf(dv[7])};
-          *reinterpret_cast<bf16x8*>(a.dqkv + r * a.lddqkv + a.D + col) = kb;
-          *reinterpret_cast<bf16x8*>(a.dqkv + r * a.lddqkv + 2 * a.D + col) = vb;
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float tk = valid ? dk[e] : 0.f, tv = valid ? dv[e] : 0.f;
-          tk += __shfl_xor(tk, 8, 64); tk += __shfl_xor(tk, 16, 64); tk += __shfl_xor(tk, 32, 64);
-          tv += __shfl_xor(tv, 8, 64); tv += __shfl_xor(tv, 16, 64); tv += __shfl_xor(tv, 32, 64);
-          if (lane < 8) { atomicAdd(side + 64 + pl * 8 + e, tk); atomicAdd(side + 128 + pl * 8 + e, tv); }
-        }
-      }
-    }
-  }
-}
-
-// Single-read backward for T <= 8.  Same math as the two-pass kernel, but pass A parks every query row it
-// loads (q_i, dO_i as packed bf16, delta_i, lse_i) in a per-wave LDS slab and K, V stay in registers, so pass B
-// (key-major, inner query loop rolled, reading its own lane's slots back) touches HBM only to store dK / dV:
-// 620 MB per launch instead of 1073 MB (PMC), and the kernel is HBM-bound.  Every lane re-reads only what
-// its own wave wrote, in program order: no barrier.  p <= 1 always, so the raw v_exp_f32 (no denormal range
-// scaling) is exact enough and saves four VALU instructions per score.
-template <int TT>
-__global__ __launch_bounds__(256) void attn_time_bwd_lds_kernel(TimeArgs a) {
-  constexpr int R = TT + 1;
-  constexpr int WAVE_LDS = R * 64 * 16 * 2 + 8 * R * 2 * 4;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63;
-  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int ng = (a.N + 7) / 8;
-  if (wid >= a.B * a.H * ng) return;
-  char* base = smem + (threadIdx.x >> 6) * WAVE_LDS;
-  bf16x8* sq = reinterpret_cast<bf16x8*>(base);
-  bf16x8* sgo = sq + R * 64;
-  float* sdl = reinterpret_cast<float*>(sgo + R * 64) + (lane >> 3) * R * 2;     // [i][delta, lse2] of this problem
-  const int bh = wid / ng, b = bh / a.H, h = bh % a.H;
-  const int n = (wid % ng) * 8 + (lane >> 3);
-  const int pl = lane & 7;
-  const bool valid = n < a.N;
-  const int nn = valid ? n : a.N - 1;
-  const size_t cls_row = (size_t)a.B * a.T * a.N + b;
-  const int col = h * 64 + pl * 8;
-  const size_t row0 = (size_t)b * TT * a.N + nn;
-  const float c2 = a.scale * T_LOG2E;
-  float* side = a.cls_side + ((size_t)b * a.H + h) * 192;
-  bf16x8 k[R], v[R];
-#pragma unroll
-  for (int j = 0; j < R; ++j) {
-    const size_t r = j < TT ? row0 + (size_t)j * a.N : cls_row;
-    k[j] = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + a.D + col);
-    v[j] = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + 2 * a.D + col);
-  }
-  // ---- pass A: dQ_i; park q_i, dO_i, delta_i, lse_i
-#pragma unroll 1
-  for (int i = 0; i < R; ++i) {
-#pragma unroll
-    for (int j = 0; j < R; ++j) { asm volatile("" : "+v"(k[j])); asm volatile("" : "+v"(v[j])); }
-    const size_t r = i < TT ? row0 + (size_t)i * a.N : cls_row;
-    const bf16x8 q = *reinterpret_cast<const bf16x8*>(a.qkv + r * a.ldqkv + col);
-    const bf16x8 go = *reinterpret_cast<const bf16x8*>(a.dout + r * a.lddo + col);
-    const bf16x8 oo = *reinterpret_cast<const bf16x8*>(a.out + r * a.ldo + col);
-    const float lse2 = a.lse[r * a.H + h] * T_LOG2E;
-    const float delta = red8(dot8(go, oo));
-    sq[i * 64 + lane] = q;
-    sgo[i * 64 + lane] = go;
-    if (pl == 0) { sdl[i * 2] = delta; sdl[i * 2 + 1] = lse2; }
-    float dq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int j = 0; j < R; ++j) {
-      float p = __builtin_amdgcn_exp2f(red8(dot8(q, k[j])) * c2 - lse2);
-      if (i == TT && j == TT && n != 0) p = 0.f;        // CLS->CLS pair is counted once (n == 0)
-      const float ds = p * (red8(dot8(go, v[j])) - delta) * a.scale;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) dq[e] += ds * bf2f(k[j][e]);
-    }
-    if (i < TT) {
-      if (valid) {
-        const bf16x8 ob = {f2bf(dq[0]), f2bf(dq[1]), f2bf(dq[2]), f2bf(dq[3]), f2bf(dq[4]), f2bf(dq[5]), f2bf(dq[6]), f2bf(dq[7])};
-        *reinterpret_cast<bf16x8*>(a.dqkv + r * a.lddqkv + col) = ob;
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float t = valid ? dq[e] : 0.f;
-        t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
-        if (lane < 8) atomicAdd(side + pl * 8 + e, t);
-      }
-    }
-  }
-  // ---- pass B: dK_j, dV_j from registers (k, v) and LDS (queries)
-#pragma unroll
-  for (int j = 0; j < R; ++j) {
-    const bf16x8 kk = k[j], vv = v[j];
-    float dk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll 1
-    for (int i = 0; i < R; ++i) {
-      const bf16x8 q = sq[i * 64 + lane], go = sgo[i * 64 + lane];
-      const float delta = sdl[i * 2], lse2 = sdl[i * 2 + 1];
-      float p = __builtin_amdgcn_exp2f(red8(dot8(q, kk)) * c2 - lse2);
-      if (i == TT && j == TT && n != 0) p = 0.f;
-      const float ds = p * (red8(dot8(go, vv)) - delta) * a.scale;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { dk[e] += ds * bf2f(q[e]); dv[e] += p * bf2f(go[e]); }
-    }
-    const size_t r = j < TT ? row0 + (size_t)j * a.N : cls_row;
-    if (j < TT) {
-      if (valid) {
-        const bf16x8 kb = {f2bf(dk[0]), f2bf(dk[1]), f2bf(dk[2]), f2bf(dk[3]), f2bf(dk[4]), f2bf(dk[5]), f2bf(dk[6]), f2bf(dk[7])};
-        const bf16x8 vb = {f2bf(dv[0]), f2bf(dv[1]), f2bf(dv[2]), f2bf(dv[3]), f2bf(dv[4]), f2bf(dv[5]), f2bf(dv[6]), f2bf(dv[7])};
-        *reinterpret_cast<bf16x8*>(a.dqkv + r * a.lddqkv + a.D + col) = kb;
-        *reinterpret_cast<bf16x8*>(a.dqkv + r * a.lddqkv + 2 * a.D + col) = vb;
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float tk = valid ? dk[e] : 0.f, tv = valid ? dv[e] : 0.f;
-        tk += __shfl_xor(tk, 8, 64); tk += __shfl_xor(tk, 16, 64); tk += __shfl_xor(tk, 32, 64);
-        tv += __shfl_xor(tv, 8, 64); tv += __shfl_xor(tv, 16, 64); tv += __shfl_xor(tv, 32, 64);
-        if (lane < 8) { atomicAdd(side + 64 + pl * 8 + e, tk); atomicAdd(side + 128 + pl * 8 + e, tv); }
-      }
-    }
-  }
-}
+// backward: the MFMA kernel of attn_space.hip on 16-row mini problems (attn_time_bwd_mfma).  The 8-lane VALU backward kernels of rounds
+// 1-3 (two-pass and single-read-LDS forms: 219 - 269 us against 140 us for the MFMA form) left the library in round 6.
 
 // ---------------------------------------------------------------- CLS query over all keys
 // one workgroup per (b,h): 32 groups of 8 lanes stride over the 1 + T*N keys with an online
@@ -494,11 +275,6 @@ __global__ __launch_bounds__(256) void attn_cls_fwd_dual_kernel(TimeArgs a, cons
 
 using namespace oat;
 
-static int g_time_two_pass = 0;   // tuning hook: 1 = force the two-pass backward for every T
-// 0 = MFMA kernel (default, T <= 16), 1 = two-pass VALU kernel, 2 = VALU kernels as before (single-read LDS kernel for T <= 8)
-namespace oat { extern int g_time_gpw; }     // attn_space.hip: position groups per workgroup of the MFMA kernel (bits 8-15, 0 = keep)
-extern "C" void oat_attn_time_set_variant(int v) { g_time_two_pass = v & 0xff; if ((v >> 8) & 0xff) oat::g_time_gpw = (v >> 8) & 0xff; }
-
 #define OAT_TIME_DISPATCH(KERNEL)                                                                     \
   switch (T) {                                                                                        \
     case 1: OAT_LAUNCH(KERNEL<1>, dim3(blocks), dim3(256), 0, s, a); break;                   \
@@ -534,9 +310,8 @@ extern "C" int oat_attn_time_bwd(const void* qkv, int ldqkv, const void* out, in
                                  int N, int H, int D, float scale, void* stream) {
   return time_bwd(qkv, ldqkv, out, ldo, lse, dout, lddo, dqkv, lddqkv, cls_side, nullptr, B, T, N, H, D, scale, stream);
 }
-// As oat_attn_time_bwd followed by oat_attn_cls_finalize: one launch on the default (MFMA) kernel - the last workgroup
-// that feeds cls_side[b][h] writes the CLS row itself (`done` = int [B, H], zero on entry and on exit) - two launches on
-// the VALU tuning variants.
+// As oat_attn_time_bwd followed by oat_attn_cls_finalize in one launch - the last workgroup that feeds cls_side[b][h] writes
+// the CLS row itself (`done` = int [B, H], zero on entry and on exit).
 extern "C" int oat_attn_time_bwd_fin(const void* qkv, int ldqkv, const void* out, int ldo, const float* lse,
                                      const void* dout, int lddo, void* dqkv, int lddqkv, float* cls_side, int* done,
                                      int B, int T, int N, int H, int D, float scale, void* stream) {
@@ -547,31 +322,9 @@ static int time_bwd(const void* qkv, int ldqkv, const void* out, int ldo, const 
                     void* dqkv, int lddqkv, float* cls_side, int* done, int B, int T, int N, int H, int D, float scale,
                     void* stream) {
   if (D != H * 64) { set_error("attn_time: head_dim must be 64"); return -3; }
-  TimeArgs a{(const bf16*)qkv, ldqkv, (bf16*)out, ldo, (float*)lse, (const bf16*)dout, lddo, (bf16*)dqkv, lddqkv,
-             cls_side, B, T, N, H, D, scale};
   hipStream_t s = (hipStream_t)stream;
-  if (g_time_two_pass == 0 && T <= 16)        // default: the MFMA kernel of attn_space.hip on 16-row mini problems
-    return attn_time_bwd_mfma(qkv, ldqkv, out, ldo, lse, dout, lddo, dqkv, lddqkv, cls_side, B, T, N, H, D, scale, s, done);
-  const int waves = B * H * ((N + 7) / 8);
-  const int blocks = (waves + 3) / 4;
-  if (T <= 8 && g_time_two_pass != 1) {
-#define OAT_TIME_LDS(TT) \
-    case TT: { \
-      constexpr int LDS = 4 * ((TT + 1) * 64 * 32 + 8 * (TT + 1) * 8); \
-      OAT_MAX_LDS(attn_time_bwd_lds_kernel<TT>, LDS); \
-      OAT_LAUNCH(attn_time_bwd_lds_kernel<TT>, dim3(blocks), dim3(256), LDS, s, a); break; }
-    switch (T) {
-      OAT_TIME_LDS(1) OAT_TIME_LDS(2) OAT_TIME_LDS(3) OAT_TIME_LDS(4) OAT_TIME_LDS(5) OAT_TIME_LDS(6) OAT_TIME_LDS(7)
-      OAT_TIME_LDS(8)
-      default: set_error("attn_time: supported frame counts are 1-8, 12, 16"); return -3;
-    }
-#undef OAT_TIME_LDS
-    const int rc = check_launch("attn_time_bwd");
-    return rc == 0 && done ? oat_attn_cls_finalize(cls_side, dqkv, lddqkv, B, T, N, H, D, stream) : rc;
-  }
-  OAT_TIME_DISPATCH(attn_time_bwd_kernel)
-  const int rc = check_launch("attn_time_bwd");
-  return rc == 0 && done ? oat_attn_cls_finalize(cls_side, dqkv, lddqkv, B, T, N, H, D, stream) : rc;
+  if (T > 16) { set_error("attn_time: supported frame counts are 1-16 (backward), 1-8, 12, 16 (forward)"); return -3; }
+  return attn_time_bwd_mfma(qkv, ldqkv, out, ldo, lse, dout, lddo, dqkv, lddqkv, cls_side, B, T, N, H, D, scale, s, done);
 }
 
 extern "C" int oat_attn_cls_fwd(const void* qkv, int ldqkv, void* out, int ldo, float* lse, int B, int T, int N, int H,

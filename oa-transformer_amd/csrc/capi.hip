@@ -21,19 +21,5 @@ int check_launch(const char* what) {
 }
 }  // namespace oat
 
-namespace oat {
-// One wave that sleeps for `ticks` of the 100 MHz real-time counter: a stream-ordered delay (see oat_delay).
-__global__ void delay_kernel(int ticks) {
-  const unsigned long long t0 = wall_clock64();
-  while ((long long)(wall_clock64() - t0) < ticks) __builtin_amdgcn_s_sleep(8);
-}
-}  // namespace oat
-
-extern "C" int oat_delay(int nanoseconds, void* stream) {
-  if (nanoseconds <= 0) return 0;
-  OAT_LAUNCH(oat::delay_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (nanoseconds + 9) / 10);
-  return oat::check_launch("delay");
-}
-
 extern "C" const char* oat_last_error(void) { return oat::g_err; }
-extern "C" int oat_abi_version(void) { return 1; }
+extern "C" int oat_abi_version(void) { return 2; }   // 2 (round 6): per-call `tune` / `grid` arguments, no oat_*_set_* entry points

@@ -93,7 +93,7 @@ __global__ void fp8_update_scales_kernel(float* amax, float* qscale, float* dq, 
 using namespace oat;
 
 extern "C" int oat_fp8_quant(const void* x, int is_bf16, int ldx, void* out8, int ld8, int M, int K, const float* qscale,
-                             float* amax, int e5m2, void* stream) {
+                             float* amax, void* stream) {
   if (M <= 0 || K <= 0) return 0;
   if (!x || !out8 || !qscale) { set_error("fp8_quant: null pointer"); return -4; }
   if (K % 8 || ldx % 8 || ld8 % 8) { set_error("fp8_quant: K, ldx, ld8 must be multiples of 8"); return -3; }
@@ -101,9 +101,7 @@ extern "C" int oat_fp8_quant(const void* x, int is_bf16, int ldx, void* out8, in
   const int grid = (int)((quads + 255) / 256 < 2048 ? (quads + 255) / 256 : 2048);
   hipStream_t s = (hipStream_t)stream;
   uint8_t* o = (uint8_t*)out8;
-  if (is_bf16 && e5m2) OAT_LAUNCH((fp8_quant_kernel<true, true, true>), dim3(grid), dim3(256), 0, s, x, ldx, o, ld8, M, K, qscale, amax);
-  else if (is_bf16) OAT_LAUNCH((fp8_quant_kernel<true, true, false>), dim3(grid), dim3(256), 0, s, x, ldx, o, ld8, M, K, qscale, amax);
-  else if (e5m2) OAT_LAUNCH((fp8_quant_kernel<false, true, true>), dim3(grid), dim3(256), 0, s, x, ldx, o, ld8, M, K, qscale, amax);
+  if (is_bf16) OAT_LAUNCH((fp8_quant_kernel<true, true, false>), dim3(grid), dim3(256), 0, s, x, ldx, o, ld8, M, K, qscale, amax);
   else OAT_LAUNCH((fp8_quant_kernel<false, true, false>), dim3(grid), dim3(256), 0, s, x, ldx, o, ld8, M, K, qscale, amax);
   return check_launch("fp8_quant");
 }
@@ -127,36 +125,35 @@ extern "C" int oat_fp8_multi(const void* desc, const int* owner, int total_block
   else OAT_LAUNCH((fp8_multi_kernel<false>), dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, (const F8Desc*)desc, owner, qscale, amax);
   return check_launch("fp8_multi");
 }
-// e5m2 != 0: the sites hold gradients quantised to e5m2 (largest finite 57344) instead of e4m3 (448)
-extern "C" int oat_fp8_update_scales(float* amax, float* qscale, float* dq, int n, float margin, int e5m2, void* stream) {
+extern "C" int oat_fp8_update_scales(float* amax, float* qscale, float* dq, int n, float margin, void* stream) {
   if (n <= 0) return 0;
   if (!amax || !qscale || !dq) { set_error("fp8_update_scales: null pointer"); return -4; }
   if (!(margin >= 1.f)) { set_error("fp8_update_scales: margin must be >= 1"); return -3; }
   OAT_LAUNCH(fp8_update_scales_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, amax, qscale, dq, n, margin,
-             e5m2 ? BF8_MAX : F8_MAX);
+             F8_MAX);
   return check_launch("fp8_update_scales");
 }
 
 // C[M, N] = dq_a dq_b (A8[M, K] . B8[N, K]^T) + bias with the bf16-output epilogues of oat_gemm_nt (EPI_BF16 = 0,
 // EPI_GELU_GRAD = 5).  A8 / B8: OCP e4m3 bytes, lda / ldb in elements.  K % 256 == 0, N % 256 == 0, N <= 4096, M >= 256.
-// a_e5m2: A8 holds e5m2 bytes (gradients), B8 always e4m3.  epi: EPI_BF16, EPI_GELU_GRAD (out = gelu'(h), out2 = gelu(h)) or
-// EPI_MUL_AUX (out = (acc + bias) * aux).  out8 (optional): fp8 copy for the NEXT GEMM, quantised with *q_out, its amax
-// recorded in *amax_out - of out2 as e4m3 (EPI_GELU_GRAD) or of out as e5m2 (EPI_MUL_AUX).
+// epi: EPI_BF16 or EPI_GELU_GRAD (out = gelu'(h), out2 = gelu(h)).  out8 (optional, EPI_GELU_GRAD): e4m3 copy of out2 for the NEXT
+// GEMM, quantised with *q_out, its amax recorded in *amax_out.  (The e5m2-operand form and the EPI_MUL_AUX epilogue of the fp8
+// data-gradient mode of rounds 2-5 left the library in round 6 with that mode.)
 extern "C" int oat_gemm_nt_f8(const void* A8, const void* B8, int M, int N, int K, int lda, int ldb, int epi, void* out, int ldc,
-                              void* out2, int ld2, const float* bias, const float* dq_a, const float* dq_b, int a_e5m2,
-                              const void* aux, int ldaux, void* out8, int ld8, const float* q_out, float* amax_out, void* stream) {
+                              void* out2, int ld2, const float* bias, const float* dq_a, const float* dq_b,
+                              void* out8, int ld8, const float* q_out, float* amax_out, void* stream) {
   const int h_u8 = (epi >> 8) & 1;          // epi | 0x100: 8-bit GELU derivative (as in oat_gemm_nt)
   epi &= 0xff;
-  if (out8 && ((epi != EPI_GELU_GRAD && epi != EPI_MUL_AUX) || !q_out || !amax_out || ld8 % 4)) { set_error("gemm_nt_f8: out8 needs EPI_GELU_GRAD / EPI_MUL_AUX, q_out, amax_out, ld8 % 4 == 0"); return -4; }
-  if (epi == EPI_MUL_AUX && !aux) { set_error("gemm_nt_f8: EPI_MUL_AUX needs aux"); return -4; }
+  if (epi != EPI_BF16 && epi != EPI_GELU_GRAD) { set_error("gemm_nt_f8: EPI_BF16 or EPI_GELU_GRAD"); return -3; }
+  if (out8 && (epi != EPI_GELU_GRAD || !q_out || !amax_out || ld8 % 4)) { set_error("gemm_nt_f8: out8 needs EPI_GELU_GRAD, q_out, amax_out, ld8 % 4 == 0"); return -4; }
   if (M <= 0 || N <= 0 || K <= 0) { set_error("gemm_nt_f8: empty problem"); return -1; }
   if (!A8 || !B8 || !out || !dq_a || !dq_b) { set_error("gemm_nt_f8: null pointer"); return -4; }
   if (epi == EPI_GELU_GRAD && !out2) { set_error("gemm_nt_f8: EPI_GELU_GRAD needs out2"); return -4; }
   if (ldc % 8 != 0) { set_error("gemm_nt_f8: ldc must be a multiple of 8"); return -3; }
-  if (h_u8 && (epi == EPI_GELU_GRAD || epi == EPI_MUL_AUX) && (epi == EPI_GELU_GRAD ? ldc : ldaux) != N) {
+  if (h_u8 && epi == EPI_GELU_GRAD && ldc != N) {
     set_error("gemm_nt_f8: the 8-bit GELU derivative is a dense blocked tensor (ld == N)"); return -3;
   }
-  GemmArgs g{(const bf16*)A8, (const bf16*)B8, M, N, K, lda, ldb, out, ldc, out2, ld2, bias, nullptr, 0, 0, (const bf16*)aux, ldaux, 0, 0,
+  GemmArgs g{(const bf16*)A8, (const bf16*)B8, M, N, K, lda, ldb, out, ldc, out2, ld2, bias, nullptr, 0, 0, nullptr, 0, 0, 0,
              nullptr, nullptr, dq_a, dq_b, out8, ld8, q_out, amax_out, h_u8};
-  return launch_pp_f8(epi, g, 256, a_e5m2 != 0, (hipStream_t)stream);
+  return launch_pp_f8(epi, g, 256, (hipStream_t)stream);
 }

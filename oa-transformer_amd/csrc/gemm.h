@@ -25,8 +25,8 @@ struct GemmArgs {
   const bf16* aux; int ldaux;
   int dbg;
   int row0;            // first row of this launch inside the caller's problem (tail launches; used by resid_mod)
-  int* ctr;            // persistent launch: 8 per-XCD tile counters of THIS launch (zero on entry), or nullptr = static walk
-  int* ctr_reset;      // counters of a launch far in the future, zeroed by this one
+  int* ctr;            // always nullptr since round 6 (static tile walk; the dynamic, counter-driven walk of round 1 lost 5-15 %)
+  int* ctr_reset;
   const float* dq_a;   // fp8 launches: device scalars, dequantisation scale of A and of B (value = quantised * dq)
   const float* dq_b;
   void* out8; int ld8;     // fp8 launches: optional copy for the next GEMM - e4m3 of out2 (EPI_GELU_GRAD) / e5m2 of out (EPI_MUL_AUX) ...
@@ -34,7 +34,7 @@ struct GemmArgs {
   float* amax_out;         // ... its max |value| recorded here
   int h_u8;                // the GELU-derivative tensor (out of EPI_GELU_GRAD / aux of EPI_MUL_AUX) is 8-bit fixed point,
                            // one byte per element, ldc / ldaux in bytes (ping-pong kernel only; gemm_nt_pp.hip HU8_*)
-  float* sk_ws; int* sk_ctr;   // split-K of the last round (gemm_nt_pp.hip): partial-tile workspace, zeroed per-tile counters
+  float* sk_ws; int* sk_ctr;   // always nullptr since round 6 (split-K of the last round: measured equal, left the library)
   int band;                    // ping-pong kernel, PPF_BAND: column tiles per band group of the per-XCD tile walk (0 = row-major walk)
 };
 
@@ -55,12 +55,17 @@ struct TnArgs {
 int launch_tn_pp(const TnArgs& g, int flags, hipStream_t s);
 
 // gemm_nt_pp.hip.  pp_supported: does the ping-pong kernel cover this launch (epilogue, shape)?
+// Per-call tuning of oat_gemm_nt (decoded from its `tune` / `grid` arguments): nothing of it lives in the library between calls.
+struct GemmTune {
+  int variant = 0;   // 0 auto, 1 force 128x128 tiles, 2 force the lockstep 256x256 kernel, 4 force the ping-pong kernel where it applies
+  int grid = 0;      // persistent workgroups: 0 = one per CU, 0xffff = one workgroup per tile, else the count
+  int m224 = 1;      // 224-row tiles of the ping-pong kernel: 0 never, 1 where they save a round's worth (default), 2 always
+  int band = -1;     // band-grouped tile walk of the ping-pong kernel (PPF_BAND): column tiles per group, 0 = off, -1 = auto
+};
 bool pp_supported(int epi, const GemmArgs& g);
-int launch_pp(int epi, const GemmArgs& g, int grid_slots, int flags, hipStream_t s);
-void pp_set_m224(int mode);
-void pp_set_band(int tiles);     // band-grouped tile walk (gemm_nt_pp.hip PPF_BAND): column tiles per group, 0 = off, -1 = auto      // 224-row tiles of the ping-pong kernel: 0 never, 1 where they save a round's worth (default), 2 always
+int launch_pp(int epi, const GemmArgs& g, int grid_slots, const GemmTune& t, hipStream_t s);
 // the same kernel on OCP fp8 (e4m3) operands with per-tensor scales (GemmArgs::dq_a / dq_b)
 bool pp_f8_supported(int epi, const GemmArgs& g);
-int launch_pp_f8(int epi, const GemmArgs& g, int grid_slots, bool a_e5m2, hipStream_t s);
+int launch_pp_f8(int epi, const GemmArgs& g, int grid_slots, hipStream_t s);
 
 }  // namespace oat

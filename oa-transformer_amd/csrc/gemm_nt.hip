@@ -611,17 +611,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
   }   // tile loop
 }
 
-// tuning hook: variant 0 = auto, 1 = force 128x128, 2 = force the lockstep 256x256, 3 = 4-wave pipelined 256x256,
-// 4 = force the ping-pong 256x256 where supported (flag bits then toggle its PPF_* options);
-// persist 0 = one workgroup per CU, 0xffff = one workgroup per tile, else the grid size
-static int g_variant = 0, g_dbg = 0, g_persist = 0, g_tail = 0;
-constexpr unsigned CTR_SETS = 1024;           // counter sets in the caller's buffer (8 ints each); set s is zeroed by launch s - 512
-static int* g_ctr = nullptr;
-static float* g_sk_ws = nullptr;      // split-K workspace of the ping-pong kernel (oat_gemm_set_splitk_workspace)
-static int* g_sk_ctr = nullptr;
-static size_t g_sk_bytes = 0;
-static std::atomic<unsigned> g_seq{0};
-
 static int cu_count() {
   static int cus = 0;
   if (cus == 0) {
@@ -633,121 +622,64 @@ static int cu_count() {
   return cus;
 }
 
-template <int EPI, int WM, int WN, int TM, int TN, int NSA, bool SPREAD, bool PIPE = false>
-static int launch_cfg(const GemmArgs& g, hipStream_t s) {
+template <int EPI, int WM, int WN, int TM, int TN, int NSA, bool SPREAD>
+static int launch_cfg(const GemmArgs& g, const GemmTune& t, hipStream_t s) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
   constexpr int LDS = (NSA * BM + 2 * BN) * BK * 2;
   const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
-  OAT_MAX_LDS((gemm_nt_kernel<EPI, WM, WN, TM, TN, NSA, SPREAD, PIPE>), LDS);
+  OAT_MAX_LDS((gemm_nt_kernel<EPI, WM, WN, TM, TN, NSA, SPREAD, false>), LDS);
   int grid = ntm * ntn;
-  GemmArgs a = g;
-  if (BM == 256 && g_persist != 0xffff) {        // persistent: one workgroup per CU walks the tiles (+1.8 % per step)
-    const int slots = g_persist > 0 ? g_persist : cu_count();
-    if (grid > slots) {
-      grid = slots;
-      if (g_ctr != nullptr && !(g_dbg & 128)) {  // dynamic tile scheduling over a ring of counter sets
-        const unsigned seq = g_seq.fetch_add(1);
-        a.ctr = g_ctr + (seq % CTR_SETS) * 8;
-        a.ctr_reset = g_ctr + ((seq + CTR_SETS / 2) % CTR_SETS) * 8;
-      }
-    }
+  if (BM == 256 && t.grid != 0xffff) {        // persistent: one workgroup per CU walks the tiles (+1.8 % per step)
+    const int slots = t.grid > 0 ? t.grid : cu_count();
+    if (grid > slots) grid = slots;
   }
-  OAT_LAUNCH((gemm_nt_kernel<EPI, WM, WN, TM, TN, NSA, SPREAD, PIPE>), dim3(grid), dim3(WM * WN * 64), LDS, s, a);
+  OAT_LAUNCH((gemm_nt_kernel<EPI, WM, WN, TM, TN, NSA, SPREAD, false>), dim3(grid), dim3(WM * WN * 64), LDS, s, g);
   return check_launch("gemm_nt");
 }
 
-static int g_pp_default = 1;     // auto tile choice prefers the ping-pong kernel (gemm_nt_pp.hip) where it applies
+static int pp_slots(const GemmTune& t) { return t.grid == 0xffff ? 0x7fffffff : t.grid > 0 ? t.grid : cu_count(); }
 
 // the 256x256 configuration of a launch: ping-pong kernel where it applies, else the lockstep kernel
 template <int EPI>
-static int launch_big(const GemmArgs& g, hipStream_t s) {
-  if ((g_variant == 4 || (g_variant == 0 && g_pp_default)) && pp_supported(EPI, g)) {
-    const int slots = g_persist == 0xffff ? 0x7fffffff : g_persist > 0 ? g_persist : cu_count();
-    if (EPI == EPI_BF16 && g_sk_ws != nullptr && !(g_dbg & 128)) {
-      // split-K of the last round (gemm_nt_pp.hip): at most slots/2 tiles x 4 partials of 256 KB, 256 counters
-      const int nwg = ((g.M + 255) / 256) * (g.N / 256), grid = nwg < slots ? nwg : slots;
-      const int r = nwg % grid;
-      if (r > 0 && 2 * r <= grid && (size_t)r * 4 * (256 << 10) <= g_sk_bytes && r <= 256) {
-        GemmArgs a = g;
-        a.sk_ws = g_sk_ws;
-        a.sk_ctr = g_sk_ctr;
-        return launch_pp(EPI, a, slots, g_variant == 4 ? g_dbg : 0, s);
-      }
-    }
-    return launch_pp(EPI, g, slots, g_variant == 4 ? g_dbg : 0, s);
-  }
-  return launch_cfg<EPI, 2, 4, 8, 4, 3, true>(g, s);
+static int launch_big(const GemmArgs& g, const GemmTune& t, hipStream_t s) {
+  if ((t.variant == 4 || t.variant == 0) && pp_supported(EPI, g)) return launch_pp(EPI, g, pp_slots(t), t, s);
+  return launch_cfg<EPI, 2, 4, 8, 4, 3, true>(g, t, s);
 }
 
 template <int EPI>
-static int launch(const GemmArgs& g, hipStream_t s) {
+static int launch(const GemmArgs& g, const GemmTune& t, hipStream_t s) {
   // 256x256 tiles need enough of them: below ~100 tiles (the object clip of the OA variants, 6304 rows x 768 columns = 75
   // tiles on 256 CUs) the 128x128 configuration's 300 quarter tiles finish 20-30 % sooner (scripts/dev/small_m_gemm.py)
-  const bool big = g_variant >= 2 || (g_variant == 0 && g.M >= 4096 && g.N % 256 == 0 &&
+  const bool big = t.variant >= 2 || (t.variant == 0 && g.M >= 4096 && g.N % 256 == 0 &&
                                       ((g.M + 255) / 256) * (g.N / 256) * 5 >= cu_count() * 2);
-  if (big && g_variant == 3) return launch_cfg<EPI, 2, 2, 8, 8, 3, false, true>(g, s);   // 4 waves x 128x128, hand-pipelined
-  if (big) {
-    // Tail split.  256x256 tiles leave the last round of workgroups mostly empty when tiles % CUs is small (N = 768 at
-    // M = 50208: 591 tiles = 2.31 rounds -> a third round with 79 of 256 CUs busy).  The row panels of the full rounds
-    // go to the 256x256 kernel, the remaining rows to the 128x128 configuration (two workgroups per CU), whose quarter
-    // tiles fill the machine once more: same per-element arithmetic, bit-identical results, no workspace.
-    const int ntm = (g.M + 255) / 256, ntn = (g.N + 255) / 256, cus = cu_count();
-    const int T = ntm * ntn, R = T / cus, r = T - R * cus;
-    const int panels_main = R * cus / ntn;
-    // Measured with the lockstep kernel: +5...9 % per launch at R = 2 (-1.6 % at R = 9).  A launch policy of the caller
-    // (oat_gemm_set_tail_split): it pays whenever the GEMM has the GPU to itself.
-    if (((g_dbg & 64) || g_tail) && R >= 1 && R <= 4 && r > 0 && r * 10 < cus * 7 && panels_main >= 1 && panels_main < ntm) {
-      const int M1 = panels_main * 256;
-      GemmArgs a = g;
-      a.M = M1;
-      int rc = launch_big<EPI>(a, s);
-      if (rc) return rc;
-      GemmArgs b = g;
-      const size_t osz = (EPI == EPI_F32 || EPI == EPI_F32_BF16) ? 4 : 2;
-      b.M = g.M - M1;
-      b.row0 = g.row0 + M1;
-      b.A = g.A + (size_t)M1 * g.lda;
-      b.out = (char*)g.out + (size_t)M1 * g.ldc * osz;
-      if (g.out2) b.out2 = (char*)g.out2 + (size_t)M1 * g.ld2 * 2;
-      if (g.aux) b.aux = g.aux + (size_t)M1 * g.ldaux;
-      if (g.resid && g.resid_mod <= 0) b.resid = g.resid + (size_t)M1 * g.ldr;
-      return launch_cfg<EPI, 2, 2, 4, 4, 2, false>(b, s);
-    }
-    return launch_big<EPI>(g, s);
-  }
-  return launch_cfg<EPI, 2, 2, 4, 4, 2, false>(g, s);
+  // (Round 6: the tail split - the last, mostly empty round of 256x256 tiles re-tiled as 128x128, measured equal with the ping-pong
+  // kernel - the 4-wave pipelined 256x256 configuration, the dynamic tile walk and the split-K workspace left the library.)
+  if (big) return launch_big<EPI>(g, t, s);
+  return launch_cfg<EPI, 2, 2, 4, 4, 2, false>(g, t, s);
 }
 
 }  // namespace oat
 
-extern "C" void oat_gemm_set_tail_split(int on) { oat::g_tail = on; }
-extern "C" int oat_gemm_set_tile_counters(void* zeroed_device_ints, size_t bytes) {
-  if (zeroed_device_ints != nullptr && bytes < oat::CTR_SETS * 8 * sizeof(int)) {
-    oat::set_error("gemm_set_tile_counters: need 32 KiB of zeroed device memory");
-    return -3;
-  }
-  oat::g_ctr = static_cast<int*>(zeroed_device_ints);
-  return 0;
+// tune: bits 0-7 kernel choice (GemmTune::variant), bits 16-17 the 224-row-tile mode (0 = default: auto, 1 = never, 2 = always),
+// bits 18-25 the band walk (0 = default: auto, 1 = off, n + 1 = n column tiles per group).  grid: GemmTune::grid.
+static oat::GemmTune decode_tune(int tune, int grid) {
+  oat::GemmTune t;
+  t.variant = tune & 0xff;
+  t.grid = grid;
+  const int m = (tune >> 16) & 3, b = (tune >> 18) & 0xff;
+  t.m224 = m == 0 ? 1 : m == 1 ? 0 : 2;
+  t.band = b == 0 ? -1 : b - 1;
+  return t;
 }
-// Workspace of the split-K last round (see gemm_nt_pp.hip): `bytes` of device memory for fp32 partial tiles (128 MiB
-// covers every launch of up to 256 workgroups) and 256 ZEROED ints.  Caller-owned; nullptr switches the feature off.
-// One ping-pong GEMM at a time may use it (launches on ONE stream).
-extern "C" int oat_gemm_set_splitk_workspace(void* ws, size_t bytes, void* zeroed_256_ints) {
-  if (ws != nullptr && (!zeroed_256_ints || bytes < ((size_t)4 << 20))) { oat::set_error("gemm_set_splitk_workspace: need >= 4 MiB and 256 zeroed ints"); return -3; }
-  oat::g_sk_ws = static_cast<float*>(ws);
-  oat::g_sk_bytes = ws ? bytes : 0;
-  oat::g_sk_ctr = ws ? static_cast<int*>(zeroed_256_ints) : nullptr;
-  return 0;
-}
-extern "C" void oat_gemm_set_m224(int mode) { oat::pp_set_m224(mode); }
-extern "C" void oat_gemm_set_band(int tiles) { oat::pp_set_band(tiles); }
-extern "C" void oat_gemm_set_variant(int v) { oat::g_variant = v & 0xff; oat::g_dbg = (v >> 8) & 0xff; oat::g_persist = (v >> 16) & 0xffff; }
 
 extern "C" int oat_gemm_nt(const void* A, const void* B, int M, int N, int K, int lda, int ldb,
                            int epi, void* out, int ldc, void* out2, int ld2,
                            const float* bias, const float* resid, int ldr, int resid_mod,
-                           const void* aux, int ldaux, void* stream) {
+                           const void* aux, int ldaux, int tune, int grid, void* stream) {
   using namespace oat;
+  if (grid < 0 || grid > 0xffff) { set_error("gemm_nt: grid must be 0 (one workgroup per CU), a workgroup count, or 0xffff (one per tile)"); return -3; }
+  const GemmTune t = decode_tune(tune, grid);
+  if (t.variant != 0 && t.variant != 1 && t.variant != 2 && t.variant != 4) { set_error("gemm_nt: unknown kernel choice in `tune`"); return -3; }
   const int h_u8 = (epi >> 8) & 1;          // epi | 0x100: the GELU-derivative tensor is 8-bit fixed point (gemm.h: h_u8)
   epi &= 0xff;
   if (M <= 0 || N <= 0 || K <= 0) { set_error("gemm_nt: empty problem"); return -1; }
@@ -757,7 +689,7 @@ extern "C" int oat_gemm_nt(const void* A, const void* B, int M, int N, int K, in
   }
   if (!A || !B || !out) { set_error("gemm_nt: null pointer"); return -4; }
   GemmArgs g{(const bf16*)A, (const bf16*)B, M, N, K, lda, ldb, out, ldc, out2, ld2,
-             bias, resid, ldr, resid_mod, (const bf16*)aux, ldaux, g_dbg, 0, nullptr, nullptr};
+             bias, resid, ldr, resid_mod, (const bf16*)aux, ldaux, 0, 0, nullptr, nullptr};
   hipStream_t s = (hipStream_t)stream;
   if (h_u8) {
     g.h_u8 = 1;
@@ -768,27 +700,26 @@ extern "C" int oat_gemm_nt(const void* A, const void* B, int M, int N, int K, in
     if ((epi == EPI_GELU_GRAD && !out2) || (epi == EPI_MUL_AUX && !aux)) { set_error("gemm_nt: missing out2 / aux"); return -4; }
     // the 8-bit derivative tensor is blocked ([row / 16][col / 64][lane][16 B], gemm_nt_pp.hip): a dense [round_up(M, 16), N] byte array
     if ((epi == EPI_GELU_GRAD ? ldc : ldaux) != N) { set_error("gemm_nt: the 8-bit GELU derivative is a dense blocked tensor (ld == N)"); return -3; }
-    const int slots = g_persist == 0xffff ? 0x7fffffff : g_persist > 0 ? g_persist : cu_count();
-    return launch_pp(epi, g, slots, 0, s);
+    return launch_pp(epi, g, pp_slots(t), t, s);
   }
   switch (epi) {
-    case EPI_BF16: return launch<EPI_BF16>(g, s);
-    case EPI_F32: return launch<EPI_F32>(g, s);
+    case EPI_BF16: return launch<EPI_BF16>(g, t, s);
+    case EPI_F32: return launch<EPI_F32>(g, t, s);
     case EPI_GELU_DUAL:
       if (!out2) { set_error("gemm_nt: EPI_GELU_DUAL needs out2"); return -4; }
-      return launch<EPI_GELU_DUAL>(g, s);
+      return launch<EPI_GELU_DUAL>(g, t, s);
     case EPI_DGELU:
       if (!aux) { set_error("gemm_nt: EPI_DGELU needs aux"); return -4; }
-      return launch<EPI_DGELU>(g, s);
+      return launch<EPI_DGELU>(g, t, s);
     case EPI_F32_BF16:
       if (!out2) { set_error("gemm_nt: EPI_F32_BF16 needs out2"); return -4; }
-      return launch<EPI_F32_BF16>(g, s);
+      return launch<EPI_F32_BF16>(g, t, s);
     case EPI_GELU_GRAD:
       if (!out2) { set_error("gemm_nt: EPI_GELU_GRAD needs out2"); return -4; }
-      return launch<EPI_GELU_GRAD>(g, s);
+      return launch<EPI_GELU_GRAD>(g, t, s);
     case EPI_MUL_AUX:
       if (!aux) { set_error("gemm_nt: EPI_MUL_AUX needs aux"); return -4; }
-      return launch<EPI_MUL_AUX>(g, s);
+      return launch<EPI_MUL_AUX>(g, t, s);
     default: set_error("gemm_nt: unknown epilogue"); return -5;
   }
 }

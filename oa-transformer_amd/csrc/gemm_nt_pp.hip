@@ -42,7 +42,6 @@ constexpr int PP_MAXN = 4096;                       // bias vector kept in LDS
 constexpr int PP_FLAG = PP_BIAS + PP_MAXN * 4;      // one word: the split-K arrival count, broadcast to the workgroup
 constexpr int PP_LDS = PP_FLAG + 16;
 
-static int g_pp_m224 = 1;           // 224-row tiles: 0 never, 1 where they save time (default), 2 always (tests); pp_set_m224
 enum : int { PPF_PRIO = 1, PPF_NOSTAGGER = 2, PPF_LGKM = 4, PPF_BONUS = 8, PPF_NOEPI = 16, PPF_PH2 = 32, PPF_WIDE = 64,
              PPF_F8 = 128, PPF_A_BF8 = 256,     // PPF_A_BF8: the A operand is e5m2 (gradients), B stays e4m3
              PPF_HU8 = 512,                     // the saved GELU derivative travels as 8-bit fixed point (see HU8_*)
@@ -694,224 +693,23 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs g) {
   }
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// Two phases per K-tile (half the barriers, 32 MFMAs per interval) and no pre-read:
-//     L1: all of A (16 ds_read_b128) + b0 (4)   M1: A x b0      L2: b1 (4, into the b0 registers)   M2: A x b1
-// 80 fragment VGPRs instead of 96.  Regions: A(s) and b0(s) are dead after L1(s), b1(s) after L2(s), so the op stream
-// of a wave is   L1(s): b1(s+1) [2 pieces]    L2(s): A(s+2), b0(s+2) [4 + 2 pieces]
-// every piece is issued 6 intervals (~3 k cycles) before its first read and every wait allows the 8 youngest pieces.
-template <int EPI, int FL>
-__global__ __launch_bounds__(512) void gemm_nt_pp2_kernel(GemmArgs g) {
-  constexpr bool PRIO = FL & PPF_PRIO, STAGGER = !(FL & PPF_NOSTAGGER), LGKM = FL & PPF_LGKM, BONUS = FL & PPF_BONUS;
-  constexpr bool NOEPI = FL & PPF_NOEPI;
-  constexpr bool WIDE = (FL & PPF_WIDE) && EPI == EPI_BF16;
-  constexpr int NST = EPI == EPI_GELU_GRAD ? 64 : WIDE ? 16 : 32;
-  constexpr int WB = 8 + NST > 63 ? 63 : 8 + NST;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-  const int ntn = g.N >> 8, ntm = (g.M + 255) >> 8, nwg = ntm * ntn;
-  const int nk = g.K >> 6;
-  const int ntl = (nwg - 1 - (int)blockIdx.x) / (int)gridDim.x + 1;
-  struct Tile { int m0, n0; };
-  auto tile_of = [&](int t) __attribute__((always_inline)) {
-    const int w = blockIdx.x + t * gridDim.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = w & 7, idx = w >> 3;
-    const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    const int tm = bid / ntn;
-    return Tile{tm << 8, (bid - tm * ntn) << 8};
-  };
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  float* const sbias = reinterpret_cast<float*>(smem + PP_BIAS);
-  for (int i = tid; i < g.N; i += 512) sbias[i] = g.bias ? g.bias[i] : 0.f;
-
-  // ---- staging (pieces, classes and swizzle as in gemm_nt_pp_kernel)
-  const int srow = lane >> 3;
-  const uint32_t c16_0 = (uint32_t)(((lane & 7) ^ (srow >> 1)) << 4);
-  const uint32_t lda2 = (uint32_t)g.lda * 2u, ldb2 = (uint32_t)g.ldb * 2u;
-  int pa[2], pb[2];
-  uint32_t boff[2][2];
-#pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    const int idx = wave * 2 + e;
-    pa[e] = idx < 8 ? idx : idx + 8;
-    pb[e] = ((idx >> 2) << 3) | (idx & 3);
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int r = (pb[e] + c * 4) * 8 + srow;
-      const int rg = (r & ~63) | ((r & 15) << 2) | ((r >> 4) & 3);
-      boff[c][e] = (uint32_t)rg * ldb2 + (c16_0 ^ (e << 6));
-    }
-  }
-  int ckt = 0, ctl = 0, crmax;
-  const bf16 *ca, *cb, *cb1 = nullptr;         // cursor (K-tile s + 2); cb1 = B panel of K-tile s + 1
-  uint32_t lda2c = lda2, bmask = ~0u, bmask1 = ~0u;
-  {
-    const Tile t = tile_of(0);
-    ca = g.A + (size_t)t.m0 * g.lda;
-    cb = g.B + (size_t)t.n0 * g.ldb;
-    crmax = g.M - 1 - t.m0;
-  }
-  auto advance = [&]() __attribute__((always_inline)) {
-    cb1 = cb;
-    bmask1 = bmask;
-    ++ckt;
-    ca += 64;
-    cb += 64;
-    if (ckt == nk) {
-      const bool more = ctl + 1 < ntl;
-      ctl += more ? 1 : 0;
-      const Tile t = tile_of(ctl);
-      ckt = more ? 0 : nk - 1;
-      ca = more ? g.A + (size_t)t.m0 * g.lda : ca - 64;
-      cb = more ? g.B + (size_t)t.n0 * g.ldb : cb - 64;
-      crmax = g.M - 1 - t.m0;
-      lda2c = more ? lda2c : 0u;
-      bmask = more ? bmask : 0x7fu;
-    }
-  };
-  auto stageA = [&](int cls, int buf) __attribute__((always_inline)) {
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int p = pa[e] + cls * 8;
-      const uint32_t r = (uint32_t)min(p * 8 + srow, crmax);
-      const uint32_t off = __umul24(r, lda2c) + (c16_0 ^ (e << 6));
-      glds16_asm_lds(ca, off, lds0 + buf * PP_A1 + p * 1024);
-    }
-  };
-  auto stageB0 = [&](int buf) __attribute__((always_inline)) {      // b0 of the cursor's K-tile
-#pragma unroll
-    for (int e = 0; e < 2; ++e)
-      glds16_asm_lds(cb, boff[0][e] & bmask, lds0 + PP_B0 + buf * PP_A1 + pb[e] * 1024);
-  };
-  auto stageB1 = [&](const bf16* base, uint32_t mask, int buf) __attribute__((always_inline)) {
-#pragma unroll
-    for (int e = 0; e < 2; ++e)
-      glds16_asm_lds(base, boff[1][e] & mask, lds0 + PP_B0 + buf * PP_A1 + (pb[e] + 4) * 1024);
-  };
-
-  const int frow = lane & 15, fk = lane >> 4;
-  const int sw = (frow >> 1) & 7;
-  typedef const __attribute__((address_space(3))) bf16x8* lds_frag;
-  uint32_t pA[2], pB[2];
-#pragma unroll
-  for (int kk = 0; kk < 2; ++kk) {
-    const int ch = ((kk * 4 + fk) ^ sw) << 4;
-    pA[kk] = lds0 + (wm * 128 + frow) * 128 + ch;
-    pB[kk] = lds0 + PP_B0 + (wn * 64 + frow) * 128 + ch;
-  }
-  f32x4 acc[8][4];
-  auto readA = [&](bf16x8 (&f)[2][8], int buf) __attribute__((always_inline)) {
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int i = 0; i < 8; ++i) f[kk][i] = *(lds_frag)(uintptr_t)(pA[kk] + buf * PP_A1 + i * 16 * 128);
-  };
-  auto readB = [&](bf16x8 (&f)[2][2], int half, int buf) __attribute__((always_inline)) {
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-        f[kk][j] = *(lds_frag)(uintptr_t)(pB[kk] + buf * PP_A1 + (half * 32 + j * 16) * 128);
-  };
-  auto endL = [&](bool bonus) __attribute__((always_inline)) {
-    if constexpr (LGKM) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (bonus) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WB) : "memory");
-    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  auto mma = [&](const bf16x8 (&fa)[2][8], const bf16x8 (&fb)[2][2], int bh) __attribute__((always_inline)) {
-    if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          mfma_inplace(acc[i][bh * 2 + j], fa[kk][i], fb[kk][j]);
-    if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-  };
-
-  // ---- prologue, canonical issue order: A(0) b0(0) | b1(0) | A(1) b0(1)      (b1(1) follows in L1 of K-tile 0)
-  stageA(0, 0); stageA(1, 0); stageB0(0);
-  stageB1(cb, bmask, 0);
-  advance();
-  stageA(0, 1); stageA(1, 1); stageB0(1);
-  advance();
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // A(0), b0(0) landed
-  __syncthreads();                                       // ... for every wave; also publishes the bias vector
-  if (STAGGER && wm == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one interval behind from here on
-  __builtin_amdgcn_sched_barrier(0);
-
-  // HEAD = first pair of a tile: after an INTERIOR epilogue (`bon`) its NST stores are younger than both targets of the
-  // first K-tile's waits (issued in the previous tile); the second K-tile's targets were issued after them.
-  auto pair = [&](auto head, const bool bon) __attribute__((always_inline)) {
-    constexpr bool HEAD = decltype(head)::value;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      bf16x8 fa[2][8], fb[2][2];
-      const bool b0 = HEAD && bon && u == 0;
-      readA(fa, u); readB(fb, 0, u); stageB1(cb1, bmask1, u ^ 1); endL(b0);
-      mma(fa, fb, 0);
-      readB(fb, 1, u); stageA(0, u); stageA(1, u); stageB0(u); endL(b0);
-      mma(fa, fb, 1);
-      advance();
-    }
-  };
-
-  bool prev_interior = false;
-  for (int tl = 0; tl < ntl; ++tl) {
-    const Tile tile = tile_of(tl);
-    const int m0 = tile.m0, n0 = tile.n0;
-    {
-      const f32x4 b = *reinterpret_cast<const f32x4*>(sbias + n0 + wn * 64 + frow * 4);
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{b[j], b[j], b[j], b[j]};
-    }
-    pair(std::true_type{}, BONUS && prev_interior);
-    for (int kt = 2; kt < nk; kt += 2) pair(std::false_type{}, false);
-    if constexpr (NOEPI) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
-      prev_interior = false;
-      continue;
-    }
-    asm volatile("s_nop 15" ::: "memory");               // asm MFMA -> VALU read of its result: wait states are ours
-    prev_interior = pp_epilogue<EPI, WIDE>(g, acc, m0, n0, wm, wn, lane);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  if (STAGGER && wm == 0) __builtin_amdgcn_s_barrier();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no LDS-DMA may outlive the workgroup's LDS allocation
-}
-
 template <int EPI, int FL>
 int launch_pp_cfg(const GemmArgs& g, int grid_slots, hipStream_t s) {
-  if constexpr (FL & PPF_PH2) OAT_MAX_LDS((gemm_nt_pp2_kernel<EPI, FL>), PP_LDS);
-  else OAT_MAX_LDS((gemm_nt_pp_kernel<EPI, FL>), PP_LDS);
+  OAT_MAX_LDS((gemm_nt_pp_kernel<EPI, FL>), PP_LDS);
   constexpr int TMH = (FL & PPF_M224) ? 224 : 256;
   const int nwg = ((g.M + TMH - 1) / TMH) * (g.N / 256);
   const int grid = nwg < grid_slots ? nwg : grid_slots;
-  if constexpr (FL & PPF_PH2) OAT_LAUNCH((gemm_nt_pp2_kernel<EPI, FL>), dim3(grid), dim3(512), PP_LDS, s, g);
-  else OAT_LAUNCH((gemm_nt_pp_kernel<EPI, FL>), dim3(grid), dim3(512), PP_LDS, s, g);
+  OAT_LAUNCH((gemm_nt_pp_kernel<EPI, FL>), dim3(grid), dim3(512), PP_LDS, s, g);
   return check_launch("gemm_nt_pp");
 }
 
 }  // namespace
 
 // 224- or 256-row tiles?  Time of a persistent launch ~ rounds x tile rows; 224 wins where it saves a whole round's worth.
-static bool pp_prefers_224(const GemmArgs& g, int slots) {
-  if (g_pp_m224 == 0) return false;
-  if (g_pp_m224 == 2) return g.M >= 224;
+// mode (GemmTune::m224): 0 never, 1 where they save time (default), 2 always (tests)
+static bool pp_prefers_224(const GemmArgs& g, int slots, int mode = 1) {
+  if (mode == 0) return false;
+  if (mode == 2) return g.M >= 224;
   const long long ntn = g.N / 256;
   auto cost = [&](int tm) {
     const long long tiles = ((g.M + tm - 1) / tm) * ntn, grid = tiles < slots ? tiles : slots;
@@ -921,28 +719,21 @@ static bool pp_prefers_224(const GemmArgs& g, int slots) {
 }
 
 bool pp_f8_supported(int epi, const GemmArgs& g) {
-  if (epi != EPI_BF16 && epi != EPI_GELU_GRAD && epi != EPI_MUL_AUX) return false;
+  if (epi != EPI_BF16 && epi != EPI_GELU_GRAD) return false;
   const int nk = g.K / 128;
   return g.K % 128 == 0 && g.N % 256 == 0 && g.N <= PP_MAXN && nk >= 2 && nk % 2 == 0 && g.M >= 256 && g.lda % 16 == 0 &&
          g.ldb % 16 == 0 && g.lda < (1 << 23) && g.ldb < (1 << 23) && g.dq_a && g.dq_b;
 }
 
-// fp8 (e4m3 x e4m3) operands: A [M, K] and B [N, K] one byte per element, lda / ldb in elements (= bytes)
-int launch_pp_f8(int epi, const GemmArgs& g, int grid_slots, bool a_e5m2, hipStream_t s) {
-  constexpr int FL = PPF_PRIO | PPF_BONUS | PPF_LGKM | PPF_F8, FLG = FL | PPF_A_BF8;
-  if (!pp_f8_supported(epi, g)) { set_error("gemm_nt_f8: shape / epilogue not covered (K % 256, N % 256, N <= 4096, M >= 256, EPI_BF16 | EPI_GELU_GRAD | EPI_MUL_AUX)"); return -3; }
-  if (epi == EPI_GELU_GRAD)                                                                  // forward only: e4m3 x e4m3
+// fp8 (e4m3 x e4m3) operands: A [M, K] and B [N, K] one byte per element, lda / ldb in elements (= bytes); forward linears only
+int launch_pp_f8(int epi, const GemmArgs& g, int grid_slots, hipStream_t s) {
+  constexpr int FL = PPF_PRIO | PPF_BONUS | PPF_LGKM | PPF_F8;
+  if (!pp_f8_supported(epi, g)) { set_error("gemm_nt_f8: shape / epilogue not covered (K % 256, N % 256, N <= 4096, M >= 256, EPI_BF16 | EPI_GELU_GRAD)"); return -3; }
+  if (epi == EPI_GELU_GRAD)
     return g.h_u8 ? launch_pp_cfg<EPI_GELU_GRAD, FL | PPF_HU8>(g, grid_slots, s) : launch_pp_cfg<EPI_GELU_GRAD, FL>(g, grid_slots, s);
-  if (epi == EPI_MUL_AUX) {
-    if (g.h_u8) return a_e5m2 ? launch_pp_cfg<EPI_MUL_AUX, FLG | PPF_HU8>(g, grid_slots, s) : launch_pp_cfg<EPI_MUL_AUX, FL | PPF_HU8>(g, grid_slots, s);
-    return a_e5m2 ? launch_pp_cfg<EPI_MUL_AUX, FLG>(g, grid_slots, s) : launch_pp_cfg<EPI_MUL_AUX, FL>(g, grid_slots, s);
-  }
-  if (pp_prefers_224(g, grid_slots))
-    return a_e5m2 ? launch_pp_cfg<EPI_BF16, FLG | PPF_M224>(g, grid_slots, s) : launch_pp_cfg<EPI_BF16, FL | PPF_M224>(g, grid_slots, s);
-  return a_e5m2 ? launch_pp_cfg<EPI_BF16, FLG>(g, grid_slots, s) : launch_pp_cfg<EPI_BF16, FL>(g, grid_slots, s);
+  if (pp_prefers_224(g, grid_slots)) return launch_pp_cfg<EPI_BF16, FL | PPF_M224>(g, grid_slots, s);
+  return launch_pp_cfg<EPI_BF16, FL>(g, grid_slots, s);
 }
-
-void pp_set_m224(int mode) { g_pp_m224 = mode; }
 
 // Band-grouped tile walk (PPF_BAND): column tiles per band group.  0 = off (row-major walk), > 0 = that many where the
 // launch qualifies, -1 = auto (default).  Measured at M = 50208 (scripts/dev/band_probe.py, us per launch, row-major ->
@@ -950,13 +741,12 @@ void pp_set_m224(int mode) { g_pp_m224 = mode; }
 // data gradient, which also streams the 154 MB derivative tensor) 249 -> 256; N 2304 / K 768 161 -> 163; N 768 shapes
 // slower.  The kernel tolerates the L2 misses of the row-major walk well (its LDS-DMA runs 14 intervals ahead), so auto
 // only takes the one case that pays: the fc1 forward launch (EPI_GELU_GRAD, N >= 3072, K <= 1024), groups of 4.
-static int g_pp_band = -1;
-void pp_set_band(int tiles) { g_pp_band = tiles; }
-static int pp_band_for(const GemmArgs& g, int slots, int tm, int epi = EPI_BF16) {
-  if (g_pp_band == 0 || g.sk_ws != nullptr) return 0;
+// (GemmTune::band carries the request per call.)
+static int pp_band_for(const GemmArgs& g, int slots, int tm, int epi, int band) {
+  if (band == 0) return 0;
   const long long ntn = g.N / 256, nwg = ((g.M + tm - 1) / tm) * ntn, grid = nwg < slots ? nwg : slots;
   if (grid % 8 != 0 || nwg < 2 * grid) return 0;           // a workgroup must stay on one XCD chunk; >= 2 rounds to gain anything
-  int gw = g_pp_band;
+  int gw = band;
   if (gw < 0) {
     if (epi != EPI_GELU_GRAD || ntn < 12 || ntn % 4 != 0 || g.K > 1024) return 0;
     gw = 4;
@@ -971,15 +761,15 @@ bool pp_supported(int epi, const GemmArgs& g) {
          g.ldb < (1 << 22);
 }
 
-// flags: tuning / ablation bits (PPF_*); 0 = the shipped configuration
-int launch_pp(int epi, const GemmArgs& g, int grid_slots, int flags, hipStream_t s) {
+// The shipped configuration of the ping-pong kernel (PRIO | BONUS | LGKM; the ablation builds of rounds 2-5 - no priority, no stagger,
+// the two-phase K-tile kernel, wide stores, split-K of the last round - were measured and left the library in round 6).
+int launch_pp(int epi, const GemmArgs& g, int grid_slots, const GemmTune& t, hipStream_t s) {
   constexpr int DEF = PPF_PRIO | PPF_BONUS | PPF_LGKM;   // LGKM: measured free, and it makes the WAR spacing strict
-  const int fl = DEF ^ flags;                    // a set bit toggles the default
+  const bool m224 = pp_prefers_224(g, grid_slots, t.m224);
+  GemmArgs a = g;
+  a.band = pp_band_for(g, grid_slots, m224 ? 224 : 256, epi, t.band);
   if (epi == EPI_GELU_GRAD || epi == EPI_MUL_AUX) {
     if (g.h_u8) {
-      const bool m224 = pp_prefers_224(g, grid_slots);
-      GemmArgs a = g;
-      a.band = pp_band_for(g, grid_slots, m224 ? 224 : 256, epi);
       if (epi == EPI_GELU_GRAD) {
         if (a.band) return m224 ? launch_pp_cfg<EPI_GELU_GRAD, DEF | PPF_HU8 | PPF_M224 | PPF_BAND>(a, grid_slots, s)
                                 : launch_pp_cfg<EPI_GELU_GRAD, DEF | PPF_HU8 | PPF_BAND>(a, grid_slots, s);
@@ -993,29 +783,9 @@ int launch_pp(int epi, const GemmArgs& g, int grid_slots, int flags, hipStream_t
     }
     return epi == EPI_GELU_GRAD ? launch_pp_cfg<EPI_GELU_GRAD, DEF>(g, grid_slots, s) : launch_pp_cfg<EPI_MUL_AUX, DEF>(g, grid_slots, s);
   }
-  if (fl == DEF && g.sk_ws != nullptr) return launch_pp_cfg<EPI_BF16, DEF | PPF_SPLITK>(g, grid_slots, s);
-  if (fl == DEF) {
-    const bool m224 = pp_prefers_224(g, grid_slots);
-    GemmArgs a = g;
-    a.band = pp_band_for(g, grid_slots, m224 ? 224 : 256);
-    if (a.band) return m224 ? launch_pp_cfg<EPI_BF16, DEF | PPF_M224 | PPF_BAND>(a, grid_slots, s)
-                            : launch_pp_cfg<EPI_BF16, DEF | PPF_BAND>(a, grid_slots, s);
-  }
-  if (fl == DEF && pp_prefers_224(g, grid_slots)) return launch_pp_cfg<EPI_BF16, DEF | PPF_M224>(g, grid_slots, s);
-  if (fl == (DEF | PPF_M224)) return launch_pp_cfg<EPI_BF16, DEF | PPF_M224>(g, grid_slots, s);      // forced (tests)
-  switch (fl) {
-    case DEF: return launch_pp_cfg<EPI_BF16, DEF>(g, grid_slots, s);
-    case DEF ^ PPF_PRIO: return launch_pp_cfg<EPI_BF16, DEF ^ PPF_PRIO>(g, grid_slots, s);
-    case DEF | PPF_NOSTAGGER: return launch_pp_cfg<EPI_BF16, DEF | PPF_NOSTAGGER>(g, grid_slots, s);
-    case DEF ^ PPF_LGKM: return launch_pp_cfg<EPI_BF16, DEF ^ PPF_LGKM>(g, grid_slots, s);
-    case DEF ^ PPF_BONUS: return launch_pp_cfg<EPI_BF16, DEF ^ PPF_BONUS>(g, grid_slots, s);
-    case DEF | PPF_NOEPI: return launch_pp_cfg<EPI_BF16, DEF | PPF_NOEPI>(g, grid_slots, s);
-    case DEF | PPF_PH2: return launch_pp_cfg<EPI_BF16, DEF | PPF_PH2>(g, grid_slots, s);
-    case (DEF | PPF_PH2) ^ PPF_BONUS: return launch_pp_cfg<EPI_BF16, (DEF | PPF_PH2) ^ PPF_BONUS>(g, grid_slots, s);
-    case DEF | PPF_PH2 | PPF_NOEPI: return launch_pp_cfg<EPI_BF16, DEF | PPF_PH2 | PPF_NOEPI>(g, grid_slots, s);
-    case DEF | PPF_PH2 | PPF_WIDE: return launch_pp_cfg<EPI_BF16, DEF | PPF_PH2 | PPF_WIDE>(g, grid_slots, s);
-    default: set_error("gemm_nt_pp: flag combination not built"); return -7;
-  }
+  if (a.band) return m224 ? launch_pp_cfg<EPI_BF16, DEF | PPF_M224 | PPF_BAND>(a, grid_slots, s)
+                          : launch_pp_cfg<EPI_BF16, DEF | PPF_BAND>(a, grid_slots, s);
+  return m224 ? launch_pp_cfg<EPI_BF16, DEF | PPF_M224>(g, grid_slots, s) : launch_pp_cfg<EPI_BF16, DEF>(g, grid_slots, s);
 }
 
 }  // namespace oat

@@ -228,7 +228,7 @@ __global__ void tn_reduce_kernel(const float* slabs, float* out, int n4, int spl
   }
 }
 
-static int g_tn_variant = 0, g_tn_dbg = 0, g_tn_slots = 0;   // 0 auto, 1 force 128^2, 2 force the lockstep 256^2, 4 force ping-pong
+// tile choice of a launch (the `tune` argument of oat_gemm_tn, per call): 0 auto, 1 force 128^2, 2 force the lockstep 256^2, 4 force ping-pong
 static int g_tn_pp_default = 1;   // auto prefers the ping-pong kernel (gemm_tn_pp.hip) for 256^2 launches
 
 static int reduce_slabs(const TnArgs& g, int splits, float* out, float* bias_out, int accumulate, hipStream_t s) {
@@ -254,19 +254,17 @@ static int launch_tn(TnArgs g, int splits, float* out, float* bias_out, int accu
 
 }  // namespace oat
 
-extern "C" void oat_gemm_tn_set_variant(int v) { oat::g_tn_variant = v & 0xff; oat::g_tn_dbg = (v >> 8) & 0xff; oat::g_tn_slots = (v >> 16) & 0xffff; }
-
 // tile shape and split count of a launch (shared by the launcher and the workspace query)
-static void tn_plan(int M, int N1, int N2, bool* big_, int* splits_, int* cps_, bool* pp_ = nullptr) {
+static void tn_plan(int M, int N1, int N2, int variant, bool* big_, int* splits_, int* cps_, bool* pp_ = nullptr) {
   using namespace oat;
   const bool fits = N1 % 256 == 0 && N2 % 256 == 0;
-  const bool big = g_tn_variant == 2 || (g_tn_variant == 4 && fits) || (g_tn_variant == 0 && M >= 4096 && fits);
-  const bool pp = big && fits && (g_tn_variant == 4 || (g_tn_variant == 0 && g_tn_pp_default));
+  const bool big = variant == 2 || (variant == 4 && fits) || (variant == 0 && M >= 4096 && fits);
+  const bool pp = big && fits && (variant == 4 || (variant == 0 && g_tn_pp_default));
   const int B = big ? 256 : 128;
   const int tiles = ((N1 + B - 1) / B) * ((N2 + B - 1) / B);
   const int unit = pp ? 64 : TK;                    // rows per chunk (ping-pong: K-tiles of 64 rows, an even number per split)
   const int nchunks = (M + unit - 1) / unit;
-  const int slots = big ? (g_tn_slots > 0 ? g_tn_slots : 256) : 512;   // one 8-wave workgroup per CU, or two 4-wave ones
+  const int slots = big ? 256 : 512;   // one 8-wave workgroup per CU, or two 4-wave ones
   int splits = slots / tiles;                       // largest split count that still fits one round
   if (splits < 1) splits = 1;
   if (splits > 32) splits = 32;
@@ -278,32 +276,34 @@ static void tn_plan(int M, int N1, int N2, bool* big_, int* splits_, int* cps_, 
   if (pp_) *pp_ = pp;
 }
 
-// M > 0: exact need of that launch; M <= 0: worst case over every M (32 splits)
-extern "C" size_t oat_gemm_tn_workspace_bytes(int M, int N1, int N2) {
+// M > 0: exact need of that launch (with the same `tune`); M <= 0: worst case over every M (32 splits)
+extern "C" size_t oat_gemm_tn_workspace_bytes(int M, int N1, int N2, int tune) {
   int splits = 32, cps = 0;
   bool big = false;
-  if (M > 0) tn_plan(M, N1, N2, &big, &splits, &cps);
+  if (M > 0) tn_plan(M, N1, N2, tune & 0xff, &big, &splits, &cps);
   return (size_t)splits * ((size_t)N1 * N2 + N1) * sizeof(float);      // weight slabs + bias slabs
 }
 
 // out[N1,N2] (+)= P^T Q ; bias_out[N1] (+)= column sums of P (NULL to skip)
 extern "C" int oat_gemm_tn(const void* P, const void* Q, int M, int N1, int N2, int ldp, int ldq,
                            float* out, float* bias_out, int accumulate, void* workspace, size_t workspace_bytes,
-                           void* stream) {
+                           int tune, void* stream) {
   using namespace oat;
+  const int variant = tune & 0xff;
+  if (variant != 0 && variant != 1 && variant != 2 && variant != 4) { set_error("gemm_tn: unknown tile choice in `tune`"); return -3; }
   if (M <= 0 || N1 <= 0 || N2 <= 0) { set_error("gemm_tn: empty problem"); return -1; }
   if (N1 % 8 || N2 % 8 || ldp % 8 || ldq % 8) { set_error("gemm_tn: N1,N2,ldp,ldq must be multiples of 8"); return -3; }
   if (!P || !Q || !out || !workspace) { set_error("gemm_tn: null pointer"); return -4; }
   bool big, pp; int splits, cps;
-  tn_plan(M, N1, N2, &big, &splits, &cps, &pp);
+  tn_plan(M, N1, N2, variant, &big, &splits, &cps, &pp);
   const size_t need = (size_t)splits * ((size_t)N1 * N2 + N1) * sizeof(float);
   if (need > workspace_bytes) { set_error("gemm_tn: workspace too small"); return -6; }
   float* slabs = (float*)workspace;
   TnArgs g{(const bf16*)P, (const bf16*)Q, M, N1, N2, ldp, ldq, slabs,
-           bias_out ? slabs + (size_t)splits * N1 * N2 : nullptr, cps, splits, g_tn_dbg};
+           bias_out ? slabs + (size_t)splits * N1 * N2 : nullptr, cps, splits, 0};
   hipStream_t s = (hipStream_t)stream;
   if (pp) {
-    int rc = launch_tn_pp(g, g_tn_variant == 4 ? g_tn_dbg : 0, s);
+    int rc = launch_tn_pp(g, 0, s);
     if (rc) return rc;
     return reduce_slabs(g, splits, out, bias_out, accumulate, s);
   }

@@ -406,19 +406,13 @@ __global__ __launch_bounds__(256) void linear_f32_small_kernel(LinArgs g) {
   }
 }
 
-static int g_lin_kg2 = 1;          // 0: one wave quartet per 64 x 64 workgroup (OAT_LIN_KG2=0, A/B measurements)
-static int g_lin_x3 = 1;           // 1 (default): M > 64 runs on the split-bf16 kernel (linear_x3_kernel); OAT_LIN_X3=0: the exact-f32 MFMA
-static int g_lin_bk = 32;          // K-tile depth (OAT_LIN_BK=16 / 32): 32 halves the barrier pairs and global round trips per
-                                   // workgroup (text tower forward 2124 -> 1950 us alone; same accumulation order, bit-identical)
+// Fixed since round 6 (the A/B knobs OAT_LIN_KG2 / OAT_LIN_X3 / OAT_LIN_BK are gone): M > 64 runs on the split-bf16 kernel
+// (linear_x3_kernel) unless the call asks for exact products; K-tiles of 32 (half the barrier pairs and global round trips of 16:
+// text tower forward 2124 -> 1950 us alone, same accumulation order, bit-identical); too few 128 x 128 tiles -> 64 x 64 workgroups of
+// two wave quartets that split K.
+constexpr int g_lin_kg2 = 1, g_lin_x3 = 1, g_lin_bk = 32;
 template <int ACT>
 static void launch_linear(const LinArgs& g, bool exact, hipStream_t s) {
-  static bool env = false;
-  if (!env) {
-    const char* e = getenv("OAT_LIN_KG2"); if (e) g_lin_kg2 = atoi(e);
-    e = getenv("OAT_LIN_BK"); if (e) g_lin_bk = atoi(e);
-    e = getenv("OAT_LIN_X3"); if (e) g_lin_x3 = atoi(e);
-    env = true;
-  }
   const bool bk32 = g_lin_bk == 32 && g.K % 32 == 0;
   if (g.M <= 64 && g.K % 64 == 0) {
     OAT_LAUNCH(linear_f32_small_kernel<ACT>, dim3((g.N + 15) / 16, (g.M + 31) / 32), dim3(256), 0, s, g);

@@ -729,12 +729,8 @@ using namespace oat;
 static int ln_fwd_launch_f8(const float* x, int ldx, const float* gamma, const float* beta, void* y, int ldy, float* mean,
                             float* rstd, int M, int D, float eps, const void* add16, int ldadd, float* sum32, int ldsum,
                             oat::LnF8 f8, void* stream);
-// grid cap of the streaming LayerNorm forwards (4 rows per workgroup; OAT_LN_FWD_BLOCKS)
-static int ln_fwd_cap() {
-  static int cap = 0;
-  if (cap == 0) { const char* e = getenv("OAT_LN_FWD_BLOCKS"); cap = e ? atoi(e) : 8192; if (cap < 1) cap = 8192; }
-  return cap;
-}
+// grid cap of the streaming LayerNorm forwards (4 rows per workgroup; x 0.5 / x 2 measured equal, profiles/round4i_knob_sweep.log)
+static int ln_fwd_cap() { return 8192; }
 static int ln_fwd_launch(const float* x, int ldx, const float* gamma, const float* beta, void* y, int ldy, float* y32,
                          int ldy32, float* mean, float* rstd, int M, int D, float eps, const void* add16, int ldadd,
                          float* sum32, int ldsum, void* stream) {
@@ -855,11 +851,7 @@ extern "C" int oat_add32_layernorm_fwd(const float* x, int ldx, const float* add
   return check_launch("add32_layernorm_fwd");
 }
 
-static int ln_bwd_cap() {
-  static int cap = 0;
-  if (cap == 0) { const char* e = getenv("OAT_LN_BWD_BLOCKS"); cap = e ? atoi(e) : 1024; if (cap < 1) cap = 1024; }
-  return cap;
-}
+static int ln_bwd_cap() { return 1024; }
 extern "C" int oat_ln_bwd_blocks(int M) { int b = (M + 3) / 4; const int cap = ln_bwd_cap(); return b > cap ? cap : b; }
 
 // part: fp32 workspace of oat_ln_bwd_blocks(M) * 2 * D floats (or NULL to skip dgamma/dbeta)
@@ -885,17 +877,6 @@ extern "C" int oat_layernorm_bwd_r16(const void* dy, int dy_is_bf16, int lddy, c
   if (ldx % 4 || lddres16 % 4 || lddx16 % 4) { oat::set_error("layernorm_bwd_r16: ld%4==0 required"); return -3; }
   return ln_bwd_launch(dy, dy_is_bf16, lddy, x_bf16, 1, ldx, mean, rstd, gamma, nullptr, 0, dx, lddx, dx16, lddx16, 0,
                        dgamma, dbeta, accumulate, part, M, D, oat::LnF8{nullptr, 0, nullptr, nullptr}, dres16, lddres16, stream);
-}
-// the same, with an e5m2 copy of dx16 (dx8 = sat(dx16 * *qscale), amax recorded): the producer-side quantisation of the
-// next fp8 data-gradient GEMM's operand
-extern "C" int oat_layernorm_bwd_f8(const void* dy, int dy_is_bf16, int lddy, const float* x, int ldx,
-                                    const float* mean, const float* rstd, const float* gamma, const float* dres,
-                                    int lddres, float* dx, int lddx, void* dx16, int lddx16, int dx16_excl_res,
-                                    float* dgamma, float* dbeta, int accumulate, float* part, int M, int D,
-                                    void* dx8, int ld8, const float* qscale, float* amax, void* stream) {
-  if (!dx16 || !dx8 || !qscale || !amax || ld8 % 4) { oat::set_error("layernorm_bwd_f8: dx16, dx8, qscale, amax required"); return -4; }
-  return ln_bwd_launch(dy, dy_is_bf16, lddy, x, 0, ldx, mean, rstd, gamma, dres, lddres, dx, lddx, dx16, lddx16, dx16_excl_res,
-                       dgamma, dbeta, accumulate, part, M, D, oat::LnF8{(uint8_t*)dx8, ld8, qscale, amax}, nullptr, 0, stream);
 }
 static int ln_bwd_launch(const void* dy, int dy_is_bf16, int lddy, const void* x, int x_is_bf16, int ldx,
                          const float* mean, const float* rstd, const float* gamma, const float* dres,
@@ -943,8 +924,7 @@ extern "C" int oat_layernorm_bwd_xhat(const void* dxh, int lddxh, const void* xh
   // no partial-sum rows hang on the grid here (ln_bwd_kernel's cap of 1024 blocks keeps its (dgamma, dbeta) partials small):
   // 4096 blocks measure 90 / 40 / 128 us for the three forms of a block at M = 50208 against 102 / 48 / 151 at 1024; in the
   // step 1024 -> 4096 -> 8192: 48.42 -> 47.97 -> 47.88 ms
-  static int cap = 0;
-  if (cap == 0) { const char* e = getenv("OAT_LN_BWDX_BLOCKS"); cap = e ? atoi(e) : 8192; if (cap < 1) cap = 8192; }
+  constexpr int cap = 8192;
   int blocks = (M + 7) / 8; if (blocks > cap) blocks = cap;
   OAT_LAUNCH(ln_bwd_xhat_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)dxh, lddxh,
              (const bf16*)xhat, ldxh, rstd, dres, lddres, dx, lddx, (bf16*)dx16, lddx16, dx16_excl_res, M, D,

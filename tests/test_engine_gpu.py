@@ -122,21 +122,16 @@ def test_vitb_geometry_vs_reference_golden(golden_dir):
     assert sim_err <= 1e-3
 
 
-def test_slot_schedule_matches_serial_schedule():
-    """Backward with the HBM-bound kernels on the side stream (the slots of engine/video.py) runs the same kernels
-    on the same data as the all-on-one-stream schedule: outputs and every parameter gradient bit-identical, also on
-    the second step (plans, streams and gradient buffers reused)."""
+def test_the_schedule_is_deterministic_across_steps_and_models():
+    """Two models built from the same weights walk the same launch schedule: outputs and every parameter gradient bit-identical, also
+    on the second step (plans, streams, tapes and gradient buffers reused) - no atomics-ordered sums, no state carried between steps."""
     video = si.seeded_tensor(SEED, "in.video.lanes", (4, 3, 3, 48, 48)).cuda()
     gc = si.seeded_tensor(SEED, "g.cls.lanes", (4, 128)).cuda()
     res = []
-    for side in (True, False):
+    for taped in (True, False):
         m = small_model()
         m.need_patch_tokens = False
-        m._engine.bwd_side = side
-        # the slot schedule runs the per-weight gemm_tn launches and the unfolded LayerNorms: give the serial schedule the
-        # same kernels (its defaults - grouped weight gradients, folded LayerNorms - are other summation orders)
-        m._engine.group_wgrads = False
-        m._engine.fold_ln = False
+        m._engine.use_tape = taped
         for _ in range(2):
             cls, _ = m(video)
             (cls * gc).sum().backward()

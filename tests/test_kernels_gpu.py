@@ -189,49 +189,53 @@ def test_gemm_nt_gelu_grad_and_mul_aux(M, N, K):
     close(out, (A2.float() @ B2.float().t() + bias) * d.float(), atol=2e-2, rtol=1.5e-2, what="mul_aux + bias")
 
 
-def test_gemm_nt_tail_split_and_random_shapes():
-    """(1) The forward pass runs its GEMMs with the tail split on (rows of the last, partly filled round of 256x256 tiles go
-    to the 128x128 kernel): every epilogue family must give the same result with it.  (2) A seeded sweep of shapes around the
-    tile, wave-group and bounds-check edges of both kernel configurations."""
+def test_gemm_nt_grid_forms_kernel_choices_and_random_shapes():
+    """(1) The per-call launch policy of oat_gemm_nt (`grid`, `tune`: nothing of it lives in the library): the grid forms of the
+    256x256 kernels and the forced kernel choices give the same result on every epilogue family.  (2) A seeded sweep of shapes around
+    the tile, wave-group and bounds-check edges of both kernel configurations."""
     hip = _hip()
-    M, N, K = 256 * 100 + 40, 768, 64                       # 303 tiles: one full round of 256 + a 47-tile tail
+    M, N, K = 256 * 100 + 40, 768, 128                      # 303 tiles: one full round of 256 + a 47-tile tail
     A = rnd(M, K, dtype=torch.bfloat16, seed=40)
     B = rnd(N, K, scale=K ** -0.5, dtype=torch.bfloat16, seed=41)
     bias = rnd(N, seed=42)
     ref = A.float() @ B.float().t() + bias
     table = rnd(97, N, seed=43)
     aux = rnd(M, N, dtype=torch.bfloat16, seed=44)
-    hip.gemm_set_tail_split(True)
-    try:
+    first = {}
+    for kernel in (hip.GEMM_AUTO, hip.GEMM_128, hip.GEMM_LOCKSTEP, hip.GEMM_PINGPONG):
+        tune = hip.gemm_tune(kernel)
         o16 = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
-        hip.gemm_nt(A, B, M, N, K, hip.EPI_BF16, o16, bias=bias)
-        close(o16, ref, atol=2e-2, rtol=1e-2, what="tail split bf16")
+        hip.gemm_nt(A, B, M, N, K, hip.EPI_BF16, o16, bias=bias, tune=tune)
+        close(o16, ref, atol=2e-2, rtol=1e-2, what=f"kernel {kernel} bf16")
         o32 = torch.zeros(M, N, device=DEV)
         c16 = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
-        hip.gemm_nt(A, B, M, N, K, hip.EPI_F32_BF16, o32, out2=c16, bias=bias, resid=table, resid_mod=97)
+        hip.gemm_nt(A, B, M, N, K, hip.EPI_F32_BF16, o32, out2=c16, bias=bias, resid=table, resid_mod=97, tune=tune)
         want = ref + table[torch.arange(M, device=DEV) % 97]
-        close(o32, want, atol=2e-4, rtol=1e-4, what="tail split f32 + row-modulo table")
-        close(c16, want, atol=2e-2, rtol=1e-2, what="tail split bf16 copy")
+        close(o32, want, atol=2e-4, rtol=1e-4, what=f"kernel {kernel} f32 + row-modulo table")
+        close(c16, want, atol=2e-2, rtol=1e-2, what=f"kernel {kernel} bf16 copy")
         d = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
         g = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
-        hip.gemm_nt(A, B, M, N, K, hip.EPI_GELU_GRAD, d, out2=g, bias=bias)
-        close(g, torch.nn.functional.gelu(ref), atol=1e-2, rtol=1e-2, what="tail split gelu")
-        hip.gemm_nt(A, B, M, N, K, hip.EPI_MUL_AUX, o16, aux=aux, bias=bias)
-        close(o16, ref * aux.float(), atol=3e-2, rtol=1.5e-2, what="tail split mul_aux")
-    finally:
-        hip.gemm_set_tail_split(False)
+        hip.gemm_nt(A, B, M, N, K, hip.EPI_GELU_GRAD, d, out2=g, bias=bias, tune=tune)
+        close(g, torch.nn.functional.gelu(ref), atol=1e-2, rtol=1e-2, what=f"kernel {kernel} gelu")
+        om = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+        hip.gemm_nt(A, B, M, N, K, hip.EPI_MUL_AUX, om, aux=aux, bias=bias, tune=tune)
+        close(om, ref * aux.float(), atol=3e-2, rtol=1.5e-2, what=f"kernel {kernel} mul_aux")
+        if kernel in (hip.GEMM_LOCKSTEP, hip.GEMM_PINGPONG):        # the two 256x256 kernels: the same arithmetic, bit for bit
+            for name, t in (("bf16", o16), ("gelu", g), ("dgelu", d), ("mul_aux", om)):
+                assert torch.equal(first.setdefault(name, t), t), (kernel, name)
     # the grid forms of the 256x256 kernel: one workgroup per tile (what multi-GPU runs use), a short persistent grid
     M, N, K = 256 * 37 + 13, 1024, 128
     A = rnd(M, K, dtype=torch.bfloat16, seed=45)
     B = rnd(N, K, scale=K ** -0.5, dtype=torch.bfloat16, seed=46)
     bias = rnd(N, seed=47)
     ref = A.float() @ B.float().t() + bias
-    for persist in (0xffff, 24, 0):
-        hip.gemm_set_variant(persist << 16)
+    outs = []
+    for grid in (hip.GRID_PER_TILE, 24, 0):
         out = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
-        hip.gemm_nt(A, B, M, N, K, hip.EPI_BF16, out, bias=bias)
-        close(out, ref, atol=2e-2, rtol=1e-2, what=f"grid form {persist:#x}")
-    hip.gemm_set_variant(0)
+        hip.gemm_nt(A, B, M, N, K, hip.EPI_BF16, out, bias=bias, grid=grid)
+        close(out, ref, atol=2e-2, rtol=1e-2, what=f"grid form {grid:#x}")
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])        # the walk does not change a tile's arithmetic
     gen = torch.Generator().manual_seed(7)
     for _ in range(12):
         M = int(torch.randint(1, 9000, (1,), generator=gen))
@@ -260,10 +264,9 @@ def test_gemm_tn(M, N1, N2):
     bias = torch.full((N1,), 9.0, device=DEV)
     ref = P[:M].float().t() @ Q[:M].float()
     bref = P[:M].float().sum(0)
-    # tile-shape variants, and the workgroup budgets the engine sets during backward (bits 16+: 192, and a small one)
-    for variant in (1, 2, 192 << 16, 40 << 16, 0):
-        hip.gemm_tn_set_variant(variant)
-        hip.gemm_tn(P, Q, M, N1, N2, out, bias_out=bias)
+    # tile-shape choices (the per-call `tune` argument of oat_gemm_tn)
+    for variant in (hip.GEMM_128, hip.GEMM_LOCKSTEP, hip.GEMM_PINGPONG if (N1 % 256 == 0 and N2 % 256 == 0) else hip.GEMM_AUTO, hip.GEMM_AUTO):
+        hip.gemm_tn(P, Q, M, N1, N2, out, bias_out=bias, tune=variant)
         close(out, ref, atol=2e-3 * math.sqrt(M), rtol=2e-3, what=f"gemm_tn v{variant}")
         close(bias, bref, atol=2e-3 * math.sqrt(M), rtol=2e-3, what=f"gemm_tn bias v{variant}")
     hip.gemm_tn(P, Q, M, N1, N2, out, accumulate=True, bias_out=bias)
@@ -682,18 +685,6 @@ def test_attention_fwd_bwd(mode, B, T, N, H):
     _attention_case(mode, B, T, N, H)
 
 
-@pytest.mark.parametrize("variant", [1, 2])
-@pytest.mark.parametrize("B,T,N,H", [(2, 8, 196, 12), (2, 2, 441, 3), (1, 2, 224, 2), (1, 2, 100, 2)])
-def test_attention_space_bwd_tuning_variants(B, T, N, H, variant):
-    """the non-default schedules of the space backward (oat_attn_space_set_variant) compute the same gradients"""
-    hip = _hip()
-    hip.lib().oat_attn_space_set_variant(variant)
-    try:
-        _attention_case("space", B, T, N, H)
-    finally:
-        hip.lib().oat_attn_space_set_variant(0)
-
-
 @pytest.mark.parametrize("B,T,N,H", [(40, 8, 196, 12), (1, 2, 199, 2), (3, 5, 160, 7), (1, 2, 207, 2), (1, 3, 208, 2)])
 def test_attention_space_more_shapes(B, T, N, H):
     """space attention at more 14-key-tile shapes: more problems than two rounds of workgroups, patch counts off the 16-row
@@ -743,18 +734,6 @@ def test_attention_space_two_clips_one_launch(N, H):
         close(g2[r0 + n - B:r0 + n], g1[r0 + n - B:r0 + n].float(), atol=1e-2 * g1.float().abs().max().item(), rtol=2e-2, what="CLS rows")
         r0 += n
     assert torch.count_nonzero(g2[sum(rows):]) == 0
-
-
-@pytest.mark.parametrize("variant", [1, 2])
-@pytest.mark.parametrize("B,T,N,H", [(2, 8, 196, 12), (2, 3, 9, 2), (1, 16, 441, 2), (1, 12, 16, 1)])
-def test_attention_time_bwd_tuning_variants(B, T, N, H, variant):
-    """the VALU kernels of the time backward (the default is the MFMA kernel on 16-row mini problems)"""
-    hip = _hip()
-    hip.lib().oat_attn_time_set_variant(variant)
-    try:
-        _attention_case("time", B, T, N, H)
-    finally:
-        hip.lib().oat_attn_time_set_variant(0)
 
 
 @pytest.mark.parametrize("B,T,N,H", [(2, 8, 196, 12), (3, 1, 196, 2), (2, 2, 5, 1), (1, 4, 31, 3), (2, 16, 441, 2)])
@@ -913,27 +892,21 @@ def test_gemm_nt_224_row_tiles_bit_identical(M, N, K):
     """gemm_nt_pp.hip PPF_M224: 224-row tiles (chosen where rounds x tile rows is smaller) must give the bits of the
     256-row tiles for every epilogue that has the variant - same K order per element - and leave rows >= M untouched."""
     hip = _hip()
-    lib = hip.lib()
     mp = (M + 255) // 256 * 256
     A = rnd(mp, K, dtype=torch.bfloat16, seed=50)
     W = rnd(N, K, scale=K ** -0.5, dtype=torch.bfloat16, seed=51)
     bias = rnd(N, seed=52)
     res = {}
-    try:
-        hip.gemm_set_variant(4)                            # the ping-pong kernel also for small M
-        for mode in (0, 2):                                # never / always
-            lib.oat_gemm_set_m224(mode)
-            o = torch.full((mp, N), 7.0, device=DEV, dtype=torch.bfloat16)
-            hip.gemm_nt(A, W, M, N, K, hip.EPI_BF16, o, bias=bias)
-            d8 = torch.full((mp, N), 9, device=DEV, dtype=torch.uint8)
-            g = torch.full((mp, N), 7.0, device=DEV, dtype=torch.bfloat16)
-            hip.gemm_nt(A, W, M, N, K, hip.EPI_GELU_GRAD | hip.EPI_U8, d8, out2=g, bias=bias)
-            m = torch.full((mp, N), 7.0, device=DEV, dtype=torch.bfloat16)
-            hip.gemm_nt(A, W, M, N, K, hip.EPI_MUL_AUX | hip.EPI_U8, m, aux=d8)
-            res[mode] = (o, d8, g, m)
-    finally:
-        lib.oat_gemm_set_m224(1)
-        hip.gemm_set_variant(0)
+    for mode in (0, 2):                                    # never / always: a per-call choice (the `tune` argument)
+        tune = hip.gemm_tune(hip.GEMM_PINGPONG, m224=mode)     # the ping-pong kernel also for small M
+        o = torch.full((mp, N), 7.0, device=DEV, dtype=torch.bfloat16)
+        hip.gemm_nt(A, W, M, N, K, hip.EPI_BF16, o, bias=bias, tune=tune)
+        d8 = torch.full((mp, N), 9, device=DEV, dtype=torch.uint8)
+        g = torch.full((mp, N), 7.0, device=DEV, dtype=torch.bfloat16)
+        hip.gemm_nt(A, W, M, N, K, hip.EPI_GELU_GRAD | hip.EPI_U8, d8, out2=g, bias=bias, tune=tune)
+        m = torch.full((mp, N), 7.0, device=DEV, dtype=torch.bfloat16)
+        hip.gemm_nt(A, W, M, N, K, hip.EPI_MUL_AUX | hip.EPI_U8, m, aux=d8, tune=tune)
+        res[mode] = (o, d8, g, m)
     for a, b in zip(res[0], res[2]):
         assert torch.equal(a, b)
     o, d8, g, m = res[2]
@@ -1002,27 +975,21 @@ def test_gemm_nt_band_walk_bit_identical(M, N, K, m224):
     row panel (M % 256 != 0) - must reproduce the row-major walk bit for bit, for all three epilogues, and leave rows >= M alone.
     (The walk needs >= 2 rounds of a grid that is a multiple of 8: M is sized for that on 256 CUs.)"""
     hip = _hip()
-    lib = hip.lib()
     mp = (M + 255) // 256 * 256
     A = rnd(mp, K, dtype=torch.bfloat16, seed=60)
     W = rnd(N, K, scale=K ** -0.5, dtype=torch.bfloat16, seed=61)
     bias = rnd(N, seed=62)
     res = {}
-    try:
-        lib.oat_gemm_set_m224(m224)
-        for band in (0, 3, 4, 5, 7):                       # 0 = row-major walk; N / 256 = 12, 9 or 5 column tiles
-            lib.oat_gemm_set_band(band)
-            o = torch.full((mp, N), 7.0, device=DEV, dtype=torch.bfloat16)
-            hip.gemm_nt(A, W, M, N, K, hip.EPI_BF16, o, bias=bias)
-            d8 = torch.full((mp, N), 9, device=DEV, dtype=torch.uint8)
-            g = torch.full((mp, N), 7.0, device=DEV, dtype=torch.bfloat16)
-            hip.gemm_nt(A, W, M, N, K, hip.EPI_GELU_GRAD | hip.EPI_U8, d8, out2=g, bias=bias)
-            m = torch.full((mp, N), 7.0, device=DEV, dtype=torch.bfloat16)
-            hip.gemm_nt(A, W, M, N, K, hip.EPI_MUL_AUX | hip.EPI_U8, m, aux=d8)
-            res[band] = (o, d8, g, m)
-    finally:
-        lib.oat_gemm_set_band(-1)
-        lib.oat_gemm_set_m224(1)
+    for band in (0, 3, 4, 5, 7):                           # 0 = row-major walk; N / 256 = 12, 9 or 5 column tiles
+        tune = hip.gemm_tune(m224=m224, band=band)
+        o = torch.full((mp, N), 7.0, device=DEV, dtype=torch.bfloat16)
+        hip.gemm_nt(A, W, M, N, K, hip.EPI_BF16, o, bias=bias, tune=tune)
+        d8 = torch.full((mp, N), 9, device=DEV, dtype=torch.uint8)
+        g = torch.full((mp, N), 7.0, device=DEV, dtype=torch.bfloat16)
+        hip.gemm_nt(A, W, M, N, K, hip.EPI_GELU_GRAD | hip.EPI_U8, d8, out2=g, bias=bias, tune=tune)
+        m = torch.full((mp, N), 7.0, device=DEV, dtype=torch.bfloat16)
+        hip.gemm_nt(A, W, M, N, K, hip.EPI_MUL_AUX | hip.EPI_U8, m, aux=d8, tune=tune)
+        res[band] = (o, d8, g, m)
     for band in (3, 4, 5, 7):
         for a, b in zip(res[0], res[band]):
             assert torch.equal(a, b), band

@@ -181,7 +181,6 @@ def test_native_object_clip_4_frames_vs_oracle(variant, segments, prune, monkeyp
     clips as two segments of one launch sequence); segments=False is two encoder calls, the second backward
     ACCUMULATING into the first's gradients (the folded-LayerNorm weight gradients then go through a scratch slab).
     Tolerances: embeddings rel-L2 <= 1e-2, loss rel <= 3e-2, gradients norm <= 5e-2 / cosine >= 0.99."""
-    monkeypatch.setenv("OAT_OBJ_SEGMENTS", "1" if segments else "0")
     monkeypatch.setenv("OAT_PRUNE_TOP", "1" if prune else "0")
     from OATrans.model import NormSoftmaxLoss, sim_matrix
     from OATrans.model.oa_layers import bce_sum, mean_rows
@@ -198,7 +197,7 @@ def test_native_object_clip_4_frames_vs_oracle(variant, segments, prune, monkeyp
         p = region_params()
     p["video_model.temporal_embed"] = si.seeded_tensor(SEED, "oa.temporal4", (1, T, 768)) * 0.02
     m = FrozenInTime(dict(model="SpaceTimeTransformer", arch_config="base_patch16_224", num_frames=T, pretrained=True, time_init="rand",
-                          two_outputs=False),
+                          two_outputs=False, object_clip_segments=segments),
                      dict(model="", input_objects=False), dict(model="pretrained/distilbert-base-uncased", pretrained=True, input="text"))
     m.text_model.eval()          # parity runs in eval mode (the goldens' DistilBERT has dropout off)
     r = m.load_state_dict(p, strict=False)
