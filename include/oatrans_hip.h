@@ -238,7 +238,7 @@ int oat_attn_time_bwd_fin(const void* qkv, int ldqkv, const void* out, int ldo, 
  * M <= 64 (CLS lane, projections): exact fp32 products.  M > 64 with K % 32 == 0 (the text tower): every fp32 operand element
  * is split into two bf16 (hi + lo, 16 mantissa bits) and the product runs as three bf16 MFMA passes with fp32 accumulation -
  * 2^-16 relative per product, 1e-5 of |y| max against fp64 (tests/test_kernels_gpu.py), 5x less matrix-pipe time; the launches
- * sit beside the video tower on a side stream and their duration is what they cost it.  OAT_LIN_X3=0: exact fp32 everywhere.
+ * sit beside the video tower on a side stream and their duration is what they cost it.  act | OAT_LIN_EXACT: exact fp32 at every M.
  * act | 0x100 (OAT_LIN_EXACT): exact fp32 products at EVERY M - what the CLS lane and the projection heads pass, so that a plan of
  * more than 64 clips (batch 64, or two clips of more than 32 samples) keeps the lane's precision. */
 #define OAT_LIN_NONE 0

@@ -406,7 +406,7 @@ __global__ __launch_bounds__(256) void linear_f32_small_kernel(LinArgs g) {
   }
 }
 
-// Fixed since round 6 (the A/B knobs OAT_LIN_KG2 / OAT_LIN_X3 / OAT_LIN_BK are gone): M > 64 runs on the split-bf16 kernel
+// Fixed since round 6 (the three A/B environment knobs of this dispatch are gone): M > 64 runs on the split-bf16 kernel
 // (linear_x3_kernel) unless the call asks for exact products; K-tiles of 32 (half the barrier pairs and global round trips of 16:
 // text tower forward 2124 -> 1950 us alone, same accumulation order, bit-identical); too few 128 x 128 tiles -> 64 x 64 workgroups of
 // two wave quartets that split K.
