@@ -25,7 +25,7 @@ struct GemmArgs {
   const bf16* aux; int ldaux;
   int dbg;
   int row0;            // first row of this launch inside the caller's problem (tail launches; used by resid_mod)
-  int* ctr;            // always nullptr since round 6 (static tile walk; the dynamic, counter-driven walk of round 1 lost 5-15 %)
+  int* ctr;            // unused since round 6 (kept so that the aggregate initialisers of the callers stay as they are)
   int* ctr_reset;
   const float* dq_a;   // fp8 launches: device scalars, dequantisation scale of A and of B (value = quantised * dq)
   const float* dq_b;
@@ -34,7 +34,7 @@ struct GemmArgs {
   float* amax_out;         // ... its max |value| recorded here
   int h_u8;                // the GELU-derivative tensor (out of EPI_GELU_GRAD / aux of EPI_MUL_AUX) is 8-bit fixed point,
                            // one byte per element, ldc / ldaux in bytes (ping-pong kernel only; gemm_nt_pp.hip HU8_*)
-  float* sk_ws; int* sk_ctr;   // always nullptr since round 6 (split-K of the last round: measured equal, left the library)
+  float* sk_ws; int* sk_ctr;   // unused since round 6 (split-K of the last round left the library)
   int band;                    // ping-pong kernel, PPF_BAND: column tiles per band group of the per-XCD tile walk (0 = row-major walk)
 };
 
@@ -47,7 +47,7 @@ struct TnArgs {
   float* bias_slabs;       // [splits][N1] or nullptr
   int chunks_per_split;    // in units of TK rows
   int splits;
-  int dbg;                 // ablation bits: 1 = no global loads after the first stages, 2 = no slab store
+  int dbg;                 // unused since round 6 (the run-time ablation bits left the kernels)
 };
 
 // gemm_tn_pp.hip: ping-pong 256x256 weight-gradient kernel.  Writes the same fp32 slabs as gemm_tn_kernel (the caller

@@ -42,7 +42,7 @@ OAT_DEV int swz(int r, int lc) { return r * 128 + ((lc ^ ((r >> 1) & 7)) << 4); 
 // configuration (3 x 32 KB + 2 x 32 KB = all 160 KB of LDS), so its loads are issued TWO K-steps ahead.
 // The LDS-DMA loads are issued from inline asm (the compiler would otherwise drain them with vmcnt(0)
 // before the first ds_read) and published by a counted s_waitcnt + raw s_barrier.
-template <int EPI, int WM, int WN, int TM, int TN, int NSA, bool SPREAD, bool PIPE = false>
+template <int EPI, int WM, int WN, int TM, int TN, int NSA, bool SPREAD>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16, NW = WM * WN;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
@@ -66,55 +66,23 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
   };
   // PREF: while a tile's epilogue runs (scratch in the upper 96 KB of the ring), the first two A stages of the
   // workgroup's NEXT tile are already streaming into A slots 0 and 1.
-  constexpr bool PREF = !PIPE && NSA == 3 && EPI != EPI_DGELU;
+  constexpr bool PREF = NSA == 3 && EPI != EPI_DGELU;
   // DIRECT: bf16 outputs are stored straight from the accumulators, with no transpose through LDS, no scratch and no
   // wave barriers.  The MFMA operands are NOT swapped here (lane l holds rows 4*(l>>4)+r, column l&15 of a 16x16 tile)
   // and the B rows (= output columns) are PERMUTED on their way into LDS: tile j, MFMA column c of a wave's 64-column
   // group is output column 4*c + j.  A lane then owns 4 consecutive columns of a row across its TN = 4 tiles (one 8-B
   // store) and the 16 consecutive lanes of a row write one full 128-byte line.
-  constexpr bool DIRECT = !PIPE && TN == 4 && (EPI == EPI_BF16 || EPI == EPI_GELU_GRAD || EPI == EPI_MUL_AUX);
+  constexpr bool DIRECT = TN == 4 && (EPI == EPI_BF16 || EPI == EPI_GELU_GRAD || EPI == EPI_MUL_AUX);
   bool prefetched = false;
-  // Tile scheduling.  Static: workgroup w walks tiles w, w + gridDim.x, ...  Dynamic (g.ctr): every workgroup pulls
-  // the next tile of ITS XCD's contiguous range from an atomic counter (and steals from the other XCDs when its own
-  // range is exhausted), so a workgroup that starts late - its CU was busy with another stream's kernel or with RCCL -
-  // simply takes fewer tiles instead of stretching the launch.  The index travels through the last word of the ring.
-  constexpr int LDS_TOTAL = (NSA * BM + 2 * BN) * BK * 2;
-  volatile int* const tile_word = reinterpret_cast<volatile int*>(smem + LDS_TOTAL - 16);
+  // Tile scheduling: static - workgroup w walks tiles w, w + gridDim.x, ... (remapped so that the column tiles of one A panel share
+  // an XCD's L2).  (The dynamic, counter-driven walk of round 1 - a late-starting workgroup takes fewer tiles - lost 5-15 % to the
+  // counter's round trip and left the library in round 6.)
   int static_tile = blockIdx.x;
-  // Thread 0 requests its XCD's counter during the main loop and uses the answer in the epilogue.  (hipcc waits for an
-  // atomic's result right where it is issued - vmcnt(0) inside the K loop - which costs 5-15 % on short-K shapes; an
-  // inline-asm atomic parked in an AGPR hung the GPU in testing.  Dynamic scheduling is therefore OPT-IN.)
-  int pending = 0;
-  auto request = [&]() {
-    if (g.ctr != nullptr && threadIdx.x == 0) pending = atomicAdd(g.ctr + (blockIdx.x & 7), 1);
-  };
   auto fetch = [&]() -> int {
-    if (g.ctr == nullptr) {
-      const int t = static_tile;
-      static_tile += gridDim.x;
-      return t < nwg ? remap(t) : -1;
-    }
-    if (threadIdx.x == 0) {
-      const int q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
-      int res = -1;
-      if (pending < q + (xcd < r ? 1 : 0)) {
-        res = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pending;
-      } else {
-        for (int d = 1; d < 8 && res < 0; ++d) {         // own range exhausted: steal (end of the launch only)
-          const int x = (xcd + d) & 7;
-          const int idx = atomicAdd(g.ctr + x, 1);
-          if (idx < q + (x < r ? 1 : 0)) res = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
-        }
-      }
-      *tile_word = res;
-    }
-    __syncthreads();
-    const int v = *tile_word;
-    __syncthreads();                       // nobody restages that word before everyone has read it
-    return v;
+    const int t = static_tile;
+    static_tile += gridDim.x;
+    return t < nwg ? remap(t) : -1;
   };
-  if (g.ctr_reset != nullptr && blockIdx.x == 0 && threadIdx.x < 8) g.ctr_reset[threadIdx.x] = 0;
-  request();
   int bid = fetch();
   while (bid >= 0) {
   const int tm = bid / ntn, tn = bid % ntn;
@@ -127,14 +95,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
   for (int i = 0; i < GA; ++i) {
     const int r = (wave * GA + i) * 8 + srow;
     const int lc = (lane & 7) ^ ((r >> 1) & 7);            // inverse swizzle on the source side
-    a_src[i] = (uint32_t)(((size_t)min(((g.dbg & 16) ? 0 : m0) + r, g.M - 1) * g.lda + lc * 8) * 2);   // clamp: ragged M reads a valid row
+    a_src[i] = (uint32_t)(((size_t)min(m0 + r, g.M - 1) * g.lda + lc * 8) * 2);   // clamp: ragged M reads a valid row
   }
 #pragma unroll
   for (int i = 0; i < GB; ++i) {
     const int r = (wave * GB + i) * 8 + srow;
     const int lc = (lane & 7) ^ ((r >> 1) & 7);
     const int rg = DIRECT ? ((r & ~63) | ((r & 15) << 2) | ((r >> 4) & 3)) : r;   // LDS row r <- B row rg
-    b_src[i] = (uint32_t)(((size_t)min(((g.dbg & 32) ? 0 : n0) + rg, g.N - 1) * g.ldb + lc * 8) * 2);
+    b_src[i] = (uint32_t)(((size_t)min(n0 + rg, g.N - 1) * g.ldb + lc * 8) * 2);
   }
   char* const sA0 = smem;
   char* const sB0 = smem + NSA * A_BYTES;
@@ -169,83 +137,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
       const float b0 = DIRECT ? bias_v[0][j & 3] : 0.f;
       acc[i][j] = f32x4{b0, b0, b0, b0};
     }
-  if constexpr (PIPE) {
-    // One wave per SIMD (4 waves x 128x128): nothing hides a wave's own LDS latency or its barrier, so the
-    // loop is software-pipelined by hand.  Fragments are double-buffered in registers (set 0 = k-half 0, set 1 =
-    // k-half 1); every group of 4 MFMAs carries one ds_read_b128 of the NEXT half and - in the second half -
-    // one LDS-DMA piece of a later stage.  The stage hand-over (counted vmcnt + barrier) sits in the MIDDLE of a
-    // K-step: stage kt is fully in registers by then, so its slots are refilled right away (W two steps ahead in
-    // a 2-slot ring, A three steps ahead in a 3-slot ring).
-    static_assert(NSA == 3 && TM == 8 && TN == 8 && GA + GB == 16, "pipelined loop is built for 4 waves of 128x128");
-    bf16x8 fa[2][TM], fb[2][TN];
-    auto ld_item = [&](int set, const char* sa, const char* sb, int kk, int it) {
-      // item order = order of first use by the next half: B0..3, A0, B4..7, A1..A7
-      if (it < 4) fb[set][it] = *reinterpret_cast<const bf16x8*>(sb + swz(wn * TN * 16 + it * 16 + frow, kk * 4 + fk));
-      else if (it == 4) fa[set][0] = *reinterpret_cast<const bf16x8*>(sa + swz(wm * TM * 16 + frow, kk * 4 + fk));
-      else if (it < 9) fb[set][it - 1] = *reinterpret_cast<const bf16x8*>(sb + swz(wn * TN * 16 + (it - 1) * 16 + frow, kk * 4 + fk));
-      else fa[set][it - 8] = *reinterpret_cast<const bf16x8*>(sa + swz(wm * TM * 16 + (it - 8) * 16 + frow, kk * 4 + fk));
-    };
-    stageA(0, 0);
-    stageB(0, 0);
-    if (nk > 1) { stageA(1, BK); stageB(1, BK); }
-    if (nk > 2) stageA(2, 2 * BK);
-    if (nk > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * GA + GB) : "memory");
-    else if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GA + GB) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-#pragma unroll
-    for (int it = 0; it < 16; ++it) ld_item(0, sA0, sB0, 0, it);
-    int abuf = 0;
-    // one K-step; MORE / MOREB / MOREA (is there a stage kt+1 / kt+2 / kt+3) are compile-time so that the
-    // steady-state body carries no branches between the MFMA groups - the last three steps are peeled
-    auto kstep = [&](int kt, auto more_c, auto moreb_c, auto morea_c) {
-      constexpr bool more = decltype(more_c)::value, moreB = decltype(moreb_c)::value, moreA = decltype(morea_c)::value;
-      const int abuf1 = abuf == 2 ? 0 : abuf + 1;
-      const char* sa = sA0 + abuf * A_BYTES;
-      const char* sb = sB0 + (kt & 1) * B_BYTES;
-      const char* sa1 = sA0 + abuf1 * A_BYTES;
-      const char* sb1 = sB0 + ((kt + 1) & 1) * B_BYTES;
-      // ---- first half: MFMAs on set 0, fetch k-half 1 of this stage into set 1
-#pragma unroll
-      for (int gq = 0; gq < 16; ++gq) {
-        const int i = gq >> 1, j0 = (gq & 1) * 4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) mfma_agpr(acc[i][j0 + j], fb[0][j0 + j], fa[0][i]);
-        ld_item(1, sa, sb, 1, gq);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      // ---- hand-over: stage kt+1 landed for everyone, stage kt no longer read by anyone
-      if constexpr (more) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if constexpr (moreB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GA) : "memory");     // only A(kt+2) may still fly
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-      }
-      // ---- second half: MFMAs on set 1, fetch k-half 0 of stage kt+1 into set 0, refill the freed slots
-#pragma unroll
-      for (int gq = 0; gq < 16; ++gq) {
-        const int i = gq >> 1, j0 = (gq & 1) * 4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) mfma_agpr(acc[i][j0 + j], fb[1][j0 + j], fa[1][i]);
-        if constexpr (more) ld_item(0, sa1, sb1, 0, gq);
-        if (gq < GB) {
-          if constexpr (moreB) glds16_asm_so(g.B + (kt + 2) * BK, b_src[gq], sB0 + (kt & 1) * B_BYTES + (wave * GB + gq) * 1024);
-        } else {
-          if constexpr (moreA) glds16_asm_so(g.A + (kt + 3) * BK, a_src[gq - GB], sA0 + abuf * A_BYTES + (wave * GA + gq - GB) * 1024);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      abuf = abuf1;
-    };
-    using T_ = std::true_type; using F_ = std::false_type;
-    request();
-    int kt = 0;
-    for (; kt + 3 < nk; ++kt) kstep(kt, T_{}, T_{}, T_{});
-    if (kt + 2 < nk) { kstep(kt, T_{}, T_{}, F_{}); ++kt; }
-    if (kt + 1 < nk) { kstep(kt, T_{}, F_{}, F_{}); ++kt; }
-    kstep(kt, F_{}, F_{}, F_{});
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // MFMA -> accvgpr_read wait states (asm MFMAs are opaque)
-  } else {
   const bool have_a = PREF && prefetched;         // A(0), A(1) were issued during the previous tile's epilogue
   if (!have_a) stageA(0, 0);
   stageB(0, 0);
@@ -265,9 +156,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
       if (moreB) stageB(bbuf_n, (kt + 1) * BK);
       if (moreA) stageA(abuf_n, ka_n);
     }
-    // the NEXT tile's counter request goes out in the second K-step: issued earlier it would be the oldest
-    // outstanding memory operation of wave 0 and every counted wait of this tile would sit on its round trip
-    if (kt == (nk > 1 ? 1 : 0)) request();
     const char* sa = sA0 + abuf * A_BYTES;
     const char* sb = sB0 + (kt & 1) * B_BYTES;
     abuf = abuf + 1 == NSA ? 0 : abuf + 1;
@@ -307,17 +195,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
     }
   }
 
-  }
-
-  if (g.dbg & 1) {   // tuning experiment: keep the accumulators live but skip the epilogue
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(acc[i][j]));
-    __syncthreads();
-    bid = fetch();
-    continue;
-  }
   // ---- epilogue.  Non-DIRECT forms: each lane owns C[row = .. + (lane & 15)][col = .. + (lane >> 4) * 4 + 0..3]
   // (4 columns = 8..16 B): storing that directly gives 32-64 B fragments per row and an
   // issue-bound store tail (measured: 40 % of a K=768 GEMM).  Instead every wave transposes
@@ -328,7 +205,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
   prefetched = false;
   const int bid_next = fetch();            // the LDS staging data is dead here: the broadcast word is safe
   if constexpr (PREF) {
-    if (bid_next >= 0 && nk > 1 && !(g.dbg & 2)) {
+    if (bid_next >= 0 && nk > 1) {
       const int m0n = (bid_next / ntn) * BM;
 #pragma unroll
       for (int i = 0; i < GA; ++i) {
@@ -376,7 +253,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
         for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
       }
     };
-    if (m0 + BM <= g.M && n0 + BN <= g.N && g.dbg == 0) {
+    if (m0 + BM <= g.M && n0 + BN <= g.N) {
       // interior tile (all but the last row panel): no bounds checks, and every address is a wave-uniform 64-bit base
       // (scalar registers, advanced with scalar adds) plus ONE 32-bit lane offset per matrix
       const size_t t0 = (size_t)wrow0;
@@ -424,9 +301,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
           if constexpr (EPI == EPI_MUL_AUX) a = *reinterpret_cast<const bf16x4*>(g.aux + (size_t)row * g.ldaux + col);
           finish(v, a, o, o2);
           if constexpr (EPI == EPI_GELU_GRAD) *reinterpret_cast<bf16x4*>((bf16*)g.out2 + (size_t)row * g.ld2 + col) = o2;
-          const int orow = (g.dbg & 4) ? (row & 1023) : row;
-          if (!(g.dbg & 8)) *reinterpret_cast<bf16x4*>((bf16*)g.out + (size_t)orow * g.ldc + col) = o;
-          else asm volatile("" ::"v"(o));
+          *reinterpret_cast<bf16x4*>((bf16*)g.out + (size_t)row * g.ldc + col) = o;
         }
       }
     }
@@ -519,9 +394,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_kernel(GemmArgs g) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) hv[e] = f2bf(bf2f(hv[e]) * bf2f(auxv[it][e]));
           }
-          const int orow = (g.dbg & 4) ? (row & 1023) : row;      // ablation: all row panels overwrite the first 1024 rows
-          if (!(g.dbg & 8)) *reinterpret_cast<bf16x8*>((bf16*)g.out + (size_t)orow * g.ldc + col) = hv;
-          else asm volatile("" ::"v"(hv));
+          *reinterpret_cast<bf16x8*>((bf16*)g.out + (size_t)row * g.ldc + col) = hv;
           if constexpr (EPI == EPI_GELU_DUAL) {
             // GELU is evaluated on the bf16-rounded pre-activation so that backward (which only
             // has the saved bf16 h) differentiates exactly the function that forward applied.
@@ -627,13 +500,13 @@ static int launch_cfg(const GemmArgs& g, const GemmTune& t, hipStream_t s) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
   constexpr int LDS = (NSA * BM + 2 * BN) * BK * 2;
   const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
-  OAT_MAX_LDS((gemm_nt_kernel<EPI, WM, WN, TM, TN, NSA, SPREAD, false>), LDS);
+  OAT_MAX_LDS((gemm_nt_kernel<EPI, WM, WN, TM, TN, NSA, SPREAD>), LDS);
   int grid = ntm * ntn;
   if (BM == 256 && t.grid != 0xffff) {        // persistent: one workgroup per CU walks the tiles (+1.8 % per step)
     const int slots = t.grid > 0 ? t.grid : cu_count();
     if (grid > slots) grid = slots;
   }
-  OAT_LAUNCH((gemm_nt_kernel<EPI, WM, WN, TM, TN, NSA, SPREAD, false>), dim3(grid), dim3(WM * WN * 64), LDS, s, g);
+  OAT_LAUNCH((gemm_nt_kernel<EPI, WM, WN, TM, TN, NSA, SPREAD>), dim3(grid), dim3(WM * WN * 64), LDS, s, g);
   return check_launch("gemm_nt");
 }
 

@@ -42,10 +42,12 @@ constexpr int PP_MAXN = 4096;                       // bias vector kept in LDS
 constexpr int PP_FLAG = PP_BIAS + PP_MAXN * 4;      // one word: the split-K arrival count, broadcast to the workgroup
 constexpr int PP_LDS = PP_FLAG + 16;
 
-enum : int { PPF_PRIO = 1, PPF_NOSTAGGER = 2, PPF_LGKM = 4, PPF_BONUS = 8, PPF_NOEPI = 16, PPF_PH2 = 32, PPF_WIDE = 64,
-             PPF_F8 = 128, PPF_A_BF8 = 256,     // PPF_A_BF8: the A operand is e5m2 (gradients), B stays e4m3
+// compile-time configuration of the kernel.  PRIO | LGKM | BONUS are the shipped schedule (their ablation builds, the two-phase
+// K-tile kernel, wide stores and the split-K of the last round were measured in rounds 2-5 and left the tree in round 6).
+enum : int { PPF_PRIO = 1, PPF_LGKM = 4, PPF_BONUS = 8,
+             PPF_F8 = 128,                      // OCP e4m3 operands (see below)
+             PPF_A_BF8 = 256,                   // (unused since round 6: the A operand as e5m2)
              PPF_HU8 = 512,                     // the saved GELU derivative travels as 8-bit fixed point (see HU8_*)
-             PPF_SPLITK = 1024,                 // split-K of the last, partial round of tiles (see `sk_*` in the kernel)
              PPF_M224 = 2048,                   // 224-row tiles (see TM in the kernel)
              PPF_BAND = 4096 };                 // band-grouped per-XCD tile walk (see `tile_of` in the kernel)
 
@@ -91,11 +93,10 @@ OAT_DEV void st_nt(T* p, const T v) { __builtin_nontemporal_store(v, p); }
 // Epilogue of one 256x256 tile (no LDS, no barriers): lane (fk, frow) owns rows 16 i + 4 fk + r and the 4 consecutive
 // columns 4 frow + j of its wave tile, so 16 consecutive lanes store one 128-byte line per row.  Returns whether the
 // tile was an interior one (then exactly NST store instructions were issued per lane, see the kernel).
-template <int EPI, bool WIDE = false, bool F8 = false, bool HU8 = false, int TM = 256>
+template <int EPI, bool F8 = false, bool HU8 = false, int TM = 256>
 OAT_DEV bool pp_epilogue(const GemmArgs& g, const f32x4 (&acc)[8][4], int m0, int n0, int wm, int wn, int lane, float dq = 1.f) {
   // TM: rows of the tile (256, or 224: wave rows of 112 = 7 row groups of 16, acc[7] unused)
   constexpr int WR = TM / 2, NI = WR / 16;
-  static_assert(!WIDE || TM == 256, "wide stores: 256-row tiles only");
   // HU8: the derivative tensor (out of EPI_GELU_GRAD, aux of EPI_MUL_AUX) is one byte per element in a blocked layout (below)
   uint32_t d8 = 0;                                                // HU8 + EPI_GELU_GRAD: the 4 derivative bytes of the last finish()
   // lane-constant store offsets are derived from an opaque copy of the lane id: hoisted out of the tile loop they would
@@ -177,43 +178,6 @@ OAT_DEV bool pp_epilogue(const GemmArgs& g, const f32x4 (&acc)[8][4], int m0, in
     }
   };
   const bool interior = m0 + TM <= g.M;
-  if constexpr (WIDE && EPI == EPI_BF16) {
-    if (interior) {
-      // 16-byte stores: neighbouring lanes (columns 4 frow .. and 4 (frow ^ 1) ..) trade two of their four rows by DPP,
-      // so the even lane ends up with rows r = 0, 1 and the odd lane with rows r = 2, 3 of 8 consecutive columns:
-      // half as many store instructions, still one full 128-byte line per 8 lanes
-      const bool odd = frow & 1;
-      char* const ob = reinterpret_cast<char*>(g.out) + ((size_t)wrow0 * g.ldc + wcol00) * 2;
-      const uint32_t lo = (uint32_t)((fk * 4 + (odd ? 2 : 0)) * g.ldc + (frow >> 1) * 8) * 2;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        uint32_t w[4][2];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const bf16x4 o = {f2bf(acc[i][0][r]), f2bf(acc[i][1][r]), f2bf(acc[i][2][r]), f2bf(acc[i][3][r])};
-          const uint2 u = __builtin_bit_cast(uint2, o);
-          w[r][0] = u.x;
-          w[r][1] = u.y;
-        }
-#pragma unroll
-        for (int pr = 0; pr < 2; ++pr) {           // row pair (pr, pr + 2)
-          uint32_t rc[2];
-#pragma unroll
-          for (int d = 0; d < 2; ++d) {
-            const uint32_t send = odd ? w[pr][d] : w[pr + 2][d];
-            rc[d] = (uint32_t)__builtin_amdgcn_mov_dpp((int)send, 0xB1, 0xf, 0xf, true);     // quad_perm [1,0,3,2]
-          }
-          uint4 v;
-          v.x = odd ? rc[0] : w[pr][0];
-          v.y = odd ? rc[1] : w[pr][1];
-          v.z = odd ? w[pr + 2][0] : rc[0];
-          v.w = odd ? w[pr + 2][1] : rc[1];
-          *reinterpret_cast<uint4*>(ob + (size_t)((uint32_t)(i * 16 + pr) * (uint32_t)g.ldc * 2) + lo) = v;
-        }
-      }
-      return true;
-    }
-  }
   // HU8: the derivative tensor is BLOCKED - [row / 16][col / 64][lane][16 bytes]: the 16 rows x 64 columns a wave's row group i
   // covers are one 1 KB block in which lane (fk, frow) owns 16 consecutive bytes, its rows 4 fk + r times its columns 4 frow + j
   // in [r][j] order.  Producer (EPI_GELU_GRAD) and consumer (EPI_MUL_AUX) are the only readers of this tensor and both hold exactly
@@ -327,8 +291,7 @@ OAT_DEV bool pp_epilogue(const GemmArgs& g, const f32x4 (&acc)[8][4], int m0, in
 
 template <int EPI, int FL>
 __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs g) {
-  constexpr bool PRIO = FL & PPF_PRIO, STAGGER = !(FL & PPF_NOSTAGGER), LGKM = FL & PPF_LGKM, BONUS = FL & PPF_BONUS;
-  constexpr bool NOEPI = FL & PPF_NOEPI;
+  constexpr bool PRIO = FL & PPF_PRIO, LGKM = FL & PPF_LGKM, BONUS = FL & PPF_BONUS;
   constexpr bool F8 = FL & PPF_F8;
   constexpr int CBSZ = (FL & PPF_A_BF8) ? 1 : 0;                // MFMA format code of A: 0 = e4m3, 1 = e5m2
   constexpr int ESH = F8 ? 0 : 1;                               // log2(bytes per operand element)
@@ -348,29 +311,9 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs g) {
   const int wm = wave >> 2, wn = wave & 3;                      // wave tile: rows wm*128.., columns wn*64..
   const int ntn = g.N >> 8, ntm = (g.M + TM - 1) / TM, nwg = ntm * ntn;
   const int nk = g.K >> (7 - ESH);                                      // K-tiles of 128 bytes per row
-  // Split-K of the last round.  A persistent launch walks nwg tiles in rounds of gridDim.x; when the last round is less
-  // than half full (N = 768 at M = 50208: 591 tiles on 256 CUs = 2.31 rounds, the third one 79 tiles wide) most CUs
-  // idle through a whole tile time.  With PPF_SPLITK each tile of that round is shared by sk_S workgroups, each taking
-  // 1 / sk_S of the K range: they write their fp32 partial tiles to a workspace, count themselves on a per-tile counter,
-  // and the LAST one to arrive sums the partials in split order (deterministic), adds the bias and runs the epilogue.
-  // No workgroup ever waits for another one.  (ntl: tiles this workgroup walks.)
-  constexpr bool SPLITK = (FL & PPF_SPLITK) != 0;
-  const int grid = (int)gridDim.x, full = nwg / grid;
-  int sk_S = 1, sk_r = 0;
-  if constexpr (SPLITK) {
-    sk_r = nwg - full * grid;
-    if (g.sk_ws != nullptr && sk_r > 0 && 2 * sk_r <= grid) {
-      sk_S = grid / sk_r;
-      if (sk_S > 4) sk_S = 4;
-      while (sk_S > 1 && nk % (2 * sk_S) != 0) --sk_S;
-      if (nk * (sk_S - 1) < 12 * sk_S) sk_S = 1;          // too short a K range to pay for the fix-up
-    }
-  }
-  const bool sk_on = sk_S > 1;
-  const int sk_tile = sk_on ? (int)blockIdx.x % sk_r : 0, sk_split = sk_on ? (int)blockIdx.x / sk_r : 0;
-  const int sk_nk = sk_on ? nk / sk_S : nk;                             // K-tiles of a split tile
-  const int ntl_rm = sk_on ? full + ((int)blockIdx.x < sk_r * sk_S ? 1 : 0)
-                           : (nwg - 1 - (int)blockIdx.x) / grid + 1;
+  // (ntl: tiles this workgroup walks.  The split-K of a less-than-half-full last round - rounds 2-5, measured equal - left in round 6.)
+  const int grid = (int)gridDim.x;
+  const int ntl_rm = (nwg - 1 - (int)blockIdx.x) / grid + 1;
   float dq = 1.f, inv_dq = 1.f;
   if constexpr (F8) {
     dq = g.dq_a[0] * g.dq_b[0];
@@ -386,7 +329,6 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs g) {
   // places.  Same tiles, same per-tile arithmetic: results are bit-identical to the row-major walk.
   // Host guarantees grid % 8 == 0 (a workgroup then stays on one XCD chunk for its whole walk).
   constexpr bool BAND = (FL & PPF_BAND) != 0;
-  static_assert(!(BAND && SPLITK), "band walk and split-K are separate variants");
   int bw_s0 = 0, bw_f = 0, bw_mid = 0, bw_pm = 0, bw_P0 = 0, bw_gw = 1;
   if constexpr (BAND) {
     const int q = nwg >> 3, r = nwg & 7, xcd = (int)blockIdx.x & 7;
@@ -415,7 +357,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs g) {
       const int tm = mid ? bw_P0 + pn : tm_r, tn = mid ? gi * bw_gw + rem - pn * wg : tn_r;
       return Tile{tm * TM, tn << 8};
     } else {
-      const int w = (sk_on && t == full) ? full * grid + sk_tile : (int)blockIdx.x + t * grid;
+      const int w = (int)blockIdx.x + t * grid;
       const int q = nwg >> 3, r = nwg & 7, xcd = w & 7, idx = w >> 3;
       const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;   // XCD-contiguous, bijective
       const int tm = bid / ntn;
@@ -471,12 +413,9 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs g) {
       const bool more = ctl + 1 < ntl;
       ctl += more ? 1 : 0;
       const Tile t = tile_of(ctl);
-      const bool split = sk_on && ctl == full;  // the next tile is this workgroup's share of a split one
-      const size_t koff = split ? (size_t)sk_split * sk_nk * 128 : 0;
       ckt = more ? 0 : cnk - 1;
-      cnk = (more && split) ? sk_nk : cnk;
-      ca = more ? A0 + (size_t)t.m0 * lda2 + koff : ca - 128;
-      cb = more ? B0 + (size_t)t.n0 * ldb2 + koff : cb - 128;
+      ca = more ? A0 + (size_t)t.m0 * lda2 : ca - 128;
+      cb = more ? B0 + (size_t)t.n0 * ldb2 : cb - 128;
       crmax = g.M - 1 - t.m0;
       lda2c = more ? lda2c : 0u;
       bmask = more ? bmask : 0x7fu;
@@ -582,7 +521,7 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs g) {
   asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // b0(0), a0(0) landed (K-tile 0's a1, b1 and K-tile 1 may fly)
   __syncthreads();                                       // ... for every wave; also publishes the bias vector
   readB(fbx, 0, 0);
-  if (STAGGER && wm == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one interval behind from here on
+  if (wm == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one interval behind from here on
   __builtin_amdgcn_sched_barrier(0);
 
   // Two K-tiles (LDS buffers 0 and 1).  HEAD = first pair of a tile: when the previous tile's epilogue was an interior
@@ -611,86 +550,22 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmArgs g) {
   for (int tl = 0; tl < ntl; ++tl) {
     const Tile tile = tile_of(tl);
     const int m0 = tile.m0, n0 = tile.n0;
-    const bool split_tile = SPLITK && sk_on && tl == full;      // always the last tile of the walk
     {
-      f32x4 b = *reinterpret_cast<const f32x4*>(sbias + n0 + wn * 64 + frow * 4);
-      if (split_tile) b = f32x4{0.f, 0.f, 0.f, 0.f};            // the bias joins the summed partials
+      const f32x4 b = *reinterpret_cast<const f32x4*>(sbias + n0 + wn * 64 + frow * 4);
 #pragma unroll
       for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{b[j], b[j], b[j], b[j]};
     }
-    const int nk_t = split_tile ? sk_nk : nk;
     pair(std::true_type{}, BONUS && prev_interior);
-    for (int kt = 2; kt < nk_t; kt += 2) pair(std::false_type{}, false);
-    if constexpr (SPLITK) {
-      if (split_tile) break;                                    // its epilogue follows the loop (needs the whole workgroup)
-    }
+    for (int kt = 2; kt < nk; kt += 2) pair(std::false_type{}, false);
     // ---- epilogue (no LDS, no barriers): lane (fk, frow) owns rows 16 i + 4 fk + r and the 4 consecutive columns
     // 4 frow + j of its wave tile, so 16 consecutive lanes store one 128-byte line per row
-    if constexpr (NOEPI) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
-      prev_interior = false;
-      continue;
-    }
-    prev_interior = pp_epilogue<EPI, false, F8, (FL & PPF_HU8) != 0, TM>(g, acc, m0, n0, wm, wn, lane, dq);
+    prev_interior = pp_epilogue<EPI, F8, (FL & PPF_HU8) != 0, TM>(g, acc, m0, n0, wm, wn, lane, dq);
     __builtin_amdgcn_sched_barrier(0);
   }
-  if (STAGGER && wm == 0) __builtin_amdgcn_s_barrier();  // pairs with group 1's extra barrier
+  if (wm == 0) __builtin_amdgcn_s_barrier();  // pairs with group 1's extra barrier
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // no LDS-DMA may outlive the workgroup's LDS allocation
-  if constexpr (SPLITK) {
-    if (sk_on && (int)blockIdx.x < sk_r * sk_S) {
-      // ---- split-K fix-up.  Partial tile layout: [wave][i][j][lane] x 4 floats - every (wave, i, j) is one 1 KB run.
-      const Tile tile = tile_of(full);
-      // The partials cross XCDs (the per-XCD L2s are not coherent with each other).  A release / acquire FENCE at agent
-      // scope would write back and invalidate the whole L2 - which holds megabytes of this launch's own output tiles:
-      // measured +100 us.  Instead every access to the workspace carries agent scope itself (sc1: stores write through,
-      // loads fetch from memory), ordered by vmcnt and the counter atomic.
-      float* const mine = g.sk_ws + ((size_t)(sk_tile * sk_S + sk_split) << 16);
-      const uint32_t slot = (uint32_t)(wave * 32 * 64 + lane) * 4u;
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(mine + slot + (uint32_t)(i * 4 + j) * 256u), "v"(acc[i][j]) : "memory");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // written through before the arrival is counted
-      __syncthreads();
-      int* const sflag = reinterpret_cast<int*>(smem + PP_FLAG);
-      if (tid == 0) *sflag = __hip_atomic_fetch_add(g.sk_ctr + sk_tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __syncthreads();
-      if (*sflag == sk_S - 1) {                          // last to arrive: every partial of this tile is complete
-        for (int sp = 0; sp < sk_S; ++sp) {
-          const float* src = g.sk_ws + ((size_t)(sk_tile * sk_S + sp) << 16) + slot;
-#pragma unroll
-          for (int half = 0; half < 2; ++half) {         // 16 loads in flight per wait: 6-8 round trips in all
-            f32x4 t[16];
-#pragma unroll
-            for (int q = 0; q < 16; ++q)
-              asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(t[q]) : "v"(src + (uint32_t)(half * 16 + q) * 256u) : "memory");
-            asm volatile("s_waitcnt vmcnt(0)"
-                         : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]), "+v"(t[8]),
-                           "+v"(t[9]), "+v"(t[10]), "+v"(t[11]), "+v"(t[12]), "+v"(t[13]), "+v"(t[14]), "+v"(t[15])
-                         :: "memory");
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-              const int i = (half * 16 + q) >> 2, j = q & 3;
-              acc[i][j] = sp == 0 ? t[q] : acc[i][j] + t[q];
-            }
-          }
-        }
-        const f32x4 b = *reinterpret_cast<const f32x4*>(sbias + tile.n0 + wn * 64 + frow * 4);
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] += f32x4{b[j], b[j], b[j], b[j]};
-        if (tid == 0) g.sk_ctr[sk_tile] = 0;             // ready for the next launch (stream-ordered after this one)
-        pp_epilogue<EPI, false, F8, (FL & PPF_HU8) != 0, TM>(g, acc, tile.m0, tile.n0, wm, wn, lane, dq);
-      }
-    }
-  }
 }
 
 template <int EPI, int FL>

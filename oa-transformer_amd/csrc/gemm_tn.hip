@@ -140,7 +140,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_tn_kernel(TnArgs g) {
     else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (ch + NS - 1 < ch1 && !(g.dbg & 1)) stage((ch + NS - 1 - ch0) % NS, ch + NS - 1);
+    if (ch + NS - 1 < ch1) stage((ch + NS - 1 - ch0) % NS, ch + NS - 1);
     char* sp = smem + ((ch - ch0) % NS) * STAGE;
     char* sq = sp + P_BYTES;
     if (ch == nchunks_total - 1 && g.M - ch * TK < TK) {
@@ -205,8 +205,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_tn_kernel(TnArgs g) {
     for (int j = 0; j < TN; ++j) {
       const int c = c2 + w2 * TN * 16 + j * 16 + gq * 4;
       if (c >= g.N2) continue;
-      if (!(g.dbg & 2)) *reinterpret_cast<f32x4*>(slab + (size_t)r * g.N2 + c) = acc[i][j];
-      else asm volatile("" ::"v"(acc[i][j]));
+      *reinterpret_cast<f32x4*>(slab + (size_t)r * g.N2 + c) = acc[i][j];
     }
     if ((bias_own >> i & 1) && gq == 0) g.bias_slabs[(size_t)split * g.N1 + r] = accb[i][0];
   }
