@@ -219,8 +219,13 @@ typedef struct OatAttnClip {
 } OatAttnClip;
 int oat_attn_space_fwd_clips(const OatAttnClip* clips, int n_clips, int ldqkv, int ldo, int N, int H, int D, float scale,
                              void* stream);
+/* cls_query_only != 0 (round 6; the pruned top block of the engine, which consumes the encoder's CLS row alone:
+ * video_transformer.py:349-351 -> oa_model.py:129-133): the caller guarantees that dO of every PATCH query is zero and its lse
+ * is +inf (3.4e38), so only the CLS query carries a gradient; frames of 97..447 patches then run an instance that computes the
+ * one query tile and query pair that hold it and writes zeros for the other dQ rows - bit-identical to the full launch, which
+ * adds the same exact zeros (smaller frames run the full kernel either way). */
 int oat_attn_space_bwd_clips(const OatAttnClip* clips, int n_clips, int ldqkv, int ldo, int lddo, int lddqkv, int N, int H,
-                             int D, float scale, void* stream);
+                             int D, float scale, int cls_query_only, void* stream);
 /* TIME attention backward + CLS-row finalize of TWO clips of different frame counts (powers of two <= 16) in one launch: the one-frame
  * object clip of the OA models (oa_model_global_local.py:170) beside the T-frame video clip; = oat_attn_time_bwd_fin per clip. */
 int oat_attn_time_bwd_clips(const OatAttnClip* clips, int n_clips, int ldqkv, int ldo, int lddo, int lddqkv, int N, int H,

@@ -903,15 +903,16 @@ class VideoEngine:
             for k in ("region_norm.weight", "region_norm.bias"):
                 hip.zero_(grads[k])
 
-    def _attn_bwd(self, pl, fin, qkv, o, lse, d_o, d_qkv):
+    def _attn_bwd(self, pl, fin, qkv, o, lse, d_o, d_qkv, cls_query_only=False):
         """attention backward with the fused CLS-row finalize (fin = hip.attn_space_bwd_fin | hip.attn_time_bwd_fin: the last workgroup
         per (sample, head) writes the CLS row), per segment - each clip is a self-contained row range; two clips of one geometry
         share a launch"""
         clips = lambda: [dict(qkv=sg.rows(qkv), out=sg.rows(o), lse=sg.rows(lse), dout=sg.rows(d_o), dqkv=sg.rows(d_qkv),
                               cls_side=sg.cls_side, done=sg.cls_done, B=sg.B, T=sg.T) for sg in pl.segs]
         two = len(pl.segs) == 2 and pl.segs[0].N == pl.segs[1].N
-        if fin is hip.attn_space_bwd_fin and two:
-            hip.attn_space_bwd_clips(clips(), pl.segs[0].N, self.H, self.D, self.scale)
+        if fin is hip.attn_space_bwd_fin and (two or (cls_query_only and len(pl.segs) == 1)):
+            # cls_query_only (pruned top block): dO of every patch query is zero and its lse +inf - the launch skips their exact zeros
+            hip.attn_space_bwd_clips(clips(), pl.segs[0].N, self.H, self.D, self.scale, cls_query_only=cls_query_only)
             return
         pow2 = lambda t: 1 <= t <= 16 and t & (t - 1) == 0
         if fin is hip.attn_time_bwd_fin and two and pl.segs[0].T == 1 and pl.segs[1].T > 1 and pow2(pl.segs[1].T):
@@ -1042,7 +1043,7 @@ class VideoEngine:
         d_o = pl.d_o_top
         for sg in segs:
             hip.gemm_nt(gb[sg.cls0:], wT("attn.proj"), sg.B, D, D, hip.EPI_BF16, d_o[sg.cls0:])
-        self._attn_bwd(pl, hip.attn_space_bwd_fin, a.qkv_s, a.o_s, a.lse_s, d_o, d_qkv_s)
+        self._attn_bwd(pl, hip.attn_space_bwd_fin, a.qkv_s, a.o_s, a.lse_s, d_o, d_qkv_s, cls_query_only=True)
         for k, sg in enumerate(segs):
             c0, Bc = sg.cls0, sg.B
             wgrad(d_h[c0:], a.a2[c0:], Bc, Hd, D, "mlp.fc1", True, False, more=k > 0)

@@ -569,11 +569,13 @@ def attn_space_fwd_clips(clips, N, H, D, scale):
            "oat_attn_space_fwd_clips")
 
 
-def attn_space_bwd_clips(clips, N, H, D, scale):
-    """clips: list of 1-2 dicts {qkv, out, lse, dout, dqkv, cls_side, done, B, T}; backward with the fused CLS-row finalize"""
+def attn_space_bwd_clips(clips, N, H, D, scale, cls_query_only=False):
+    """clips: list of 1-2 dicts {qkv, out, lse, dout, dqkv, cls_side, done, B, T}; backward with the fused CLS-row finalize.
+    cls_query_only: the caller guarantees dO = 0 and lse = 3.4e38 on every patch query (the pruned top block): the launch skips the
+    exact zeros those queries contribute (bit-identical gradients)"""
     c = clips[0]
     _check(lib().oat_attn_space_bwd_clips(_clip_array(clips), len(clips), c["qkv"].stride(0), c["out"].stride(0), c["dout"].stride(0),
-                                          c["dqkv"].stride(0), N, H, D, _f(scale), _stream()), "oat_attn_space_bwd_clips")
+                                          c["dqkv"].stride(0), N, H, D, _f(scale), int(bool(cls_query_only)), _stream()), "oat_attn_space_bwd_clips")
 
 
 def attn_time_bwd_clips(clips, N, H, D, scale):

@@ -265,8 +265,14 @@ __global__ __launch_bounds__(FWD_THREADS, NKT <= 14 ? 4 : 2) void attn_space_fwd
 // them, so its three gradients stay in registers across the walk and cost one set of atomics per workgroup (one per
 // group put 7 M contended atomics on 4.6 K addresses).  TT = frame count at compile time (row <-> (position, frame)
 // is a division per row otherwise).
-template <int NKT, bool BIG, int WIDE, bool TIME = false, int TT = 0>
+// CLSQ (round 6, the pruned top block: engine/video.py _top_block_bwd_pruned): only the CLS query carries a gradient - dO of every
+// patch query is exactly zero and its lse is +inf, so P = dS = 0 there and everything those queries contribute is an exact zero
+// (the kernel run in full adds 12 of 13 query tiles of zeros).  The instance skips them: phase A computes the one tile that holds
+// query N and stores zeros for the other dQ rows, phase B walks only the query pair that holds it, and delta / lse are fetched
+// for row N alone.  Skipped terms are +0.0 added to fp32 accumulators: the gradients are bit-identical to the full launch.
+template <int NKT, bool BIG, int WIDE, bool TIME = false, int TT = 0, bool CLSQ = false>
 OAT_DEV void attn_space_bwd_body(const SpaceArgs& a, const int bid) {
+  static_assert(!CLSQ || !TIME, "CLS-query-only instance: SPACE mode");
   constexpr int NKP = NKT * 16;
   constexpr int THR = WIDE == 1 ? 1024 : WIDE == 3 ? 64 : BWD_THREADS, STEP = (WIDE == 1 || WIDE == 2) ? 1 : 2;
   static_assert(!TIME || (!BIG && NKT == 2), "time mode = 16 local rows + CLS");
@@ -321,6 +327,10 @@ OAT_DEV void attn_space_bwd_body(const SpaceArgs& a, const int bid) {
       const int idx = it * THR + threadIdx.x;
       const int j = min(idx >> 3, N), c = idx & 7;
       const size_t r = rq.row<TIME>(j);
+      if (CLSQ && j != N) {                              // a patch query of the pruned top block: dO = 0, lse = +inf
+        gv[it] = bf16x8{}; ov[it] = bf16x8{}; lv[it] = INFINITY;
+        continue;
+      }
       gv[it] = *reinterpret_cast<const bf16x8*>(a.dout + r * a.lddo + h * 64 + c * 8);
       ov[it] = *reinterpret_cast<const bf16x8*>(a.out + r * a.ldo + h * 64 + c * 8);
       lv[it] = a.lse[r * a.H + h];
@@ -411,6 +421,17 @@ OAT_DEV void attn_space_bwd_body(const SpaceArgs& a, const int bid) {
   // streamed over key pairs: dS of keys [32u, 32u+32) is consumed by the dQ MFMAs right away
   for (int pr = wave; pr * STEP < ntile; pr += THR / 64) {
     const int qt0 = pr * STEP;
+    if constexpr (CLSQ) {
+      static_assert(!CLSQ || STEP == 1, "CLS-query-only instance: one tile per wave");
+      if (qt0 != N / 16) {                                 // wave-uniform: a tile of patch queries only - dQ is exactly zero
+        const f32x4 z[4] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+        store_rows16(scr, z, 0.f, lane, [&](int j) -> bf16* {
+          const int q = qt0 * 16 + j;
+          return q < N ? a.dqkv + rm.row<TIME>(q) * a.lddqkv + h * 64 : nullptr;
+        });
+        continue;
+      }
+    }
     const bool two = STEP == 2 && qt0 + 1 < ntile;                   // wave-uniform
     const int qiA = qt0 * 16 + (lane & 15), qiB = qiA + 16;
     const float lqA = lse_s[qiA], dlA = del_s[qiA], lqB = lse_s[qiB], dlB = del_s[qiB];
@@ -578,7 +599,7 @@ OAT_DEV void attn_space_bwd_body(const SpaceArgs& a, const int bid) {
       dkA[dt] = f32x4{0, 0, 0, 0}; dvA[dt] = f32x4{0, 0, 0, 0}; dkB[dt] = f32x4{0, 0, 0, 0}; dvB[dt] = f32x4{0, 0, 0, 0};
     }
 #pragma unroll 1
-    for (int u = 0; u < nu; ++u) {
+    for (int u = CLSQ ? N / 32 : 0; u < nu; ++u) {       // CLSQ: only the query pair that holds query N has P != 0
       f32x4 pvA[2], svA[2], pvB[2], svB[2];
       // wave-uniform.  Patch keys only: every pass is plain - a padding query has lse = +inf (P = 0 without a select), the CLS query sees
       // every patch key.  Only the key tile that holds the CLS key and the padding keys keeps the masked form.
@@ -715,10 +736,10 @@ OAT_DEV void attn_space_bwd_body(const SpaceArgs& a, const int bid) {
   }
 }
 
-template <int NKT, bool BIG, int WIDE, bool TIME = false, int TT = 0>
+template <int NKT, bool BIG, int WIDE, bool TIME = false, int TT = 0, bool CLSQ = false>
 __global__ __launch_bounds__(WIDE == 1 ? 1024 : WIDE == 3 ? 64 : 512, WIDE == 2 ? 4 : 2) void attn_space_bwd_kernel(SpaceArgs2 aa) {
   const bool second = (int)blockIdx.x >= aa.n0;            // workgroup-uniform
-  attn_space_bwd_body<NKT, BIG, WIDE, TIME, TT>(aa.s[second ? 1 : 0], (int)blockIdx.x - (second ? aa.n0 : 0));
+  attn_space_bwd_body<NKT, BIG, WIDE, TIME, TT, CLSQ>(aa.s[second ? 1 : 0], (int)blockIdx.x - (second ? aa.n0 : 0));
 }
 // TIME backward of two clips with DIFFERENT frame counts in one launch (the one-frame object clip of the OA models beside the T-frame
 // clip): each clip runs the body compiled for its own frame count (a run-time T costs the kernel 16 spilled registers).
@@ -766,11 +787,11 @@ static int launch_fwd(const SpaceArgs2& aa, hipStream_t s) {
   OAT_LAUNCH(attn_space_fwd_kernel<NKT>, dim3(space_blocks(aa)), dim3(FWD_THREADS), lds, s, aa);
   return check_launch("attn_space_fwd");
 }
-template <int NKT, bool BIG = false, int WIDE = 0>
+template <int NKT, bool BIG = false, int WIDE = 0, bool CLSQ = false>
 static int launch_bwd(const SpaceArgs2& aa, hipStream_t s) {
   const int lds = (BIG ? 2 : 4) * NKT * 16 * 128 + 2 * NKT * 16 * 4 + (WIDE == 1 ? 16 : BWD_THREADS / 64) * SCR_BYTES;
-  OAT_MAX_LDS((attn_space_bwd_kernel<NKT, BIG, WIDE>), lds);
-  OAT_LAUNCH((attn_space_bwd_kernel<NKT, BIG, WIDE>), dim3(space_blocks(aa)), dim3(WIDE == 1 ? 1024 : BWD_THREADS), lds, s, aa);
+  OAT_MAX_LDS((attn_space_bwd_kernel<NKT, BIG, WIDE, false, 0, CLSQ>), lds);
+  OAT_LAUNCH((attn_space_bwd_kernel<NKT, BIG, WIDE, false, 0, CLSQ>), dim3(space_blocks(aa)), dim3(WIDE == 1 ? 1024 : BWD_THREADS), lds, s, aa);
   return check_launch("attn_space_bwd");
 }
 // 97..223 patches: two 8-wave workgroups per CU on the two-tile layout, one tile per wave; 224..447 patches: 16 waves x one tile.
@@ -862,7 +883,7 @@ extern "C" int oat_attn_space_fwd(const void* qkv, int ldqkv, void* out, int ldo
 
 // cls_side: fp32 [B, H, 3, 64], must be ZERO on entry (caller memsets); it receives the CLS row's
 // dq/dk/dv partial sums.  Call oat_attn_cls_finalize afterwards to write them into dqkv (it zeroes cls_side again).
-static int space_bwd2(const SpaceArgs2& aa, int N, int H, int D, void* stream) {
+static int space_bwd2(const SpaceArgs2& aa, int N, int H, int D, void* stream, bool clsq = false) {
   if (D != H * 64) { set_error("attn_space: head_dim must be 64"); return -3; }
   const int nkt = pick_nkt(N);
   if (nkt < 0) { set_error("attn_space: patches per frame > 447 not supported by this build"); return -3; }
@@ -871,8 +892,10 @@ static int space_bwd2(const SpaceArgs2& aa, int N, int H, int D, void* stream) {
     case 2: return launch_bwd<2>(aa, s);
     case 4: return launch_bwd<4>(aa, s);
     case 8: return launch_bwd<8>(aa, s);
-    case 14: return launch_bwd<14, true, 2>(aa, s);
-    default: return launch_bwd<28, true, 1>(aa, s);
+    // clsq: the CLS-query-only instance (bit-identical to the full launch when every patch query has dO = 0 and lse = +inf; frames
+    // of fewer than 97 patches - test sizes - run the full kernel, which adds the same exact zeros)
+    case 14: return clsq ? launch_bwd<14, true, 2, true>(aa, s) : launch_bwd<14, true, 2>(aa, s);
+    default: return clsq ? launch_bwd<28, true, 1, true>(aa, s) : launch_bwd<28, true, 1>(aa, s);
   }
 }
 static int space_bwd(const void* qkv, int ldqkv, const void* out, int ldo, const float* lse, const void* dout, int lddo,
@@ -894,7 +917,7 @@ extern "C" int oat_attn_space_fwd_clips(const OatAttnClip* c, int n_clips, int l
   return space_fwd(n_clips == 2 ? two_clips(a[0], a[1]) : one_clip(a[0], a[0].B * a[0].T * H), N, H, D, stream);
 }
 extern "C" int oat_attn_space_bwd_clips(const OatAttnClip* c, int n_clips, int ldqkv, int ldo, int lddo, int lddqkv, int N, int H,
-                                        int D, float scale, void* stream) {
+                                        int D, float scale, int cls_query_only, void* stream) {
   if (!c || n_clips < 1 || n_clips > 2) { set_error("attn_space_bwd_clips: one or two clips"); return -4; }
   SpaceArgs a[2];
   for (int i = 0; i < n_clips; ++i) {
@@ -902,7 +925,7 @@ extern "C" int oat_attn_space_bwd_clips(const OatAttnClip* c, int n_clips, int l
     a[i] = SpaceArgs{(const bf16*)c[i].qkv, ldqkv, (bf16*)c[i].out, ldo, c[i].lse, (const bf16*)c[i].dout, lddo, (bf16*)c[i].dqkv, lddqkv,
                      c[i].cls_side, c[i].B, c[i].T, N, H, D, scale, 0, c[i].done};
   }
-  return space_bwd2(n_clips == 2 ? two_clips(a[0], a[1]) : one_clip(a[0], a[0].B * a[0].T * H), N, H, D, stream);
+  return space_bwd2(n_clips == 2 ? two_clips(a[0], a[1]) : one_clip(a[0], a[0].B * a[0].T * H), N, H, D, stream, cls_query_only != 0);
 }
 // TIME attention backward (with the fused CLS-row finalize) of two clips in one launch (1 + {2, 4, 8, 16} frames; other pairs: two launches)
 extern "C" int oat_attn_time_bwd_clips(const OatAttnClip* c, int n_clips, int ldqkv, int ldo, int lddo, int lddqkv, int N, int H,

@@ -692,6 +692,53 @@ def test_attention_space_more_shapes(B, T, N, H):
     _attention_case("space", B, T, N, H)
 
 
+@pytest.mark.parametrize("N,H,clips", [(196, 12, [(3, 2)]), (196, 3, [(2, 1), (2, 3)]), (441, 2, [(2, 2)]), (100, 2, [(2, 2)]), (9, 2, [(3, 2)])])
+def test_attention_space_bwd_cls_query_only_is_bit_identical(N, H, clips):
+    """oat_attn_space_bwd_clips(cls_query_only = 1), the space-attention backward of the engine's pruned top block
+    (engine/video.py _top_block_bwd_pruned; the reference computes the patch rows of that block and drops them,
+    video_transformer.py:349-351 -> oa_model.py:129-133): with dO = 0 and lse = 3.4e38 on every patch query only the CLS query carries
+    a gradient, and the instance that skips the other queries' exact zeros must give the BITS of the full launch on the patch rows
+    (dQ = 0, dK, dV) and the same CLS rows up to the order of their fp32 atomics.  One and two clips; 9 patches: the full kernel either way."""
+    hip = _hip()
+    D = H * 64
+    scale = 64 ** -0.5
+    rows = [B * T * N + B for B, T in clips]
+    Mp = (sum(rows) + 255) // 256 * 256
+    qkv = torch.zeros(Mp, 3 * D, dtype=torch.bfloat16, device=DEV); qkv[:sum(rows)] = rnd(sum(rows), 3 * D, scale=1.5, dtype=torch.bfloat16, seed=70)
+    dout = torch.zeros(Mp, D, dtype=torch.bfloat16, device=DEV)
+    out = torch.zeros(Mp, D, dtype=torch.bfloat16, device=DEV); lse = torch.zeros(Mp, H, device=DEV)
+    r0 = 0
+    for (B, T), n in zip(clips, rows):                          # what the pruned forward leaves behind: CLS rows real, patch rows "never run"
+        sl = slice(r0, r0 + n)
+        hip.attn_cls_fwd(qkv[sl], out[sl], lse[sl], B, T, N, H, D, scale)
+        hip.fill_bytes_(lse[r0:r0 + n - B], 0x7f)
+        out[r0:r0 + n - B] = rnd(n - B, D, dtype=torch.bfloat16, seed=71)          # stale rows: must not matter
+        dout[r0 + n - B:r0 + n] = rnd(B, D, dtype=torch.bfloat16, seed=72)
+        r0 += n
+    res = []
+    for flag in (False, True):
+        dq = torch.full((Mp, 3 * D), 3.0, dtype=torch.bfloat16, device=DEV)
+        side = [torch.zeros(B, H, 3, 64, device=DEV) for B, _ in clips]
+        done = [torch.zeros(B, H, dtype=torch.int32, device=DEV) for B, _ in clips]
+        segs, r0 = [], 0
+        for (B, T), n, sd, dn in zip(clips, rows, side, done):
+            sl = slice(r0, r0 + n); r0 += n
+            segs.append(dict(qkv=qkv[sl], out=out[sl], lse=lse[sl], dout=dout[sl], dqkv=dq[sl], cls_side=sd, done=dn, B=B, T=T))
+        hip.attn_space_bwd_clips(segs, N, H, D, scale, cls_query_only=flag)
+        torch.cuda.synchronize()
+        assert all(torch.count_nonzero(x) == 0 for x in side + done)
+        res.append(dq)
+    full, fast = res
+    r0 = 0
+    for (B, T), n in zip(clips, rows):
+        assert torch.equal(full[r0:r0 + n - B], fast[r0:r0 + n - B])                       # patch rows: bit for bit
+        assert torch.count_nonzero(fast[r0:r0 + n - B, :D]) == 0                            # their dQ is exactly zero
+        assert torch.count_nonzero(fast[r0:r0 + n - B, D:]) > 0
+        close(fast[r0 + n - B:r0 + n], full[r0 + n - B:r0 + n].float(), atol=1e-2 * full.float().abs().max().item(), rtol=2e-2, what="CLS rows")
+        r0 += n
+    assert bool((fast[sum(rows):] == 3.0).all())
+
+
 @pytest.mark.parametrize("N,H", [(196, 12), (9, 2), (441, 2)])
 def test_attention_space_two_clips_one_launch(N, H):
     """oat_attn_space_fwd_clips / _bwd_clips: the object frame (T = 1) and a video clip (T = 3) of the OA models as segments of
